@@ -1,0 +1,190 @@
+"""Shared, reference-free builders for the tiny parity workloads.
+
+Everything here is deterministic numpy (legacy ``RandomState``), so that the golden
+generator (``tools/make_golden.py``, which imports the reference in the build container), the
+oracle tests (CPU) and the HIP parity tests (GPU box, no reference present) all see the *same*
+weights and batches without shipping weight blobs.
+
+Weight names follow the on-disk Qwen2.5-VL checkpoint layout the reference loads with
+``from_pretrained`` (``visual.blocks.N.attn.qkv.weight``, ``model.layers.N.self_attn.q_proj.weight``,
+``lm_head.weight`` ...; /root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:118-119).
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+# A Qwen2.5-VL-shaped model small enough for the CPU oracle but using the *real* head sizes the
+# HIP attention kernels are built for (text head_dim 128, vision head_dim 80), a ragged vision MLP
+# width (324 ~ the real 3420, not a multiple of 8) and both windowed and full ViT blocks.
+TINY = {
+    "text": {
+        "vocab_size": 640,
+        "hidden_size": 256,
+        "intermediate_size": 512,
+        "num_hidden_layers": 2,
+        "num_attention_heads": 2,
+        "num_key_value_heads": 1,
+        "rms_norm_eps": 1e-6,
+        "rope_theta": 1000000.0,
+        "mrope_section": [16, 24, 24],
+    },
+    "vision": {
+        "depth": 4,
+        "hidden_size": 160,
+        "intermediate_size": 324,
+        "num_heads": 2,
+        "in_channels": 3,
+        "patch_size": 14,
+        "spatial_merge_size": 2,
+        "temporal_patch_size": 2,
+        "window_size": 112,
+        "out_hidden_size": 256,
+        "fullatt_block_indexes": [1, 3],
+    },
+    "image_token_id": 630,
+    "video_token_id": 631,
+    "vision_start_token_id": 628,
+    "vision_end_token_id": 629,
+    "eos_token_id": 1,
+    "pad_token_id": 2,
+    "tie_word_embeddings": True,
+}
+
+
+def param_shapes(cfg: dict) -> dict[str, tuple[int, ...]]:
+    """Checkpoint-name -> shape for a Qwen2.5-VL config dict like ``TINY``."""
+    t, v = cfg["text"], cfg["vision"]
+    h, inter = t["hidden_size"], t["intermediate_size"]
+    hd = h // t["num_attention_heads"]
+    kvd = hd * t["num_key_value_heads"]
+    vh, vi = v["hidden_size"], v["intermediate_size"]
+    p = v["patch_size"]
+    mu = v["spatial_merge_size"] ** 2
+    s: dict[str, tuple[int, ...]] = {}
+    s["visual.patch_embed.proj.weight"] = (vh, v["in_channels"], v["temporal_patch_size"], p, p)
+    for i in range(v["depth"]):
+        b = f"visual.blocks.{i}."
+        s[b + "norm1.weight"] = (vh,)
+        s[b + "norm2.weight"] = (vh,)
+        s[b + "attn.qkv.weight"] = (3 * vh, vh)
+        s[b + "attn.qkv.bias"] = (3 * vh,)
+        s[b + "attn.proj.weight"] = (vh, vh)
+        s[b + "attn.proj.bias"] = (vh,)
+        s[b + "mlp.gate_proj.weight"] = (vi, vh)
+        s[b + "mlp.gate_proj.bias"] = (vi,)
+        s[b + "mlp.up_proj.weight"] = (vi, vh)
+        s[b + "mlp.up_proj.bias"] = (vi,)
+        s[b + "mlp.down_proj.weight"] = (vh, vi)
+        s[b + "mlp.down_proj.bias"] = (vh,)
+    s["visual.merger.ln_q.weight"] = (vh,)
+    s["visual.merger.mlp.0.weight"] = (vh * mu, vh * mu)
+    s["visual.merger.mlp.0.bias"] = (vh * mu,)
+    s["visual.merger.mlp.2.weight"] = (v["out_hidden_size"], vh * mu)
+    s["visual.merger.mlp.2.bias"] = (v["out_hidden_size"],)
+    s["model.embed_tokens.weight"] = (t["vocab_size"], h)
+    for i in range(t["num_hidden_layers"]):
+        b = f"model.layers.{i}."
+        s[b + "input_layernorm.weight"] = (h,)
+        s[b + "self_attn.q_proj.weight"] = (h, h)
+        s[b + "self_attn.q_proj.bias"] = (h,)
+        s[b + "self_attn.k_proj.weight"] = (kvd, h)
+        s[b + "self_attn.k_proj.bias"] = (kvd,)
+        s[b + "self_attn.v_proj.weight"] = (kvd, h)
+        s[b + "self_attn.v_proj.bias"] = (kvd,)
+        s[b + "self_attn.o_proj.weight"] = (h, h)
+        s[b + "post_attention_layernorm.weight"] = (h,)
+        s[b + "mlp.gate_proj.weight"] = (inter, h)
+        s[b + "mlp.up_proj.weight"] = (inter, h)
+        s[b + "mlp.down_proj.weight"] = (h, inter)
+    s["model.norm.weight"] = (h,)
+    if not cfg.get("tie_word_embeddings", False):
+        s["lm_head.weight"] = (t["vocab_size"], h)
+    return s
+
+
+def _bf16_round(a: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (so bf16 kernels and the fp32 oracle share weights)."""
+    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def make_weights(cfg: dict, seed: int = 0, std: float = 0.05, bf16_exact: bool = True) -> dict[str, np.ndarray]:
+    """Seeded weights keyed by checkpoint name.  Norm gains ~ 1 + 0.1 N(0,1), biases ~ 0.02 N(0,1),
+    matrices ~ std N(0,1).  Values are bf16-representable when ``bf16_exact``."""
+    out = {}
+    for name, shape in param_shapes(cfg).items():
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        x = rs.standard_normal(shape).astype(np.float32)
+        if name.endswith("norm.weight") or "norm1.weight" in name or "norm2.weight" in name or name.endswith("ln_q.weight") or "layernorm.weight" in name:
+            x = 1.0 + 0.1 * x
+        elif name.endswith(".bias"):
+            x = 0.02 * x
+        else:
+            x = std * x
+        out[name] = _bf16_round(x) if bf16_exact else x
+    return out
+
+
+def perturb_weights(w: dict[str, np.ndarray], seed: int, scale: float = 0.02) -> dict[str, np.ndarray]:
+    """A second, nearby parameter set (the 'policy' next to the frozen 'ref') so that KL != 0."""
+    out = {}
+    for name, a in w.items():
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 104729 * seed) & 0x7FFFFFFF)
+        out[name] = _bf16_round(a + scale * np.abs(a).mean() * rs.standard_normal(a.shape).astype(np.float32))
+    return out
+
+
+def synth_pixel_values(grid_thw: list[tuple[int, int, int]], cfg: dict, seed: int = 1234) -> np.ndarray:
+    """Processor-shaped patches ``[sum(t*h*w), C*T*P*P]`` fp32, bf16-representable, ~N(0,1)
+    (what Qwen2VLImageProcessor emits after normalisation)."""
+    v = cfg["vision"]
+    k = v["in_channels"] * v["temporal_patch_size"] * v["patch_size"] ** 2
+    n = sum(t * h * w for t, h, w in grid_thw)
+    rs = np.random.RandomState(seed)
+    return _bf16_round(rs.standard_normal((n, k)).astype(np.float32))
+
+
+def n_image_tokens(grid: tuple[int, int, int], cfg: dict) -> int:
+    t, h, w = grid
+    return t * h * w // cfg["vision"]["spatial_merge_size"] ** 2
+
+
+def synth_prompt(grid: tuple[int, int, int], n_text: int, cfg: dict, seed: int) -> list[int]:
+    """`<prefix> <|vision_start|> <|image_pad|>*N <|vision_end|> <text>*n_text` token ids."""
+    rs = np.random.RandomState(seed)
+    lo, hi = 3, cfg["vision_start_token_id"]  # avoid pad/eos/special ids
+    prefix = rs.randint(lo, hi, size=3).tolist()
+    body = rs.randint(lo, hi, size=n_text).tolist()
+    return (
+        prefix
+        + [cfg["vision_start_token_id"]]
+        + [cfg["image_token_id"]] * n_image_tokens(grid, cfg)
+        + [cfg["vision_end_token_id"]]
+        + body
+    )
+
+
+def left_pad(rows: list[list[int]], pad_id: int) -> tuple[np.ndarray, np.ndarray]:
+    m = max(len(r) for r in rows)
+    ids = np.full((len(rows), m), pad_id, dtype=np.int64)
+    mask = np.zeros((len(rows), m), dtype=np.int64)
+    for i, r in enumerate(rows):
+        ids[i, m - len(r):] = r
+        mask[i, m - len(r):] = 1
+    return ids, mask
+
+
+def synth_completions(n: int, max_len: int, cfg: dict, seed: int, eos_rows: dict[int, int] | None = None) -> list[list[int]]:
+    """``n`` ragged completions; rows listed in ``eos_rows`` end with EOS at that index."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        ln = max_len if (eos_rows is None or i not in eos_rows) else eos_rows[i] + 1
+        ids = rs.randint(3, cfg["vision_start_token_id"], size=ln).tolist()
+        if eos_rows is not None and i in eos_rows:
+            ids[-1] = cfg["eos_token_id"]
+        out.append(ids)
+    return out

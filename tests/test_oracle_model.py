@@ -1,0 +1,135 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors captured from the reference
+(tools/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_util as fx
+from oracle import qwen25vl as oq
+from oracle import sc_grpo as og
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_window_and_position_indices(golden_dir):
+    obj = json.load(open(os.path.join(golden_dir, "vision_index.json")))
+    for c in obj["window"]:
+        grids = [tuple(g) for g in c["grid_thw"]]
+        wi, cu = oq.vision_window_index(grids)
+        assert wi.tolist() == c["window_index"]
+        assert cu == c["cu_window_seqlens"]
+        assert oq.vision_position_ids(grids).tolist() == c["position_ids"]
+        assert oq.vision_cu_seqlens(grids) == c["cu_seqlens"]
+    for c in obj["rope_index"]:
+        pos, d = oq.mrope_position_ids(torch.tensor(c["input_ids"]), torch.tensor(c["attention_mask"]), [tuple(g) for g in c["grid_thw"]], fx.TINY["image_token_id"])
+        assert pos.tolist() == c["position_ids"]
+        assert d.tolist() == c["rope_deltas"]
+
+
+def test_forward_left_padded_batch(golden_dir):
+    g = _load(golden_dir, "logps_padded.npz")
+    m = oq.Qwen25VLOracle(fx.TINY, fx.make_weights(fx.TINY, 0))
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    pv = torch.from_numpy(g["pixel_values"])
+    grids = [tuple(int(z) for z in r) for r in g["image_grid_thw"]]
+    with torch.no_grad():
+        merged, last = m.visual(pv, grids, return_last_hidden=True)
+        np.testing.assert_allclose(last.numpy(), g["vit_last_hidden"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(merged.numpy(), g["image_embeds"], rtol=2e-4, atol=2e-4)
+        pos, _ = oq.mrope_position_ids(ids, mask, grids, fx.TINY["image_token_id"])
+        assert np.array_equal(pos.numpy(), g["position_ids"])
+        x = m.embed(ids, merged)
+        np.testing.assert_allclose(x.numpy(), g["hidden_0"], rtol=2e-4, atol=2e-4)
+        h, hs = m.text_model(x, mask, pos, return_hidden=True)
+        keep = mask.bool().numpy()
+        np.testing.assert_allclose(hs[1].numpy()[keep], g["hidden_1"][keep], rtol=5e-4, atol=5e-4)
+        np.testing.assert_allclose(h.numpy()[keep], g["hidden_last"][keep], rtol=5e-4, atol=5e-4)
+        logits = h @ m.w["lm_head.weight"].t()
+        np.testing.assert_allclose(logits.numpy()[keep], g["logits"][keep], rtol=1e-3, atol=1e-3)
+        lp = m.per_token_logps(ids, mask, pv, grids)
+    # left-pad rows: positions whose *target* is real and whose query is real
+    valid = (mask[:, 1:] * mask[:, :-1]).bool().numpy()
+    np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["sc_grpo_g4.npz", "sc_grpo_g8.npz"])
+def test_sc_grpo_compute_loss(golden_dir, name):
+    g = _load(golden_dir, name)
+    meta = json.loads(str(g["meta"]))
+    G, C, seed = meta["G"], meta["C"], meta["seed"]
+    cfg = fx.TINY
+    w_ref = fx.make_weights(cfg, 0)
+    pol = oq.Qwen25VLOracle(cfg, fx.perturb_weights(w_ref, 1), requires_grad=True)
+    ref = oq.Qwen25VLOracle(cfg, w_ref)
+    grid = tuple(meta["grid"])
+    rows = [fx.synth_prompt(grid, meta["n_text"], cfg, seed)]
+    ids, mask = fx.left_pad(rows, cfg["pad_token_id"])
+    pv = fx.synth_pixel_values([grid], cfg, seed=seed)
+    eos_rows = {int(k): v for k, v in meta["eos_rows"].items()}
+    comps = fx.synth_completions(G, C, cfg, seed + 100, eos_rows)
+    assert np.array_equal(og.right_pad(comps, cfg["pad_token_id"]).numpy(), g["completion_ids"])
+    out = og.sc_grpo_step(pol, ref, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pv), [grid], comps,
+                          torch.from_numpy(g["rewards_per_func"]), G, 0.04, cfg["eos_token_id"], cfg["pad_token_id"])
+    assert np.array_equal(out["completion_mask"].numpy(), g["completion_mask"])
+    assert np.array_equal(out["ids"].numpy(), g["prompt_completion_ids"])
+    assert np.array_equal(out["mask"].numpy(), g["attention_mask"])
+    np.testing.assert_allclose(out["logps"].detach().numpy(), g["per_token_logps"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(out["ref_logps"].numpy(), g["ref_per_token_logps"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(out["kl"].detach().numpy(), g["per_token_kl"], rtol=2e-2, atol=2e-5)
+    np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=1e-5, atol=1e-6)
+    assert abs(out["loss"].item() - float(g["loss"])) < 2e-6
+    assert abs(out["metrics"]["kl"] - float(g["metric_kl"])) < 2e-6
+    assert out["metrics"]["completion_length"] == float(g["metric_completion_length"])
+    assert abs(out["metrics"]["reward"] - float(g["metric_reward"])) < 1e-6
+    assert abs(out["metrics"]["reward_std"] - float(g["metric_reward_std"])) < 1e-5
+    out["loss"].backward()
+    grads = dict(pol.parameters())
+    names = [str(n) for n in g["grad_norm_names"]]
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        if n == "lm_head.weight":
+            continue
+        got = float(grads[n].grad.norm())
+        assert abs(got - ref_norm) <= 2e-3 * ref_norm + 1e-7, (n, got, ref_norm)
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(grads[k[6:]].grad.numpy(), g[k], rtol=5e-3, atol=1e-6 + 5e-3 * np.abs(g[k]).max())
+
+
+def test_greedy_rollout_token_ids(golden_dir):
+    g = _load(golden_dir, "greedy.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = fx.TINY
+    m = oq.Qwen25VLOracle(cfg, fx.make_weights(cfg, 0))
+    grids = [tuple(x) for x in meta["grids"]]
+    pv = torch.from_numpy(fx.synth_pixel_values(grids, cfg, seed=meta["seed"]))
+    seqs = m.greedy_generate(torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["prompt_mask"]), pv, grids, meta["new_tokens"])
+    assert np.array_equal(seqs.numpy(), g["sequences"])  # bit-exact token ids
+
+
+def test_sft_loss_curve(golden_dir):
+    g = _load(golden_dir, "sft.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = fx.TINY
+    m = oq.Qwen25VLOracle(cfg, fx.make_weights(cfg, 0), requires_grad=True)
+    grids = [tuple(int(z) for z in r) for r in g["image_grid_thw"]]
+    ids, mask, labels = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels"))
+    pv = torch.from_numpy(g["pixel_values"])
+    params = dict(m.parameters())
+    decay = [p for n, p in params.items() if p.ndim >= 2]
+    no_decay = [p for n, p in params.items() if p.ndim < 2]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": meta["wd"]}, {"params": no_decay, "weight_decay": 0.0}], lr=meta["lr"])
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = m.sft_loss(ids, mask, labels, pv, grids)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)

@@ -1,0 +1,549 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference and the installed transformers); nothing
+here travels to the GPU box.  The fixtures it writes are *data*: inputs + outputs of the
+reference's own functions:
+
+  rewards.json        train/stage_rl/reward.py:13-101  accuracy_reward / consistency_reward,
+                      reward_process/type_reward.py:155-232 compute_reward,
+                      reward_process/location_reward.py:1-49 map_location_to_region
+  pad.json            trl/trl/trainer/utils.py:418-478 pad
+  sc_grpo_g4.npz,     train/stage_rl/trainer/sc_grpo_trainer.py:586-819 SCGRPOTrainer.compute_loss on a
+  sc_grpo_g8.npz      tiny random-init Qwen2_5_VLForConditionalGeneration (mocked processor / vLLM)
+  logps_padded.npz    sc_grpo_trainer.py:384-514 _get_per_token_logps on a left-padded 2-prompt batch
+  vision_index.json   transformers.vision_utils get_vision_window_index / get_vision_position_ids,
+                      Qwen2_5_VLModel.get_rope_index
+  greedy.npz          HF generate(do_sample=False) token ids (the rollout's bit-exact target)
+  sft.npz             HF forward(labels=...) loss (transformers loss_utils.ForCausalLMLoss) and a
+                      3-step torch.optim.AdamW loss curve (llamafactory sft trainer semantics)
+
+Recipe for importing SCGRPOTrainer without vllm / sentence_transformers: SURVEY.md section 8(c).
+Goldens are captured against transformers == the version recorded in each fixture's `meta`.
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib.machinery
+import io
+import json
+import os
+import sys
+import types
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(REF, "trl"))
+sys.path.insert(0, os.path.join(REF, "train", "stage_rl"))
+
+import fixture_util as fx  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    st_models = _stub("sentence_transformers.models")
+    _stub("sentence_transformers", SentenceTransformer=object, models=st_models)
+    import trl  # noqa: F401  (vendored trl from the reference tree)
+
+    _stub("vllm", LLM=object, SamplingParams=object)
+    import reward  # reference train/stage_rl/reward.py
+    from reward_process import location_reward, type_reward
+    from trainer import SCGRPOTrainer
+    from trl.trainer.utils import pad
+
+    return reward, type_reward, location_reward, SCGRPOTrainer, pad
+
+
+def meta():
+    import transformers
+
+    return {"transformers": transformers.__version__, "torch": torch.__version__, "reference": "Yanhui-Lee/IAD-R1 @ 2025-12-26"}
+
+
+# ----------------------------------------------------------------------------------------------
+# rewards
+# ----------------------------------------------------------------------------------------------
+TYPE_STRINGS = [
+    "scratch", "Scratch", "surface scratch", "scratch mark", "linear scratch", "a long scratch mark on the surface",
+    "scrach", "scratchh", "contamination", "Contamination", "stain", "dirt", "color anomaly", "colour anomaly",
+    "surface contamination", "impurity", "foreign object", "presence of foreign objects", "foreign body", "debris",
+    "unwanted object", "missing parts", "missing part", "notch", "gap", "chip", "surface notch", "deformation",
+    "shape distortion", "warping", "bending", "bent component", "bent", "hole", "opening", "puncture", "cavity",
+    "void", "through-hole", "through hole", "damage", "structural damage", "breakage", "fracture", "broken", "rupture",
+    "surface damage", "abrasion", "wear", "surface wear", "wear mark", "grinding damage", "surface anomalies",
+    "surface anomaly", "structural anomalies", "Structural Anomaly", "structural anomaly.", "crack", "misalignment",
+    "discoloration", "", "   ", "!!!", "hole, damage", "scratch and stain", "perforation!", "twisting ", "irregularity",
+    "geometric  distortion", "material damage", "deterioration", "aperture", "penetration defect", "score mark",
+    "linear anomaly", "extraneous material", "foreign element", "foreign matter", "contaminant object",
+    "surface discontinuity", "surface erosion", "shape deviation",
+]
+LOCATION_STRINGS = [
+    "top left", "top-left corner", "upper left", "left", "center", "centre", "middle", "right", "upper right",
+    "top right", "bottom left", "lower left", "bottom", "lower right", "bottom right corner", "top", "upper",
+    "lower", "the left side near the top", "right edge", "", "everywhere", "topleft", "Bottom-Right", "TOP",
+    "left and right", "upper bottom",
+]
+
+
+def build_reward_cases():
+    rs = np.random.RandomState(20250929)
+    comps, sols = [], []
+
+    def yes_comp(t, loc, ans="yes", think="looks odd"):
+        return f"<think>{think}</think><location>{loc}</location><type>{t}</type><answer>{ans}</answer>"
+
+    def no_comp(ans="no", think="looks fine"):
+        return f"<think>{think}</think><answer>{ans}</answer>"
+
+    def yes_sol(t, loc):
+        return f"<think>gt</think><location>{loc}</location><type>{t}</type><answer>yes</answer>"
+
+    # systematic: every type string against a handful of gt types
+    gts = ["scratch", "Contamination", "hole", "structural damage", "surface anomalies", "Structural Anomalies", "bent component", "foreign object", "wear"]
+    for t in TYPE_STRINGS:
+        for g in gts:
+            comps.append(yes_comp(t, "top left"))
+            sols.append(yes_sol(g, "upper left"))
+    # locations
+    for a in LOCATION_STRINGS:
+        for b in LOCATION_STRINGS[::3]:
+            comps.append(yes_comp("scratch", a))
+            sols.append(yes_sol("scratch", b))
+    # answer variants / malformed
+    odd = [
+        no_comp(), no_comp("No"), no_comp(" no "), no_comp("yes"), no_comp("maybe"), "no", "<answer>no</answer>",
+        "<think>x</think>\n<answer>no</answer>", "<think>a</think><answer>no</answer> trailing", "prefix <think>a</think><answer>no</answer>",
+        "<think>a</think><location>l</location><answer>no</answer>", "<think>a</think><type>t</type><answer>no</answer>",
+        yes_comp("scratch", "left", "yes"), yes_comp("scratch", "left", "Yes"), yes_comp("scratch", "left", "no"),
+        yes_comp("scratch", "left", ""), "<think>a</think><type>scratch</type><location>left</location><answer>yes</answer>",
+        "<think>a</think><location>left</location><type>scratch</type>", "<location>left</location><type>scratch</type><answer>yes</answer>",
+        "<think>line1\nline2</think><location>top\nleft</location><type>scratch</type><answer>yes</answer>",
+        "<think>a</think> <location>left</location><type>scratch</type><answer>yes</answer>",
+        "<think></think><location></location><type></type><answer></answer>", "", "<answer>yes</answer><answer>no</answer>",
+        "<think>a</think><answer>no</answer><answer>yes</answer>", "<THINK>a</THINK><ANSWER>no</ANSWER>",
+        "<think>a</think><location>left</location><type>scratch</type><answer>yes</answer><type>hole</type>",
+    ]
+    sol_variants = [
+        "<think>g</think><answer>no</answer>", "<answer>no</answer>", "no", "No", " NO ", yes_sol("scratch", "left"),
+        "<answer>yes</answer>", "yes", "<think>g</think><location>left</location><answer>yes</answer>",
+        "<think>g</think><type>scratch</type><answer>yes</answer>", "<answer>Yes</answer>",
+    ]
+    for c in odd:
+        for s in sol_variants:
+            comps.append(c)
+            sols.append(s)
+    # random mixes
+    for _ in range(150):
+        t = TYPE_STRINGS[rs.randint(len(TYPE_STRINGS))]
+        g = TYPE_STRINGS[rs.randint(len(TYPE_STRINGS))]
+        a = LOCATION_STRINGS[rs.randint(len(LOCATION_STRINGS))]
+        b = LOCATION_STRINGS[rs.randint(len(LOCATION_STRINGS))]
+        ans = ["yes", "no", "Yes", "unsure"][rs.randint(4)]
+        comps.append(yes_comp(t, a, ans))
+        sols.append(yes_sol(g, b))
+    return comps, sols
+
+
+def gen_rewards(reward, type_reward, location_reward):
+    comps, sols = build_reward_cases()
+    wrapped = [[{"role": "assistant", "content": c}] for c in comps]
+    with contextlib.redirect_stdout(io.StringIO()):
+        acc = reward.accuracy_reward(wrapped, sols)
+        fmt = reward.consistency_reward(wrapped, sols)
+    assert len(acc) == len(comps) and len(fmt) == len(comps)
+    calc = type_reward.AnomalyRewardCalculator()
+    type_pairs = [(a, b) for a in TYPE_STRINGS for b in TYPE_STRINGS[::2]]
+    type_scores = [calc.compute_reward(a, b) for a, b in type_pairs]
+    loc_pairs = [(a, b) for a in LOCATION_STRINGS for b in LOCATION_STRINGS]
+    loc_scores = [location_reward.map_location_to_region(a, b) for a, b in loc_pairs]
+    # the reference quirk of SURVEY Appendix B.8: gt neither yes/no -> consistency_reward emits nothing
+    with contextlib.redirect_stdout(io.StringIO()):
+        short = reward.consistency_reward([[{"role": "assistant", "content": "x"}]] * 2, ["maybe", "<answer>no</answer>"])
+    obj = {
+        "meta": meta(),
+        "completions": comps, "solutions": sols, "accuracy": acc, "format": fmt,
+        "type_pairs": type_pairs, "type_scores": type_scores,
+        "location_pairs": loc_pairs, "location_scores": loc_scores,
+        "format_len_quirk": len(short),
+    }
+    with open(os.path.join(OUT, "rewards.json"), "w") as f:
+        json.dump(obj, f, indent=0)
+    print(f"rewards.json: {len(comps)} reward cases, {len(type_pairs)} type pairs, {len(loc_pairs)} location pairs")
+
+
+def gen_pad(pad):
+    cases = []
+    rs = np.random.RandomState(7)
+    specs = [
+        ([[1, 2, 3], [4, 5]], 0, "right", None), ([[1, 2, 3], [4, 5]], 0, "left", None),
+        ([[1], [2, 3, 4, 5], [6, 7]], 9, "right", None), ([[1], [2, 3, 4, 5], [6, 7]], 9, "left", 4),
+        ([[1, 2, 3, 4, 5]], -1, "right", 4), ([[[1, 2], [3, 4]], [[5, 6]]], 0, "right", None),
+        ([[[1, 2], [3, 4]], [[5, 6]]], 0, "left", None),
+    ]
+    for _ in range(5):
+        n = rs.randint(1, 6)
+        specs.append(([rs.randint(0, 99, size=rs.randint(1, 9)).tolist() for _ in range(n)], int(rs.randint(0, 5)), ["left", "right"][rs.randint(2)], [None, 8][rs.randint(2)]))
+    for rows, val, side, mult in specs:
+        out = pad([torch.tensor(r) for r in rows], padding_value=val, padding_side=side, pad_to_multiple_of=mult)
+        cases.append({"rows": rows, "padding_value": val, "padding_side": side, "pad_to_multiple_of": mult, "out": out.tolist()})
+    with open(os.path.join(OUT, "pad.json"), "w") as f:
+        json.dump({"meta": meta(), "cases": cases}, f)
+    print(f"pad.json: {len(cases)} cases")
+
+
+# ----------------------------------------------------------------------------------------------
+# tiny HF model
+# ----------------------------------------------------------------------------------------------
+def hf_name(name: str) -> str:
+    if name.startswith("visual."):
+        return "model." + name
+    if name.startswith("model."):
+        return "model.language_model." + name[len("model."):]
+    return name
+
+
+def build_hf_model(cfg: dict, weights: dict[str, np.ndarray]):
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+
+    t, v = cfg["text"], cfg["vision"]
+    hf_cfg = Qwen2_5_VLConfig(
+        text_config=dict(
+            vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
+            num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
+            num_key_value_heads=t["num_key_value_heads"], rms_norm_eps=t["rms_norm_eps"],
+            rope_parameters={"rope_type": "default", "rope_theta": t["rope_theta"], "mrope_section": t["mrope_section"]},
+            pad_token_id=cfg["pad_token_id"], eos_token_id=cfg["eos_token_id"], bos_token_id=None,
+        ),
+        vision_config=dict(
+            depth=v["depth"], hidden_size=v["hidden_size"], intermediate_size=v["intermediate_size"], num_heads=v["num_heads"],
+            in_channels=v["in_channels"], patch_size=v["patch_size"], spatial_merge_size=v["spatial_merge_size"],
+            temporal_patch_size=v["temporal_patch_size"], window_size=v["window_size"], out_hidden_size=v["out_hidden_size"],
+            fullatt_block_indexes=list(v["fullatt_block_indexes"]),
+        ),
+        image_token_id=cfg["image_token_id"], video_token_id=cfg["video_token_id"],
+        vision_start_token_id=cfg["vision_start_token_id"], vision_end_token_id=cfg["vision_end_token_id"],
+        tie_word_embeddings=cfg["tie_word_embeddings"],
+    )
+    hf_cfg._attn_implementation = "eager"
+    model = Qwen2_5_VLForConditionalGeneration(hf_cfg)
+    sd = {hf_name(k): torch.from_numpy(a.copy()) for k, a in weights.items()}
+    if cfg["tie_word_embeddings"]:
+        sd["lm_head.weight"] = sd["model.language_model.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("inv_freq" in m for m in missing), missing
+    model.config._attn_implementation = "eager"
+    model.float()
+    return model
+
+
+CANNED = [
+    "<think>surface looks uniform</think><answer>no</answer>",
+    "<think>a line on the left</think><location>upper left</location><type>scratch</type><answer>yes</answer>",
+    "<think>dark blob</think><location>center</location><type>stain</type><answer>yes</answer>",
+    "<think>hmm</think><location>bottom right</location><type>hole</type><answer>no</answer>",
+    "no tags at all",
+    "<think>x</think><location>top left corner</location><type>surface scratch</type><answer>yes</answer>",
+    "<think>y</think><location>left</location><type>structural anomaly</type><answer>yes</answer>",
+    "<think>z</think><location>top</location><type>scrach</type><answer>yes</answer> extra",
+]
+SOLUTION = "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"
+
+
+class FakeProcessor:
+    """Stands in for AutoProcessor: returns preset tensors (the reference only forwards them)."""
+
+    def __init__(self, cfg, batch, completions_text, n_completion):
+        self.cfg = cfg
+        # transformers>=5 derives M-RoPE from `mm_token_type_ids` (the pinned
+        # 4.51.3 derives it from input_ids).  The trainer swaps in prompt+completion input_ids but
+        # forwards the processor's other tensors untouched, so the mock emits the type ids already at
+        # prompt+completion length (completion tokens are text = 0).
+        batch = dict(batch)
+        tt = batch["mm_token_type_ids"]
+        batch["mm_token_type_ids"] = torch.cat([tt, torch.zeros(tt.shape[0], n_completion, dtype=tt.dtype)], 1)
+        self.batch = batch
+        self.pad_token_id = cfg["pad_token_id"]
+        self.eos_token_id = cfg["eos_token_id"]
+        self.tokenizer = self
+        self._texts = completions_text
+        self.chat_template = "x"
+
+    def apply_chat_template(self, conversation, **kw):
+        return "PROMPT"
+
+    def __call__(self, text=None, images=None, **kw):
+        from transformers import BatchFeature
+
+        return BatchFeature({k: v.clone() for k, v in self.batch.items()})
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return list(self._texts[: len(ids)])
+
+
+class FakeLLM:
+    def __init__(self, completions):
+        self.completions = completions
+
+    def generate(self, prompts, sampling_params=None, use_tqdm=False):
+        assert len(prompts) == len(self.completions), (len(prompts), len(self.completions))
+        return [types.SimpleNamespace(outputs=[types.SimpleNamespace(token_ids=list(c))]) for c in self.completions]
+
+
+def make_trainer(SCGRPOTrainer, reward, cfg, model_ref, batch, completions, texts, G, max_completion_length):
+    t = SCGRPOTrainer.__new__(SCGRPOTrainer)
+    dev = torch.device("cpu")
+    t.accelerator = types.SimpleNamespace(device=dev, process_index=0, is_main_process=True, gather_for_metrics=lambda x: x, unwrap_model=lambda m: m)
+    t.processing_class = FakeProcessor(cfg, batch, texts, max(len(c) for c in completions))
+    t.use_vllm = True
+    t.llm = FakeLLM(completions)
+    t.sampling_params = None
+    t.num_generations = G
+    t.max_prompt_length = 4096
+    t.max_completion_length = max_completion_length
+    t.beta = 0.04
+    t.ref_model = model_ref
+    t.model_id = "tiny-qwen2.5-vl"
+    t.reward_funcs = [reward.accuracy_reward, reward.consistency_reward]
+    t.reward_processing_classes = [None, None]
+    t._metrics = defaultdict(list)
+    t._last_loaded_step = 0
+    t.state = types.SimpleNamespace(global_step=0)
+    t.args = types.SimpleNamespace(device=dev, past_index=-1, ds3_gather_for_generation=True)
+    t.is_deepspeed_enabled = False
+    t._past = None
+    return t
+
+
+def capture_locals(fn, code_name):
+    """Run fn(); return (result, f_locals of the frame named code_name at its return)."""
+    grabbed = {}
+
+    def prof(frame, event, arg):
+        if event == "return" and frame.f_code.co_name == code_name:
+            grabbed.update(frame.f_locals)
+
+    sys.setprofile(prof)
+    try:
+        res = fn()
+    finally:
+        sys.setprofile(None)
+    return res, grabbed
+
+
+def tiny_batch(cfg, grids, n_texts, seed):
+    rows = [fx.synth_prompt(g, n, cfg, seed + i) for i, (g, n) in enumerate(zip(grids, n_texts))]
+    ids, mask = fx.left_pad(rows, cfg["pad_token_id"])
+    pv = fx.synth_pixel_values(grids, cfg, seed=seed)
+    return {
+        "input_ids": torch.from_numpy(ids),
+        "attention_mask": torch.from_numpy(mask),
+        "pixel_values": torch.from_numpy(pv),
+        "image_grid_thw": torch.tensor(grids, dtype=torch.long),
+        "mm_token_type_ids": torch.from_numpy((ids == cfg["image_token_id"]).astype(np.int32)),
+    }
+
+
+GRAD_FULL = [
+    "model.norm.weight", "model.layers.1.self_attn.k_proj.bias", "model.layers.0.input_layernorm.weight",
+    "visual.merger.ln_q.weight", "visual.blocks.0.attn.qkv.bias", "visual.blocks.3.norm2.weight", "visual.merger.mlp.2.bias",
+]
+
+
+def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed):
+    cfg = fx.TINY
+    w_ref = fx.make_weights(cfg, seed=0)
+    w_pol = fx.perturb_weights(w_ref, seed=1)
+    ref = build_hf_model(cfg, w_ref).eval()
+    pol = build_hf_model(cfg, w_pol).train()
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    grid = (1, 16, 12)
+    batch = tiny_batch(cfg, [grid], [9], seed)
+    comps = fx.synth_completions(G, C, cfg, seed + 100, eos_rows)
+    texts = [CANNED[i % len(CANNED)] for i in range(G)]
+    t = make_trainer(SCGRPOTrainer, reward, cfg, ref, batch, comps, texts, G, C)
+    inputs = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "q"}]}], "image": [object()], "solution": SOLUTION}]
+    # the trainer opens str images with PIL; pass non-str objects straight through (sc_grpo_trainer.py:610)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss, loc = capture_locals(lambda: t.compute_loss(pol, inputs), "compute_loss")
+    loss.backward()
+    grads = {k: p.grad for k, p in pol.named_parameters() if p.grad is not None}
+    inv = {hf_name(k): k for k in fx.param_shapes(cfg)}
+    gnorm = {inv[k]: float(g.norm()) for k, g in grads.items() if k in inv}
+    out = {
+        "meta": json.dumps({**meta(), "G": G, "C": C, "grid": grid, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows or {}, "weights": "fixture_util.make_weights(TINY,0) / perturb_weights(.,1)"}),
+        "completion_ids": loc["completion_ids"].numpy(),
+        "prompt_completion_ids": loc["prompt_completion_ids"].numpy(),
+        "attention_mask": loc["attention_mask"].numpy(),
+        "completion_mask": loc["completion_mask"].numpy(),
+        "per_token_logps": loc["per_token_logps"].detach().numpy(),
+        "ref_per_token_logps": loc["ref_per_token_logps"].numpy(),
+        "per_token_kl": loc["per_token_kl"].detach().numpy(),
+        "rewards_per_func": loc["rewards_per_func"].numpy(),
+        "advantages": loc["advantages"].numpy(),
+        "loss": np.float64(loss.item()),
+        "metric_completion_length": np.float64(t._metrics["completion_length"][0]),
+        "metric_reward": np.float64(t._metrics["reward"][0]),
+        "metric_reward_std": np.float64(t._metrics["reward_std"][0]),
+        "metric_kl": np.float64(t._metrics["kl"][0]),
+        "metric_rewards_accuracy": np.float64(t._metrics["rewards/accuracy_reward"][0]),
+        "metric_rewards_format": np.float64(t._metrics["rewards/consistency_reward"][0]),
+        "grad_norm_names": np.array(sorted(gnorm)),
+        "grad_norms": np.array([gnorm[k] for k in sorted(gnorm)], dtype=np.float64),
+        "completions_text": np.array(texts),
+        "solution": np.array(SOLUTION),
+    }
+    for k in GRAD_FULL:
+        out["grad::" + k] = grads[hf_name(k)].numpy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(f"{name}: loss={loss.item():.8f} reward={t._metrics['reward'][0]:.4f} kl={t._metrics['kl'][0]:.6f} len={t._metrics['completion_length'][0]}")
+
+
+def gen_logps_padded(SCGRPOTrainer):
+    """_get_per_token_logps on two different left-padded prompts with two different grids + the
+    intermediate activations used to pin the oracle layer by layer."""
+    cfg = fx.TINY
+    w = fx.make_weights(cfg, seed=0)
+    model = build_hf_model(cfg, w).eval()
+    grids = [(1, 16, 12), (1, 8, 8)]
+    batch = tiny_batch(cfg, grids, [5, 17], seed=77)
+    comp = np.array(fx.synth_completions(2, 6, cfg, 5)).astype(np.int64)
+    ids = torch.cat([batch["input_ids"], torch.from_numpy(comp)], 1)
+    mask = torch.cat([batch["attention_mask"], torch.ones(2, 6, dtype=torch.long)], 1)
+    inputs = dict(batch, input_ids=ids, attention_mask=mask, mm_token_type_ids=(ids == cfg["image_token_id"]).int())
+    holder = types.SimpleNamespace(model_id="tiny-qwen2.5-vl")
+    with torch.no_grad():
+        logps = SCGRPOTrainer._get_per_token_logps(holder, model, **inputs)
+        vis = model.model.visual(inputs["pixel_values"], grid_thw=inputs["image_grid_thw"])
+        pos, deltas = model.model.get_rope_index(ids, mm_token_type_ids=inputs["mm_token_type_ids"], image_grid_thw=inputs["image_grid_thw"], attention_mask=mask)
+        out = model(**inputs, output_hidden_states=True)
+    np.savez_compressed(
+        os.path.join(OUT, "logps_padded.npz"),
+        meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 77}),
+        input_ids=ids.numpy(), attention_mask=mask.numpy(), pixel_values=inputs["pixel_values"].numpy(),
+        image_grid_thw=inputs["image_grid_thw"].numpy(), per_token_logps=logps.numpy(),
+        image_embeds=vis.pooler_output.numpy(), vit_last_hidden=vis.last_hidden_state.numpy(),
+        position_ids=pos.numpy(), rope_deltas=deltas.numpy(),
+        logits=out.logits.numpy().astype(np.float32),
+        hidden_0=out.hidden_states[0].numpy(), hidden_1=out.hidden_states[1].numpy(), hidden_last=out.hidden_states[-1].numpy(),
+    )
+    print("logps_padded.npz:", tuple(logps.shape))
+
+
+def gen_vision_index():
+    from transformers import vision_utils as vu
+
+    cfg = fx.TINY
+    model = build_hf_model(cfg, fx.make_weights(cfg, seed=0))
+    cases = []
+    for grids in ([(1, 32, 32)], [(1, 16, 12)], [(1, 8, 8), (1, 20, 14)], [(1, 6, 34), (1, 18, 18), (1, 4, 4)]):
+        g = torch.tensor(grids)
+        wi, cu = vu.get_vision_window_index(g, spatial_merge_size=2, window_size=112, patch_size=14)
+        pid = vu.get_vision_position_ids(g, 2)
+        cs = vu.get_vision_cu_seqlens(g)
+        cases.append({"grid_thw": grids, "window_index": wi.tolist(), "cu_window_seqlens": cu.tolist(), "position_ids": pid.tolist(), "cu_seqlens": cs.tolist()})
+    rope = []
+    for grids, n_text in (([(1, 32, 32)], [251]), ([(1, 16, 12), (1, 8, 8)], [4, 30])):
+        b = tiny_batch(cfg, grids, n_text, seed=3)
+        pos, d = model.model.get_rope_index(b["input_ids"], mm_token_type_ids=b["mm_token_type_ids"], image_grid_thw=b["image_grid_thw"], attention_mask=b["attention_mask"])
+        rope.append({"grid_thw": grids, "input_ids": b["input_ids"].tolist(), "attention_mask": b["attention_mask"].tolist(), "position_ids": pos.tolist(), "rope_deltas": d.tolist()})
+    with open(os.path.join(OUT, "vision_index.json"), "w") as f:
+        json.dump({"meta": meta(), "window": cases, "rope_index": rope}, f)
+    print("vision_index.json:", len(cases), "window cases,", len(rope), "rope cases")
+
+
+def gen_greedy():
+    cfg = fx.TINY
+    model = build_hf_model(cfg, fx.make_weights(cfg, seed=0)).eval()
+    grids = [(1, 16, 12), (1, 8, 8)]
+    b = tiny_batch(cfg, grids, [5, 17], seed=77)
+    with torch.no_grad():
+        out = model.generate(**b, do_sample=False, max_new_tokens=12, min_new_tokens=12, use_cache=True, pad_token_id=cfg["pad_token_id"], eos_token_id=None)
+        # also the per-step top-2 logit margin (fp32), so a bf16 device path can tell a real
+        # mismatch from a near-tie
+        ids = out
+        mask = torch.cat([b["attention_mask"], torch.ones(2, 12, dtype=torch.long)], 1)
+        logits = model(input_ids=ids, attention_mask=mask, pixel_values=b["pixel_values"], image_grid_thw=b["image_grid_thw"], mm_token_type_ids=(ids == cfg["image_token_id"]).int()).logits
+        P = b["input_ids"].shape[1]
+        step_logits = logits[:, P - 1 : P - 1 + 12].float()
+        top2 = step_logits.topk(2, -1).values
+    np.savez_compressed(
+        os.path.join(OUT, "greedy.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 77, "new_tokens": 12}),
+        prompt_ids=b["input_ids"].numpy(), prompt_mask=b["attention_mask"].numpy(), sequences=out.numpy(),
+        margin=(top2[..., 0] - top2[..., 1]).numpy(),
+    )
+    print("greedy.npz:", out[:, P:].tolist(), "min margin", float((top2[..., 0] - top2[..., 1]).min()))
+
+
+def gen_sft():
+    """PA-SFT numeric oracle: HF forward(labels) loss + 3 AdamW steps (lr 1e-3 for visible motion,
+    wd 0.1 as PA_SFT_*.sh:38-44, betas/eps = torch defaults = HF Trainer defaults)."""
+    cfg = fx.TINY
+    model = build_hf_model(cfg, fx.make_weights(cfg, seed=0)).train()
+    grids = [(1, 16, 12), (1, 8, 8)]
+    b = tiny_batch(cfg, grids, [5, 17], seed=11)
+    resp = np.array(fx.synth_completions(2, 8, cfg, 9)).astype(np.int64)
+    ids = torch.cat([b["input_ids"], torch.from_numpy(resp)], 1)
+    mask = torch.cat([b["attention_mask"], torch.ones(2, 8, dtype=torch.long)], 1)
+    labels = ids.clone()
+    labels[:, : b["input_ids"].shape[1]] = -100  # prompt tokens masked (llamafactory supervised.py:34-87)
+    inputs = dict(input_ids=ids, attention_mask=mask, pixel_values=b["pixel_values"], image_grid_thw=b["image_grid_thw"], mm_token_type_ids=(ids == cfg["image_token_id"]).int(), labels=labels)
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        (no_decay if (p.ndim < 2 or "norm" in n or "ln_q" in n or n.endswith(".bias")) else decay).append(p)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = model(**inputs).loss
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    np.savez_compressed(
+        os.path.join(OUT, "sft.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 11, "lr": 1e-3, "wd": 0.1, "no_decay": "ndim<2 (norm gains, biases)"}),
+        input_ids=ids.numpy(), attention_mask=mask.numpy(), labels=labels.numpy(), pixel_values=b["pixel_values"].numpy(),
+        image_grid_thw=b["image_grid_thw"].numpy(), losses=np.array(losses, dtype=np.float64),
+    )
+    print("sft.npz: losses", losses)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    reward, type_reward, location_reward, SCGRPOTrainer, pad = import_reference()
+    only = set(sys.argv[1:])
+    if not only or "rewards" in only:
+        gen_rewards(reward, type_reward, location_reward)
+    if not only or "pad" in only:
+        gen_pad(pad)
+    if not only or "index" in only:
+        gen_vision_index()
+    if not only or "grpo" in only:
+        gen_sc_grpo(SCGRPOTrainer, reward, G=4, C=10, eos_rows={1: 6, 3: 0}, name="sc_grpo_g4.npz", seed=21)
+        gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={0: 11, 2: 3, 5: 7}, name="sc_grpo_g8.npz", seed=22)
+    if not only or "logps" in only:
+        gen_logps_padded(SCGRPOTrainer)
+    if not only or "greedy" in only:
+        gen_greedy()
+    if not only or "sft" in only:
+        gen_sft()
+
+
+if __name__ == "__main__":
+    main()
