@@ -1,0 +1,662 @@
+// Flash-style attention for gfx950 (reference arithmetic
+// TF:modeling_qwen2_5_vl.py:186-208 (softmax in fp32 over QK^T*d^-0.5 + mask, then PV), ViT segments
+// :225-291 (non-causal inside cu_seqlens windows), decoder :641-689 (causal + left-pad key mask, GQA)).
+//
+// One family of kernels for both towers, parameterised by head dim D (128 text, 80 vision -> the QK^T
+// contraction is zero-padded to 96) and by an explicit segment list (start,end) in the flat token axis:
+// ViT windows / images are segments, decoder sequences are segments that skip their left padding.
+//
+// Dataflow (all MFMA 16x16x32 bf16, fp32 accumulate).  Everything is computed TRANSPOSED so that no
+// cross-lane transpose of the probability tile is ever needed:
+//   S^T[key,q] = K . Q^T          A = K rows from LDS (row-major tile), B = Q fragment held in VGPRs
+//   P^T = softmax columns         a lane owns ONE q column: max/sum = in-lane + 2 shuffles (xor 16, 32)
+//   O^T[d,q]  += V^T . P^T        A = V^T rows from LDS (tile stored transposed), B = P^T straight from
+//                                 the S^T accumulators.  The K rows of S^T tiles are permuted
+//                                 (row i of tile 2j <-> key 8*(i/4)+i%4, tile 2j+1 <-> +4) so that the
+//                                 accumulator registers of a lane are 8 CONSECUTIVE keys = one B fragment.
+// Backward = the same trick twice: bwd_dq owns q columns (dQ^T += K^T . dS^T), bwd_dkdv owns key
+// columns (dV^T += dO^T . P, dK^T += Q^T . dS) and loops the GQA group so dK/dV need no atomics.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    bf16_t* o;
+    float* lse;             // [Hq, T] natural-log logsumexp of the scaled scores
+    const int* seg_start;   // [nseg] first token (flat index) of each segment
+    const int* seg_end;     // [nseg] one past the last token
+    long long ldq, ldk, ldv, ldo;  // token row strides (elements); head h lives at column h*D
+    int T, Hq, Hkv;
+    int causal;
+    float scale;
+    // backward only
+    const bf16_t* dout;
+    const float* delta;     // [Hq, T] rowsum(dO * O)
+    bf16_t* dq;
+    bf16_t* dk;
+    bf16_t* dv;
+    long long lddo, lddq, lddk, lddv;
+};
+
+template <int D>
+struct Cfg {
+    static constexpr int DQK = (D + 31) / 32 * 32;  // contraction length of QK^T, zero padded
+    static constexpr int KS = DQK / 32;             // MFMA k-steps over d
+    static constexpr int DT = D / 16;               // 16-wide output tiles over d
+    static constexpr int LD = DQK + 8;              // LDS row stride (elements) of row-major [rows][d] tiles
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag_g(const bf16_t* p, bool ok) {
+    u32x4_t v = {0, 0, 0, 0};
+    if (ok) v = *(const u32x4_t*)p;
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t ld_frag_s(const bf16_t* p) { return *(const bf16x8_t*)p; }
+
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t a, const f32x4_t b) {
+    u32x4_t v = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// key (or q) row that MFMA-tile row i of 16-row tile `t` stands for, inside a 64/32-row block
+__device__ __forceinline__ int perm_row(int t, int i) { return (t >> 1) * 32 + (i >> 2) * 8 + (i & 3) + 4 * (t & 1); }
+
+// Stage `rows` token rows x D columns (global, row stride ld) into LDS row-major [rows][LD], zero filling
+// rows >= nvalid and columns >= D.
+template <int D, int ROWS>
+__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long long ld, int nvalid) {
+    constexpr int CPR = Cfg<D>::DQK / 8;
+    for (int idx = threadIdx.x; idx < ROWS * CPR; idx += 256) {
+        const int r = idx / CPR, c = idx - r * CPR;
+        u32x4_t v = {0, 0, 0, 0};
+        if (r < nvalid && c * 8 < D) v = *(const u32x4_t*)(src + (long long)r * ld + c * 8);
+        *(u32x4_t*)(dst + r * Cfg<D>::LD + c * 8) = v;
+    }
+}
+// Same tile stored TRANSPOSED: dst[d][r], row stride LDT (elements), d in [0, DQK)
+template <int D, int ROWS, int LDT>
+__device__ __forceinline__ void stage_rows_t(bf16_t* dst, const bf16_t* src, long long ld, int nvalid) {
+    constexpr int CPR = Cfg<D>::DQK / 8;
+    for (int idx = threadIdx.x; idx < ROWS * CPR; idx += 256) {
+        // lanes walk rows fastest inside groups of 16 so that a wave's LDS writes hit 16 consecutive columns
+        const int r = (idx & 15) + (idx / (16 * CPR)) * 16, c = (idx >> 4) % CPR;
+        u32x4_t v = {0, 0, 0, 0};
+        if (r < nvalid && c * 8 < D) v = *(const u32x4_t*)(src + (long long)r * ld + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[(c * 8 + 2 * e) * LDT + r] = (bf16_t)(v[e] & 0xffffu);
+            dst[(c * 8 + 2 * e + 1) * LDT + r] = (bf16_t)(v[e] >> 16);
+        }
+    }
+}
+
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+template <int D, int R>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    using C = Cfg<D>;
+    constexpr int BM = 64 * R, BN = 64, LDT = BN + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = (bf16_t*)smem;          // [BN][LD]
+    bf16_t* Vt = Ks + BN * C::LD;        // [DQK][LDT]
+
+    const int seg = blockIdx.y, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
+    const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
+    const int ntile = (slen + BM - 1) / BM;
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;  // heaviest (last) causal tiles first
+    if (qt >= ntile) return;
+    const int q0 = qt * BM;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
+
+    bf16x8_t qf[R][C::KS];
+    int qrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        qrow[r] = q0 + (w * R + r) * 16 + li;
+        const bf16_t* src = p.q + (long long)(s0 + qrow[r]) * p.ldq + head * D;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            qf[r][ks] = ld_frag_g(src + d0, qrow[r] < slen && d0 < D);
+        }
+    }
+    float m[R], lsum[R];
+    f32x4_t acc[C::DT][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        m[r] = -INFINITY;
+        lsum[r] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) acc[dt][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const float c = p.scale * LOG2E;
+    const int kv_end = p.causal ? min(slen, q0 + BM) : slen;
+
+    for (int kv0 = 0; kv0 < kv_end; kv0 += BN) {
+        __syncthreads();
+        stage_rows<D, BN>(Ks, p.k + (long long)(s0 + kv0) * p.ldk + kvh * D, p.ldk, slen - kv0);
+        stage_rows_t<D, BN, LDT>(Vt, p.v + (long long)(s0 + kv0) * p.ldv + kvh * D, p.ldv, slen - kv0);
+        __syncthreads();
+
+        f32x4_t s[4][R];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[kt][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            bf16x8_t kf[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) kf[kt] = ld_frag_s(Ks + perm_row(kt, li) * C::LD + ks * 32 + g * 8);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < R; ++r) s[kt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[r][ks], s[kt][r], 0, 0, 0);
+        }
+        // lane (g, e) of tile kt holds key kv0 + (kt>>1)*32 + g*8 + (kt&1)*4 + e for q column qrow[r]
+        const bool need_mask = (kv0 + BN > slen) || (p.causal && kv0 + BN > q0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = s[kt][r][e] * c;
+                    if (need_mask) {
+                        const int key = kv0 + (kt >> 1) * 32 + g * 8 + (kt & 1) * 4 + e;
+                        if (key >= slen || (p.causal && key > qrow[r])) t = -INFINITY;
+                    }
+                    s[kt][r][e] = t;
+                    mx = fmaxf(mx, t);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            const float mn = fmaxf(m[r], mx);
+            const float alpha = (mn == -INFINITY) ? 1.f : exp2f(m[r] - mn);
+            const float mref = (mn == -INFINITY) ? 0.f : mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = exp2f(s[kt][r][e] - mref);
+                    s[kt][r][e] = pv;
+                    ps += pv;
+                }
+            lsum[r] = lsum[r] * alpha + ps;
+            m[r] = mn;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) acc[dt][r] *= alpha;
+        }
+        bf16x8_t pf[R][2];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pf[r][j] = pack_frag(s[2 * j][r], s[2 * j + 1][r]);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8_t vf = ld_frag_s(Vt + (dt * 16 + li) * LDT + j * 32 + g * 8);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[dt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[r][j], acc[dt][r], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float lt = lsum[r];
+        lt += __shfl_xor(lt, 16, WAVE);
+        lt += __shfl_xor(lt, 32, WAVE);
+        if (qrow[r] >= slen) continue;
+        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        bf16_t* dst = p.o + (long long)(s0 + qrow[r]) * p.ldo + head * D;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            const f32x4_t a = acc[dt][r];
+            *(u32x2_t*)(dst + dt * 16 + g * 4) = (u32x2_t){pack2bf(a[0] * inv, a[1] * inv), pack2bf(a[2] * inv, a[3] * inv)};
+        }
+        if (g == 0 && p.lse) p.lse[(long long)head * p.T + s0 + qrow[r]] = (lt > 0.f) ? (m[r] + log2f(lt)) * LN2 : -INFINITY;
+    }
+}
+
+// =====================================================================================================
+// backward, part 0: delta[h][t] = sum_d dO[t,h,d] * O[t,h,d]
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, long long ldo, const bf16_t* dout, long long lddo, float* delta,
+                                                         int T, int Hq) {
+    // 16 lanes per (token, head): each lane covers D/16 elements
+    const long long item = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (item >= (long long)T * Hq) return;
+    const long long t = item / Hq;
+    const int h = (int)(item % Hq);
+    float s = 0.f;
+    for (int d = sub * 8; d < D; d += 128) {
+        const u32x4_t a = *(const u32x4_t*)(o + t * ldo + h * D + d), b = *(const u32x4_t*)(dout + t * lddo + h * D + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += lo_bf(a[e]) * lo_bf(b[e]) + hi_bf(a[e]) * hi_bf(b[e]);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+    if (sub == 0) delta[(long long)h * T + t] = s;
+}
+
+// =====================================================================================================
+// backward, part 1: dQ.  Block = 64 q rows of one (segment, q head); wave = 16 q columns.
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    using C = Cfg<D>;
+    constexpr int BM = 64, KB = 32, LDT = KB + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = (bf16_t*)smem;       // [KB][LD]
+    bf16_t* Vs = Ks + KB * C::LD;     // [KB][LD]
+    bf16_t* Kt = Vs + KB * C::LD;     // [DQK][LDT]
+
+    const int seg = blockIdx.y, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
+    const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
+    const int ntile = (slen + BM - 1) / BM;
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
+    if (qt >= ntile) return;
+    const int q0 = qt * BM;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
+    const int qrow = q0 + w * 16 + li;
+    const bool qok = qrow < slen;
+
+    bf16x8_t qf[C::KS], dof[C::KS];
+    {
+        const bf16_t* qs = p.q + (long long)(s0 + qrow) * p.ldq + head * D;
+        const bf16_t* ds = p.dout + (long long)(s0 + qrow) * p.lddo + head * D;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            qf[ks] = ld_frag_g(qs + d0, qok && d0 < D);
+            dof[ks] = ld_frag_g(ds + d0, qok && d0 < D);
+        }
+    }
+    const float c = p.scale * LOG2E;
+    const float lse2 = qok ? p.lse[(long long)head * p.T + s0 + qrow] * LOG2E : 0.f;
+    const float dl = qok ? p.delta[(long long)head * p.T + s0 + qrow] : 0.f;
+
+    f32x4_t acc[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int kv_end = p.causal ? min(slen, q0 + BM) : slen;
+    for (int kv0 = 0; kv0 < kv_end; kv0 += KB) {
+        __syncthreads();
+        const bf16_t* ksrc = p.k + (long long)(s0 + kv0) * p.ldk + kvh * D;
+        stage_rows<D, KB>(Ks, ksrc, p.ldk, slen - kv0);
+        stage_rows<D, KB>(Vs, p.v + (long long)(s0 + kv0) * p.ldv + kvh * D, p.ldv, slen - kv0);
+        stage_rows_t<D, KB, LDT>(Kt, ksrc, p.ldk, slen - kv0);
+        __syncthreads();
+
+        f32x4_t st[2], dpt[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { st[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dpt[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int row = perm_row(kt, li);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Ks + row * C::LD + ks * 32 + g * 8), qf[ks], st[kt], 0, 0, 0);
+                dpt[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Vs + row * C::LD + ks * 32 + g * 8), dof[ks], dpt[kt], 0, 0, 0);
+            }
+        f32x4_t ds[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = kv0 + g * 8 + kt * 4 + e;
+                const bool ok = qok && key < slen && !(p.causal && key > qrow);
+                const float pv = ok ? exp2f(st[kt][e] * c - lse2) : 0.f;
+                ds[kt][e] = pv * (dpt[kt][e] - dl);
+            }
+        const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Kt + (dt * 16 + li) * LDT + g * 8), dsf, acc[dt], 0, 0, 0);
+    }
+    if (!qok) return;
+    bf16_t* dst = p.dq + (long long)(s0 + qrow) * p.lddq + head * D;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+        const f32x4_t a = acc[dt] * p.scale;
+        *(u32x2_t*)(dst + dt * 16 + g * 4) = (u32x2_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+    }
+}
+
+// =====================================================================================================
+// backward, part 2: dK, dV.  Block = 64 keys of one (segment, kv head); wave = 16 key columns; loops
+// over the q heads of the GQA group and over 32-row q blocks.
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+    using C = Cfg<D>;
+    constexpr int BN = 64, QB = 32, LDT = QB + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Qs = (bf16_t*)smem;        // [QB][LD]
+    bf16_t* dOs = Qs + QB * C::LD;     // [QB][LD]
+    bf16_t* Qt = dOs + QB * C::LD;     // [DQK][LDT]
+    bf16_t* dOt = Qt + C::DQK * LDT;   // [DQK][LDT]
+    float* lse_s = (float*)(dOt + C::DQK * LDT);  // [QB]
+    float* del_s = lse_s + QB;                    // [QB]
+
+    const int seg = blockIdx.y, kvh = blockIdx.z, group = p.Hq / p.Hkv;
+    const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
+    const int ntile = (slen + BN - 1) / BN;
+    const int kt0 = blockIdx.x;  // causal: low kv tiles see the most q rows and are scheduled first
+    if (kt0 >= ntile) return;
+    const int kv0 = kt0 * BN;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
+    const int key = kv0 + w * 16 + li;
+    const bool kok = key < slen;
+
+    bf16x8_t kf[C::KS], vf[C::KS];
+    {
+        const bf16_t* ks_ = p.k + (long long)(s0 + key) * p.ldk + kvh * D;
+        const bf16_t* vs_ = p.v + (long long)(s0 + key) * p.ldv + kvh * D;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            kf[ks] = ld_frag_g(ks_ + d0, kok && d0 < D);
+            vf[ks] = ld_frag_g(vs_ + d0, kok && d0 < D);
+        }
+    }
+    const float c = p.scale * LOG2E;
+    f32x4_t dkacc[C::DT], dvacc[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) { dkacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+    const int q_begin = p.causal ? (kv0 / QB) * QB : 0;
+    for (int hh = 0; hh < group; ++hh) {
+        const int head = kvh * group + hh;
+        for (int q0 = q_begin; q0 < slen; q0 += QB) {
+            __syncthreads();
+            const bf16_t* qsrc = p.q + (long long)(s0 + q0) * p.ldq + head * D;
+            const bf16_t* dsrc = p.dout + (long long)(s0 + q0) * p.lddo + head * D;
+            stage_rows<D, QB>(Qs, qsrc, p.ldq, slen - q0);
+            stage_rows<D, QB>(dOs, dsrc, p.lddo, slen - q0);
+            stage_rows_t<D, QB, LDT>(Qt, qsrc, p.ldq, slen - q0);
+            stage_rows_t<D, QB, LDT>(dOt, dsrc, p.lddo, slen - q0);
+            if (threadIdx.x < QB) {
+                const int qr = q0 + threadIdx.x;
+                lse_s[threadIdx.x] = qr < slen ? p.lse[(long long)head * p.T + s0 + qr] * LOG2E : 0.f;
+                del_s[threadIdx.x] = qr < slen ? p.delta[(long long)head * p.T + s0 + qr] : 0.f;
+            }
+            __syncthreads();
+
+            // S[q, key] and dP[q, key]: A = Q / dO rows (permuted so a lane's registers are 8 consecutive q), B = K / V fragments
+            f32x4_t s[2], dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = perm_row(t, li);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Qs + row * C::LD + ks * 32 + g * 8), kf[ks], s[t], 0, 0, 0);
+                    dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(dOs + row * C::LD + ks * 32 + g * 8), vf[ks], dp[t], 0, 0, 0);
+                }
+            // lane (g, e) of tile t holds q = q0 + g*8 + t*4 + e for key column `key`
+            f32x4_t pv[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qi = g * 8 + t * 4 + e, qr = q0 + qi;
+                    const bool ok = kok && qr < slen && !(p.causal && key > qr);
+                    const float pp = ok ? exp2f(s[t][e] * c - lse_s[qi]) : 0.f;
+                    pv[t][e] = pp;
+                    ds[t][e] = pp * (dp[t][e] - del_s[qi]);
+                }
+            const bf16x8_t pf = pack_frag(pv[0], pv[1]), dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(dOt + (dt * 16 + li) * LDT + g * 8), pf, dvacc[dt], 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Qt + (dt * 16 + li) * LDT + g * 8), dsf, dkacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!kok) return;
+    bf16_t* dkd = p.dk + (long long)(s0 + key) * p.lddk + kvh * D;
+    bf16_t* dvd = p.dv + (long long)(s0 + key) * p.lddv + kvh * D;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+        const f32x4_t a = dkacc[dt] * p.scale, b = dvacc[dt];
+        *(u32x2_t*)(dkd + dt * 16 + g * 4) = (u32x2_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+        *(u32x2_t*)(dvd + dt * 16 + g * 4) = (u32x2_t){pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    }
+}
+
+// =====================================================================================================
+// Paged-KV decode attention (rollout).  One query token per sequence.
+//   K cache page: [Hkv][PAGE=32][D] row-major;  V cache page: [Hkv][D][PAGE] (keys contiguous) so that both
+//   MFMA A operands are 16-byte contiguous global loads; a page is exactly one 32-key MFMA k-step.
+//   Block = (sequence, kv head); the `group` q heads of that kv head are the MFMA N dimension (<=16).
+//   4 waves take pages round-robin, each keeps an online-softmax state; combined through LDS at the end.
+//   Sequences of one GRPO group share their prompt pages through the block table (prefill once per prompt).
+// =====================================================================================================
+struct DecodeArgs {
+    const bf16_t* q;          // [B, Hq*D] (row stride ldq)
+    const bf16_t* kcache;     // [npages][Hkv][32][D]
+    const bf16_t* vcache;     // [npages][Hkv][D][32]
+    const int* block_table;   // [B][max_pages]
+    const int* ctx_len;       // [B] number of valid keys (including the current token)
+    bf16_t* o;                // [B, Hq*D]
+    long long ldq, ldo;
+    int B, Hq, Hkv, max_pages;
+    float scale;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
+    constexpr int KS = D / 32, DT = D / 16, PAGE = 32;
+    __shared__ float red_m[4][16], red_l[4][16];
+    __shared__ float red_o[4][D][16 + 1];
+    const int b = blockIdx.x, kvh = blockIdx.y, group = p.Hq / p.Hkv;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
+    const int n = p.ctx_len[b];
+    const int npage = (n + PAGE - 1) / PAGE;
+
+    bf16x8_t qf[KS];
+    {
+        const bool ok = li < group;
+        const bf16_t* src = p.q + (long long)b * p.ldq + (kvh * group + li) * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = ld_frag_g(src + ks * 32 + g * 8, ok);
+    }
+    float m = -INFINITY, lsum = 0.f;
+    f32x4_t acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const float c = p.scale * LOG2E;
+
+    for (int pg = w; pg < npage; pg += 4) {
+        const int phys = p.block_table[(long long)b * p.max_pages + pg];
+        const bf16_t* kp = p.kcache + ((long long)phys * p.Hkv + kvh) * PAGE * D;
+        const bf16_t* vp = p.vcache + ((long long)phys * p.Hkv + kvh) * D * PAGE;
+        f32x4_t s[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = (li >> 2) * 8 + (li & 3) + 4 * t;  // perm_row within one 32-key page
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_g(kp + row * D + ks * 32 + g * 8, true), qf[ks], s[t], 0, 0, 0);
+            }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = pg * PAGE + g * 8 + t * 4 + e;
+                const float tv = key < n ? s[t][e] * c : -INFINITY;
+                s[t][e] = tv;
+                mx = fmaxf(mx, tv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+        const float mn = fmaxf(m, mx);
+        const float alpha = (mn == -INFINITY) ? 1.f : exp2f(m - mn);
+        const float mref = (mn == -INFINITY) ? 0.f : mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = exp2f(s[t][e] - mref);
+                s[t][e] = pv;
+                ps += pv;
+            }
+        lsum = lsum * alpha + ps;
+        m = mn;
+        const bf16x8_t pf = pack_frag(s[0], s[1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            acc[dt] *= alpha;
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_g(vp + (dt * 16 + li) * PAGE + g * 8, true), pf, acc[dt], 0, 0, 0);
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, WAVE);
+    lsum += __shfl_xor(lsum, 32, WAVE);
+    if (g == 0) { red_m[w][li] = m; red_l[w][li] = lsum; }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red_o[w][dt * 16 + g * 4 + e][li] = acc[dt][e];
+    __syncthreads();
+    // combine the 4 partial states: thread -> (q head j, d)
+    for (int idx = threadIdx.x; idx < group * D; idx += 256) {
+        const int j = idx / D, d = idx - j * D;
+        float M = fmaxf(fmaxf(red_m[0][j], red_m[1][j]), fmaxf(red_m[2][j], red_m[3][j]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float f = (red_m[ww][j] == -INFINITY) ? 0.f : exp2f(red_m[ww][j] - M);
+            num += f * red_o[ww][d][j];
+            den += f * red_l[ww][j];
+        }
+        p.o[(long long)b * p.ldo + (kvh * group + j) * D + d] = f2bf(den > 0.f ? num / den : 0.f);
+    }
+}
+
+// Write K/V rows of `T` tokens into the paged cache (prefill: many tokens; decode: one per sequence).
+// slot[t] = physical page * 32 + offset, or < 0 to skip (padding).
+template <int D>
+__global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* k, long long ldk, const bf16_t* v, long long ldv, const long long* slot,
+                                                       bf16_t* kcache, bf16_t* vcache, int T, int Hkv) {
+    constexpr int CPR = D / 8;
+    const long long total = (long long)T * Hkv * CPR;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % CPR);
+        const long long th = i / CPR;
+        const int h = (int)(th % Hkv);
+        const long long t = th / Hkv;
+        const long long sl = slot[t];
+        if (sl < 0) continue;
+        const long long page = sl >> 5;
+        const int off = (int)(sl & 31);
+        const u32x4_t kv = *(const u32x4_t*)(k + t * ldk + h * D + c * 8);
+        *(u32x4_t*)(kcache + ((page * Hkv + h) * 32 + off) * D + c * 8) = kv;
+        const u32x4_t vv = *(const u32x4_t*)(v + t * ldv + h * D + c * 8);
+        bf16_t* vd = vcache + (page * Hkv + h) * (long long)D * 32 + off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vd[(c * 8 + 2 * e) * 32] = (bf16_t)(vv[e] & 0xffffu);
+            vd[(c * 8 + 2 * e + 1) * 32] = (bf16_t)(vv[e] >> 16);
+        }
+    }
+}
+
+template <typename K>
+void set_smem(K kern, int bytes) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+
+}  // namespace
+
+static int check_common(int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv, long long ldo) {
+    IADR1_REQUIRE(D == 128 || D == 80, "attention: head dim %d not built (128 and 80 are)", D);
+    IADR1_REQUIRE(T > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention: bad head counts Hq=%d Hkv=%d", Hq, Hkv);
+    IADR1_REQUIRE((ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 8) == 0, "attention: row strides must be multiples of 8 elements");
+    return IADR1_OK;
+}
+
+extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start, const int* seg_end,
+                              int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
+                              long long ldo, int causal, float scale, hipStream_t stream) {
+    if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
+    IADR1_REQUIRE(nseg > 0 && max_seqlen > 0, "attn_fwd: empty segment list");
+    AttnArgs p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
+    p.seg_start = seg_start; p.seg_end = seg_end; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
+    const bool small = max_seqlen <= 64;  // ViT windows: one 64-row tile per segment
+#define LAUNCH_FWD(DD, RR)                                                                                           \
+    do {                                                                                                             \
+        const int smem = (64 * Cfg<DD>::LD + Cfg<DD>::DQK * 72) * 2;                                                 \
+        set_smem(attn_fwd_kernel<DD, RR>, smem);                                                                     \
+        const int bm = 64 * RR;                                                                                      \
+        hipLaunchKernelGGL((attn_fwd_kernel<DD, RR>), dim3((max_seqlen + bm - 1) / bm, nseg, Hq), dim3(256), smem, stream, p); \
+    } while (0)
+    if (D == 128) { if (small) LAUNCH_FWD(128, 1); else LAUNCH_FWD(128, 2); }
+    else { if (small) LAUNCH_FWD(80, 1); else LAUNCH_FWD(80, 2); }
+#undef LAUNCH_FWD
+    return iadr1_check_launch("attn_fwd");
+}
+
+extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta,
+                              void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end, int nseg, int max_seqlen, int T,
+                              int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv, long long ldo, long long lddo,
+                              long long lddq, long long lddk, long long lddv, int causal, float scale, hipStream_t stream) {
+    if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
+    IADR1_REQUIRE((lddo % 8) == 0 && (lddq % 8) == 0 && (lddk % 8) == 0 && (lddv % 8) == 0, "attn_bwd: gradient row strides must be multiples of 8");
+    IADR1_REQUIRE(nseg > 0 && max_seqlen > 0, "attn_bwd: empty segment list");
+    AttnArgs p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.lse = (float*)lse;
+    p.seg_start = seg_start; p.seg_end = seg_end; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
+    p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+    p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    const long long items = (long long)T * Hq * 16;
+#define LAUNCH_BWD(DD)                                                                                                                   \
+    do {                                                                                                                                 \
+        hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)o, ldo,    \
+                           (const bf16_t*)dout, lddo, delta, T, Hq);                                                                     \
+        const int smem_dq = (2 * 32 * Cfg<DD>::LD + Cfg<DD>::DQK * 40) * 2;                                                              \
+        set_smem(attn_bwd_dq_kernel<DD>, smem_dq);                                                                                       \
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hq), dim3(256), smem_dq, stream, p);               \
+        const int smem_kv = (2 * 32 * Cfg<DD>::LD + 2 * Cfg<DD>::DQK * 40) * 2 + 64 * 4;                                                 \
+        set_smem(attn_bwd_dkdv_kernel<DD>, smem_kv);                                                                                     \
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hkv), dim3(256), smem_kv, stream, p);            \
+    } while (0)
+    if (D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(80);
+#undef LAUNCH_BWD
+    return iadr1_check_launch("attn_bwd");
+}
+
+extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len, void* o,
+                                 int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, hipStream_t stream) {
+    IADR1_REQUIRE(D == 128, "attn_decode: head dim %d not built (128 is)", D);
+    IADR1_REQUIRE(B > 0 && Hq % Hkv == 0 && Hq / Hkv <= 16, "attn_decode: GQA group must be <= 16");
+    IADR1_REQUIRE((ldq % 8) == 0, "attn_decode: ldq must be a multiple of 8");
+    DecodeArgs p{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale};
+    hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(B, Hkv), dim3(256), 0, stream, p);
+    return iadr1_check_launch("attn_decode");
+}
+
+extern "C" int iadr1_kv_store(const void* k, long long ldk, const void* v, long long ldv, const long long* slot, void* kcache, void* vcache,
+                              int T, int Hkv, int D, hipStream_t stream) {
+    IADR1_REQUIRE(D == 128, "kv_store: head dim %d not built (128 is)", D);
+    IADR1_REQUIRE(T > 0 && (ldk % 8) == 0 && (ldv % 8) == 0, "kv_store: strides must be multiples of 8");
+    long long blocks = ((long long)T * Hkv * 16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(kv_store_kernel<128>, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, slot, (bf16_t*)kcache, (bf16_t*)vcache, T, Hkv);
+    return iadr1_check_launch("kv_store");
+}

@@ -1,0 +1,81 @@
+// Common device/host helpers for the iadr1 gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all arithmetic is fp32
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // MFMA 16x16 C/D fragment
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;  // 16-byte load/store unit
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float lo_bf(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// block-wide reductions through a small LDS scratch (>= 16 floats); all threads get the result
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    constexpr int NW = NT / WAVE;
+    if constexpr (NW == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += scratch[i];
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    constexpr int NW = NT / WAVE;
+    if constexpr (NW == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+// ---- host side -------------------------------------------------------------------------------
+#define IADR1_OK 0
+#define IADR1_ERR_ARG (-1)
+#define IADR1_ERR_LAUNCH (-2)
+#define IADR1_ERR_UNSUPPORTED (-3)
+
+void iadr1_set_error(const char* fmt, ...);
+int iadr1_check_launch(const char* what);
+
+#define IADR1_REQUIRE(cond, ...)              \
+    do {                                      \
+        if (!(cond)) {                        \
+            iadr1_set_error(__VA_ARGS__);     \
+            return IADR1_ERR_ARG;             \
+        }                                     \
+    } while (0)

@@ -1,0 +1,337 @@
+// HBM-bound elementwise / gather kernels of the hot path (gfx950): rotary embeddings, SwiGLU, GELU,
+// bias-gradient column sums, embedding gather + image-feature scatter, dtype casts, transposes.
+// All use 16-byte accesses (8 bf16 per lane) and fp32 arithmetic.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Rotary embedding, in place on `nheads` consecutive heads of width D inside each token row.
+//   out[j]      = x[j]*cos[j]      - sign*x[j+D/2]*sin[j]
+//   out[j+D/2]  = x[j+D/2]*cos[j]  + sign*x[j]*sin[j]            (j < D/2)
+// sign=+1: forward rotate-half form (TF:modeling_qwen2_5_vl.py:153-171 vision, :557-599 M-RoPE, whose
+// per-section t/h/w selection is folded into the cos/sin table by the host); sign=-1: its transpose
+// (backward).  cos/sin: fp32 [T, D/2].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* x, long long ld, const float* cs, const float* sn, int T, int nheads,
+                                                   int D, float sign) {
+    const int half = D >> 1, cpr = half >> 2;  // 4-element chunks per half head
+    const long long total = (long long)T * nheads * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr);
+        const long long th = i / cpr;
+        const int h = (int)(th % nheads);
+        const long long t = th / nheads;
+        bf16_t* p = x + t * ld + (long long)h * D + c * 4;
+        const u32x2_t lo = *(const u32x2_t*)p, hi = *(const u32x2_t*)(p + half);
+        const f32x4_t cc = *(const f32x4_t*)(cs + t * half + c * 4), ss = *(const f32x4_t*)(sn + t * half + c * 4);
+        const float a[4] = {lo_bf(lo[0]), hi_bf(lo[0]), lo_bf(lo[1]), hi_bf(lo[1])};
+        const float b[4] = {lo_bf(hi[0]), hi_bf(hi[0]), lo_bf(hi[1]), hi_bf(hi[1])};
+        float oa[4], ob[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oa[e] = a[e] * cc[e] - sign * b[e] * ss[e];
+            ob[e] = b[e] * cc[e] + sign * a[e] * ss[e];
+        }
+        *(u32x2_t*)p = (u32x2_t){pack2bf(oa[0], oa[1]), pack2bf(oa[2], oa[3])};
+        *(u32x2_t*)(p + half) = (u32x2_t){pack2bf(ob[0], ob[1]), pack2bf(ob[2], ob[3])};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU (TF:modeling_qwen2_5_vl.py:95-96, 552-554): gu = [gate | up] halves of one row, width 2*I.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* gu, long long ldg, bf16_t* a, long long lda, int T, int I) {
+    const int cpr = I >> 3;
+    const long long total = (long long)T * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long t = i / cpr;
+        const int c = (int)(i % cpr);
+        const u32x4_t g = *(const u32x4_t*)(gu + t * ldg + c * 8), u = *(const u32x4_t*)(gu + t * ldg + I + c * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // the reference rounds act(gate) to bf16 before the multiply
+            const float s0 = bf2f(f2bf(silu_f(lo_bf(g[e])))), s1 = bf2f(f2bf(silu_f(hi_bf(g[e]))));
+            o[e] = pack2bf(s0 * lo_bf(u[e]), s1 * hi_bf(u[e]));
+        }
+        *(u32x4_t*)(a + t * lda + c * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* da, long long lda, const bf16_t* gu, long long ldg, bf16_t* dgu,
+                                                         long long ldd, int T, int I) {
+    const int cpr = I >> 3;
+    const long long total = (long long)T * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long t = i / cpr;
+        const int c = (int)(i % cpr);
+        const u32x4_t g = *(const u32x4_t*)(gu + t * ldg + c * 8), u = *(const u32x4_t*)(gu + t * ldg + I + c * 8);
+        const u32x4_t d = *(const u32x4_t*)(da + t * lda + c * 8);
+        u32x4_t og, ou;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r[2][2];
+#pragma unroll
+            for (int hsel = 0; hsel < 2; ++hsel) {
+                const float gv = hsel ? hi_bf(g[e]) : lo_bf(g[e]), uv = hsel ? hi_bf(u[e]) : lo_bf(u[e]), dv = hsel ? hi_bf(d[e]) : lo_bf(d[e]);
+                const float sg = 1.f / (1.f + __expf(-gv));
+                const float sl = gv * sg;
+                r[hsel][0] = dv * uv * (sg * (1.f + gv * (1.f - sg)));  // d gate
+                r[hsel][1] = dv * sl;                                   // d up
+            }
+            og[e] = pack2bf(r[0][0], r[1][0]);
+            ou[e] = pack2bf(r[0][1], r[1][1]);
+        }
+        *(u32x4_t*)(dgu + t * ldd + c * 8) = og;
+        *(u32x4_t*)(dgu + t * ldd + I + c * 8) = ou;
+    }
+}
+
+// exact GELU (nn.GELU() in the patch merger, TF:modeling_qwen2_5_vl.py:143)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* z, bf16_t* a, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4_t v = *(const u32x4_t*)(z + i * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = lo_bf(v[e]), a1 = hi_bf(v[e]);
+            o[e] = pack2bf(0.5f * a0 * (1.f + erff(a0 * 0.70710678f)), 0.5f * a1 * (1.f + erff(a1 * 0.70710678f)));
+        }
+        *(u32x4_t*)(a + i * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* da, const bf16_t* z, bf16_t* dz, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4_t v = *(const u32x4_t*)(z + i * 8), d = *(const u32x4_t*)(da + i * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r[2];
+#pragma unroll
+            for (int hsel = 0; hsel < 2; ++hsel) {
+                const float x = hsel ? hi_bf(v[e]) : lo_bf(v[e]), dv = hsel ? hi_bf(d[e]) : lo_bf(d[e]);
+                const float cdf = 0.5f * (1.f + erff(x * 0.70710678f));
+                const float pdf = 0.3989422804f * __expf(-0.5f * x * x);
+                r[hsel] = dv * (cdf + x * pdf);
+            }
+            o[e] = pack2bf(r[0], r[1]);
+        }
+        *(u32x4_t*)(dz + i * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column sums of a bf16 matrix into fp32 (bias gradients): out[n] += sum_t dY[t][n].
+// Block = 64 columns x 4 row-lanes... each thread owns 8 columns (16 B) and strides over rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, long long ld, float* out, int T, int N) {
+    __shared__ float red[8][32 * 8 + 1];
+    const int cchunk = threadIdx.x & 31, rlane = threadIdx.x >> 5;  // 32 chunks (256 cols) x 8 row lanes
+    const int col = blockIdx.x * 256 + cchunk * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        for (int t = blockIdx.y * 8 + rlane; t < T; t += gridDim.y * 8) {
+            const u32x4_t v = *(const u32x4_t*)(dy + (long long)t * ld + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += lo_bf(v[e]); acc[2 * e + 1] += hi_bf(v[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rlane][cchunk * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (blockIdx.x * 256 + c < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][c];
+        atomicAdd(out + blockIdx.x * 256 + c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token embedding gather with image-feature scatter (TF:modeling_qwen2_5_vl.py:1204-1215): row t of the
+// output is img[img_index[t]] when img_index[t] >= 0 (an <|image_pad|> slot), else E[ids[t]].
+// Backward: fp32 atomics into dE (text rows) / dimg (image rows; several sequences may share one image).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* ids, const int* img_index, const bf16_t* E, const bf16_t* img,
+                                                        bf16_t* out, int T, int H) {
+    const int cpr = H >> 3;
+    const long long total = (long long)T * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long t = i / cpr;
+        const int c = (int)(i % cpr);
+        const int ii = img_index ? img_index[t] : -1;
+        const bf16_t* src = ii >= 0 ? img + (long long)ii * H : E + ids[t] * (long long)H;
+        *(u32x4_t*)(out + t * H + c * 8) = *(const u32x4_t*)(src + c * 8);
+    }
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* ids, const int* img_index, const bf16_t* dx, float* dE,
+                                                        float* dimg, int T, int H) {
+    const int cpr = H >> 3;
+    const long long total = (long long)T * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long t = i / cpr;
+        const int c = (int)(i % cpr);
+        const int ii = img_index ? img_index[t] : -1;
+        float* dst;
+        if (ii >= 0) {
+            if (!dimg) continue;
+            dst = dimg + (long long)ii * H + c * 8;
+        } else {
+            if (!dE) continue;
+            dst = dE + ids[t] * (long long)H + c * 8;
+        }
+        const u32x4_t v = *(const u32x4_t*)(dx + t * H + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(dst + 2 * e, lo_bf(v[e]));
+            atomicAdd(dst + 2 * e + 1, hi_bf(v[e]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// casts / strided copies
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* in, long long ldi, bf16_t* out, long long ldo, int R, int C, int Cpad) {
+    // out[r][0:C] = bf16(in[r][0:C]); out[r][C:Cpad] = 0  (K padding for the patch-embed GEMM)
+    const long long total = (long long)R * Cpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / Cpad;
+        const int c = (int)(i % Cpad);
+        out[r * ldo + c] = c < C ? f2bf(in[r * ldi + c]) : (bf16_t)0;
+    }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* in, float* out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = bf2f(in[i]);
+}
+__global__ __launch_bounds__(256) void add_f32_to_bf16_kernel(const float* in, const bf16_t* bias, bf16_t* out, long long R, int C) {
+    // out = bf16(in + bias)  ([R,C] fp32 split-K sums -> bf16 activation); `in` is re-zeroed
+    const long long total = R * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float v = in[i];
+        ((float*)in)[i] = 0.f;
+        if (bias) v += bf2f(bias[i % C]);
+        out[i] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 transpose: out[c][r] = in[r][c], 64x64 tiles through LDS (padded), 16-byte global accesses.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long long ldi, bf16_t* out, long long ldo, int R, int C) {
+    __shared__ bf16_t tile[64][64 + 2];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = it * 256 + t, r = idx >> 3, ch = idx & 7;
+        const int gr = r0 + r, gc = c0 + ch * 8;
+        bf16_t v[8];
+        if (gr < R && gc + 8 <= C) {
+            *(u32x4_t*)v = *(const u32x4_t*)(in + (long long)gr * ldi + gc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (gr < R && gc + e < C) ? in[(long long)gr * ldi + gc + e] : (bf16_t)0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][ch * 8 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = it * 256 + t, c = idx >> 3, ch = idx & 7;
+        const int gc = c0 + c, gr = r0 + ch * 8;
+        if (gc >= C) continue;
+        bf16_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[ch * 8 + e][c];
+        bf16_t* dst = out + (long long)gc * ldo + gr;
+        if (gr + 8 <= R && (ldo & 7) == 0) {
+            *(u32x4_t*)dst = *(const u32x4_t*)v;
+        } else {
+            for (int e = 0; e < 8 && gr + e < R; ++e) dst[e] = v[e];
+        }
+    }
+}
+
+inline int grid_for(long long work, int block = 256, int cap = 256 * 8) {
+    long long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+extern "C" int iadr1_rope_inplace(void* x, long long ld, const float* cos_t, const float* sin_t, int T, int nheads, int D, int backward,
+                                  hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && nheads > 0 && (D % 8) == 0, "rope: D=%d must be a multiple of 8", D);
+    IADR1_REQUIRE((ld % 4) == 0, "rope: ld must be a multiple of 4");
+    const long long total = (long long)T * nheads * (D / 8);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (bf16_t*)x, ld, cos_t, sin_t, T, nheads, D, backward ? -1.f : 1.f);
+    return iadr1_check_launch("rope_inplace");
+}
+
+extern "C" int iadr1_swiglu_fwd(const void* gu, long long ldg, void* a, long long lda, int T, int I, hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && I > 0 && (I % 8) == 0 && (ldg % 8) == 0 && (lda % 8) == 0, "swiglu_fwd: I, ld must be multiples of 8");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for((long long)T * (I / 8))), dim3(256), 0, stream, (const bf16_t*)gu, ldg, (bf16_t*)a, lda, T, I);
+    return iadr1_check_launch("swiglu_fwd");
+}
+extern "C" int iadr1_swiglu_bwd(const void* da, long long lda, const void* gu, long long ldg, void* dgu, long long ldd, int T, int I,
+                                hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && I > 0 && (I % 8) == 0 && (ldg % 8) == 0 && (lda % 8) == 0 && (ldd % 8) == 0, "swiglu_bwd: I, ld must be multiples of 8");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long long)T * (I / 8))), dim3(256), 0, stream, (const bf16_t*)da, lda, (const bf16_t*)gu, ldg, (bf16_t*)dgu, ldd, T, I);
+    return iadr1_check_launch("swiglu_bwd");
+}
+extern "C" int iadr1_gelu_fwd(const void* z, void* a, long long n, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0 && (n % 8) == 0, "gelu_fwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)z, (bf16_t*)a, n / 8);
+    return iadr1_check_launch("gelu_fwd");
+}
+extern "C" int iadr1_gelu_bwd(const void* da, const void* z, void* dz, long long n, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0 && (n % 8) == 0, "gelu_bwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)da, (const bf16_t*)z, (bf16_t*)dz, n / 8);
+    return iadr1_check_launch("gelu_bwd");
+}
+extern "C" int iadr1_colsum_acc(const void* dy, long long ld, float* out, int T, int N, hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && N > 0 && (N % 8) == 0 && (ld % 8) == 0, "colsum: N, ld must be multiples of 8");
+    int gy = (T + 63) / 64;
+    if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, gy), dim3(256), 0, stream, (const bf16_t*)dy, ld, out, T, N);
+    return iadr1_check_launch("colsum_acc");
+}
+extern "C" int iadr1_embed_fwd(const long long* ids, const int* img_index, const void* E, const void* img, void* out, int T, int H,
+                               hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && (H % 8) == 0, "embed_fwd: H must be a multiple of 8");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)E, (const bf16_t*)img, (bf16_t*)out, T, H);
+    return iadr1_check_launch("embed_fwd");
+}
+extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
+                               hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && (H % 8) == 0, "embed_bwd: H must be a multiple of 8");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)dx, dE, dimg, T, H);
+    return iadr1_check_launch("embed_bwd");
+}
+extern "C" int iadr1_cast_f32_to_bf16(const float* in, long long ldi, void* out, long long ldo, int R, int C, int Cpad, hipStream_t stream) {
+    IADR1_REQUIRE(R > 0 && C > 0 && Cpad >= C, "cast_f32_to_bf16: bad shape");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((long long)R * Cpad)), dim3(256), 0, stream, in, ldi, (bf16_t*)out, ldo, R, C, Cpad);
+    return iadr1_check_launch("cast_f32_to_bf16");
+}
+extern "C" int iadr1_cast_bf16_to_f32(const void* in, float* out, long long n, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0, "cast_bf16_to_f32: empty");
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const bf16_t*)in, out, n);
+    return iadr1_check_launch("cast_bf16_to_f32");
+}
+extern "C" int iadr1_f32_bias_to_bf16(float* in, const void* bias, void* out, long long R, int C, hipStream_t stream) {
+    IADR1_REQUIRE(R > 0 && C > 0, "f32_bias_to_bf16: empty");
+    hipLaunchKernelGGL(add_f32_to_bf16_kernel, dim3(grid_for(R * C)), dim3(256), 0, stream, in, (const bf16_t*)bias, (bf16_t*)out, R, C);
+    return iadr1_check_launch("f32_bias_to_bf16");
+}
+extern "C" int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, hipStream_t stream) {
+    IADR1_REQUIRE(R > 0 && C > 0 && (ldi % 8) == 0, "transpose: ldi must be a multiple of 8");
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C);
+    return iadr1_check_launch("transpose_bf16");
+}

@@ -1,0 +1,344 @@
+// iadr1 GEMM family for gfx950 (CDNA4).
+//
+//   C[M,N] (+)= act( A[M,K] . B[N,K]^T + bias[N] )       "NT": both operands K-contiguous
+//
+// This is the contraction behind every Linear of the hot path (SURVEY.md section 2.3 K1,K6,K7,K8,K12,
+// K14,K15; reference call sites TF:modeling_qwen2_5_vl.py:85-96,116-122,148-150,218-219,634-637,
+// 552-554,1386-1387).  Forward uses W[N,K] directly; dgrad / wgrad reuse the same kernel on
+// transposed copies produced by transpose.hip.
+//
+// Kernel gemm_nt_128: 128x128x64 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16,
+// operands staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round trip), 2 LDS buffers so the
+// DMA of tile t+1 overlaps the MFMAs of tile t, XOR-swizzled LDS image (swizzle applied on the
+// per-lane SOURCE address and on the ds_read address; the LDS destination of the DMA stays
+// lane-linear as the hardware requires), XCD-aware block->tile map (8 XCDs, private L2s) with
+// 8-tile-high bands so the 64 blocks resident on one XCD share A/B panels in its L2.
+// MFMA operands are swapped (B-tile as the A operand) so each lane ends up with 4 consecutive
+// output columns of one row: bf16 results are staged through LDS and leave as 16-byte row-contiguous
+// stores; fp32 results (logit chunks, wgrad accumulation) leave as 16-byte stores/RMW per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // double buffered: 64 KiB
+constexpr int C_LD = BN + 8;                     // bf16 epilogue row stride (elements)
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    const bf16_t* bias;
+    const void* zeros;  // >=16 zero bytes, source for out-of-range K chunks
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int act;  // 0 none, 1 exact GELU
+};
+
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2 };
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane*16 (hardware rule); source address is per lane.
+    __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+template <int OUT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_128(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l = t & 63;
+
+    // ---- block -> tile map (XCD-aware, bijective for any grid) --------------------------------
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int band = wg / (8 * tiles_n), in_band = wg - band * 8 * tiles_n;
+    const int band_rows = min(8, tiles_m - band * 8);
+    const int tm = band * 8 + in_band % band_rows, tn = in_band / band_rows;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-thread DMA sources: 4 A chunks + 4 B chunks (16 B each) per K tile --------------------
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+    int chunk_k[4];  // element offset of the (swizzled) source chunk inside the K tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = (i * 4 + w) * 64 + l;  // linear 16-B slot in the LDS tile image
+        const int row = L >> 3, c = L & 7;
+        const int cs = c ^ ((row >> 1) & 7);  // source chunk that must land in slot (row, c)
+        chunk_k[i] = cs * 8;
+        a_src[i] = p.A + (long long)min(m0 + row, p.M - 1) * p.lda + cs * 8;
+        b_src[i] = p.B + (long long)min(n0 + row, p.N - 1) * p.ldb + cs * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = k0 + chunk_k[i] < p.K;
+            glds16(ok ? (const void*)(a_src[i] + k0) : p.zeros, base + (i * 4 + w) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = k0 + chunk_k[i] < p.K;
+            glds16(ok ? (const void*)(b_src[i] + k0) : p.zeros, base + TILE_BYTES + (i * 4 + w) * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (swizzled), wave tile 64x64 -------------------------------------------
+    const int wm = w >> 1, wn = w & 1;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = kk * 4 + (l >> 4);
+        const int ra = wm * 64 + (l & 15), rb = wn * 64 + (l & 15);
+        a_off[kk] = ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4);
+        b_off[kk] = TILE_BYTES + rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4);
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();  // tile kt landed (vmcnt(0) + barrier); everyone is done reading buffer cur^1
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sbase = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(sbase + a_off[kk] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8_t*)(sbase + b_off[kk] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    // swapped operands: D[row = n][col = m] -> lane owns 4 consecutive n of one m
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    const int lm = l & 15, lq = l >> 4;
+    if constexpr (OUT == OUT_BF16) {
+        __syncthreads();  // all waves finished reading the operand buffers
+        bf16_t* cs = (bf16_t*)smem;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + lq * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = (n0 + nl + e < p.N) ? bf2f(p.bias[n0 + nl + e]) : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = wm * 64 + i * 16 + lm;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][e] + bv[e];
+                    if (p.act == 1) v[e] = gelu_erf(v[e]);
+                }
+                u32x2_t pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                *(u32x2_t*)(cs + ml * C_LD + nl) = pk;
+            }
+        }
+        __syncthreads();
+        bf16_t* C = (bf16_t*)p.C;
+        const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * NTHREADS + t;
+            const int row = idx >> 4, ch = idx & 15;
+            const int gm = m0 + row, gn = n0 + ch * 8;
+            if (gm >= p.M || gn >= p.N) continue;
+            const u32x4_t v = *(const u32x4_t*)(cs + row * C_LD + ch * 8);
+            bf16_t* dst = C + (long long)gm * p.ldc + gn;
+            if (vec_ok && gn + 8 <= p.N) {
+                *(u32x4_t*)dst = v;
+            } else {
+                const bf16_t* sv = cs + row * C_LD + ch * 8;  // scalar tail straight from LDS
+                for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = sv[e];
+            }
+        }
+    } else {
+        float* C = (float*)p.C;
+        const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + wm * 64 + i * 16 + lm;
+            if (gm >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + wn * 64 + j * 16 + lq * 4;
+                if (gn >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][e];
+                    if (p.bias && gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
+                    if (p.act == 1) v[e] = gelu_erf(v[e]);
+                }
+                float* dst = C + (long long)gm * p.ldc + gn;
+                if (vec_ok && gn + 4 <= p.N) {
+                    f32x4_t o = {v[0], v[1], v[2], v[3]};
+                    if constexpr (OUT == OUT_F32_ACC) {
+                        const f32x4_t old = *(const f32x4_t*)dst;
+                        o += old;
+                    }
+                    *(f32x4_t*)dst = o;
+                } else {
+                    for (int e = 0; e < 4 && gn + e < p.N; ++e) {
+                        if constexpr (OUT == OUT_F32_ACC) dst[e] += v[e];
+                        else dst[e] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Skinny GEMM for the rollout decode step:  Y[M<=64.., N] += X[M,K] . W[N,K]^T  with fp32 atomics.
+// HBM-bound weight stream (6.17 GB of bf16 weights per decode step for 3B):
+// one wave = one (32-column, K-slice) work item, W fragments loaded straight HBM->VGPR (16 B per lane,
+// streamed once, non-temporal), X fragments from L2, fp32 partial sums combined with global atomics into
+// a zero-initialised fp32 buffer that the next fused kernel consumes (and re-zeroes).
+// ------------------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+    const bf16_t* X;
+    const bf16_t* W;
+    float* Y;
+    int M, N, K;
+    long long ldx, ldw, ldy;
+    int ksplit;      // number of K slices (grid.y)
+    int kslice;      // K elements per slice (multiple of 64)
+};
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int lm = l & 15, lq = l >> 4;
+    const int n0 = (blockIdx.x * 4 + w) * 32;  // this wave's 32 output columns
+    if (n0 >= p.N) return;
+    const int m_base = blockIdx.z * 64;
+    const int k_begin = blockIdx.y * p.kslice;
+    const int k_end = min(p.K, k_begin + p.kslice);
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wrow[j] = p.W + (long long)min(n0 + j * 16 + lm, p.N - 1) * p.ldw + lq * 8;
+    const bf16_t* xrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xrow[i] = p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
+
+    for (int k = k_begin; k < k_end; k += 64) {
+        bf16x8_t wf[2][2], xf[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bool ok = k + kk * 32 + lq * 8 < k_end;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4_t v = {0, 0, 0, 0};
+                if (ok) v = __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + k + kk * 32));
+                wf[j][kk] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4_t v = {0, 0, 0, 0};
+                if (ok) v = *(const u32x4_t*)(xrow[i] + k + kk * 32);
+                xf[i][kk] = __builtin_bit_cast(bf16x8_t, v);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], xf[i][kk], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m_base + i * 16 + lm;
+        if (gm >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gn = n0 + j * 16 + lq * 4 + e;
+                if (gn < p.N) atomicAdd(p.Y + (long long)gm * p.ldy + gn, acc[i][j][e]);
+            }
+    }
+}
+
+__device__ char g_zero16[64] __attribute__((aligned(64)));
+
+}  // namespace
+
+static const void* zeros_ptr() {
+    static void* z = nullptr;
+    if (!z) (void)hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero16));
+    return z;
+}
+
+extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                                  long long lda, long long ldb, long long ldc, int out_mode, int act, hipStream_t stream) {
+    IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+    IADR1_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0, "gemm_nt: K, lda, ldb must be multiples of 8 (16-byte chunks); K=%d lda=%lld ldb=%lld", K, lda, ldb);
+    IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, "gemm_nt: A/B must be 16-byte aligned");
+    IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2, "gemm_nt: bad out_mode %d", out_mode);
+    GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act};
+    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        attr_done = true;
+    }
+    if (out_mode == 0) hipLaunchKernelGGL(gemm_nt_128<OUT_BF16>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
+    else if (out_mode == 1) hipLaunchKernelGGL(gemm_nt_128<OUT_F32>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_128<OUT_F32_ACC>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
+    return iadr1_check_launch("gemm_nt_bf16");
+}
+
+extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, float* Y, int M, int N, int K, long long ldx,
+                                      long long ldw, long long ldy, hipStream_t stream) {
+    IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_skinny: empty problem");
+    IADR1_REQUIRE((K % 8) == 0 && (ldx % 8) == 0 && (ldw % 8) == 0, "gemm_skinny: K, ldx, ldw must be multiples of 8");
+    IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_skinny: X/W must be 16-byte aligned");
+    const int nblk = (N + 127) / 128;
+    // enough work items to cover 256 CUs a few times over: split K until >= 1024 waves
+    int ksplit = 1;
+    const int kt = (K + 63) / 64;
+    while (nblk * 4 * ksplit < 1024 && ksplit * 2 <= kt && ksplit < 16) ksplit *= 2;
+    const int kslice = ((kt + ksplit - 1) / ksplit) * 64;
+    ksplit = (K + kslice - 1) / kslice;
+    SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, M, N, K, ldx, ldw, ldy, ksplit, kslice};
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nblk, ksplit, (M + 63) / 64), dim3(256), 0, stream, p);
+    return iadr1_check_launch("gemm_skinny_bf16");
+}

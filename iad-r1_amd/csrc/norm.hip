@@ -1,0 +1,221 @@
+// RMSNorm forward / backward for gfx950 (reference arithmetic
+// TF:modeling_qwen2_5_vl.py:74-79: fp32 statistics, the normalised value is cast back to the storage
+// dtype BEFORE the multiply by the gain).  HBM-bound: one wave per row, the whole row lives in
+// registers (16-byte loads, 8 bf16 per lane per chunk), wave-shuffle reduction, no LDS.
+// Optional fusions: residual add on the way in (writes the new residual stream), fp32 split-K partial
+// sums as the branch input (decode path; the buffer is re-zeroed for the next skinny GEMM), and in the
+// backward the add of the gradient arriving on the residual path.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;  // 16-byte chunks per lane -> rows up to 8*64*8 = 4096 elements
+
+struct RmsFwdArgs {
+    const bf16_t* x;      // branch input [T,H] bf16 (or null when x32 is used)
+    float* x32;           // branch input [T,H] fp32 partial sums (decode); zeroed after reading
+    const bf16_t* xbias;  // optional bias [H] added to x32 (e.g. none for o_proj/down)
+    const bf16_t* res;    // optional residual [T,H]
+    bf16_t* res_out;      // where x+res is written (may alias res); null = do not write
+    const bf16_t* w;      // gain [H]
+    bf16_t* y;            // normalised output [T,H]
+    float* rstd;          // optional [T]
+    int T, H;
+    long long ldx, ldr, ldy;
+    float eps;
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(RmsFwdArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.T) return;
+    const int nchunk = p.H >> 3;
+    float v[NC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+            if (p.x32) {
+                float* src = p.x32 + (long long)row * p.ldx + ch * 8;
+                const f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
+                const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                *(f32x4_t*)src = z;
+                *(f32x4_t*)(src + 4) = z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[c][e] = a[e]; v[c][4 + e] = b[e]; }
+                if (p.xbias) {
+                    const u32x4_t bb = *(const u32x4_t*)(p.xbias + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[c][2 * e] += lo_bf(bb[e]); v[c][2 * e + 1] += hi_bf(bb[e]); }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = bf2f(f2bf(v[c][e]));  // the branch output is a bf16 tensor in the reference
+            } else {
+                const u32x4_t a = *(const u32x4_t*)(p.x + (long long)row * p.ldx + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[c][2 * e] = lo_bf(a[e]); v[c][2 * e + 1] = hi_bf(a[e]); }
+            }
+            if (p.res) {
+                const u32x4_t r = *(const u32x4_t*)(p.res + (long long)row * p.ldr + ch * 8);
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s0 = v[c][2 * e] + lo_bf(r[e]), s1 = v[c][2 * e + 1] + hi_bf(r[e]);
+                    o[e] = pack2bf(s0, s1);
+                    v[c][2 * e] = lo_bf(o[e]);  // the reference's residual stream is bf16: norm sees the rounded sum
+                    v[c][2 * e + 1] = hi_bf(o[e]);
+                }
+                if (p.res_out) *(u32x4_t*)(p.res_out + (long long)row * p.ldr + ch * 8) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[c][e] * v[c][e];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)p.H + p.eps);
+    if (p.rstd && lane == 0) p.rstd[row] = rstd;
+    if (!p.y) return;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+            const u32x4_t g = *(const u32x4_t*)(p.w + ch * 8);
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float n0 = bf2f(f2bf(v[c][2 * e] * rstd)), n1 = bf2f(f2bf(v[c][2 * e + 1] * rstd));
+                o[e] = pack2bf(lo_bf(g[e]) * n0, hi_bf(g[e]) * n1);
+            }
+            *(u32x4_t*)(p.y + (long long)row * p.ldy + ch * 8) = o;
+        }
+    }
+}
+
+struct RmsBwdArgs {
+    const bf16_t* dy;    // [T,H]
+    const bf16_t* x;     // pre-norm input [T,H]
+    const bf16_t* w;     // [H]
+    const float* rstd;   // [T]
+    const bf16_t* dres;  // optional gradient arriving on the residual path [T,H]
+    bf16_t* dx;          // [T,H] = dres + d(rmsnorm)/dx
+    float* dw;           // [H] fp32, accumulated with atomics (may be null for frozen gains)
+    int T, H;
+    long long ld;
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(RmsBwdArgs p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nchunk = p.H >> 3;
+    float dwacc[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[c][e] = 0.f;
+    float g[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+            const u32x4_t gg = *(const u32x4_t*)(p.w + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[c][2 * e] = lo_bf(gg[e]); g[c][2 * e + 1] = hi_bf(gg[e]); }
+        }
+    }
+    for (int row = blockIdx.x * 4 + wv; row < p.T; row += gridDim.x * 4) {
+        const float rstd = p.rstd[row];
+        float n[NC][8], dn[NC][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = c * 64 + lane;
+            if (ch < nchunk) {
+                const u32x4_t a = *(const u32x4_t*)(p.x + (long long)row * p.ld + ch * 8);
+                const u32x4_t d = *(const u32x4_t*)(p.dy + (long long)row * p.ld + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    n[c][2 * e] = lo_bf(a[e]) * rstd;
+                    n[c][2 * e + 1] = hi_bf(a[e]) * rstd;
+                    const float d0 = lo_bf(d[e]), d1 = hi_bf(d[e]);
+                    dwacc[c][2 * e] += d0 * n[c][2 * e];
+                    dwacc[c][2 * e + 1] += d1 * n[c][2 * e + 1];
+                    dn[c][2 * e] = d0 * g[c][2 * e];
+                    dn[c][2 * e + 1] = d1 * g[c][2 * e + 1];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot += dn[c][e] * n[c][e];
+            }
+        }
+        dot = wave_sum(dot) / (float)p.H;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = c * 64 + lane;
+            if (ch < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dn[c][e] - n[c][e] * dot);
+                if (p.dres) {
+                    const u32x4_t r = *(const u32x4_t*)(p.dres + (long long)row * p.ld + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[2 * e] += lo_bf(r[e]); o[2 * e + 1] += hi_bf(r[e]); }
+                }
+                u32x4_t ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = pack2bf(o[2 * e], o[2 * e + 1]);
+                *(u32x4_t*)(p.dx + (long long)row * p.ld + ch * 8) = ov;
+            }
+        }
+    }
+    if (!p.dw) return;
+    // block-level combine of the 4 waves' partial gain gradients, then one atomic per column per block
+    extern __shared__ float sdw[];  // [4][H]
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdw[wv * p.H + ch * 8 + e] = dwacc[c][e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.H; i += 256) atomicAdd(p.dw + i, sdw[i] + sdw[p.H + i] + sdw[2 * p.H + i] + sdw[3 * p.H + i]);
+}
+
+}  // namespace
+
+#define DISPATCH_NC(H, CALL)                                                          \
+    do {                                                                              \
+        const int nc_ = ((H) / 8 + 63) / 64;                                           \
+        if (nc_ <= 1) { CALL(1); } else if (nc_ <= 2) { CALL(2); } else if (nc_ <= 3) { CALL(3); } \
+        else if (nc_ <= 4) { CALL(4); } else if (nc_ <= 6) { CALL(6); } else { CALL(8); } \
+    } while (0)
+
+extern "C" int iadr1_rmsnorm_fwd(const void* x, float* x32, const void* xbias, const void* res, void* res_out, const void* w,
+                                 void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy, float eps,
+                                 hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0 && H <= MAXC * 512, "rmsnorm_fwd: H=%d must be a multiple of 8 and <= %d", H, MAXC * 512);
+    IADR1_REQUIRE((x != nullptr) != (x32 != nullptr), "rmsnorm_fwd: exactly one of x / x32");
+    IADR1_REQUIRE((ldx % 8) == 0 && (ldr % 8) == 0 && (ldy % 8) == 0, "rmsnorm_fwd: leading dims must be multiples of 8");
+    RmsFwdArgs p{(const bf16_t*)x, x32, (const bf16_t*)xbias, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (bf16_t*)y, rstd, T, H, ldx, ldr, ldy, eps};
+    const dim3 grid((T + 3) / 4), block(256);
+#define CALL(NC) hipLaunchKernelGGL(rmsnorm_fwd_kernel<NC>, grid, block, 0, stream, p)
+    DISPATCH_NC(H, CALL);
+#undef CALL
+    return iadr1_check_launch("rmsnorm_fwd");
+}
+
+extern "C" int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                                 float* dw, int T, int H, long long ld, hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0 && H <= MAXC * 512, "rmsnorm_bwd: H=%d must be a multiple of 8 and <= %d", H, MAXC * 512);
+    IADR1_REQUIRE((ld % 8) == 0, "rmsnorm_bwd: ld must be a multiple of 8");
+    RmsBwdArgs p{(const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw, T, H, ld};
+    int blocks = (T + 3) / 4;
+    if (blocks > 512) blocks = 512;  // grid-stride: bounds the number of dw atomics
+    const dim3 grid(blocks), block(256);
+#define CALL(NC) hipLaunchKernelGGL(rmsnorm_bwd_kernel<NC>, grid, block, (size_t)(dw ? 4 * H * sizeof(float) : 0), stream, p)
+    DISPATCH_NC(H, CALL);
+#undef CALL
+    return iadr1_check_launch("rmsnorm_bwd");
+}

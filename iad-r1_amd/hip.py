@@ -1,0 +1,86 @@
+"""ctypes binding of libiadr1_hip.so (include/iadr1_hip.h).  The prototypes are parsed from the header
+itself so the Python side cannot drift from the C ABI.  There is NO fallback: if the library is missing
+or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "iadr1_hip.h")
+LIB_PATH = os.path.join(HERE, "lib", "libiadr1_hip.so")
+
+_CTYPE = {
+    "int": ctypes.c_int, "unsigned": ctypes.c_uint, "float": ctypes.c_float, "long long": ctypes.c_longlong,
+    "unsigned long long": ctypes.c_ulonglong, "iadr1_stream_t": ctypes.c_void_p,
+}
+
+
+def parse_header(path: str = HEADER) -> dict[str, tuple[str, list[tuple[str, str]]]]:
+    """name -> (return type, [(ctype-name, arg-name)])"""
+    txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(int|const char\*)\s+(iadr1_\w+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        parsed = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    parsed.append(("ptr", a.split("*")[-1].strip()))
+                else:
+                    parts = a.rsplit(" ", 1)
+                    parsed.append((parts[0].replace("const ", "").strip(), parts[1]))
+        protos[name] = (ret, parsed)
+    return protos
+
+
+PROTOS = parse_header()
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in PROTOS.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = ctypes.c_char_p if ret != "int" else ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p if t == "ptr" else _CTYPE[t] for t, _ in args]
+        _lib = L
+    return _lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.data_ptr()
+    return int(x)
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Call iadr1_<name>(*args, stream) on torch's current stream.  Tensors -> device pointers."""
+    full = "iadr1_" + name
+    proto = PROTOS[full][1]
+    if len(args) != len(proto) - 1:
+        raise TypeError(f"{full}: expected {len(proto) - 1} args (+stream), got {len(args)}")
+    conv = []
+    for (t, an), a in zip(proto, args):
+        conv.append(_ptr(a) if t == "ptr" else a)
+    rc = getattr(lib(), full)(*conv, stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{full} failed ({rc}): {lib().iadr1_last_error().decode()}")
+
+
+def version() -> int:
+    return lib().iadr1_version()

@@ -1,0 +1,203 @@
+"""Functional wrappers over the C ABI (iadr1_amd.hip): allocate outputs with torch (device memory is
+torch's job, arithmetic is not) and launch on torch's current HIP stream.  2-D tensors are row-major
+views; a non-unit inner stride is an error, an outer stride is passed through as `ld`."""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _ld(x: torch.Tensor) -> int:
+    assert x.dim() == 2 and x.stride(1) == 1, f"need a row-major 2-D view, got shape {tuple(x.shape)} stride {x.stride()}"
+    return x.stride(0)
+
+
+def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
+    """out[M,N] (+)= act(a[M,K] @ b[N,K]^T + bias)"""
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2 and a.dtype == BF16 and b.dtype == BF16
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    mode = 0 if out.dtype == BF16 else (2 if accumulate else 1)
+    assert not (accumulate and out.dtype != F32)
+    hip.call("gemm_nt_bf16", a, b, out, bias, M, N, K, _ld(a), _ld(b), _ld(out), mode, act)
+    return out
+
+
+def gemm_skinny(x, w, y32):
+    """y32[M,N] (fp32, pre-zeroed) += x[M,K] @ w[N,K]^T"""
+    M, K = x.shape
+    N = w.shape[0]
+    hip.call("gemm_skinny_bf16", x, w, y32, M, N, K, _ld(x), _ld(w), _ld(y32))
+    return y32
+
+
+def transpose(x, out=None):
+    R, C = x.shape
+    if out is None:
+        out = torch.empty(C, R, dtype=BF16, device=x.device)
+    hip.call("transpose_bf16", x, _ld(x), out, _ld(out), R, C)
+    return out
+
+
+def rmsnorm_fwd(x, w, eps, res=None, res_out=None, x32=None, xbias=None, want_rstd=False, out=None):
+    src = x if x is not None else x32
+    T, H = src.shape
+    y = out if out is not None else torch.empty(T, H, dtype=BF16, device=src.device)
+    rstd = torch.empty(T, dtype=F32, device=src.device) if want_rstd else None
+    ldr = _ld(res) if res is not None else (_ld(res_out) if res_out is not None else H)
+    hip.call("rmsnorm_fwd", x, x32, xbias, res, res_out, w, y, rstd, T, H, _ld(src), ldr, _ld(y), float(eps))
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw=None, out=None):
+    T, H = x.shape
+    dx = out if out is not None else torch.empty(T, H, dtype=BF16, device=x.device)
+    assert _ld(dy) == _ld(x) == _ld(dx) and (dres is None or _ld(dres) == _ld(x))
+    hip.call("rmsnorm_bwd", dy, x, w, rstd, dres, dx, dw, T, H, _ld(x))
+    return dx
+
+
+def rope_(x, cos, sin, nheads, D, backward=False):
+    T = x.shape[0]
+    assert cos.dtype == F32 and cos.shape == (T, D // 2) and cos.is_contiguous() and sin.is_contiguous()
+    hip.call("rope_inplace", x, _ld(x), cos, sin, T, nheads, D, 1 if backward else 0)
+    return x
+
+
+def swiglu_fwd(gu, out=None):
+    T, I2 = gu.shape
+    a = out if out is not None else torch.empty(T, I2 // 2, dtype=BF16, device=gu.device)
+    hip.call("swiglu_fwd", gu, _ld(gu), a, _ld(a), T, I2 // 2)
+    return a
+
+
+def swiglu_bwd(da, gu, out=None):
+    T, I2 = gu.shape
+    dgu = out if out is not None else torch.empty(T, I2, dtype=BF16, device=gu.device)
+    hip.call("swiglu_bwd", da, _ld(da), gu, _ld(gu), dgu, _ld(dgu), T, I2 // 2)
+    return dgu
+
+
+def gelu_fwd(z):
+    a = torch.empty_like(z)
+    hip.call("gelu_fwd", z, a, z.numel())
+    return a
+
+
+def gelu_bwd(da, z):
+    dz = torch.empty_like(z)
+    hip.call("gelu_bwd", da, z, dz, z.numel())
+    return dz
+
+
+def colsum_acc(dy, out32):
+    T, N = dy.shape
+    hip.call("colsum_acc", dy, _ld(dy), out32, T, N)
+    return out32
+
+
+def embed_fwd(ids, img_index, E, img, out=None):
+    T = ids.numel()
+    H = E.shape[1]
+    o = out if out is not None else torch.empty(T, H, dtype=BF16, device=E.device)
+    hip.call("embed_fwd", ids, img_index, E, img, o, T, H)
+    return o
+
+
+def embed_bwd(ids, img_index, dx, dE, dimg):
+    T, H = dx.shape
+    hip.call("embed_bwd", ids, img_index, dx, dE, dimg, T, H)
+
+
+def cast_f32_to_bf16(x, cpad=None):
+    R, C = x.shape
+    cpad = cpad or C
+    out = torch.empty(R, cpad, dtype=BF16, device=x.device)
+    hip.call("cast_f32_to_bf16", x, _ld(x), out, _ld(out), R, C, cpad)
+    return out
+
+
+def f32_bias_to_bf16(x32, bias, out=None):
+    R, C = x32.shape
+    o = out if out is not None else torch.empty(R, C, dtype=BF16, device=x32.device)
+    hip.call("f32_bias_to_bf16", x32, bias, o, R, C)
+    return o
+
+
+class Segments:
+    """Explicit attention segments on the flat token axis (device int32 arrays)."""
+
+    def __init__(self, starts, ends, device):
+        self.n = len(starts)
+        self.max_len = max(e - s for s, e in zip(starts, ends)) if self.n else 0
+        self.start = torch.tensor(starts, dtype=torch.int32, device=device)
+        self.end = torch.tensor(ends, dtype=torch.int32, device=device)
+
+    @staticmethod
+    def from_cu(cu, device):
+        return Segments(list(cu[:-1]), list(cu[1:]), device)
+
+
+def attn_fwd(q, k, v, seg: Segments, Hq, Hkv, D, causal, scale, out=None, want_lse=True):
+    T = q.shape[0]
+    o = out if out is not None else torch.zeros(T, Hq * D, dtype=BF16, device=q.device)
+    lse = torch.empty(Hq, T, dtype=F32, device=q.device) if want_lse else None
+    hip.call("attn_fwd", q, k, v, o, lse, seg.start, seg.end, seg.n, seg.max_len, T, Hq, Hkv, D, _ld(q), _ld(k), _ld(v), _ld(o), 1 if causal else 0, float(scale))
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq, dk, dv):
+    T = q.shape[0]
+    delta = torch.empty(Hq, T, dtype=F32, device=q.device)
+    hip.call("attn_bwd", q, k, v, o, dout, lse, delta, dq, dk, dv, seg.start, seg.end, seg.n, seg.max_len, T, Hq, Hkv, D,
+             _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout), _ld(dq), _ld(dk), _ld(dv), 1 if causal else 0, float(scale))
+
+
+def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=None):
+    B = q.shape[0]
+    o = out if out is not None else torch.empty(B, Hq * D, dtype=BF16, device=q.device)
+    hip.call("attn_decode", q, kcache, vcache, block_table, ctx_len, o, B, Hq, Hkv, D, block_table.shape[1], _ld(q), _ld(o), float(scale))
+    return o
+
+
+def kv_store(k, v, slot, kcache, vcache, Hkv, D):
+    hip.call("kv_store", k, _ld(k), v, _ld(v), slot, kcache, vcache, k.shape[0], Hkv, D)
+
+
+def logprob_rows(logits32, targets, want_lse=True):
+    R, V = logits32.shape
+    logp = torch.empty(R, dtype=F32, device=logits32.device)
+    lse = torch.empty(R, dtype=F32, device=logits32.device) if want_lse else None
+    hip.call("logprob_rows", logits32, _ld(logits32), targets, logp, lse, R, V)
+    return logp, lse
+
+
+def dlogits_rows(logits32, targets, lse, g, out=None):
+    R, V = logits32.shape
+    dl = out if out is not None else torch.empty(R, V, dtype=BF16, device=logits32.device)
+    hip.call("dlogits_rows", logits32, _ld(logits32), targets, lse, g, dl, _ld(dl), R, V)
+    return dl
+
+
+def grpo_loss(logp, ref_logp, adv, mask, beta):
+    N, C = logp.shape
+    dev = logp.device
+    dlogp = torch.empty(N, C, dtype=F32, device=dev)
+    kl = torch.empty(N, C, dtype=F32, device=dev)
+    row_loss = torch.empty(N, dtype=F32, device=dev)
+    row_kl = torch.empty(N, dtype=F32, device=dev)
+    hip.call("grpo_loss", logp, ref_logp, adv, mask, float(beta), dlogp, kl, row_loss, row_kl, N, C)
+    return dlogp, kl, row_loss, row_kl
+
+
+def sample(logits32, temperature, top_k, top_p, seed, step, suppress_token=-1, step_ptr=None, out=None):
+    B, V = logits32.shape
+    o = out if out is not None else torch.empty(B, dtype=torch.int64, device=logits32.device)
+    hip.call("sample_topk_topp", logits32, _ld(logits32), o, B, V, float(temperature), int(top_k), float(top_p), int(suppress_token), int(seed), int(step), step_ptr)
+    return o

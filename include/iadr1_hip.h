@@ -1,0 +1,130 @@
+/* iadr1_hip.h -- C ABI of libiadr1_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the IAD-R1
+ * post-training hot path (PA-SFT / SC-GRPO on Qwen2.5-VL).
+ *
+ * The reference (Yanhui-Lee/IAD-R1) is pure Python and has no FFI of its own;
+ * each entry point below replaces the third-party kernel the reference reaches at the cited call site
+ * (TF: = transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py as installed, 5.15.0 line numbers;
+ * REF: = /root/reference).  INTEGRATION.md shows the ctypes / AttentionInterface stubs a maintainer
+ * of the reference would add to bind them.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  All pointers are DEVICE pointers unless noted.
+ *   - the caller owns every buffer; nothing here allocates, frees or synchronises.
+ *   - asynchronous and stream-ordered on `stream` (a hipStream_t, passed as void*); legal inside
+ *     hipGraph capture; re-entrant (no mutable global state).
+ *   - bf16 tensors are raw uint16 bit patterns; arithmetic is fp32; row strides (`ld*`) are in elements.
+ *   - return 0 on success, negative on error; iadr1_last_error() returns the thread-local message.
+ */
+#ifndef IADR1_HIP_H
+#define IADR1_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* iadr1_stream_t; /* hipStream_t */
+
+int iadr1_version(void);
+const char* iadr1_last_error(void);
+
+/* ---- dense contractions ----------------------------------------------------------------------------
+ * C[M,N] (+)= act(A[M,K] . B[N,K]^T + bias[N]).  out_mode: 0 = bf16 store, 1 = fp32 store, 2 = fp32
+ * accumulate (C += ...).  act: 0 none, 1 exact GELU.  K, lda, ldb multiples of 8; A/B 16-byte aligned.
+ * Replaces every nn.Linear / the stride==kernel Conv3d of the path: TF:85-96 (ViT MLP), :116-122 (patch
+ * embed), :148-150 (merger), :218-219 (ViT qkv/proj), :552-554 (decoder MLP), :634-637 (q/k/v/o),
+ * :1386-1387 (lm_head), and their autograd backward (dgrad / wgrad run on transposed operands). */
+int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
+                       long long ldb, long long ldc, int out_mode, int act, iadr1_stream_t stream);
+/* Decode-time skinny GEMM: Y[M,N] (fp32, pre-zeroed) += X[M,K] . W[N,K]^T with split-K atomics; HBM-bound
+ * weight stream.  Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/
+ * sc_grpo_trainer.py:667 -> llm.generate). */
+int iadr1_gemm_skinny_bf16(const void* X, const void* W, float* Y, int M, int N, int K, long long ldx, long long ldw,
+                           long long ldy, iadr1_stream_t stream);
+int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
+
+/* ---- RMSNorm (TF:65-79) --------------------------------------------------------------------------------
+ * y = w * bf16((x [+ res]) * rsqrt(mean((x+res)^2) + eps)).  Exactly one of x (bf16) / x32 (fp32 split-K
+ * sums, re-zeroed after the read, optional bias xbias) is given.  res_out receives x+res (new residual
+ * stream), rstd the per-row statistic for the backward.  Any output pointer may be NULL. */
+int iadr1_rmsnorm_fwd(const void* x, float* x32, const void* xbias, const void* res, void* res_out, const void* w,
+                      void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy, float eps,
+                      iadr1_stream_t stream);
+/* dx = dres + d rmsnorm / dx ; dw (fp32, may be NULL) += sum_t dy * x * rstd */
+int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                      float* dw, int T, int H, long long ld, iadr1_stream_t stream);
+
+/* ---- rotary embeddings: vision 2-D rotary TF:153-171 and decoder M-RoPE TF:557-599 -----------------------
+ * In place on `nheads` consecutive heads of width D per token row; cos/sin fp32 [T, D/2] (the M-RoPE
+ * t/h/w section select is folded into the table by the host).  backward != 0 applies the transpose. */
+int iadr1_rope_inplace(void* x, long long ld, const float* cos_t, const float* sin_t, int T, int nheads, int D,
+                       int backward, iadr1_stream_t stream);
+
+/* ---- activations ---------------------------------------------------------------------------------------
+ * SwiGLU TF:95-96,552-554 over gu = [gate | up] (width 2*I); exact GELU of the patch merger TF:143. */
+int iadr1_swiglu_fwd(const void* gu, long long ldg, void* a, long long lda, int T, int I, iadr1_stream_t stream);
+int iadr1_swiglu_bwd(const void* da, long long lda, const void* gu, long long ldg, void* dgu, long long ldd, int T, int I,
+                     iadr1_stream_t stream);
+int iadr1_gelu_fwd(const void* z, void* a, long long n, iadr1_stream_t stream);
+int iadr1_gelu_bwd(const void* da, const void* z, void* dz, long long n, iadr1_stream_t stream);
+/* out[n] (fp32) += sum_t dy[t][n]   (bias gradients) */
+int iadr1_colsum_acc(const void* dy, long long ld, float* out, int T, int N, iadr1_stream_t stream);
+
+/* ---- embedding lookup + image-feature scatter (TF:1204-1215 masked_scatter) -----------------------------------
+ * out[t] = img_index[t] >= 0 ? img[img_index[t]] : E[ids[t]].  Backward accumulates fp32 with atomics. */
+int iadr1_embed_fwd(const long long* ids, const int* img_index, const void* E, const void* img, void* out, int T, int H,
+                    iadr1_stream_t stream);
+int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
+                    iadr1_stream_t stream);
+
+/* ---- casts ---------------------------------------------------------------------------------------------- */
+int iadr1_cast_f32_to_bf16(const float* in, long long ldi, void* out, long long ldo, int R, int C, int Cpad,
+                           iadr1_stream_t stream);
+int iadr1_cast_bf16_to_f32(const void* in, float* out, long long n, iadr1_stream_t stream);
+int iadr1_f32_bias_to_bf16(float* in_zeroed_after, const void* bias, void* out, long long R, int C, iadr1_stream_t stream);
+
+/* ---- attention -------------------------------------------------------------------------------------------
+ * Flash-style varlen attention over explicit segments [seg_start[i], seg_end[i]) of the flat token axis;
+ * D in {128, 80}; GQA via Hq/Hkv.  Replaces flash-attn / eager attention at TF:186-208,225-291 (ViT,
+ * non-causal windows) and TF:641-689 (decoder, causal, left padding = segments that start late).
+ * lse: [Hq, T] fp32.  Backward also needs a delta scratch [Hq, T] fp32. */
+int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start,
+                   const int* seg_end, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq,
+                   long long ldk, long long ldv, long long ldo, int causal, float scale, iadr1_stream_t stream);
+int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   float* delta, void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end, int nseg,
+                   int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
+                   long long ldo, long long lddo, long long lddq, long long lddk, long long lddv, int causal,
+                   float scale, iadr1_stream_t stream);
+/* Paged-KV decode attention + cache writes for the group rollout (vLLM's role at REF:...sc_grpo_trainer.py:
+ * 343-358,667).  Pages hold 32 keys: K page [Hkv][32][D], V page [Hkv][D][32].  slot = page*32 + offset. */
+int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len,
+                      void* o, int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale,
+                      iadr1_stream_t stream);
+int iadr1_kv_store(const void* k, long long ldk, const void* v, long long ldv, const long long* slot, void* kcache,
+                   void* vcache, int T, int Hkv, int D, iadr1_stream_t stream);
+
+/* ---- log-probs / losses -----------------------------------------------------------------------------------
+ * logprob_rows: REF:train/stage_rl/trainer/sc_grpo_trainer.py:510-513 (log_softmax + gather, no temperature)
+ * and PA-SFT cross entropy TF:loss/loss_utils.py:32-71 (logp = -CE; target < 0 is ignored).
+ * dlogits_rows: g[row] * (onehot - softmax) in bf16.   grpo_loss: REF:...sc_grpo_trainer.py:746,796-798,816. */
+int iadr1_logprob_rows(const float* logits, long long ld, const long long* targets, float* logp, float* lse, int R, int V,
+                       iadr1_stream_t stream);
+int iadr1_dlogits_rows(const float* logits, long long ld, const long long* targets, const float* lse, const float* g,
+                       void* dl, long long ldd, int R, int V, iadr1_stream_t stream);
+int iadr1_grpo_loss(const float* logp, const float* ref_logp, const float* adv, const int* mask, float beta, float* dlogp,
+                    float* kl, float* row_loss, float* row_kl, int N, int C, iadr1_stream_t stream);
+
+/* ---- optimizer (HF Trainer default AdamW + clip_grad_norm_, TF:trainer.py:1168) ------------------------------- */
+int iadr1_sumsq_acc(const float* g, long long n, float* out, iadr1_stream_t stream);
+int iadr1_adamw_flat(float* master, float* m, float* v, float* grad_zeroed_after, void* param_bf16, long long n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     const float* norm2, float max_norm, iadr1_stream_t stream);
+
+/* ---- sampler (vLLM SamplingParams(temperature, top_p, top_k), REF:...sc_grpo_trainer.py:353-358) -------------- */
+int iadr1_sample_topk_topp(const float* logits, long long ld, long long* out, int B, int V, float temperature, int top_k,
+                           float top_p, int suppress_token, unsigned long long seed, unsigned step,
+                           const unsigned* step_ptr, iadr1_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,355 @@
+"""Per-kernel parity of the HIP library (through the C ABI) against plain torch fp32 on the same
+bf16-rounded inputs.  GPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import iadr1_amd  # noqa: E402,F401
+from iadr1_amd import ops  # noqa: E402
+
+DEV = "cuda"
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax(err - tol))
+        idx = np.unravel_index(i, tuple(ref.shape)) if ref.dim() else ()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{ref.numel()} out of tol; worst at {idx}: got {got.flatten()[i].item():.6g} ref {ref.flatten()[i].item():.6g} (max|err| {err.max().item():.4g}, max|ref| {ref.abs().max().item():.4g})")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (100, 200, 72), (1000, 520, 1216), (333, 324, 160), (64, 1280, 3456), (4096, 2048, 2048)])
+@pytest.mark.parametrize("mode", ["bf16", "bf16_bias", "bf16_bias_gelu", "f32", "f32_acc"])
+def test_gemm_nt(M, N, K, mode):
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.5)
+    bias = rnd(N, seed=3) if "bias" in mode else None
+    ref = a.float() @ b.float().t()
+    if bias is not None:
+        ref = ref + bias.float()
+    if "gelu" in mode:
+        ref = torch.nn.functional.gelu(ref)
+    if mode.startswith("bf16"):
+        out = ops.gemm_nt(a, b, bias=bias, act=1 if "gelu" in mode else 0)
+        close(out, ref, 1e-2, 1e-2 * math.sqrt(K) * 0.5, f"gemm {mode} {M}x{N}x{K}")
+    elif mode == "f32":
+        out = ops.gemm_nt(a, b, out_dtype=F32)
+        close(out, ref, 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"gemm f32 {M}x{N}x{K}")
+    else:
+        base = rnd(M, N, seed=4, dtype=F32)
+        out = base.clone()
+        ops.gemm_nt(a, b, out=out, accumulate=True)
+        close(out, ref + base.float(), 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"gemm f32 acc {M}x{N}x{K}")
+
+
+def test_gemm_nt_strided_views():
+    # operands / outputs that are column slices of wider buffers (the fused qkv / gate|up layouts)
+    big_a, big_b = rnd(300, 512, seed=5), rnd(260, 512, seed=6)
+    a, b = big_a[:, 128:384], big_b[:, 64:320]
+    outbuf = torch.zeros(300, 520, dtype=BF, device=DEV)
+    ops.gemm_nt(a, b, out=outbuf[:, 256:516])
+    close(outbuf[:, 256:516], a.float() @ b.float().t(), 1e-2, 0.1, "gemm strided")
+    assert float(outbuf[:, :256].abs().sum()) == 0 and float(outbuf[:, 516:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (64, 640, 256), (8, 256, 512), (100, 1000, 1032)])
+def test_gemm_skinny(M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3)
+    y = torch.zeros(M, N, dtype=F32, device=DEV)
+    ops.gemm_skinny(x, w, y)
+    close(y, x.float() @ w.float().t(), 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"skinny {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("R,C", [(64, 64), (100, 200), (4096, 2560), (37, 8)])
+def test_transpose(R, C):
+    x = rnd(R, ((C + 7) // 8) * 8, seed=3)[:, :C]
+    out = ops.transpose(x)
+    assert torch.equal(out, x.t().contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ norm
+def _rms_ref(x, w, eps):
+    xf = x.float()
+    n = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(BF)
+    return (w * n).to(BF)
+
+
+@pytest.mark.parametrize("T,H", [(5, 256), (300, 2048), (130, 1280), (64, 160), (33, 3584)])
+def test_rmsnorm_fwd_bwd(T, H):
+    x, w, res = rnd(T, H, seed=1), (1 + 0.1 * rnd(H, seed=2).float()).to(BF), rnd(T, H, seed=3)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-6, want_rstd=True)
+    assert torch.equal(y, _rms_ref(x, w, 1e-6)) or (y.float() - _rms_ref(x, w, 1e-6).float()).abs().max() <= 2 ** -6 * y.float().abs().max()
+    close(rstd, torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6), 1e-5, 1e-6, "rstd")
+    # fused residual
+    ro = torch.empty_like(x)
+    y2, _ = ops.rmsnorm_fwd(x, w, 1e-6, res=res, res_out=ro)
+    s = (x.float() + res.float()).to(BF)
+    assert torch.equal(ro, s)
+    close(y2, _rms_ref(s, w, 1e-6), 2e-2, 1e-3, "rmsnorm+res")
+    # fp32 partial-sum input (decode path) + zeroing
+    x32 = x.float().clone()
+    y3, _ = ops.rmsnorm_fwd(None, w, 1e-6, res=res, res_out=ro, x32=x32)
+    assert float(x32.abs().sum()) == 0.0
+    close(y3, y2, 2e-2, 1e-3, "rmsnorm x32")
+    # backward vs autograd (fp32)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    yy = wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    dy = rnd(T, H, seed=4)
+    yy.backward(dy.float())
+    dw = torch.zeros(H, dtype=F32, device=DEV)
+    dres = rnd(T, H, seed=5)
+    dx = ops.rmsnorm_bwd(dy, x, w, rstd, dres=dres, dw=dw)
+    close(dx, xr.grad + dres.float(), 2e-2, 2e-2, "rmsnorm dx")
+    close(dw, wr.grad, 1e-2, 1e-2 * math.sqrt(T), "rmsnorm dw")
+
+
+# ------------------------------------------------------------------------------------------------ rope / act
+@pytest.mark.parametrize("D,nh", [(128, 3), (80, 4)])
+def test_rope(D, nh):
+    T = 77
+    width = (nh + 2) * D
+    x = rnd(T, width, seed=1)
+    ang = torch.rand(T, D // 2, generator=torch.Generator().manual_seed(2)) * 6.28
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    ref = x.float().clone()
+    h = ref[:, : nh * D].view(T, nh, D)
+    c2, s2 = torch.cat([cos, cos], -1).unsqueeze(1), torch.cat([sin, sin], -1).unsqueeze(1)
+    rot = torch.cat([-h[..., D // 2:], h[..., : D // 2]], -1)
+    ref[:, : nh * D] = (h * c2 + rot * s2).reshape(T, nh * D)
+    y = x.clone()
+    ops.rope_(y, cos, sin, nh, D)
+    close(y, ref, 1e-2, 1e-2, "rope fwd")
+    assert torch.equal(y[:, nh * D:], x[:, nh * D:])
+    # backward = transpose: applying it to the forward output restores the input (orthogonal map)
+    ops.rope_(y, cos, sin, nh, D, backward=True)
+    close(y, x, 2e-2, 2e-2, "rope bwd∘fwd")
+
+
+def test_swiglu_gelu_colsum():
+    T, I = 70, 328
+    gu = rnd(T, 2 * I, seed=1)
+    a = ops.swiglu_fwd(gu)
+    g, u = gu[:, :I].float(), gu[:, I:].float()
+    close(a, torch.nn.functional.silu(g) * u, 1e-2, 1e-2, "swiglu fwd")
+    da = rnd(T, I, seed=2)
+    gr, ur = g.clone().requires_grad_(True), u.clone().requires_grad_(True)
+    (torch.nn.functional.silu(gr) * ur).backward(da.float())
+    dgu = ops.swiglu_bwd(da, gu)
+    close(dgu[:, :I], gr.grad, 1e-2, 1e-2, "swiglu dgate")
+    close(dgu[:, I:], ur.grad, 1e-2, 1e-2, "swiglu dup")
+    z = rnd(T, 640, seed=3)
+    close(ops.gelu_fwd(z), torch.nn.functional.gelu(z.float()), 1e-2, 1e-2, "gelu fwd")
+    zr = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zr).backward(rnd(T, 640, seed=4).float())
+    close(ops.gelu_bwd(rnd(T, 640, seed=4), z), zr.grad, 1e-2, 1e-2, "gelu bwd")
+    dy = rnd(1000, 520, seed=5)
+    out = torch.ones(520, dtype=F32, device=DEV)
+    ops.colsum_acc(dy, out)
+    close(out, 1 + dy.float().sum(0), 1e-4, 1e-2, "colsum")
+
+
+def test_embed():
+    V, H, T = 100, 64, 50
+    E, img = rnd(V, H, seed=1), rnd(7, H, seed=2)
+    ids = torch.randint(0, V, (T,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    idx = torch.full((T,), -1, dtype=torch.int32)
+    idx[5:12] = torch.arange(7, dtype=torch.int32)
+    idx[30:33] = torch.tensor([1, 2, 3], dtype=torch.int32)  # the same image rows used twice (G copies share an image)
+    idx = idx.to(DEV)
+    out = ops.embed_fwd(ids, idx, E, img)
+    ref = E[ids].clone()
+    m = idx >= 0
+    ref[m] = img[idx[m].long()]
+    assert torch.equal(out, ref)
+    dx = rnd(T, H, seed=4)
+    dE, dimg = torch.zeros(V, H, dtype=F32, device=DEV), torch.zeros(7, H, dtype=F32, device=DEV)
+    ops.embed_bwd(ids, idx, dx, dE, dimg)
+    rE, rI = torch.zeros_like(dE), torch.zeros_like(dimg)
+    rE.index_add_(0, ids[~m], dx.float()[~m])
+    rI.index_add_(0, idx[m].long(), dx.float()[m])
+    close(dE, rE, 1e-5, 1e-5, "dE")
+    close(dimg, rI, 1e-5, 1e-5, "dimg")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, segs, Hq, Hkv, D, causal, scale):
+    T = q.shape[0]
+    qf, kf, vf = q.float().view(T, Hq, D), k.float().view(T, Hkv, D), v.float().view(T, Hkv, D)
+    out = torch.zeros(T, Hq, D, device=q.device)
+    lse = torch.full((Hq, T), float("-inf"), device=q.device)
+    grp = Hq // Hkv
+    for s, e in segs:
+        qs, ks, vs = qf[s:e].transpose(0, 1), kf[s:e].transpose(0, 1).repeat_interleave(grp, 0), vf[s:e].transpose(0, 1).repeat_interleave(grp, 0)
+        sc = (qs @ ks.transpose(1, 2)) * scale
+        if causal:
+            n = e - s
+            sc = sc.masked_fill(~torch.ones(n, n, dtype=torch.bool, device=q.device).tril(), float("-inf"))
+        lse[:, s:e] = torch.logsumexp(sc, -1)
+        out[s:e] = (torch.softmax(sc, -1) @ vs).transpose(0, 1)
+    return out.view(T, Hq * D), lse
+
+
+ATTN_CASES = [
+    # D, Hq, Hkv, causal, segments
+    (128, 4, 2, True, [(0, 200), (205, 333), (340, 341), (400, 477)]),
+    (128, 2, 1, True, [(3, 131)]),
+    (128, 16, 2, True, [(0, 768), (768, 1536)]),
+    (80, 2, 2, False, [(0, 64), (64, 128), (128, 176), (176, 192)]),
+    (80, 3, 3, False, [(0, 300), (300, 364), (364, 1388)]),
+    (128, 2, 2, False, [(0, 100)]),
+]
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,causal,segs", ATTN_CASES)
+def test_attn_fwd_bwd(D, Hq, Hkv, causal, segs):
+    T = segs[-1][1] + 5
+    W = (Hq + 2 * Hkv) * D
+    qkv = rnd(T, W, seed=1, scale=1.0)
+    q, k, v = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    scale = D ** -0.5
+    seg = ops.Segments([s for s, _ in segs], [e for _, e in segs], DEV)
+    o, lse = ops.attn_fwd(q, k, v, seg, Hq, Hkv, D, causal, scale)
+    ref_o, ref_lse = _attn_ref(q, k, v, segs, Hq, Hkv, D, causal, scale)
+    inside = torch.zeros(T, dtype=torch.bool, device=DEV)
+    for s, e in segs:
+        inside[s:e] = True
+    close(o[inside], ref_o[inside], 2e-2, 2e-2, "attn o")
+    close(lse[:, inside], ref_lse[:, inside], 1e-3, 1e-2, "attn lse")
+    # backward vs autograd of the fp32 reference
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ro, _ = _attn_ref(qr, kr, vr, segs, Hq, Hkv, D, causal, scale)
+    do = rnd(T, Hq * D, seed=2)
+    do[~inside] = 0
+    ro.backward(do.float())
+    dqkv = torch.zeros(T, W, dtype=BF, device=DEV)
+    ops.attn_bwd(q, k, v, o, do, lse, seg, Hq, Hkv, D, causal, scale, dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:])
+    mag = lambda t: float(t.abs().max())
+    close(dqkv[:, : Hq * D][inside], qr.grad[inside], 3e-2, 2e-2 * mag(qr.grad), "attn dq")
+    close(dqkv[:, Hq * D: (Hq + Hkv) * D][inside], kr.grad[inside], 3e-2, 2e-2 * mag(kr.grad), "attn dk")
+    close(dqkv[:, (Hq + Hkv) * D:][inside], vr.grad[inside], 3e-2, 2e-2 * mag(vr.grad), "attn dv")
+
+
+@pytest.mark.parametrize("Hq,Hkv,B,lens", [(16, 2, 5, [1, 33, 64, 517, 768]), (2, 1, 3, [7, 32, 100]), (28, 4, 2, [300, 31])])
+def test_decode_attention_and_kv_store(Hq, Hkv, B, lens):
+    D = 128
+    maxp = (max(lens) + 31) // 32
+    npages = B * maxp + 3
+    kc = torch.zeros(npages, Hkv, 32, D, dtype=BF, device=DEV)
+    vc = torch.zeros(npages, Hkv, D, 32, dtype=BF, device=DEV)
+    perm = torch.randperm(npages, generator=torch.Generator().manual_seed(0))[: B * maxp].view(B, maxp).to(torch.int32)
+    ks, vs, slots = [], [], []
+    for b, n in enumerate(lens):
+        ks.append(rnd(n, Hkv * D, seed=10 + b))
+        vs.append(rnd(n, Hkv * D, seed=20 + b))
+        pos = torch.arange(n)
+        slots.append(perm[b, pos // 32].long() * 32 + pos % 32)
+    kall, vall, slot = torch.cat(ks), torch.cat(vs), torch.cat(slots).to(DEV)
+    slot_pad = torch.cat([slot, torch.tensor([-1], device=DEV)])  # a skipped (padding) row
+    kall2, vall2 = torch.cat([kall, rnd(1, Hkv * D, seed=99)]), torch.cat([vall, rnd(1, Hkv * D, seed=98)])
+    ops.kv_store(kall2, vall2, slot_pad, kc, vc, Hkv, D)
+    q = rnd(B, Hq * D, seed=5)
+    o = ops.attn_decode(q, kc, vc, perm.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), Hq, Hkv, D, D ** -0.5)
+    for b, n in enumerate(lens):
+        qf = q[b].float().view(Hq, 1, D)
+        kf = ks[b].float().view(n, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+        vf = vs[b].float().view(n, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+        ref = (torch.softmax(qf @ kf.transpose(1, 2) * D ** -0.5, -1) @ vf).reshape(Hq * D)
+        close(o[b], ref, 2e-2, 2e-2, f"decode b={b} n={n}")
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def test_logprob_dlogits_grpo():
+    R, V = 37, 1288
+    lg = rnd(R, V, seed=1, scale=3.0, dtype=F32)
+    tg = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    tg[3] = -100
+    logp, lse = ops.logprob_rows(lg, tg)
+    lp = torch.log_softmax(lg, -1)
+    ref = lp.gather(1, tg.clamp(min=0).view(-1, 1)).squeeze(1)
+    ref[3] = 0
+    close(logp, ref, 1e-5, 1e-5, "logp")
+    close(lse, torch.logsumexp(lg, -1), 1e-6, 1e-5, "lse")
+    g = rnd(R, seed=3, dtype=F32)
+    dl = ops.dlogits_rows(lg, tg, lse, g)
+    oh = torch.zeros(R, V, device=DEV)
+    oh[torch.arange(R, device=DEV)[tg >= 0], tg[tg >= 0]] = 1
+    close(dl, g.view(-1, 1) * (oh - torch.softmax(lg, -1)), 1e-2, 1e-4, "dlogits")
+    N, C = 8, 12
+    p = (rnd(N, C, seed=4, dtype=F32) * 0.3 - 2).requires_grad_(True)
+    r = p.detach() + rnd(N, C, seed=5, dtype=F32) * 0.1
+    adv = rnd(N, seed=6, dtype=F32)
+    mask = (torch.rand(N, C, generator=torch.Generator().manual_seed(7)) > 0.3).int().to(DEV)
+    mask[:, 0] = 1
+    kl = torch.exp(r - p) - (r - p) - 1
+    ptl = -(torch.exp(p - p.detach()) * adv.unsqueeze(1) - 0.04 * kl)
+    loss = ((ptl * mask).sum(1) / mask.sum(1)).mean()
+    loss.backward()
+    dlogp, klo, row_loss, row_kl = ops.grpo_loss(p.detach(), r, adv, mask, 0.04)
+    close(dlogp, p.grad, 1e-4, 1e-7, "dlogp")
+    close(klo, kl.detach(), 1e-4, 1e-7, "kl")
+    close(row_loss.mean(), loss.detach(), 1e-5, 1e-7, "loss")
+    close(row_kl.mean(), ((kl * mask).sum(1) / mask.sum(1)).mean().detach(), 1e-5, 1e-7, "mean kl")
+
+
+def test_adamw_matches_torch():
+    from iadr1_amd import hip
+    n = 10007
+    w0 = rnd(n, seed=1, dtype=F32)
+    master, m, v = w0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.empty(n, dtype=BF, device=DEV)
+    wt = w0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([wt], lr=1e-2, weight_decay=0.1)
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step, dtype=F32) * 3
+        wt.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([wt], 1.0)
+        opt.step()
+        grad = g.clone()
+        norm2 = torch.zeros(1, device=DEV)
+        hip.call("sumsq_acc", grad, n, norm2)
+        close(norm2[0], (g * g).sum(), 1e-4, 1e-3, "sumsq")
+        hip.call("adamw_flat", master, m, v, grad, pb, n, 1e-2, 0.9, 0.999, 1e-8, 0.1, step, 1.0, norm2, 1.0)
+        assert float(grad.abs().sum()) == 0.0
+        close(master, wt.detach(), 1e-5, 1e-6, f"adamw step {step}")
+        assert torch.equal(pb, master.to(BF))
+
+
+# ------------------------------------------------------------------------------------------------ sampler
+def test_sampler_greedy_and_topk_topp():
+    from oracle import sampler as osamp
+    B, V = 16, 5000
+    lg = rnd(B, V, seed=1, scale=2.5, dtype=F32)
+    lg[2, 17] = lg[2, 4000] = 50.0  # tie: lowest index wins
+    out = ops.sample(lg, 0.0, 50, 0.9, seed=1, step=0)
+    assert out.tolist() == lg.argmax(-1).tolist() and out[2].item() == 17
+    sup = int(lg[5].argmax())
+    out2 = ops.sample(lg, 0.0, 50, 0.9, seed=1, step=0, suppress_token=sup)
+    assert out2[5].item() != sup
+    lgc = lg.cpu().numpy()
+    mism = 0
+    for step in range(20):
+        got = ops.sample(lg, 0.9, 50, 0.9, seed=1234567890123, step=step).tolist()
+        for b in range(B):
+            ids, _ = osamp.candidates(lgc[b], 0.9, 50, 0.9)
+            assert got[b] in set(ids.tolist()), "sampled token outside the top-k/top-p candidate set"
+            ref, margin = osamp.sample_row(lgc[b], 0.9, 50, 0.9, 1234567890123, b, step)
+            if margin > 1e-4:
+                mism += got[b] != ref
+    assert mism == 0
+    # device-resident step counter gives the same stream as the argument
+    sp = torch.tensor([7], dtype=torch.int32, device=DEV)
+    assert torch.equal(ops.sample(lg, 0.9, 50, 0.9, seed=5, step=0, step_ptr=sp), ops.sample(lg, 0.9, 50, 0.9, seed=5, step=7))
