@@ -335,3 +335,57 @@ extern "C" int iadr1_transpose_bf16(const void* in, long long ldi, void* out, lo
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C);
     return iadr1_check_launch("transpose_bf16");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Rollout bookkeeping kept ON DEVICE so that one decode step is a fixed launch sequence (hipGraph replay):
+// rope_table: cos/sin rows for the current text positions (all three M-RoPE components equal for text,
+//   TF:modeling_qwen2_5_vl.py:1165-1176: pos = kv_len + rope_delta).
+// decode_advance: append the sampled token, EOS/pad handling as the reference's padded completions
+//   (REF:train/stage_rl/trainer/sc_grpo_trainer.py:680-683,722-726), bump positions / cache slots / step.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void rope_table_kernel(const int* pos, const float* inv_freq, float* cs, float* sn, int B, int half) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    const float a = (float)pos[b] * inv_freq[j];
+    cs[i] = cosf(a);
+    sn[i] = sinf(a);
+}
+
+__global__ __launch_bounds__(256) void decode_advance_kernel(const long long* sampled, long long* cur_tok, long long* out_tokens, int C,
+                                                             int* pos, int* ctx_len, long long* slot, const int* block_table,
+                                                             int max_pages, int* finished, unsigned* step, int eos, int pad, int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const unsigned st = *step;
+    if (b < B) {
+        long long tok = sampled[b];
+        if (finished[b]) tok = pad;
+        else if (eos >= 0 && tok == eos) finished[b] = 1;
+        if ((int)st < C) out_tokens[(long long)b * C + st] = tok;
+        cur_tok[b] = tok;
+        pos[b] += 1;
+        const int n = ctx_len[b];  // keys already in the cache (includes the token just processed)
+        ctx_len[b] = n + 1;
+        slot[b] = (long long)block_table[(long long)b * max_pages + n / 32] * 32 + (n & 31);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __threadfence();
+        *step = st + 1;
+    }
+}
+}  // namespace
+
+extern "C" int iadr1_rope_table(const int* pos, const float* inv_freq, float* cos_t, float* sin_t, int B, int half, hipStream_t stream) {
+    IADR1_REQUIRE(B > 0 && half > 0, "rope_table: empty");
+    hipLaunchKernelGGL(rope_table_kernel, dim3((B * half + 255) / 256), dim3(256), 0, stream, pos, inv_freq, cos_t, sin_t, B, half);
+    return iadr1_check_launch("rope_table");
+}
+extern "C" int iadr1_decode_advance(const long long* sampled, long long* cur_tok, long long* out_tokens, int C, int* pos, int* ctx_len,
+                                    long long* slot, const int* block_table, int max_pages, int* finished, unsigned* step, int eos,
+                                    int pad, int B, hipStream_t stream) {
+    IADR1_REQUIRE(B > 0 && B <= 256, "decode_advance: B must be in [1,256] (single block so the step bump is ordered)");
+    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(256), 0, stream, sampled, cur_tok, out_tokens, C, pos, ctx_len, slot, block_table, max_pages, finished, step, eos, pad, B);
+    return iadr1_check_launch("decode_advance");
+}

@@ -217,81 +217,94 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_128(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Skinny GEMM for the rollout decode step:  Y[M<=64.., N] += X[M,K] . W[N,K]^T  with fp32 atomics.
-// HBM-bound weight stream (6.17 GB of bf16 weights per decode step for 3B):
-// one wave = one (32-column, K-slice) work item, W fragments loaded straight HBM->VGPR (16 B per lane,
-// streamed once, non-temporal), X fragments from L2, fp32 partial sums combined with global atomics into
-// a zero-initialised fp32 buffer that the next fused kernel consumes (and re-zeroes).
+// Skinny GEMM for the rollout decode step:  Y[M<=64 per grid.z, N] = X[M,K] . W[N,K]^T (+ bias).
+// HBM-bound weight stream (6.17 GB of bf16 weights per decode step for 3B).
+// Block = 4 waves that share 16*NB output columns and split K four ways (interleaved 64-wide slabs, so
+// the block streams whole 128-byte lines of each W row); W fragments go straight HBM->VGPR with
+// non-temporal 16-byte loads, several slabs in flight per wave; X fragments come from L2.  The four
+// partial 64 x 16NB tiles are combined through LDS and leave as bf16 (or fp32 logits) -- no atomics,
+// no zero-init, bias fused.
 // ------------------------------------------------------------------------------------------------------
 struct SkinnyArgs {
     const bf16_t* X;
     const bf16_t* W;
-    float* Y;
+    void* Y;
+    const bf16_t* bias;
     int M, N, K;
     long long ldx, ldw, ldy;
-    int ksplit;      // number of K slices (grid.y)
-    int kslice;      // K elements per slice (multiple of 64)
+    int out_f32;
 };
 
+template <int NB, int U>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
+    __shared__ float red[4][64][16 * NB + 1];
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int lm = l & 15, lq = l >> 4;
-    const int n0 = (blockIdx.x * 4 + w) * 32;  // this wave's 32 output columns
-    if (n0 >= p.N) return;
-    const int m_base = blockIdx.z * 64;
-    const int k_begin = blockIdx.y * p.kslice;
-    const int k_end = min(p.K, k_begin + p.kslice);
+    const int n0 = blockIdx.x * 16 * NB;
+    const int m_base = blockIdx.y * 64;
 
-    f32x4_t acc[4][2];
+    f32x4_t acc[4][NB];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const bf16_t* wrow[2];
+    const bf16_t* wrow[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wrow[j] = p.W + (long long)min(n0 + j * 16 + lm, p.N - 1) * p.ldw + lq * 8;
+    for (int j = 0; j < NB; ++j) wrow[j] = p.W + (long long)min(n0 + j * 16 + lm, p.N - 1) * p.ldw + lq * 8;
     const bf16_t* xrow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) xrow[i] = p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
 
-    for (int k = k_begin; k < k_end; k += 64) {
-        bf16x8_t wf[2][2], xf[4][2];
+    // wave w owns the 64-wide K slabs w, w+4, w+8, ...; U slabs are fetched per trip
+    for (int kb = w * 64; kb < p.K; kb += 4 * 64 * U) {
+        bf16x8_t wf[U][2][NB], xf[U][2][4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bool ok = k + kk * 32 + lq * 8 < k_end;
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                u32x4_t v = {0, 0, 0, 0};
-                if (ok) v = __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + k + kk * 32));
-                wf[j][kk] = __builtin_bit_cast(bf16x8_t, v);
+            for (int kk = 0; kk < 2; ++kk) {
+                const int k = kb + u * 256 + kk * 32;
+                const bool ok = k + lq * 8 < p.K;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    u32x4_t v = {0, 0, 0, 0};
+                    if (ok) v = __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + k));
+                    wf[u][kk][j] = __builtin_bit_cast(bf16x8_t, v);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32x4_t v = {0, 0, 0, 0};
+                    if (ok) v = *(const u32x4_t*)(xrow[i] + k);
+                    xf[u][kk][i] = __builtin_bit_cast(bf16x8_t, v);
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u32x4_t v = {0, 0, 0, 0};
-                if (ok) v = *(const u32x4_t*)(xrow[i] + k + kk * 32);
-                xf[i][kk] = __builtin_bit_cast(bf16x8_t, v);
-            }
-        }
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], xf[i][kk], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][kk][j], xf[u][kk][i], acc[i][j], 0, 0, 0);
     }
+    // lane owns rows n = j*16 + lq*4 + e of column m = i*16 + lm  (swapped-operand C layout)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m_base + i * 16 + lm;
-        if (gm >= p.M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gn = n0 + j * 16 + lq * 4 + e;
-                if (gn < p.N) atomicAdd(p.Y + (long long)gm * p.ldy + gn, acc[i][j][e]);
-            }
+            for (int e = 0; e < 4; ++e) red[w][i * 16 + lm][j * 16 + lq * 4 + e] = acc[i][j][e];
+    __syncthreads();
+    constexpr int BNC = 16 * NB;
+    for (int idx = t; idx < 64 * BNC; idx += 256) {
+        const int m = idx / BNC, n = idx - m * BNC;
+        const int gm = m_base + m, gn = n0 + n;
+        if (gm >= p.M || gn >= p.N) continue;
+        float v = red[0][m][n] + red[1][m][n] + red[2][m][n] + red[3][m][n];
+        if (p.bias) v += bf2f(p.bias[gn]);
+        if (p.out_f32) ((float*)p.Y)[(long long)gm * p.ldy + gn] = v;
+        else ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
     }
 }
 
@@ -326,19 +339,14 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     return iadr1_check_launch("gemm_nt_bf16");
 }
 
-extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, float* Y, int M, int N, int K, long long ldx,
-                                      long long ldw, long long ldy, hipStream_t stream) {
+extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
+                                      long long ldw, long long ldy, int out_f32, hipStream_t stream) {
     IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_skinny: empty problem");
     IADR1_REQUIRE((K % 8) == 0 && (ldx % 8) == 0 && (ldw % 8) == 0, "gemm_skinny: K, ldx, ldw must be multiples of 8");
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_skinny: X/W must be 16-byte aligned");
-    const int nblk = (N + 127) / 128;
-    // enough work items to cover 256 CUs a few times over: split K until >= 1024 waves
-    int ksplit = 1;
-    const int kt = (K + 63) / 64;
-    while (nblk * 4 * ksplit < 1024 && ksplit * 2 <= kt && ksplit < 16) ksplit *= 2;
-    const int kslice = ((kt + ksplit - 1) / ksplit) * 64;
-    ksplit = (K + kslice - 1) / kslice;
-    SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, M, N, K, ldx, ldw, ldy, ksplit, kslice};
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(nblk, ksplit, (M + 63) / 64), dim3(256), 0, stream, p);
+    SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, (const bf16_t*)bias, M, N, K, ldx, ldw, ldy, out_f32};
+    const int mz = (M + 63) / 64;
+    if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), dim3((N + 31) / 32, mz), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), dim3((N + 15) / 16, mz), dim3(256), 0, stream, p);
     return iadr1_check_launch("gemm_skinny_bf16");
 }

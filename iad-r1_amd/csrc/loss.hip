@@ -112,9 +112,9 @@ extern "C" int iadr1_dlogits_rows(const float* logits, long long ld, const long 
     hipLaunchKernelGGL(dlogits_rows_kernel, dim3(gx, R), dim3(256), 0, stream, logits, ld, targets, lse, g, (bf16_t*)dl, ldd, R, V);
     return iadr1_check_launch("dlogits_rows");
 }
-extern "C" int iadr1_grpo_loss(const float* logp, const float* ref_logp, const float* adv, const int* mask, float beta, float* dlogp,
-                               float* kl, float* row_loss, float* row_kl, int N, int C, hipStream_t stream) {
-    IADR1_REQUIRE(N > 0 && C > 0, "grpo_loss: empty");
-    hipLaunchKernelGGL(grpo_loss_kernel, dim3(N), dim3(256), 0, stream, logp, ref_logp, adv, mask, beta, 1.f / (float)N, dlogp, kl, row_loss, row_kl, N, C);
+extern "C" int iadr1_grpo_loss(const float* logp, const float* ref_logp, const float* adv, const int* mask, float beta, int n_total_rows,
+                               float* dlogp, float* kl, float* row_loss, float* row_kl, int N, int C, hipStream_t stream) {
+    IADR1_REQUIRE(N > 0 && C > 0 && n_total_rows >= N, "grpo_loss: need 0 < N <= n_total_rows");
+    hipLaunchKernelGGL(grpo_loss_kernel, dim3(N), dim3(256), 0, stream, logp, ref_logp, adv, mask, beta, 1.f / (float)n_total_rows, dlogp, kl, row_loss, row_kl, N, C);
     return iadr1_check_launch("grpo_loss");
 }

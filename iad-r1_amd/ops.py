@@ -29,12 +29,14 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
-def gemm_skinny(x, w, y32):
-    """y32[M,N] (fp32, pre-zeroed) += x[M,K] @ w[N,K]^T"""
+def gemm_skinny(x, w, bias=None, out=None, out_dtype=BF16):
+    """out[M,N] = x[M,K] @ w[N,K]^T + bias   (decode-time, HBM-bound weight stream)"""
     M, K = x.shape
     N = w.shape[0]
-    hip.call("gemm_skinny_bf16", x, w, y32, M, N, K, _ld(x), _ld(w), _ld(y32))
-    return y32
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    hip.call("gemm_skinny_bf16", x, w, out, bias, M, N, K, _ld(x), _ld(w), _ld(out), 1 if out.dtype == F32 else 0)
+    return out
 
 
 def transpose(x, out=None):
@@ -185,14 +187,14 @@ def dlogits_rows(logits32, targets, lse, g, out=None):
     return dl
 
 
-def grpo_loss(logp, ref_logp, adv, mask, beta):
+def grpo_loss(logp, ref_logp, adv, mask, beta, n_total_rows=None):
     N, C = logp.shape
     dev = logp.device
     dlogp = torch.empty(N, C, dtype=F32, device=dev)
     kl = torch.empty(N, C, dtype=F32, device=dev)
     row_loss = torch.empty(N, dtype=F32, device=dev)
     row_kl = torch.empty(N, dtype=F32, device=dev)
-    hip.call("grpo_loss", logp, ref_logp, adv, mask, float(beta), dlogp, kl, row_loss, row_kl, N, C)
+    hip.call("grpo_loss", logp, ref_logp, adv, mask, float(beta), int(n_total_rows or N), dlogp, kl, row_loss, row_kl, N, C)
     return dlogp, kl, row_loss, row_kl
 
 
@@ -201,3 +203,13 @@ def sample(logits32, temperature, top_k, top_p, seed, step, suppress_token=-1, s
     o = out if out is not None else torch.empty(B, dtype=torch.int64, device=logits32.device)
     hip.call("sample_topk_topp", logits32, _ld(logits32), o, B, V, float(temperature), int(top_k), float(top_p), int(suppress_token), int(seed), int(step), step_ptr)
     return o
+
+
+def rope_table(pos, inv_freq, cos, sin):
+    B, half = cos.shape
+    hip.call("rope_table", pos, inv_freq, cos, sin, B, half)
+
+
+def decode_advance(sampled, cur_tok, out_tokens, pos, ctx_len, slot, block_table, finished, step, eos, pad):
+    B, C = out_tokens.shape
+    hip.call("decode_advance", sampled, cur_tok, out_tokens, C, pos, ctx_len, slot, block_table, block_table.shape[1], finished, step, int(eos), int(pad), B)

@@ -1,0 +1,373 @@
+"""Model configuration + parameter store for the Qwen2.5-VL engine.
+
+Memory layout (MI355X-first: 288 GB HBM, no sharding): every parameter of the model lives in ONE flat bf16
+buffer (GEMM operands), with fused layouts chosen for the kernels -- q|k|v rows in one matrix, gate|up rows
+in one matrix (ViT widths zero-padded to a multiple of 64) -- plus, for a trainable copy, flat fp32 master /
+Adam m / Adam v / gradient buffers with the same offsets, so the optimizer is one launch per decay group, the
+DDP all-reduce walks one buffer in large buckets, and a transposed shadow ([K,N]) of every GEMM weight is kept
+for the dgrad GEMMs.  Names on the outside are the checkpoint names the reference loads / saves
+(`visual.blocks.N.attn.qkv.weight`, `model.layers.N.self_attn.q_proj.weight`, `lm_head.weight`, ...;
+/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:118-119, grpo_ad.py:203)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class VLMConfig:
+    # text decoder
+    vocab_size: int
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    rms_norm_eps: float
+    rope_theta: float
+    mrope_section: tuple
+    # vision tower
+    v_depth: int
+    v_hidden: int
+    v_inter: int
+    v_heads: int
+    v_in_channels: int
+    v_patch: int
+    v_merge: int
+    v_temporal: int
+    v_window: int
+    v_fullatt: tuple
+    # tokens
+    image_token_id: int
+    vision_start_token_id: int
+    vision_end_token_id: int
+    eos_token_id: int
+    pad_token_id: int
+    tie_word_embeddings: bool
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def v_head_dim(self):
+        return self.v_hidden // self.v_heads
+
+    @property
+    def qkv_width(self):
+        return (self.num_attention_heads + 2 * self.num_key_value_heads) * self.head_dim
+
+    @property
+    def v_inter_pad(self):
+        return _rup(self.v_inter, 64)
+
+    @property
+    def patch_dim(self):
+        return self.v_in_channels * self.v_temporal * self.v_patch * self.v_patch
+
+    @staticmethod
+    def from_dict(d: dict) -> "VLMConfig":
+        """Accepts the nested {text, vision, ...} form of tests/fixture_util.TINY."""
+        t, v = d["text"], d["vision"]
+        return VLMConfig(
+            vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
+            num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
+            num_key_value_heads=t["num_key_value_heads"], rms_norm_eps=t["rms_norm_eps"], rope_theta=t["rope_theta"],
+            mrope_section=tuple(t["mrope_section"]), v_depth=v["depth"], v_hidden=v["hidden_size"], v_inter=v["intermediate_size"],
+            v_heads=v["num_heads"], v_in_channels=v["in_channels"], v_patch=v["patch_size"], v_merge=v["spatial_merge_size"],
+            v_temporal=v["temporal_patch_size"], v_window=v["window_size"], v_fullatt=tuple(v["fullatt_block_indexes"]),
+            image_token_id=d["image_token_id"], vision_start_token_id=d["vision_start_token_id"],
+            vision_end_token_id=d["vision_end_token_id"], eos_token_id=d["eos_token_id"], pad_token_id=d["pad_token_id"],
+            tie_word_embeddings=d.get("tie_word_embeddings", False),
+        )
+
+    @staticmethod
+    def from_hf_config(c: dict) -> "VLMConfig":
+        """config.json of a Qwen2.5-VL checkpoint (flat 4.51-style or nested text_config 5.x-style)."""
+        t = c.get("text_config", c)
+        v = c["vision_config"]
+        rope = t.get("rope_parameters") or t.get("rope_scaling") or c.get("rope_scaling") or {}
+        eos = t.get("eos_token_id", c.get("eos_token_id", 151645))
+        return VLMConfig(
+            vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
+            num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
+            num_key_value_heads=t.get("num_key_value_heads", t["num_attention_heads"]), rms_norm_eps=t.get("rms_norm_eps", 1e-6),
+            rope_theta=float(rope.get("rope_theta", t.get("rope_theta", 1e6))), mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))),
+            v_depth=v["depth"], v_hidden=v["hidden_size"], v_inter=v["intermediate_size"], v_heads=v["num_heads"],
+            v_in_channels=v.get("in_channels", v.get("in_chans", 3)), v_patch=v["patch_size"], v_merge=v["spatial_merge_size"],
+            v_temporal=v["temporal_patch_size"], v_window=v["window_size"], v_fullatt=tuple(v["fullatt_block_indexes"]),
+            image_token_id=c.get("image_token_id", 151655), vision_start_token_id=c.get("vision_start_token_id", 151652),
+            vision_end_token_id=c.get("vision_end_token_id", 151653), eos_token_id=eos[0] if isinstance(eos, (list, tuple)) else eos,
+            pad_token_id=t.get("pad_token_id") or c.get("pad_token_id") or 151643, tie_word_embeddings=c.get("tie_word_embeddings", False),
+        )
+
+    @staticmethod
+    def qwen25vl_3b() -> "VLMConfig":
+        """Qwen2.5-VL-3B-Instruct shapes (public config.json)."""
+        return VLMConfig(
+            vocab_size=151936, hidden_size=2048, intermediate_size=11008, num_hidden_layers=36, num_attention_heads=16,
+            num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=1e6, mrope_section=(16, 24, 24), v_depth=32, v_hidden=1280,
+            v_inter=3420, v_heads=16, v_in_channels=3, v_patch=14, v_merge=2, v_temporal=2, v_window=112, v_fullatt=(7, 15, 23, 31),
+            image_token_id=151655, vision_start_token_id=151652, vision_end_token_id=151653, eos_token_id=151645, pad_token_id=151643,
+            tie_word_embeddings=True,
+        )
+
+    @staticmethod
+    def qwen25vl_7b() -> "VLMConfig":
+        c = VLMConfig.qwen25vl_3b()
+        c.vocab_size, c.hidden_size, c.intermediate_size, c.num_hidden_layers = 152064, 3584, 18944, 28
+        c.num_attention_heads, c.num_key_value_heads, c.tie_word_embeddings = 28, 4, False
+        return c
+
+
+@dataclass
+class _Slot:
+    name: str
+    shape: tuple
+    offset: int
+    decay: bool
+    gemm: bool  # has a transposed shadow
+    t_offset: int = -1
+
+
+class ParamStore:
+    """Flat parameter buffers + named views in the engine's fused layout."""
+
+    def __init__(self, cfg: VLMConfig, device, trainable: bool, with_transposes: bool | None = None):
+        self.cfg, self.device, self.trainable = cfg, torch.device(device), trainable
+        self.with_transposes = trainable if with_transposes is None else with_transposes
+        c = cfg
+        H, I, D = c.hidden_size, c.intermediate_size, c.head_dim
+        vh, vip = c.v_hidden, c.v_inter_pad
+        specs = []  # (name, shape, decay, gemm)
+
+        def add(name, shape, decay, gemm):
+            specs.append((name, tuple(shape), decay, gemm))
+
+        add("visual.patch_embed", (vh, c.patch_dim), True, True)
+        for i in range(c.v_depth):
+            b = f"visual.blocks.{i}."
+            add(b + "norm1", (vh,), False, False)
+            add(b + "qkv.w", (3 * vh, vh), True, True)
+            add(b + "qkv.b", (3 * vh,), False, False)
+            add(b + "proj.w", (vh, vh), True, True)
+            add(b + "proj.b", (vh,), False, False)
+            add(b + "norm2", (vh,), False, False)
+            add(b + "gu.w", (2 * vip, vh), True, True)
+            add(b + "gu.b", (2 * vip,), False, False)
+            add(b + "down.w", (vh, vip), True, True)
+            add(b + "down.b", (vh,), False, False)
+        mu = c.v_merge**2
+        add("visual.merger.ln_q", (vh,), False, False)
+        add("visual.merger.fc1.w", (vh * mu, vh * mu), True, True)
+        add("visual.merger.fc1.b", (vh * mu,), False, False)
+        add("visual.merger.fc2.w", (H, vh * mu), True, True)
+        add("visual.merger.fc2.b", (H,), False, False)
+        add("embed", (c.vocab_size, H), True, True)
+        for i in range(c.num_hidden_layers):
+            b = f"layers.{i}."
+            add(b + "ln1", (H,), False, False)
+            add(b + "qkv.w", (c.qkv_width, H), True, True)
+            add(b + "qkv.b", (c.qkv_width,), False, False)
+            add(b + "o.w", (H, c.num_attention_heads * D), True, True)
+            add(b + "ln2", (H,), False, False)
+            add(b + "gu.w", (2 * I, H), True, True)
+            add(b + "down.w", (H, I), True, True)
+        add("norm", (H,), False, False)
+        if not c.tie_word_embeddings:
+            add("lm_head", (c.vocab_size, H), True, True)
+
+        # decayed tensors first, then the no-decay group (two AdamW launches)
+        order = [s for s in specs if s[2]] + [s for s in specs if not s[2]]
+        self.slots: dict[str, _Slot] = {}
+        off = toff = 0
+        for name, shape, decay, gemm in order:
+            n = int(np.prod(shape))
+            s = _Slot(name, shape, off, decay, gemm)
+            off += _rup(n, 64)
+            if gemm and self.with_transposes:
+                s.t_offset = toff
+                toff += _rup(n, 64)
+            self.slots[name] = s
+        self.n_total = off
+        self.n_decay = sum(_rup(int(np.prod(s[1])), 64) for s in order if s[2])
+        self.flat = torch.zeros(self.n_total, dtype=BF16, device=self.device)
+        self.flat_t = torch.zeros(toff, dtype=BF16, device=self.device) if self.with_transposes else None
+        if trainable:
+            self.master = torch.zeros(self.n_total, dtype=F32, device=self.device)
+            self.m = torch.zeros(self.n_total, dtype=F32, device=self.device)
+            self.v = torch.zeros(self.n_total, dtype=F32, device=self.device)
+            self.grad = torch.zeros(self.n_total, dtype=F32, device=self.device)
+        self._views, self._tviews, self._gviews = {}, {}, {}
+
+    # ---- views -------------------------------------------------------------------------------------------
+    def w(self, name: str) -> torch.Tensor:
+        v = self._views.get(name)
+        if v is None:
+            s = self.slots[name]
+            v = self.flat[s.offset: s.offset + int(np.prod(s.shape))].view(*s.shape)
+            self._views[name] = v
+        return v
+
+    def wT(self, name: str) -> torch.Tensor:
+        """Transposed shadow [K, N] of GEMM weight `name` ([N, K])."""
+        v = self._tviews.get(name)
+        if v is None:
+            s = self.slots[name]
+            assert s.t_offset >= 0, f"{name}: no transposed shadow"
+            v = self.flat_t[s.t_offset: s.t_offset + int(np.prod(s.shape))].view(s.shape[1], s.shape[0])
+            self._tviews[name] = v
+        return v
+
+    def g(self, name: str) -> torch.Tensor:
+        v = self._gviews.get(name)
+        if v is None:
+            s = self.slots[name]
+            v = self.grad[s.offset: s.offset + int(np.prod(s.shape))].view(*s.shape)
+            self._gviews[name] = v
+        return v
+
+    def lm_head_name(self):
+        return "embed" if self.cfg.tie_word_embeddings else "lm_head"
+
+    def refresh_transposes(self):
+        if not self.with_transposes:
+            return
+        for name, s in self.slots.items():
+            if s.t_offset >= 0:
+                ops.transpose(self.w(name), out=self.wT(name))
+
+    def sync_master_from_bf16(self):
+        from . import hip
+        hip.call("cast_bf16_to_f32", self.flat, self.master, self.n_total)
+
+    # ---- checkpoint-name <-> fused layout -----------------------------------------------------------------------------
+    def _assign(self, name, tensor):
+        dst = self.w(name)
+        src = torch.as_tensor(tensor)
+        assert tuple(src.shape) == tuple(dst.shape), (name, tuple(src.shape), tuple(dst.shape))
+        dst.copy_(src.to(BF16))
+
+    def load_named(self, sd: dict):
+        """`sd`: checkpoint-name -> array/tensor (HF Qwen2.5-VL names)."""
+        c = self.cfg
+        t = lambda k: torch.as_tensor(sd[k]).float()
+        vi, vip = c.v_inter, c.v_inter_pad
+        self._assign("visual.patch_embed", t("visual.patch_embed.proj.weight").reshape(c.v_hidden, -1))
+        for i in range(c.v_depth):
+            s, b = f"visual.blocks.{i}.", f"visual.blocks.{i}."
+            self._assign(b + "norm1", t(s + "norm1.weight"))
+            self._assign(b + "norm2", t(s + "norm2.weight"))
+            self._assign(b + "qkv.w", t(s + "attn.qkv.weight"))
+            self._assign(b + "qkv.b", t(s + "attn.qkv.bias"))
+            self._assign(b + "proj.w", t(s + "attn.proj.weight"))
+            self._assign(b + "proj.b", t(s + "attn.proj.bias"))
+            gu = torch.zeros(2 * vip, c.v_hidden)
+            gu[:vi] = t(s + "mlp.gate_proj.weight")
+            gu[vip: vip + vi] = t(s + "mlp.up_proj.weight")
+            gb = torch.zeros(2 * vip)
+            gb[:vi] = t(s + "mlp.gate_proj.bias")
+            gb[vip: vip + vi] = t(s + "mlp.up_proj.bias")
+            dn = torch.zeros(c.v_hidden, vip)
+            dn[:, :vi] = t(s + "mlp.down_proj.weight")
+            self._assign(b + "gu.w", gu)
+            self._assign(b + "gu.b", gb)
+            self._assign(b + "down.w", dn)
+            self._assign(b + "down.b", t(s + "mlp.down_proj.bias"))
+        self._assign("visual.merger.ln_q", t("visual.merger.ln_q.weight"))
+        self._assign("visual.merger.fc1.w", t("visual.merger.mlp.0.weight"))
+        self._assign("visual.merger.fc1.b", t("visual.merger.mlp.0.bias"))
+        self._assign("visual.merger.fc2.w", t("visual.merger.mlp.2.weight"))
+        self._assign("visual.merger.fc2.b", t("visual.merger.mlp.2.bias"))
+        self._assign("embed", t("model.embed_tokens.weight"))
+        for i in range(c.num_hidden_layers):
+            s, b = f"model.layers.{i}.", f"layers.{i}."
+            self._assign(b + "ln1", t(s + "input_layernorm.weight"))
+            self._assign(b + "ln2", t(s + "post_attention_layernorm.weight"))
+            self._assign(b + "qkv.w", torch.cat([t(s + "self_attn.q_proj.weight"), t(s + "self_attn.k_proj.weight"), t(s + "self_attn.v_proj.weight")], 0))
+            self._assign(b + "qkv.b", torch.cat([t(s + "self_attn.q_proj.bias"), t(s + "self_attn.k_proj.bias"), t(s + "self_attn.v_proj.bias")], 0))
+            self._assign(b + "o.w", t(s + "self_attn.o_proj.weight"))
+            self._assign(b + "gu.w", torch.cat([t(s + "mlp.gate_proj.weight"), t(s + "mlp.up_proj.weight")], 0))
+            self._assign(b + "down.w", t(s + "mlp.down_proj.weight"))
+        self._assign("norm", t("model.norm.weight"))
+        if not c.tie_word_embeddings:
+            self._assign("lm_head", t("lm_head.weight"))
+        self.finalize()
+
+    def finalize(self):
+        if self.trainable:
+            self.sync_master_from_bf16()
+        self.refresh_transposes()
+
+    def export_named(self, source: str = "param") -> dict:
+        """Inverse of load_named (bf16 params, or fp32 `grad` views for tests): checkpoint-name -> CPU tensor."""
+        c = self.cfg
+        get = (lambda n: self.w(n).float().cpu()) if source == "param" else (lambda n: self.g(n).float().cpu())
+        vi, vip = c.v_inter, c.v_inter_pad
+        out = {}
+        out["visual.patch_embed.proj.weight"] = get("visual.patch_embed").view(c.v_hidden, c.v_in_channels, c.v_temporal, c.v_patch, c.v_patch)
+        for i in range(c.v_depth):
+            s, b = f"visual.blocks.{i}.", f"visual.blocks.{i}."
+            out[s + "norm1.weight"], out[s + "norm2.weight"] = get(b + "norm1"), get(b + "norm2")
+            out[s + "attn.qkv.weight"], out[s + "attn.qkv.bias"] = get(b + "qkv.w"), get(b + "qkv.b")
+            out[s + "attn.proj.weight"], out[s + "attn.proj.bias"] = get(b + "proj.w"), get(b + "proj.b")
+            gu, gb, dn = get(b + "gu.w"), get(b + "gu.b"), get(b + "down.w")
+            out[s + "mlp.gate_proj.weight"], out[s + "mlp.up_proj.weight"] = gu[:vi].clone(), gu[vip: vip + vi].clone()
+            out[s + "mlp.gate_proj.bias"], out[s + "mlp.up_proj.bias"] = gb[:vi].clone(), gb[vip: vip + vi].clone()
+            out[s + "mlp.down_proj.weight"], out[s + "mlp.down_proj.bias"] = dn[:, :vi].clone(), get(b + "down.b")
+        out["visual.merger.ln_q.weight"] = get("visual.merger.ln_q")
+        out["visual.merger.mlp.0.weight"], out["visual.merger.mlp.0.bias"] = get("visual.merger.fc1.w"), get("visual.merger.fc1.b")
+        out["visual.merger.mlp.2.weight"], out["visual.merger.mlp.2.bias"] = get("visual.merger.fc2.w"), get("visual.merger.fc2.b")
+        out["model.embed_tokens.weight"] = get("embed")
+        hq, hk = c.num_attention_heads * c.head_dim, c.num_key_value_heads * c.head_dim
+        for i in range(c.num_hidden_layers):
+            s, b = f"model.layers.{i}.", f"layers.{i}."
+            out[s + "input_layernorm.weight"], out[s + "post_attention_layernorm.weight"] = get(b + "ln1"), get(b + "ln2")
+            qw, qb = get(b + "qkv.w"), get(b + "qkv.b")
+            out[s + "self_attn.q_proj.weight"], out[s + "self_attn.k_proj.weight"], out[s + "self_attn.v_proj.weight"] = qw[:hq].clone(), qw[hq: hq + hk].clone(), qw[hq + hk:].clone()
+            out[s + "self_attn.q_proj.bias"], out[s + "self_attn.k_proj.bias"], out[s + "self_attn.v_proj.bias"] = qb[:hq].clone(), qb[hq: hq + hk].clone(), qb[hq + hk:].clone()
+            out[s + "self_attn.o_proj.weight"] = get(b + "o.w")
+            gu = get(b + "gu.w")
+            out[s + "mlp.gate_proj.weight"], out[s + "mlp.up_proj.weight"] = gu[: c.intermediate_size].clone(), gu[c.intermediate_size:].clone()
+            out[s + "mlp.down_proj.weight"] = get(b + "down.w")
+        out["model.norm.weight"] = get("norm")
+        if not c.tie_word_embeddings:
+            out["lm_head.weight"] = get("lm_head")
+        return out
+
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        """Random-init weights of the architecture (benchmarks; no checkpoints exist offline): N(0, std) matrices,
+        unit norm gains, zero biases; padded regions stay zero."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        c = self.cfg
+        for name, s in self.slots.items():
+            v = self.w(name)
+            if name.endswith(("norm1", "norm2", "ln1", "ln2", "ln_q")) or name == "norm":
+                v.fill_(1.0)
+            elif name.endswith(".b"):
+                v.zero_()
+            else:
+                v.copy_((torch.randn(v.shape, generator=g, device=self.device, dtype=F32) * std).to(BF16))
+        vi, vip = c.v_inter, c.v_inter_pad
+        if vip != vi:
+            for i in range(c.v_depth):
+                b = f"visual.blocks.{i}."
+                self.w(b + "gu.w")[vi:vip].zero_()
+                self.w(b + "gu.w")[vip + vi:].zero_()
+                self.w(b + "down.w")[:, vi:].zero_()
+        self.finalize()
+
+    def copy_from(self, other: "ParamStore"):
+        self.flat.copy_(other.flat)
+        self.finalize()

@@ -1,0 +1,191 @@
+"""GRPO group rollout: the in-process replacement for the reference's vLLM engine on a side GPU
+(/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:314-358 construction, :637-683 call).
+
+  * shares the policy's weights (no `_move_model_to_vllm` weight push, REF:569-579);
+  * prefill runs once per PROMPT with the training kernels and writes K/V into a paged cache; the G
+    completions of a prompt share its full prompt pages through the block table (what vLLM's
+    `enable_prefix_caching=True` buys the reference, REF:351);
+  * one decode step is a fixed launch sequence over static buffers -- embed, per layer {RMSNorm(+residual),
+    skinny qkv GEMM, RoPE, KV append, paged attention, skinny o GEMM, RMSNorm, skinny gate|up, SwiGLU, skinny
+    down}, final norm, lm_head, fused top-k/top-p sampler, bookkeeping -- captured ONCE in a hipGraph
+    (torch.cuda.CUDAGraph) and replayed max_completion_length-1 times; positions, cache slots, context
+    lengths, the RNG step and the EOS state all live on the device.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .vlm import Engine, TextPlan
+
+BF16, F32 = torch.bfloat16, torch.float32
+PAGE = 32
+
+
+class Rollout:
+    def __init__(self, engine: Engine, max_seqs: int, max_prompt: int, max_new: int, max_prompts: int | None = None, use_graph: bool = True):
+        self.e = engine
+        c = engine.cfg
+        dev = engine.dev
+        self.N, self.max_new, self.use_graph = max_seqs, max_new, use_graph
+        L, H, D, Hq, Hkv, I, V = c.num_hidden_layers, c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads, c.intermediate_size, c.vocab_size
+        max_prompts = max_prompts or max_seqs
+        self.max_pages = (max_prompt + max_new + PAGE - 1) // PAGE + 1
+        # page pool: shared prompt pages + private pages (tail of the prompt + completion) per sequence
+        self.n_pages = max_prompts * ((max_prompt + PAGE - 1) // PAGE) + max_seqs * ((max_new + 2 * PAGE - 1) // PAGE + 1) + 1
+        self.kc = torch.zeros(L, self.n_pages, Hkv, PAGE, D, dtype=BF16, device=dev)
+        self.vc = torch.zeros(L, self.n_pages, Hkv, D, PAGE, dtype=BF16, device=dev)
+        N = max_seqs
+        i32, i64 = torch.int32, torch.int64
+        self.block_table = torch.zeros(N, self.max_pages, dtype=i32, device=dev)
+        self.pos = torch.zeros(N, dtype=i32, device=dev)
+        self.ctx_len = torch.zeros(N, dtype=i32, device=dev)
+        self.slot = torch.zeros(N, dtype=i64, device=dev)
+        self.finished = torch.zeros(N, dtype=i32, device=dev)
+        self.step = torch.zeros(1, dtype=i32, device=dev)
+        self.cur_tok = torch.zeros(N, dtype=i64, device=dev)
+        self.sampled = torch.zeros(N, dtype=i64, device=dev)
+        self.out_tokens = torch.zeros(N, max_new, dtype=i64, device=dev)
+        # activations of one decode step
+        self.x = torch.empty(N, H, dtype=BF16, device=dev)
+        self.h = torch.empty(N, H, dtype=BF16, device=dev)
+        self.qkv = torch.empty(N, c.qkv_width, dtype=BF16, device=dev)
+        self.o = torch.empty(N, Hq * D, dtype=BF16, device=dev)
+        self.br = torch.empty(N, H, dtype=BF16, device=dev)
+        self.gu = torch.empty(N, 2 * I, dtype=BF16, device=dev)
+        self.a = torch.empty(N, I, dtype=BF16, device=dev)
+        self.logits = torch.empty(N, V, dtype=F32, device=dev)
+        self.cos = torch.empty(N, D // 2, dtype=F32, device=dev)
+        self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
+        self.graph = None
+        self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
+
+    # ---- one decode step (graph body) -------------------------------------------------------------------------
+    def _decode_step(self):
+        e, c, P = self.e, self.e.cfg, self.e.p
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        qw, kw = Hq * D, Hkv * D
+        s = self.sampling
+        ops.embed_fwd(self.cur_tok, None, P.w("embed"), None, out=self.x)
+        ops.rope_table(self.pos, e.inv_freq, self.cos, self.sin)
+        branch = None
+        for i in range(c.num_hidden_layers):
+            b = f"layers.{i}."
+            if branch is None:
+                ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h)
+            else:
+                ops.rmsnorm_fwd(branch, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, out=self.h)
+            ops.gemm_skinny(self.h, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=self.qkv)
+            ops.rope_(self.qkv, self.cos, self.sin, Hq + Hkv, D)
+            ops.kv_store(self.qkv[:, qw: qw + kw], self.qkv[:, qw + kw:], self.slot, self.kc[i], self.vc[i], Hkv, D)
+            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o)
+            ops.gemm_skinny(self.o, P.w(b + "o.w"), out=self.br)
+            ops.rmsnorm_fwd(self.br, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, out=self.h)
+            ops.gemm_skinny(self.h, P.w(b + "gu.w"), out=self.gu)
+            ops.swiglu_fwd(self.gu, out=self.a)
+            ops.gemm_skinny(self.a, P.w(b + "down.w"), out=self.br)
+            branch = self.br
+        ops.rmsnorm_fwd(branch, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, out=self.h)
+        ops.gemm_skinny(self.h, P.w(P.lm_head_name()), out=self.logits)
+        self._sample_and_advance()
+
+    def _sample_and_advance(self):
+        s = self.sampling
+        ops.sample(self.logits, s["temperature"], s["top_k"], s["top_p"], s["seed"], 0, suppress_token=s["suppress"], step_ptr=self.step, out=self.sampled)
+        ops.decode_advance(self.sampled, self.cur_tok, self.out_tokens, self.pos, self.ctx_len, self.slot, self.block_table, self.finished, self.step, s["eos"], s["pad"])
+
+    def _capture(self):
+        # warm-up on a side stream (first-call attribute setup must not happen under capture), then capture once
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._decode_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_step()
+        self.graph = g
+
+    # ---- public ---------------------------------------------------------------------------------------------------
+    def generate(self, plan: TextPlan, img_embeds, G: int, max_new: int, temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress_eos=False,
+                 stop_at_eos=True) -> torch.Tensor:
+        """plan: the Bp left-padded prompts.  Returns completion ids [Bp*G, max_new] (prompt-major order: p0 x G,
+        p1 x G, ...), pad after the first EOS."""
+        e, c = self.e, self.e.cfg
+        dev = e.dev
+        Bp, S = plan.B, plan.S
+        N = Bp * G
+        assert N == self.N, f"rollout was built for {self.N} sequences, got {N}"
+        assert max_new <= self.max_new
+        sampling = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p), seed=int(seed),
+                        suppress=c.eos_token_id if suppress_eos else -1, eos=c.eos_token_id if stop_at_eos and not suppress_eos else -1, pad=c.pad_token_id)
+        if sampling != self.sampling:
+            self.sampling = sampling
+            self.graph = None  # sampling parameters are kernel arguments frozen in the graph
+        lengths = plan.lengths
+        # ---- page tables ------------------------------------------------------------------------------------
+        next_page = 1  # page 0 is a scratch page for unused table entries
+        bt = np.zeros((N, self.max_pages), dtype=np.int32)
+        slot_shared = np.full(Bp * S, -1, dtype=np.int64)
+        slot_tail = np.full((G, Bp * S), -1, dtype=np.int64)
+        any_tail = False
+        for b in range(Bp):
+            n = int(lengths[b])
+            full = n // PAGE
+            shared = list(range(next_page, next_page + full))
+            next_page += full
+            first = S - n  # left padding
+            for j in range(full * PAGE):
+                slot_shared[b * S + first + j] = shared[j // PAGE] * PAGE + j % PAGE
+            priv = (n - full * PAGE + max_new + PAGE - 1) // PAGE + 1
+            for gi in range(G):
+                r = b * G + gi
+                pages = shared + list(range(next_page, next_page + priv))
+                next_page += priv
+                assert len(pages) <= self.max_pages and next_page <= self.n_pages, "KV page pool too small"
+                bt[r, : len(pages)] = pages
+                for j in range(full * PAGE, n):
+                    slot_tail[gi, b * S + first + j] = pages[j // PAGE] * PAGE + j % PAGE
+                    any_tail = True
+        self.block_table.copy_(torch.from_numpy(bt))
+        slot_shared_d = torch.from_numpy(slot_shared).to(dev)
+        slot_tail_d = torch.from_numpy(slot_tail).to(dev) if any_tail else None
+        Hkv, D = c.num_key_value_heads, c.head_dim
+
+        def kv_sink(i, k, v):
+            ops.kv_store(k, v, slot_shared_d, self.kc[i], self.vc[i], Hkv, D)
+            if slot_tail_d is not None:
+                for gi in range(G):
+                    ops.kv_store(k, v, slot_tail_d[gi], self.kc[i], self.vc[i], Hkv, D)
+
+        # ---- prefill (once per prompt) ----------------------------------------------------------------------
+        hf, _ = e.text_forward(plan, img_embeds, save=False, kv_sink=kv_sink)
+        last_rows = torch.arange(Bp, device=dev, dtype=torch.int64) * S + (S - 1)
+        lg = e.logits_rows(hf, last_rows)                                    # [Bp, V] fp32
+        self.logits.copy_(lg.repeat_interleave(G, 0))
+        del hf, lg
+        # ---- device state for the first generated token ----------------------------------------------------
+        rep = lambda a: np.repeat(a, G)
+        first_pos = rep(lengths + plan.rope_deltas)                         # M-RoPE position of the first new token
+        self.pos.copy_(torch.from_numpy((first_pos - 1).astype(np.int32)))
+        self.ctx_len.copy_(torch.from_numpy(rep(lengths).astype(np.int32)))
+        self.finished.zero_()
+        self.step.zero_()
+        self.out_tokens.fill_(c.pad_token_id)
+        self._sample_and_advance()                                           # token 0 from the prefill logits
+        # ---- decode ----------------------------------------------------------------------------------------------
+        if self.use_graph and self.graph is None:
+            saved = [t.clone() for t in (self.pos, self.ctx_len, self.slot, self.finished, self.step, self.cur_tok, self.out_tokens)]
+            self._capture()  # warm-up + capture advance the state twice: restore it (K/V written meanwhile are rewritten by the real steps)
+            for t, s_ in zip((self.pos, self.ctx_len, self.slot, self.finished, self.step, self.cur_tok, self.out_tokens), saved):
+                t.copy_(s_)
+        for it in range(1, max_new):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._decode_step()
+            if sampling["eos"] >= 0 and it % 32 == 0 and bool(self.finished.all()):
+                break
+        return self.out_tokens[:, :max_new].clone()

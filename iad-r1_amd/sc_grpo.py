@@ -1,0 +1,289 @@
+"""SC-GRPO micro-step on the HIP engine: the arithmetic of `SCGRPOTrainer.compute_loss`
+(/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:586-819) + backward + optimizer, re-scheduled for
+one MI355X per rank:
+
+  rollout (in-process, shared weights, hipGraph decode)  ->  rewards (CPU plugin functions)  ->
+  advantages (per-prompt groups, rank-local)  ->  frozen-ref log-probs  ->  policy log-probs + backward  ->
+  bucketed gradient all-reduce over RCCL (overlapped with the tail of backward)  ->  fused AdamW.
+
+Ordering: sequences are laid out prompt-major (p0 x G, p1 x G, ...) everywhere, i.e. the interleaved order the
+reference's reward / advantage code assumes (REF:754,775-792); its tensor tiling (REF:625-628) coincides with
+this at per_device_train_batch_size=1, the only setting its scripts use.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import hip, ops
+from .params import ParamStore, VLMConfig
+from .rollout import Rollout
+from .vlm import Engine
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@dataclass
+class GRPOArgs:
+    """The subset of trl.GRPOConfig / TrainingArguments the reference's SC-GRPO path actually reads
+    (SURVEY.md section 2.1 #12 and section 5), with the same defaults."""
+    num_generations: int = 8
+    max_prompt_length: int | None = 512
+    max_completion_length: int = 256
+    beta: float = 0.04
+    temperature: float = 0.9
+    top_k: int = 50            # hard-coded in the reference (REF:353-358)
+    top_p: float = 0.9
+    learning_rate: float = 1e-6
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 1.0
+    gradient_accumulation_steps: int = 1
+    micro_batch_seqs: int = 16  # sequences per forward/backward pass (activation memory knob; results do not depend on it)
+    seed: int = 42
+    suppress_eos: bool = False  # benchmark mode: fixed-length completions
+    use_hip_graph: bool = True
+
+
+def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.ndarray:
+    """REF:722-726 -- keep tokens up to and including the first EOS."""
+    is_eos = completion_ids == eos_token_id
+    n, c = is_eos.shape
+    eos_idx = np.where(is_eos.any(1), is_eos.argmax(1), c)
+    return (np.arange(c)[None, :] <= eos_idx[:, None]).astype(np.int32)
+
+
+def right_pad(rows, pad_value: int) -> np.ndarray:
+    """trl `pad(..., padding_side='right')` for 1-D id lists (REF:682)."""
+    m = max((len(r) for r in rows), default=0)
+    out = np.full((len(rows), m), pad_value, dtype=np.int64)
+    for i, r in enumerate(rows):
+        out[i, : len(r)] = r
+    return out
+
+
+def group_advantages(rewards: torch.Tensor, G: int):
+    """REF:787-793: group mean, UNBIASED std, eps 1e-4."""
+    r = rewards.view(-1, G)
+    mean = r.mean(1).repeat_interleave(G)
+    std = r.std(1).repeat_interleave(G) if G > 1 else torch.zeros_like(mean)
+    return (rewards - mean) / (std + 1e-4), std
+
+
+class GradReducer:
+    """Data-parallel gradient exchange: the ONLY collective of the path.  The flat fp32
+    gradient buffer is all-reduced in large contiguous buckets on a side stream; decoder-layer buckets are
+    launched as soon as the last micro-batch's backward has left that layer, so the exchange overlaps the
+    rest of backward.  Works on CPU/gloo too (tests)."""
+
+    def __init__(self, store: ParamStore, group=None):
+        import torch.distributed as dist
+        self.dist, self.store, self.group = dist, store, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.cuda = store.grad.is_cuda
+        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        c = store.cfg
+        s = store.slots
+        self.layer_range = []
+        for i in range(c.num_hidden_layers):
+            lo = s[f"layers.{i}.qkv.w"].offset
+            hi = s[f"layers.{i + 1}.qkv.w"].offset if i + 1 < c.num_hidden_layers else (s["lm_head"].offset if "lm_head" in s else store.n_decay)
+            self.layer_range.append((lo, hi))
+        self.first_layer_off = s["layers.0.qkv.w"].offset
+        self.reset()
+
+    def reset(self):
+        self.done = []
+        self.work = []
+
+    def _reduce(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        buf = self.store.grad[lo:hi]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.work.append(self.dist.all_reduce(buf, group=self.group, async_op=True))
+        else:
+            self.dist.all_reduce(buf, group=self.group)
+        self.done.append((lo, hi))
+
+    def layer_ready(self, i):
+        self._reduce(*self.layer_range[i])
+
+    def finish(self):
+        """Reduce whatever has not been sent yet (vision tower, embedding, lm_head, norm gains / biases) and join."""
+        covered = sorted(self.done)
+        cur = 0
+        for lo, hi in covered + [(self.store.n_total, self.store.n_total)]:
+            if lo > cur:
+                self._reduce(cur, lo)
+            cur = max(cur, hi)
+        for w in self.work:
+            w.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.reset()
+
+
+class SCGRPOEngine:
+    def __init__(self, cfg: VLMConfig, policy: ParamStore, ref: ParamStore, args: GRPOArgs, group=None):
+        self.cfg, self.args = cfg, args
+        self.pol, self.ref = Engine(policy), Engine(ref)
+        self.dev = policy.device
+        self.reducer = GradReducer(policy, group)
+        self.opt_step = 0
+        self.accum = 0
+        self._rollout = None
+        self.norm2 = torch.zeros(1, dtype=F32, device=self.dev)
+
+    # ---- vision: once per unique image ---------------------------------------------------------------------
+    def _vision(self, batch, want_policy_ctx: bool):
+        grids = [tuple(int(z) for z in g) for g in np.asarray(batch["image_grid_thw"])]
+        plan_v = self.pol.vision_plan(grids)
+        px = batch["pixel_values"]
+        px = torch.as_tensor(px).to(self.dev)
+        px = px if px.dtype == BF16 else ops.cast_f32_to_bf16(px.to(F32).contiguous())
+        m2 = self.cfg.v_merge**2
+        rows = np.cumsum([0] + [g[0] * g[1] * g[2] // m2 for g in grids])
+        return grids, plan_v, px, rows
+
+    def _per_row_images(self, batch, grids, rows):
+        ipp = batch.get("images_per_prompt") or [1] * len(batch["input_ids"])
+        gpr, off, k = [], [], 0
+        for n in ipp:
+            gpr.append(grids[k: k + n])
+            off.append([int(rows[j]) for j in range(k, k + n)])
+            k += n
+        return gpr, off
+
+    # ---- rollout -------------------------------------------------------------------------------------------------
+    def vision_policy(self, batch, save: bool):
+        """Policy vision tower once per step: its output feeds both the rollout prefill and the training forward."""
+        grids, plan_v, px, rows = self._vision(batch, save)
+        img, vctx = self.pol.vision_forward(px, plan_v, save=save)
+        return {"grids": grids, "plan": plan_v, "px": px, "rows": rows, "img": img, "ctx": vctx}
+
+    def rollout(self, batch, vis=None, greedy=False) -> np.ndarray:
+        """Completion ids [Bp*G, <=C] (numpy, right-padded with pad after EOS like REF:680-683)."""
+        a = self.args
+        ids, mask = np.asarray(batch["input_ids"]), np.asarray(batch["attention_mask"])
+        if a.max_prompt_length is not None:
+            ids, mask = ids[:, -a.max_prompt_length:], mask[:, -a.max_prompt_length:]
+        vis = vis or self.vision_policy(batch, save=False)
+        grids, rows, img_pol = vis["grids"], vis["rows"], vis["img"]
+        gpr, off = self._per_row_images(batch, grids, rows)
+        plan = self.pol.text_plan(ids, mask, gpr, off)
+        Bp = ids.shape[0]
+        N = Bp * a.num_generations
+        if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_pages * 32 < ids.shape[1] + a.max_completion_length:
+            self._rollout = Rollout(self.pol, N, ids.shape[1], a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph)
+        toks = self._rollout.generate(plan, img_pol, a.num_generations, a.max_completion_length, temperature=0.0 if greedy else a.temperature,
+                                      top_k=a.top_k, top_p=a.top_p, seed=a.seed + 1000003 * self.opt_step + 7919 * self.accum, suppress_eos=a.suppress_eos)
+        return toks.cpu().numpy()
+
+    # ---- loss + gradients for given completions ------------------------------------------------------------------
+    def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None):
+        """completions: list of Bp*G id lists (prompt-major) or an [N,C] array already padded;
+        rewards_per_func: [N, n_funcs] float tensor/array.  Accumulates gradients into policy.grad."""
+        a, c = self.args, self.cfg
+        G = a.num_generations
+        ids_p, mask_p = np.asarray(batch["input_ids"]), np.asarray(batch["attention_mask"])
+        if a.max_prompt_length is not None:
+            ids_p, mask_p = ids_p[:, -a.max_prompt_length:], mask_p[:, -a.max_prompt_length:]
+        Bp, P = ids_p.shape
+        N = Bp * G
+        comp = completions if isinstance(completions, np.ndarray) else right_pad(completions, c.pad_token_id)
+        assert comp.shape[0] == N
+        C = comp.shape[1]
+        cmask = eos_completion_mask(comp, c.eos_token_id)
+        ids = np.concatenate([np.repeat(ids_p, G, 0), comp], 1)
+        mask = np.concatenate([np.repeat(mask_p, G, 0), cmask.astype(mask_p.dtype)], 1)
+        S = P + C
+        rewards_per_func = torch.as_tensor(np.asarray(rewards_per_func), dtype=F32)
+        rewards = rewards_per_func.sum(1)
+        adv, std = group_advantages(rewards, G)
+        adv_d = adv.to(self.dev)
+        cmask_d = torch.from_numpy(cmask).to(self.dev)
+
+        if vis is None or (backward and vis["ctx"] is None):
+            vis = self.vision_policy(batch, save=backward)
+        grids, plan_v, px, rows, img_pol, vctx = vis["grids"], vis["plan"], vis["px"], vis["rows"], vis["img"], vis["ctx"]
+        img_ref, _ = self.ref.vision_forward(px, plan_v, save=False)
+        gpr, off = self._per_row_images(batch, grids, rows)
+        dimg32 = torch.zeros(img_pol.shape, dtype=F32, device=self.dev) if backward else None
+
+        logp_all = torch.empty(N, C, dtype=F32, device=self.dev)
+        ref_all = torch.empty(N, C, dtype=F32, device=self.dev)
+        kl_all = torch.empty(N, C, dtype=F32, device=self.dev)
+        row_loss = torch.empty(N, dtype=F32, device=self.dev)
+        row_kl = torch.empty(N, dtype=F32, device=self.dev)
+        mb = max(1, min(a.micro_batch_seqs, N))
+        starts = list(range(0, N, mb))
+        col = np.arange(C)
+        for si, r0 in enumerate(starts):
+            r1 = min(N, r0 + mb)
+            n = r1 - r0
+            rows_b = [r // G for r in range(r0, r1)]
+            plan = self.pol.text_plan(ids[r0:r1], mask[r0:r1], [gpr[b] for b in rows_b], [off[b] for b in rows_b])
+            sel = (np.arange(n)[:, None] * S + (P - 1) + col[None, :]).reshape(-1)        # logits rows P-1 .. S-2
+            rows_d = torch.from_numpy(sel.astype(np.int64)).to(self.dev)
+            tgt_d = torch.from_numpy(ids[r0:r1, P:].reshape(-1).astype(np.int64)).to(self.dev)
+            hf, _ = self.ref.text_forward(plan, img_ref, save=False)
+            rl, _ = self.ref.logprobs(hf, rows_d, tgt_d, save=False)
+            del hf
+            hf, ctx = self.pol.text_forward(plan, img_pol, save=backward)
+            lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward)
+            dlogp, kl, rloss, rkl = ops.grpo_loss(lp.view(n, C), rl.view(n, C), adv_d[r0:r1].contiguous(), cmask_d[r0:r1].contiguous(), a.beta, n_total_rows=N)
+            logp_all[r0:r1], ref_all[r0:r1], kl_all[r0:r1] = lp.view(n, C), rl.view(n, C), kl
+            row_loss[r0:r1], row_kl[r0:r1] = rloss, rkl
+            if backward:
+                dhf = self.pol.logprobs_backward(dlogp.view(-1), lctx)
+                del hf, lctx
+                hook = self.reducer.layer_ready if (last_micro_step and si == len(starts) - 1) else None
+                self.pol.text_backward(dhf, ctx, dimg32, layer_done=hook)
+                del ctx, dhf
+        if backward:
+            dimg = ops.f32_bias_to_bf16(dimg32, None)
+            self.pol.vision_backward(dimg, vctx)
+            self.accum += 1
+        metrics = {
+            "loss": float(row_loss.mean()),
+            "completion_length": float(cmask.sum(1).mean()),
+            "reward": float(rewards.mean()),
+            "reward_std": float(std.mean()),
+            "kl": float(row_kl.mean()),
+        }
+        return {"metrics": metrics, "logps": logp_all, "ref_logps": ref_all, "kl": kl_all, "advantages": adv, "completion_mask": cmask,
+                "rewards_per_func": rewards_per_func, "ids": ids, "mask": mask}
+
+    # ---- optimizer -------------------------------------------------------------------------------------------------
+    def optimizer_step(self):
+        a, st = self.args, self.pol.p
+        self.reducer.finish()
+        self.opt_step += 1
+        scale = 1.0 / (self.reducer.world * max(1, self.accum))
+        self.norm2.zero_()
+        hip.call("sumsq_acc", st.grad, st.n_total, self.norm2)
+        for lo, hi, wd in ((0, st.n_decay, a.weight_decay), (st.n_decay, st.n_total, 0.0)):
+            if hi > lo:
+                hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,
+                         a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd, self.opt_step, scale, self.norm2, a.max_grad_norm)
+        st.refresh_transposes()
+        self.accum = 0
+
+    # ---- the whole micro-step ----------------------------------------------------------------------------------------
+    def step(self, batch, reward_fn, do_optimizer_step=True):
+        """reward_fn(completion_ids: np.ndarray [N,C]) -> [N, n_funcs] rewards (decode + plugin functions live with
+        the caller, which owns the tokenizer)."""
+        vis = self.vision_policy(batch, save=True)
+        comp = self.rollout(batch, vis=vis)
+        rewards = reward_fn(comp)
+        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=do_optimizer_step, vis=vis)
+        if do_optimizer_step:
+            self.optimizer_step()
+        return out["metrics"]

@@ -1,0 +1,102 @@
+"""PA-SFT step on the HIP engine: model(**batch, labels) -> shifted cross-entropy with ignore_index=-100
+(TF:loss/loss_utils.py:32-71 via TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:1389-1393), gradient-accumulation
+rescale of /root/reference/train/stage_sft/llamafactory/train/sft/trainer.py:92-107, AdamW with decoupled weight
+decay on >=2-D parameters (HF Trainer parameter groups)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import hip, ops
+from .params import ParamStore, VLMConfig
+from .sc_grpo import GradReducer
+from .vlm import Engine
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@dataclass
+class SFTArgs:
+    learning_rate: float = 1e-5
+    weight_decay: float = 0.1
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 1.0
+    gradient_accumulation_steps: int = 1
+    micro_batch_seqs: int = 16
+
+
+class SFTEngine:
+    def __init__(self, cfg: VLMConfig, params: ParamStore, args: SFTArgs, group=None):
+        self.cfg, self.args = cfg, args
+        self.eng = Engine(params)
+        self.dev = params.device
+        self.reducer = GradReducer(params, group)
+        self.opt_step = 0
+        self.accum = 0
+        self.norm2 = torch.zeros(1, dtype=F32, device=self.dev)
+
+    def loss_and_grads(self, batch, backward=True, num_items_in_batch=None, last_micro_step=True):
+        """batch: input_ids, attention_mask, labels [B,S] (numpy), pixel_values [n,patch_dim], image_grid_thw [n_img,3],
+        images_per_row (default 1).  Loss = sum CE over labels != -100 / count (or / num_items_in_batch)."""
+        c, e = self.cfg, self.eng
+        ids, mask, labels = (np.asarray(batch[k]) for k in ("input_ids", "attention_mask", "labels"))
+        B, S = ids.shape
+        grids = [tuple(int(z) for z in g) for g in np.asarray(batch["image_grid_thw"])]
+        plan_v = e.vision_plan(grids)
+        px = torch.as_tensor(batch["pixel_values"]).to(self.dev)
+        px = px if px.dtype == BF16 else ops.cast_f32_to_bf16(px.to(F32).contiguous())
+        img, vctx = e.vision_forward(px, plan_v, save=backward)
+        m2 = c.v_merge**2
+        rows = np.cumsum([0] + [g[0] * g[1] * g[2] // m2 for g in grids])
+        ipr = batch.get("images_per_row") or [1] * B
+        gpr, off, k = [], [], 0
+        for n in ipr:
+            gpr.append(grids[k: k + n])
+            off.append([int(rows[j]) for j in range(k, k + n)])
+            k += n
+        # shifted targets: position s predicts labels[s+1]; only supervised positions are sent through the lm_head
+        tgt = np.full((B, S), -100, dtype=np.int64)
+        tgt[:, :-1] = labels[:, 1:]
+        n_items = int((tgt != -100).sum()) if num_items_in_batch is None else int(num_items_in_batch)
+        dimg32 = torch.zeros(img.shape, dtype=F32, device=self.dev) if backward else None
+        total = torch.zeros((), dtype=F32, device=self.dev)
+        mb = max(1, min(self.args.micro_batch_seqs, B))
+        starts = list(range(0, B, mb))
+        for si, r0 in enumerate(starts):
+            r1 = min(B, r0 + mb)
+            plan = e.text_plan(ids[r0:r1], mask[r0:r1], gpr[r0:r1], off[r0:r1])
+            sel = np.flatnonzero(tgt[r0:r1].reshape(-1) != -100)
+            if len(sel) == 0:
+                continue
+            rows_d = torch.from_numpy(sel.astype(np.int64)).to(self.dev)
+            tgt_d = torch.from_numpy(tgt[r0:r1].reshape(-1)[sel]).to(self.dev)
+            hf, ctx = e.text_forward(plan, img, save=backward)
+            lp, lctx = e.logprobs(hf, rows_d, tgt_d, save=backward)
+            total += -lp.sum()
+            if backward:
+                g = torch.full((len(sel),), -1.0 / n_items, dtype=F32, device=self.dev)
+                dhf = e.logprobs_backward(g, lctx)
+                hook = self.reducer.layer_ready if (last_micro_step and si == len(starts) - 1) else None
+                e.text_backward(dhf, ctx, dimg32, layer_done=hook)
+        if backward:
+            e.vision_backward(ops.f32_bias_to_bf16(dimg32, None), vctx)
+            self.accum += 1
+        return float(total) / n_items
+
+    def optimizer_step(self):
+        a, st = self.args, self.eng.p
+        self.reducer.finish()
+        self.opt_step += 1
+        scale = 1.0 / (self.reducer.world * max(1, self.accum))
+        self.norm2.zero_()
+        hip.call("sumsq_acc", st.grad, st.n_total, self.norm2)
+        for lo, hi, wd in ((0, st.n_decay, a.weight_decay), (st.n_decay, st.n_total, 0.0)):
+            if hi > lo:
+                hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,
+                         a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd, self.opt_step, scale, self.norm2, a.max_grad_norm)
+        st.refresh_transposes()
+        self.accum = 0

@@ -1,0 +1,322 @@
+"""Qwen2.5-VL forward / backward on the HIP kernel library -- the engine behind `model(**inputs).logits`
+at /root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:505 and the PA-SFT forward(labels)
+(TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:1308-1400).  Explicit (hand-scheduled) backward instead of a
+tracing autograd: every saved tensor, every GEMM and its operand layout is chosen here.
+
+Conventions: activations are flat [tokens, width] bf16; a decoder micro-batch of B sequences x S positions
+is T = B*S rows (left padding stays in place but belongs to no attention segment); the vision tower runs
+ONCE per unique image per step and its output rows are fanned out to every sequence that shows that image
+(the reference recomputes it G times on identical pixels -- same values, same summed gradients).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import indexing, ops
+from .params import ParamStore, VLMConfig
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ------------------------------------------------------------------------------------------------------------
+# plans: host-side integer work + small device tables
+# ------------------------------------------------------------------------------------------------------------
+@dataclass
+class VisionPlan:
+    n_patches: int
+    win_index: torch.Tensor      # [N/m2] int64 gather (window order <- raster order of merged groups)
+    rev_index: torch.Tensor      # inverse permutation
+    seg_window: ops.Segments
+    seg_full: ops.Segments
+    cos: torch.Tensor            # [N, d/2] fp32, already in window order
+    sin: torch.Tensor
+
+
+@dataclass
+class TextPlan:
+    B: int
+    S: int
+    ids: torch.Tensor            # [T] int64
+    img_index: torch.Tensor      # [T] int32, row of the image-embed matrix or -1
+    seg: ops.Segments            # one segment per sequence, skipping left padding
+    cos: torch.Tensor            # [T, D/2] fp32 (M-RoPE component already selected per frequency)
+    sin: torch.Tensor
+    rope_deltas: np.ndarray      # [B]
+    lengths: np.ndarray          # [B] number of real tokens
+
+
+class Engine:
+    def __init__(self, params: ParamStore):
+        self.p = params
+        self.cfg: VLMConfig = params.cfg
+        self.dev = params.device
+        c = self.cfg
+        hd = c.head_dim
+        self.inv_freq = torch.tensor(1.0 / (c.rope_theta ** (np.arange(0, hd, 2, dtype=np.float32) / hd)), dtype=F32, device=self.dev)
+        self.mrope_comp = torch.tensor(indexing.mrope_component_of_channel(c.mrope_section, hd // 2), dtype=torch.long, device=self.dev)
+        vd = c.v_head_dim
+        self.v_inv_freq = 1.0 / (10000.0 ** (np.arange(0, vd // 2, 2, dtype=np.float32) / (vd // 2)))
+        self.lm_chunk = 4096
+
+    # ========================================================================================================
+    # plans
+    # ========================================================================================================
+    def vision_plan(self, grids) -> VisionPlan:
+        c = self.cfg
+        grids = [tuple(int(z) for z in g) for g in grids]
+        m2 = c.v_merge**2
+        win, cu_win = indexing.vision_window_index(grids, c.v_merge, c.v_window, c.v_patch)
+        cu_full = indexing.vision_cu_seqlens(grids)
+        pos = indexing.vision_position_ids(grids, c.v_merge).astype(np.float32)  # [N,2]
+        n = pos.shape[0]
+        rot = (pos[:, :, None] * self.v_inv_freq[None, None, :]).reshape(n, -1)     # [N, d/2]: h freqs then w freqs
+        rot = rot.reshape(n // m2, m2, -1)[win].reshape(n, -1)
+        rot_t = torch.from_numpy(rot).to(self.dev)
+        win_t = torch.from_numpy(win).to(self.dev)
+        rev = torch.from_numpy(np.argsort(win)).to(self.dev)
+        return VisionPlan(n, win_t, rev, ops.Segments.from_cu(cu_win, self.dev), ops.Segments.from_cu(cu_full, self.dev), rot_t.cos().contiguous(), rot_t.sin().contiguous())
+
+    def text_plan(self, input_ids: np.ndarray, attention_mask: np.ndarray, grids_per_row, img_row_offset) -> TextPlan:
+        """input_ids / attention_mask: [B,S] numpy.  grids_per_row[b]: list of (t,h,w) of the images in row b.
+        img_row_offset[b]: list, per image of row b, of the first row of that image in the image-embed matrix
+        (several sequences may point at the same rows)."""
+        c = self.cfg
+        B, S = input_ids.shape
+        flat_grids = [g for row in grids_per_row for g in row]
+        pos, deltas = indexing.mrope_position_ids(input_ids, attention_mask, flat_grids, c.image_token_id, c.v_merge)
+        img_index = np.full((B, S), -1, dtype=np.int32)
+        m2 = c.v_merge**2
+        for b in range(B):
+            cols = np.flatnonzero((input_ids[b] == c.image_token_id) & (attention_mask[b] != 0))
+            k = 0
+            for g, off in zip(grids_per_row[b], img_row_offset[b]):
+                n = g[0] * g[1] * g[2] // m2
+                img_index[b, cols[k: k + n]] = off + np.arange(n)
+                k += n
+            if k != len(cols):
+                raise ValueError(f"row {b}: {len(cols)} image tokens but grids supply {k}")
+        lengths = attention_mask.sum(1).astype(np.int64)
+        starts = [b * S + int(S - lengths[b]) if attention_mask[b, 0] == 0 else b * S for b in range(B)]
+        # general masks (not only left padding) are not attention segments; the reference path only produces left padding
+        for b in range(B):
+            first = int(np.argmax(attention_mask[b] != 0)) if lengths[b] else S
+            if lengths[b] and not attention_mask[b, first:].all():
+                raise ValueError("attention_mask must be left-padding only (contiguous ones at the end)")
+            starts[b] = b * S + first
+        ends = [(b + 1) * S for b in range(B)]
+        pos_t = torch.from_numpy(pos.reshape(3, B * S)).to(self.dev)
+        sel = pos_t[self.mrope_comp]                                   # [D/2, T]: component per frequency
+        ang = sel.t().to(F32) * self.inv_freq[None, :]                  # [T, D/2] fp32, as TF::525-538
+        return TextPlan(B, S, torch.from_numpy(input_ids.reshape(-1).astype(np.int64)).to(self.dev), torch.from_numpy(img_index.reshape(-1)).to(self.dev),
+                        ops.Segments(starts, ends, self.dev), ang.cos().contiguous(), ang.sin().contiguous(), deltas, lengths)
+
+    # ========================================================================================================
+    # vision tower  (TF::408-471)
+    # ========================================================================================================
+    def vision_forward(self, pixel_values: torch.Tensor, plan: VisionPlan, save: bool):
+        """pixel_values: [N, C*T*P*P] fp32 or bf16 on device -> merged image embeds [N/m2, H] bf16 (raster order)."""
+        c, P = self.cfg, self.p
+        vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
+        N = plan.n_patches
+        px = pixel_values if pixel_values.dtype == BF16 else ops.cast_f32_to_bf16(pixel_values)
+        x = ops.gemm_nt(px, P.w("visual.patch_embed"))                                   # K1: conv3d(stride==kernel) == GEMM
+        x = ops.embed_fwd(plan.win_index, None, x.view(N // m2, m2 * vh), None).view(N, vh)  # K2: window-order gather
+        ctx = {"px": px, "layers": []} if save else None
+        res, branch, bias = x, None, None
+        for i in range(c.v_depth):
+            b = f"visual.blocks.{i}."
+            seg = plan.seg_full if i in c.v_fullatt else plan.seg_window
+            x_in = torch.empty_like(res) if (save and branch is not None) else res
+            if branch is None:
+                h1, rstd1 = ops.rmsnorm_fwd(res, P.w(b + "norm1"), 1e-6, want_rstd=save)
+            else:
+                h1, rstd1 = ops.rmsnorm_fwd(branch, P.w(b + "norm1"), 1e-6, res=res, res_out=x_in, want_rstd=save)
+            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"))
+            ops.rope_(qkv, plan.cos, plan.sin, 2 * nh, d)
+            o, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh: 2 * vh], qkv[:, 2 * vh:], seg, nh, nh, d, False, d**-0.5, want_lse=save)
+            ab = ops.gemm_nt(o, P.w(b + "proj.w"), bias=P.w(b + "proj.b"))
+            x_mid = torch.empty_like(x_in) if save else x_in
+            h2, rstd2 = ops.rmsnorm_fwd(ab, P.w(b + "norm2"), 1e-6, res=x_in, res_out=x_mid, want_rstd=save)
+            gu = ops.gemm_nt(h2, P.w(b + "gu.w"), bias=P.w(b + "gu.b"))
+            a = ops.swiglu_fwd(gu)
+            branch = ops.gemm_nt(a, P.w(b + "down.w"), bias=P.w(b + "down.b"))
+            res = x_mid
+            if save:
+                ctx["layers"].append((x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a, seg))
+        x_last = torch.empty_like(res) if save else res
+        hq, rstdq = ops.rmsnorm_fwd(branch, P.w("visual.merger.ln_q"), 1e-6, res=res, res_out=x_last, want_rstd=save)
+        hq4 = hq.view(N // m2, m2 * vh)
+        z = ops.gemm_nt(hq4, P.w("visual.merger.fc1.w"), bias=P.w("visual.merger.fc1.b"))
+        ga = ops.gelu_fwd(z)
+        mo = ops.gemm_nt(ga, P.w("visual.merger.fc2.w"), bias=P.w("visual.merger.fc2.b"))
+        out = ops.embed_fwd(plan.rev_index, None, mo, None)                               # K2^-1: back to raster order
+        if save:
+            ctx.update(x_last=x_last, rstdq=rstdq, hq4=hq4, z=z, ga=ga, plan=plan)
+        return out, ctx
+
+    def _wgrad(self, name, dy, x):
+        """grad[name] ([N,K] fp32) += dy[T,N]^T . x[T,K]   (NT kernel on transposed copies)"""
+        ops.gemm_nt(ops.transpose(dy), ops.transpose(x), out=self.p.g(name), accumulate=True)
+
+    def vision_backward(self, d_out: torch.Tensor, ctx):
+        """d_out: [N/m2, H] bf16 gradient of the merged image embeds (raster order)."""
+        c, P = self.cfg, self.p
+        vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
+        plan: VisionPlan = ctx["plan"]
+        N = plan.n_patches
+        dmo = ops.embed_fwd(plan.win_index, None, d_out, None)                          # inverse of the reverse gather
+        ops.colsum_acc(dmo, P.g("visual.merger.fc2.b"))
+        dga = ops.gemm_nt(dmo, P.wT("visual.merger.fc2.w"))
+        self._wgrad("visual.merger.fc2.w", dmo, ctx["ga"])
+        dz = ops.gelu_bwd(dga, ctx["z"])
+        ops.colsum_acc(dz, P.g("visual.merger.fc1.b"))
+        dhq4 = ops.gemm_nt(dz, P.wT("visual.merger.fc1.w"))
+        self._wgrad("visual.merger.fc1.w", dz, ctx["hq4"])
+        dres = ops.rmsnorm_bwd(dhq4.view(N, vh), ctx["x_last"], P.w("visual.merger.ln_q"), ctx["rstdq"], dw=P.g("visual.merger.ln_q"))
+        for i in reversed(range(c.v_depth)):
+            b = f"visual.blocks.{i}."
+            x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a, seg = ctx["layers"][i]
+            ops.colsum_acc(dres, P.g(b + "down.b"))
+            da = ops.gemm_nt(dres, P.wT(b + "down.w"))
+            self._wgrad(b + "down.w", dres, a)
+            dgu = ops.swiglu_bwd(da, gu)
+            ops.colsum_acc(dgu, P.g(b + "gu.b"))
+            dh2 = ops.gemm_nt(dgu, P.wT(b + "gu.w"))
+            self._wgrad(b + "gu.w", dgu, h2)
+            dx_mid = ops.rmsnorm_bwd(dh2, x_mid, P.w(b + "norm2"), rstd2, dres=dres, dw=P.g(b + "norm2"))
+            ops.colsum_acc(dx_mid, P.g(b + "proj.b"))
+            do = ops.gemm_nt(dx_mid, P.wT(b + "proj.w"))
+            self._wgrad(b + "proj.w", dx_mid, o)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :vh], qkv[:, vh: 2 * vh], qkv[:, 2 * vh:], o, do, lse, seg, nh, nh, d, False, d**-0.5,
+                         dqkv[:, :vh], dqkv[:, vh: 2 * vh], dqkv[:, 2 * vh:])
+            ops.rope_(dqkv, plan.cos, plan.sin, 2 * nh, d, backward=True)
+            ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
+            dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"))
+            self._wgrad(b + "qkv.w", dqkv, h1)
+            dres = ops.rmsnorm_bwd(dh1, x_in, P.w(b + "norm1"), rstd1, dres=dx_mid, dw=P.g(b + "norm1"))
+        dx = ops.embed_fwd(plan.rev_index, None, dres.view(N // m2, m2 * vh), None).view(N, vh)  # undo the window gather
+        self._wgrad("visual.patch_embed", dx, ctx["px"])
+
+    # ========================================================================================================
+    # text decoder (TF::790-873; layer ::708-757)
+    # ========================================================================================================
+    def text_forward(self, plan: TextPlan, img_embeds, save: bool, kv_sink=None):
+        c, P = self.cfg, self.p
+        H, D, Hq, Hkv = c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        qw, kw = Hq * D, Hkv * D
+        x = ops.embed_fwd(plan.ids, plan.img_index if img_embeds is not None else None, P.w("embed"), img_embeds)
+        ctx = {"layers": [], "plan": plan} if save else None
+        res, branch = x, None
+        eps = c.rms_norm_eps
+        for i in range(c.num_hidden_layers):
+            b = f"layers.{i}."
+            x_in = torch.empty_like(res) if (save and branch is not None) else res
+            if branch is None:
+                h1, rstd1 = ops.rmsnorm_fwd(res, P.w(b + "ln1"), eps, want_rstd=save)
+            else:
+                h1, rstd1 = ops.rmsnorm_fwd(branch, P.w(b + "ln1"), eps, res=res, res_out=x_in, want_rstd=save)
+            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"))
+            ops.rope_(qkv, plan.cos, plan.sin, Hq + Hkv, D)
+            if kv_sink is not None:
+                kv_sink(i, qkv[:, qw: qw + kw], qkv[:, qw + kw:])
+            o, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], plan.seg, Hq, Hkv, D, True, D**-0.5, want_lse=save)
+            ab = ops.gemm_nt(o, P.w(b + "o.w"))
+            x_mid = torch.empty_like(x_in) if save else x_in
+            h2, rstd2 = ops.rmsnorm_fwd(ab, P.w(b + "ln2"), eps, res=x_in, res_out=x_mid, want_rstd=save)
+            gu = ops.gemm_nt(h2, P.w(b + "gu.w"))
+            a = ops.swiglu_fwd(gu)
+            branch = ops.gemm_nt(a, P.w(b + "down.w"))
+            res = x_mid
+            if save:
+                ctx["layers"].append((x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a))
+        x_last = torch.empty_like(res) if save else res
+        hf, rstdf = ops.rmsnorm_fwd(branch, P.w("norm"), eps, res=res, res_out=x_last, want_rstd=save)
+        if save:
+            ctx.update(x_last=x_last, rstdf=rstdf)
+        return hf, ctx
+
+    def text_backward(self, dhf: torch.Tensor, ctx, dimg32=None, layer_done=None):
+        """dhf: gradient of the final-norm output [T,H] bf16.  Accumulates parameter grads; image-embed
+        gradients are accumulated (fp32 atomics) into dimg32 [n_img_rows, H]."""
+        c, P = self.cfg, self.p
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        qw, kw = Hq * D, Hkv * D
+        plan: TextPlan = ctx["plan"]
+        dres = ops.rmsnorm_bwd(dhf, ctx["x_last"], P.w("norm"), ctx["rstdf"], dw=P.g("norm"))
+        for i in reversed(range(c.num_hidden_layers)):
+            b = f"layers.{i}."
+            x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a = ctx["layers"][i]
+            da = ops.gemm_nt(dres, P.wT(b + "down.w"))
+            self._wgrad(b + "down.w", dres, a)
+            dgu = ops.swiglu_bwd(da, gu)
+            dh2 = ops.gemm_nt(dgu, P.wT(b + "gu.w"))
+            self._wgrad(b + "gu.w", dgu, h2)
+            dx_mid = ops.rmsnorm_bwd(dh2, x_mid, P.w(b + "ln2"), rstd2, dres=dres, dw=P.g(b + "ln2"))
+            do = ops.gemm_nt(dx_mid, P.wT(b + "o.w"))
+            self._wgrad(b + "o.w", dx_mid, o)
+            dqkv = torch.zeros_like(qkv)  # rows of left padding belong to no segment: their gradient is exactly 0
+            ops.attn_bwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, do, lse, plan.seg, Hq, Hkv, D, True, D**-0.5,
+                         dqkv[:, :qw], dqkv[:, qw: qw + kw], dqkv[:, qw + kw:])
+            ops.rope_(dqkv, plan.cos, plan.sin, Hq + Hkv, D, backward=True)
+            ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
+            dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"))
+            self._wgrad(b + "qkv.w", dqkv, h1)
+            dres = ops.rmsnorm_bwd(dh1, x_in, P.w(b + "ln1"), rstd1, dres=dx_mid, dw=P.g(b + "ln1"))
+            ctx["layers"][i] = None  # release this layer's activations
+            if layer_done is not None:
+                layer_done(i)  # this layer's weight gradients are final: the DDP bucket can leave
+        ops.embed_bwd(plan.ids, plan.img_index if dimg32 is not None else None, dres, P.g("embed"), dimg32)
+
+    # ========================================================================================================
+    # lm_head + log-softmax + gather (REF sc_grpo_trainer.py:505-513), only on the rows that are consumed
+    # ========================================================================================================
+    def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool):
+        """logp[r] = log_softmax(lm_head(hf[rows[r]]))[targets[r]]  (targets < 0 -> 0).  The [R,V] logits exist
+        only as fp32 chunks of `lm_chunk` rows."""
+        P = self.p
+        W = P.w(P.lm_head_name())
+        hsel = ops.embed_fwd(rows, None, hf, None)
+        R = rows.numel()
+        logp = torch.empty(R, dtype=F32, device=self.dev)
+        lse = torch.empty(R, dtype=F32, device=self.dev)
+        for r0 in range(0, R, self.lm_chunk):
+            r1 = min(R, r0 + self.lm_chunk)
+            lg = ops.gemm_nt(hsel[r0:r1], W, out_dtype=F32)
+            lp, ls = ops.logprob_rows(lg, targets[r0:r1])
+            logp[r0:r1] = lp
+            lse[r0:r1] = ls
+            del lg
+        ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0]} if save else None
+        return logp, ctx
+
+    def logprobs_backward(self, g: torch.Tensor, ctx) -> torch.Tensor:
+        """g[r] = dLoss/dlogp[r] (fp32).  Returns dLoss/dhf [T,H] bf16; accumulates the lm_head (= embedding when tied) grad."""
+        P = self.p
+        name = P.lm_head_name()
+        W, WT = P.w(name), P.wT(name)
+        hsel, rows, targets, lse = ctx["hsel"], ctx["rows"], ctx["targets"], ctx["lse"]
+        R, H = hsel.shape
+        dhsel = torch.empty(R, H, dtype=BF16, device=self.dev)
+        for r0 in range(0, R, self.lm_chunk):
+            r1 = min(R, r0 + self.lm_chunk)
+            lg = ops.gemm_nt(hsel[r0:r1], W, out_dtype=F32)
+            dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1])
+            del lg
+            ops.gemm_nt(dl, WT, out=dhsel[r0:r1])
+            self._wgrad(name, dl, hsel[r0:r1])
+            del dl
+        # scatter rows back: dhf[t] = dhsel[inv[t]] or 0
+        inv = torch.full((ctx["T"],), -1, dtype=torch.int32, device=self.dev)
+        inv[rows] = torch.arange(R, dtype=torch.int32, device=self.dev)
+        zero_row = torch.zeros(1, H, dtype=BF16, device=self.dev)
+        return ops.embed_fwd(torch.zeros(ctx["T"], dtype=torch.int64, device=self.dev), inv, zero_row, dhsel)
+
+    def logits_rows(self, hf: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """fp32 logits of a FEW rows (rollout prefill: last prompt position of each prompt)."""
+        P = self.p
+        hsel = ops.embed_fwd(rows, None, hf, None)
+        return ops.gemm_nt(hsel, P.w(P.lm_head_name()), out_dtype=F32)

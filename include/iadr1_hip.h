@@ -34,11 +34,11 @@ const char* iadr1_last_error(void);
  * :1386-1387 (lm_head), and their autograd backward (dgrad / wgrad run on transposed operands). */
 int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
                        long long ldb, long long ldc, int out_mode, int act, iadr1_stream_t stream);
-/* Decode-time skinny GEMM: Y[M,N] (fp32, pre-zeroed) += X[M,K] . W[N,K]^T with split-K atomics; HBM-bound
- * weight stream.  Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/
- * sc_grpo_trainer.py:667 -> llm.generate). */
-int iadr1_gemm_skinny_bf16(const void* X, const void* W, float* Y, int M, int N, int K, long long ldx, long long ldw,
-                           long long ldy, iadr1_stream_t stream);
+/* Decode-time skinny GEMM: Y[M,N] = X[M,K] . W[N,K]^T + bias (bf16 out, or fp32 when out_f32), M small
+ * (processed 64 rows per pass); HBM-bound weight stream, 4-way in-block split-K, no atomics.  Replaces the
+ * same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667 -> llm.generate). */
+int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
+                           long long ldw, long long ldy, int out_f32, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
 
 /* ---- RMSNorm (TF:65-79) --------------------------------------------------------------------------------
@@ -110,8 +110,9 @@ int iadr1_logprob_rows(const float* logits, long long ld, const long long* targe
                        iadr1_stream_t stream);
 int iadr1_dlogits_rows(const float* logits, long long ld, const long long* targets, const float* lse, const float* g,
                        void* dl, long long ldd, int R, int V, iadr1_stream_t stream);
-int iadr1_grpo_loss(const float* logp, const float* ref_logp, const float* adv, const int* mask, float beta, float* dlogp,
-                    float* kl, float* row_loss, float* row_kl, int N, int C, iadr1_stream_t stream);
+/* n_total_rows: number of sequences the batch mean runs over (>= N when the step is micro-batched) */
+int iadr1_grpo_loss(const float* logp, const float* ref_logp, const float* adv, const int* mask, float beta, int n_total_rows,
+                    float* dlogp, float* kl, float* row_loss, float* row_kl, int N, int C, iadr1_stream_t stream);
 
 /* ---- optimizer (HF Trainer default AdamW + clip_grad_norm_, TF:trainer.py:1168) ------------------------------- */
 int iadr1_sumsq_acc(const float* g, long long n, float* out, iadr1_stream_t stream);
@@ -123,6 +124,16 @@ int iadr1_adamw_flat(float* master, float* m, float* v, float* grad_zeroed_after
 int iadr1_sample_topk_topp(const float* logits, long long ld, long long* out, int B, int V, float temperature, int top_k,
                            float top_p, int suppress_token, unsigned long long seed, unsigned step,
                            const unsigned* step_ptr, iadr1_stream_t stream);
+
+/* ---- device-resident rollout bookkeeping (one decode step = a fixed, graph-replayable launch sequence) ------
+ * rope_table: cos/sin [B, half] for the current text positions (TF:1165-1176: pos = kv_len + rope_delta).
+ * decode_advance: append sampled token (EOS -> finished, then pad; REF:...sc_grpo_trainer.py:680-683,722-726),
+ * bump pos / ctx_len / cache slot / step.  B <= 256. */
+int iadr1_rope_table(const int* pos, const float* inv_freq, float* cos_t, float* sin_t, int B, int half,
+                     iadr1_stream_t stream);
+int iadr1_decode_advance(const long long* sampled, long long* cur_tok, long long* out_tokens, int C, int* pos, int* ctx_len,
+                         long long* slot, const int* block_table, int max_pages, int* finished, unsigned* step, int eos,
+                         int pad, int B, iadr1_stream_t stream);
 
 #ifdef __cplusplus
 }

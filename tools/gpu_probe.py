@@ -52,8 +52,8 @@ sk = []
 for M, N, K in [(64, 2560, 2048), (64, 2048, 2048), (64, 22016, 2048), (64, 2048, 11008), (64, 151936, 2048)]:
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = torch.randn(N, K, device=dev).to(torch.bfloat16)
-    y = torch.zeros(M, N, dtype=torch.float32, device=dev)
-    t = bench(lambda: ops.gemm_skinny(x, w, y), iters=50)
+    y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    t = bench(lambda: ops.gemm_skinny(x, w, out=y), iters=50)
     t2 = bench(lambda: torch.matmul(x, w.t()), iters=50)
     sk.append({"M": M, "N": N, "K": K, "us": t * 1e6, "GBps": N * K * 2 / t / 1e9, "torch_us": t2 * 1e6})
     print(sk[-1], flush=True)
