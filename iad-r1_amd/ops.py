@@ -39,10 +39,15 @@ def gemm_skinny(x, w, bias=None, out=None, out_dtype=BF16):
     return out
 
 
-def transpose(x, out=None):
+def transpose(x, out=None, pad_rows_to=1):
+    """out[C, Rp] = x[R, C]^T; Rp = R rounded up to `pad_rows_to` (extra columns zero) so the result can be a
+    K-contiguous GEMM operand (K must be a multiple of 8)."""
     R, C = x.shape
     if out is None:
-        out = torch.empty(C, R, dtype=BF16, device=x.device)
+        Rp = (R + pad_rows_to - 1) // pad_rows_to * pad_rows_to
+        out = torch.empty(C, Rp, dtype=BF16, device=x.device)
+        if Rp != R:
+            out[:, R:].zero_()
     hip.call("transpose_bf16", x, _ld(x), out, _ld(out), R, C)
     return out
 

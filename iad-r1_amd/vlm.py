@@ -99,14 +99,16 @@ class Engine:
             if k != len(cols):
                 raise ValueError(f"row {b}: {len(cols)} image tokens but grids supply {k}")
         lengths = attention_mask.sum(1).astype(np.int64)
-        starts = [b * S + int(S - lengths[b]) if attention_mask[b, 0] == 0 else b * S for b in range(B)]
-        # general masks (not only left padding) are not attention segments; the reference path only produces left padding
+        # A row is  [left padding 0..][real tokens 1..][0.. after the first EOS]  (REF:722-731 builds exactly this):
+        # the real tokens form ONE attention segment; slots outside it are never attended to and never read.
+        starts, ends = [], []
         for b in range(B):
-            first = int(np.argmax(attention_mask[b] != 0)) if lengths[b] else S
-            if lengths[b] and not attention_mask[b, first:].all():
-                raise ValueError("attention_mask must be left-padding only (contiguous ones at the end)")
-            starts[b] = b * S + first
-        ends = [(b + 1) * S for b in range(B)]
+            nz = np.flatnonzero(attention_mask[b])
+            first, last = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (S, S)
+            if last - first != len(nz):
+                raise ValueError("attention_mask rows must be one contiguous run of ones (left padding / post-EOS padding only)")
+            starts.append(b * S + first)
+            ends.append(b * S + last)
         pos_t = torch.from_numpy(pos.reshape(3, B * S)).to(self.dev)
         sel = pos_t[self.mrope_comp]                                   # [D/2, T]: component per frequency
         ang = sel.t().to(F32) * self.inv_freq[None, :]                  # [T, D/2] fp32, as TF::525-538
@@ -159,7 +161,7 @@ class Engine:
 
     def _wgrad(self, name, dy, x):
         """grad[name] ([N,K] fp32) += dy[T,N]^T . x[T,K]   (NT kernel on transposed copies)"""
-        ops.gemm_nt(ops.transpose(dy), ops.transpose(x), out=self.p.g(name), accumulate=True)
+        ops.gemm_nt(ops.transpose(dy, pad_rows_to=8), ops.transpose(x, pad_rows_to=8), out=self.p.g(name), accumulate=True)
 
     def vision_backward(self, d_out: torch.Tensor, ctx):
         """d_out: [N/m2, H] bf16 gradient of the merged image embeds (raster order)."""
