@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X: GRPO samples/sec for the full SC-GRPO step
+(hipGraph group rollout + CPU rewards + frozen-ref forward + policy forward/backward + DDP all-reduce + AdamW)
+on Qwen2.5-VL-3B shapes, 8 prompts x group 8 per GPU, one 448x448 image + 512 prompt positions, 256 new tokens.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : dominant kernel = gemm_nt_128 (bf16 MFMA).  achieved = sum of algorithmic 2*M*N*K over its launches
+                 in the timed region / sum of their durations, measured live with HIP events on the launch stream.
+  cpu_baseline : the CPU oracle (oracle/qwen25vl.py, kind "port") timed on this box's host cores on a bounded
+                 sample of the same workload, extrapolated by algorithmic FLOPs (see `sample`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="3b", choices=["3b", "7b", "tiny"])
+    ap.add_argument("--prompts", type=int, default=8)
+    ap.add_argument("--group", type=int, default=8)
+    ap.add_argument("--prompt-len", type=int, default=512)
+    ap.add_argument("--gen-len", type=int, default=256)
+    ap.add_argument("--micro-batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+CANNED = [
+    "<think>surface looks uniform</think><answer>no</answer>",
+    "<think>a line on the left</think><location>upper left</location><type>scratch</type><answer>yes</answer>",
+    "<think>dark blob</think><location>center</location><type>stain</type><answer>yes</answer>",
+    "<think>hmm</think><location>bottom right</location><type>hole</type><answer>no</answer>",
+    "no tags at all",
+    "<think>x</think><location>top left corner</location><type>surface scratch</type><answer>yes</answer>",
+    "<think>y</think><location>left</location><type>structural anomaly</type><answer>yes</answer>",
+    "<think>z</think><location>top</location><type>scrach</type><answer>yes</answer> extra",
+]
+SOLUTION = "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"
+
+
+def synth_batch(cfg, n_prompts, prompt_len, seed):
+    """3 prefix ids + <|vision_start|> + 256 x <|image_pad|> + <|vision_end|> + text ids,
+    one 448x448 image (grid 1x32x32 -> 1024 patches) per prompt; pixel rows ~ N(0,1) as after normalisation."""
+    rs = np.random.RandomState(seed)
+    grid = (1, 32, 32)
+    n_img = 256
+    n_text = prompt_len - (3 + 1 + n_img + 1)
+    assert n_text >= 0
+    hi = min(150000, cfg.vocab_size - 8, cfg.vision_start_token_id)
+    lo = min(1000, hi - 1)
+    rows = []
+    for _ in range(n_prompts):
+        rows.append(rs.randint(lo, hi, 3).tolist() + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_token_id] + rs.randint(lo, hi, n_text).tolist())
+    ids = np.array(rows, dtype=np.int64)
+    px = rs.standard_normal((n_prompts * 1024, cfg.patch_dim)).astype(np.float32)
+    return {"input_ids": ids, "attention_mask": np.ones_like(ids), "pixel_values": torch.from_numpy(px), "image_grid_thw": [grid] * n_prompts}
+
+
+class GemmTimer:
+    """HIP-event timing of every gemm_nt launch on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        from iadr1_amd import ops
+        orig = ops.gemm_nt
+        timer = self
+
+        def timed(a, b, bias=None, out=None, out_dtype=torch.bfloat16, accumulate=False, act=0):
+            if not timer.enabled:
+                return orig(a, b, bias=bias, out=out, out_dtype=out_dtype, accumulate=accumulate, act=act)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(a, b, bias=bias, out=out, out_dtype=out_dtype, accumulate=accumulate, act=act)
+            e1.record()
+            timer.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            return r
+
+        ops.gemm_nt = timed
+
+    def summary(self):
+        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records) * 1e-3
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), t, fl
+
+
+def cpu_baseline(cfg_dict_3b, seconds_budget):
+    """Oracle (CPU port) on a bounded sample: policy log-prob forward+backward of G=2 sequences (S=768) through
+    ONE decoder layer + ONE ViT block of the 3B shapes, fp32, all host cores; extrapolated by algorithmic FLOPs."""
+    from oracle import qwen25vl as oq
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    d = json.loads(json.dumps(cfg_dict_3b))
+    d["text"]["num_hidden_layers"] = 1
+    d["text"]["vocab_size"] = 2048
+    d["vision"]["depth"] = 1
+    d["vision"]["fullatt_block_indexes"] = [0]
+    d.update(image_token_id=2040, vision_start_token_id=2041, vision_end_token_id=2042, eos_token_id=1, pad_token_id=2)
+    g = torch.Generator().manual_seed(0)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixture_util as fx
+    w = {k: (torch.randn(s, generator=g) * 0.02) for k, s in fx.param_shapes(d).items()}
+    m = oq.Qwen25VLOracle(d, w, requires_grad=True)
+    S, P, G = 768, 512, 2
+    ids = torch.randint(3, 2000, (G, S), generator=g)
+    ids[:, 4:260] = d["image_token_id"]
+    mask = torch.ones(G, S, dtype=torch.long)
+    pv = torch.randn(G * 1024, 1176, generator=g)
+    grids = [(1, 32, 32)] * G
+    t0 = time.time()
+    reps = 0
+    while True:
+        lp = m.per_token_logps(ids, mask, pv, grids)[:, P - 1:]
+        lp.sum().backward()
+        reps += 1
+        if time.time() - t0 > seconds_budget * 0.5 or reps >= 3:
+            break
+    dt = (time.time() - t0) / reps
+    f = oq.flops_per_sequence(d, S, 1024, logits_positions=S)
+    sample_flops = 3.0 * G * (f["llm_gemm"] + f["llm_attn"] + f["lm_head"] + f["vit"])   # fwd + bwd = 3x fwd
+    flops_per_sample_full = 26.8e12  # rollout + 3x policy + 1x ref, P=512, C=256
+    tf = sample_flops / dt / 1e12
+    return {"value": tf * 1e12 / flops_per_sample_full, "unit": "samples/s (extrapolated)", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 fwd+bwd of {G} sequences (S={S}, 448^2 image) through 1 decoder layer + 1 ViT block of the 3B shapes, {reps} reps, {dt:.2f} s each = {tf:.3f} TFLOP/s; scaled to 26.8 TFLOP per sample"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import rewards
+    from iadr1_amd.params import ParamStore, VLMConfig
+    from iadr1_amd.sc_grpo import GRPOArgs, SCGRPOEngine
+
+    if a.model == "3b":
+        cfg = VLMConfig.qwen25vl_3b()
+    elif a.model == "7b":
+        cfg = VLMConfig.qwen25vl_7b()
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fixture_util as fx
+        cfg = VLMConfig.from_dict(fx.TINY)
+    pol = ParamStore(cfg, dev, trainable=True)
+    pol.init_random(seed=0)
+    ref = ParamStore(cfg, dev, trainable=False)
+    ref.copy_from(pol)
+    args = GRPOArgs(num_generations=a.group, max_prompt_length=a.prompt_len, max_completion_length=a.gen_len, micro_batch_seqs=a.micro_batch,
+                    suppress_eos=True, use_hip_graph=not a.no_graph, seed=1234 + rank)
+    eng = SCGRPOEngine(cfg, pol, ref, args)
+    timer = GemmTimer()
+    timer.install()
+    N = a.prompts * a.group
+    texts = [CANNED[i % len(CANNED)] for i in range(N)]
+    sols = [SOLUTION] * N
+
+    def reward_fn(comp_ids):
+        comps = [[{"role": "assistant", "content": t}] for t in texts]  # canned strings stand in for batch_decode (no tokenizer offline)
+        acc = rewards.accuracy_reward(comps, sols)
+        fmt = rewards.consistency_reward(comps, sols)
+        return np.stack([acc, fmt], 1).astype(np.float32)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_id = 0
+    for _ in range(a.warmup):
+        eng.step(synth_batch(cfg, a.prompts, a.prompt_len, seed=1234 + 7919 * rank + step_id), reward_fn)
+        step_id += 1
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    metrics = None
+    for _ in range(a.steps):
+        metrics = eng.step(synth_batch(cfg, a.prompts, a.prompt_len, seed=1234 + 7919 * rank + step_id), reward_fn)
+        step_id += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        n_launch, t_gemm, fl_gemm = timer.summary()
+        ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
+        out = {
+            "metric": "GRPO samples/sec (img448+512tok, group=8) Qwen2.5-VL-3B" if a.model == "3b" else f"GRPO samples/sec {a.model}",
+            "value": world * N * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}"},
+            "samples_per_sec_per_gpu": N * a.steps / dt,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
+            "last_step_metrics": metrics,
+        }
+        if not a.no_cpu_baseline and a.model == "3b":
+            d3 = {"text": {"vocab_size": 151936, "hidden_size": 2048, "intermediate_size": 11008, "num_hidden_layers": 36, "num_attention_heads": 16,
+                           "num_key_value_heads": 2, "rms_norm_eps": 1e-6, "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
+                  "vision": {"depth": 32, "hidden_size": 1280, "intermediate_size": 3420, "num_heads": 16, "in_channels": 3, "patch_size": 14,
+                             "spatial_merge_size": 2, "temporal_patch_size": 2, "window_size": 112, "out_hidden_size": 2048, "fullatt_block_indexes": [7, 15, 23, 31]},
+                  "tie_word_embeddings": True}
+            out["cpu_baseline"] = cpu_baseline(d3, a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
