@@ -457,11 +457,11 @@ struct DecodeArgs {
     float scale;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
+template <int D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
     constexpr int KS = D / 32, DT = D / 16, PAGE = 32;
-    __shared__ float red_m[4][16], red_l[4][16];
-    __shared__ float red_o[4][D][16 + 1];
+    __shared__ float red_m[WAVES][16], red_l[WAVES][16];
+    __shared__ float red_o[WAVES][D][16 + 1];
     const int b = blockIdx.x, kvh = blockIdx.y, group = p.Hq / p.Hkv;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
     const int n = p.ctx_len[b];
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
     for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const float c = p.scale * LOG2E;
 
-    for (int pg = w; pg < npage; pg += 4) {
+    for (int pg = w; pg < npage; pg += WAVES) {
         const int phys = p.block_table[(long long)b * p.max_pages + pg];
         const bf16_t* kp = p.kcache + ((long long)phys * p.Hkv + kvh) * PAGE * D;
         const bf16_t* vp = p.vcache + ((long long)phys * p.Hkv + kvh) * D * PAGE;
@@ -534,12 +534,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
         for (int e = 0; e < 4; ++e) red_o[w][dt * 16 + g * 4 + e][li] = acc[dt][e];
     __syncthreads();
     // combine the 4 partial states: thread -> (q head j, d)
-    for (int idx = threadIdx.x; idx < group * D; idx += 256) {
+    for (int idx = threadIdx.x; idx < group * D; idx += WAVES * 64) {
         const int j = idx / D, d = idx - j * D;
-        float M = fmaxf(fmaxf(red_m[0][j], red_m[1][j]), fmaxf(red_m[2][j], red_m[3][j]));
+        float M = red_m[0][j];
+#pragma unroll
+        for (int ww = 1; ww < WAVES; ++ww) M = fmaxf(M, red_m[ww][j]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
+        for (int ww = 0; ww < WAVES; ++ww) {
             const float f = (red_m[ww][j] == -INFINITY) ? 0.f : exp2f(red_m[ww][j] - M);
             num += f * red_o[ww][d][j];
             den += f * red_l[ww][j];
@@ -572,6 +574,54 @@ __global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* k, long lon
         for (int e = 0; e < 4; ++e) {
             vd[(c * 8 + 2 * e) * 32] = (bf16_t)(vv[e] & 0xffffu);
             vd[(c * 8 + 2 * e + 1) * 32] = (bf16_t)(vv[e] >> 16);
+        }
+    }
+}
+
+// Decode-step fusion: rotary on the q and k heads of each new token (in place for q; k goes straight to its
+// cache row) + v into the transposed cache page.  One launch instead of rope + kv_store.
+template <int D>
+__global__ __launch_bounds__(256) void rope_kv_store_kernel(bf16_t* qkv, long long ld, const float* cs, const float* sn, const long long* slot,
+                                                            bf16_t* kcache, bf16_t* vcache, int T, int Hq, int Hkv) {
+    constexpr int HALF = D / 2, RC = HALF / 4, VC = D / 8;   // rope items (4-element pairs) and v items (8 elements) per head
+    const int per_tok = (Hq + Hkv) * RC + Hkv * VC;
+    const long long total = (long long)T * per_tok;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long t = i / per_tok;
+        int r = (int)(i - t * per_tok);
+        const long long sl = slot[t];
+        const long long page = sl >> 5;
+        const int off = (int)(sl & 31);
+        bf16_t* row = qkv + t * ld;
+        if (r < (Hq + Hkv) * RC) {
+            const int h = r / RC, c = r - h * RC;
+            bf16_t* p = row + h * D + c * 4;
+            const u32x2_t lo = *(const u32x2_t*)p, hi = *(const u32x2_t*)(p + HALF);
+            const f32x4_t cc = *(const f32x4_t*)(cs + t * HALF + c * 4), ss = *(const f32x4_t*)(sn + t * HALF + c * 4);
+            const float a[4] = {lo_bf(lo[0]), hi_bf(lo[0]), lo_bf(lo[1]), hi_bf(lo[1])};
+            const float b[4] = {lo_bf(hi[0]), hi_bf(hi[0]), lo_bf(hi[1]), hi_bf(hi[1])};
+            float oa[4], ob[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oa[e] = a[e] * cc[e] - b[e] * ss[e]; ob[e] = b[e] * cc[e] + a[e] * ss[e]; }
+            const u32x2_t va = {pack2bf(oa[0], oa[1]), pack2bf(oa[2], oa[3])}, vb = {pack2bf(ob[0], ob[1]), pack2bf(ob[2], ob[3])};
+            if (h < Hq) {
+                *(u32x2_t*)p = va;
+                *(u32x2_t*)(p + HALF) = vb;
+            } else if (sl >= 0) {
+                bf16_t* kd = kcache + ((page * Hkv + (h - Hq)) * 32 + off) * D + c * 4;
+                *(u32x2_t*)kd = va;
+                *(u32x2_t*)(kd + HALF) = vb;
+            }
+        } else if (sl >= 0) {
+            r -= (Hq + Hkv) * RC;
+            const int h = r / VC, c = r - h * VC;
+            const u32x4_t vv = *(const u32x4_t*)(row + (Hq + Hkv + h) * D + c * 8);
+            bf16_t* vd = vcache + (page * Hkv + h) * (long long)D * 32 + off;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vd[(c * 8 + 2 * e) * 32] = (bf16_t)(vv[e] & 0xffffu);
+                vd[(c * 8 + 2 * e + 1) * 32] = (bf16_t)(vv[e] >> 16);
+            }
         }
     }
 }
@@ -647,7 +697,7 @@ extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* 
     IADR1_REQUIRE(B > 0 && Hq % Hkv == 0 && Hq / Hkv <= 16, "attn_decode: GQA group must be <= 16");
     IADR1_REQUIRE((ldq % 8) == 0, "attn_decode: ldq must be a multiple of 8");
     DecodeArgs p{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale};
-    hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(B, Hkv), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((attn_decode_kernel<128, 8>), dim3(B, Hkv), dim3(512), 0, stream, p);
     return iadr1_check_launch("attn_decode");
 }
 
@@ -659,4 +709,15 @@ extern "C" int iadr1_kv_store(const void* k, long long ldk, const void* v, long 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(kv_store_kernel<128>, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, slot, (bf16_t*)kcache, (bf16_t*)vcache, T, Hkv);
     return iadr1_check_launch("kv_store");
+}
+
+extern "C" int iadr1_rope_kv_store(void* qkv, long long ld, const float* cos_t, const float* sin_t, const long long* slot, void* kcache,
+                                   void* vcache, int T, int Hq, int Hkv, int D, hipStream_t stream) {
+    IADR1_REQUIRE(D == 128, "rope_kv_store: head dim %d not built (128 is)", D);
+    IADR1_REQUIRE(T > 0 && (ld % 8) == 0, "rope_kv_store: ld must be a multiple of 8");
+    const long long total = (long long)T * ((Hq + Hkv) * 16 + Hkv * 16);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rope_kv_store_kernel<128>, dim3((int)blocks), dim3(256), 0, stream, (bf16_t*)qkv, ld, cos_t, sin_t, slot, (bf16_t*)kcache, (bf16_t*)vcache, T, Hq, Hkv);
+    return iadr1_check_launch("rope_kv_store");
 }

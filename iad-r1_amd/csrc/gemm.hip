@@ -217,13 +217,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_128(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Skinny GEMM for the rollout decode step:  Y[M<=64 per grid.z, N] = X[M,K] . W[N,K]^T (+ bias).
-// HBM-bound weight stream (6.17 GB of bf16 weights per decode step for 3B).
-// Block = 4 waves that share 16*NB output columns and split K four ways (interleaved 64-wide slabs, so
-// the block streams whole 128-byte lines of each W row); W fragments go straight HBM->VGPR with
-// non-temporal 16-byte loads, several slabs in flight per wave; X fragments come from L2.  The four
-// partial 64 x 16NB tiles are combined through LDS and leave as bf16 (or fp32 logits) -- no atomics,
-// no zero-init, bias fused.
+// Skinny GEMM for the rollout decode step:  Y[M (64 per grid.y), N] = X[M,K] . W[N,K]^T (+ bias).
+// HBM-bound weight stream (6.17 GB of bf16 weights per decode step for 3B), and
+// for the small projections latency-bound: the whole K extent is therefore spread over MANY waves --
+// a block is WAVES (8/16) waves that share 16*NB output columns and take the 64-wide K slabs round-robin
+// (optionally also split over grid.z), every wave keeps U slabs in flight, W fragments go straight
+// HBM->VGPR with non-temporal 16-byte loads, X fragments come from L2.  The per-wave partial 64 x 16NB tiles
+// are combined through LDS and leave as bf16 (+bias), fp32 logits, or -- when K is also split over grid.z --
+// as fp32 partial slabs [z][M][N] that the fused residual+RMSNorm kernel sums (no atomics, no zero-init).
 // ------------------------------------------------------------------------------------------------------
 struct SkinnyArgs {
     const bf16_t* X;
@@ -232,16 +233,21 @@ struct SkinnyArgs {
     const bf16_t* bias;
     int M, N, K;
     long long ldx, ldw, ldy;
-    int out_f32;
+    int out_mode;  // 0 bf16 (+bias), 1 fp32, 2 fp32 partial slabs [gridDim.z][M][ldy]
 };
 
-template <int NB, int U>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
-    __shared__ float red[4][64][16 * NB + 1];
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
+    constexpr int U = 2, BNC = 16 * NB, RLD = BNC + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = (float*)smem_raw;  // [WAVES][64][RLD]
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int lm = l & 15, lq = l >> 4;
-    const int n0 = blockIdx.x * 16 * NB;
+    const int n0 = blockIdx.x * BNC;
     const int m_base = blockIdx.y * 64;
+    const int nslab = (p.K + 63) >> 6;
+    const int per_z = (nslab + gridDim.z - 1) / gridDim.z;
+    const int s_begin = blockIdx.z * per_z, s_end = min(nslab, s_begin + per_z);
 
     f32x4_t acc[4][NB];
 #pragma unroll
@@ -256,15 +262,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) xrow[i] = p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
 
-    // wave w owns the 64-wide K slabs w, w+4, w+8, ...; U slabs are fetched per trip
-    for (int kb = w * 64; kb < p.K; kb += 4 * 64 * U) {
+    for (int sb = s_begin + w; sb < s_end; sb += WAVES * U) {
         bf16x8_t wf[U][2][NB], xf[U][2][4];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const int k = kb + u * 256 + kk * 32;
-                const bool ok = k + lq * 8 < p.K;
+                const int k = (sb + u * WAVES) * 64 + kk * 32;
+                const bool ok = (sb + u * WAVES < s_end) && (k + lq * 8 < p.K);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     u32x4_t v = {0, 0, 0, 0};
@@ -289,22 +294,29 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][kk][j], xf[u][kk][i], acc[i][j], 0, 0, 0);
     }
     // lane owns rows n = j*16 + lq*4 + e of column m = i*16 + lm  (swapped-operand C layout)
+    float* mine = red + (size_t)w * 64 * RLD;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[w][i * 16 + lm][j * 16 + lq * 4 + e] = acc[i][j][e];
+            for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + j * 16 + lq * 4 + e] = acc[i][j][e];
     __syncthreads();
-    constexpr int BNC = 16 * NB;
-    for (int idx = t; idx < 64 * BNC; idx += 256) {
+    for (int idx = t; idx < 64 * BNC; idx += WAVES * 64) {
         const int m = idx / BNC, n = idx - m * BNC;
         const int gm = m_base + m, gn = n0 + n;
         if (gm >= p.M || gn >= p.N) continue;
-        float v = red[0][m][n] + red[1][m][n] + red[2][m][n] + red[3][m][n];
-        if (p.bias) v += bf2f(p.bias[gn]);
-        if (p.out_f32) ((float*)p.Y)[(long long)gm * p.ldy + gn] = v;
-        else ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+        if (p.out_mode == 0) {
+            if (p.bias) v += bf2f(p.bias[gn]);
+            ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
+        } else if (p.out_mode == 1) {
+            ((float*)p.Y)[(long long)gm * p.ldy + gn] = v;
+        } else {
+            ((float*)p.Y)[((long long)blockIdx.z * p.M + gm) * p.ldy + gn] = v;
+        }
     }
 }
 
@@ -340,13 +352,21 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
 }
 
 extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
-                                      long long ldw, long long ldy, int out_f32, hipStream_t stream) {
+                                      long long ldw, long long ldy, int out_mode, int ksplit, hipStream_t stream) {
     IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_skinny: empty problem");
     IADR1_REQUIRE((K % 8) == 0 && (ldx % 8) == 0 && (ldw % 8) == 0, "gemm_skinny: K, ldx, ldw must be multiples of 8");
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_skinny: X/W must be 16-byte aligned");
-    SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, (const bf16_t*)bias, M, N, K, ldx, ldw, ldy, out_f32};
+    IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny: ksplit > 1 needs out_mode 2 (partial slabs)");
+    SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, (const bf16_t*)bias, M, N, K, ldx, ldw, ldy, out_mode};
     const int mz = (M + 63) / 64;
-    if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), dim3((N + 31) / 32, mz), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), dim3((N + 15) / 16, mz), dim3(256), 0, stream, p);
+    static bool attr_done = false;
+    constexpr int SM1 = 16 * 64 * 17 * 4, SM2 = 8 * 64 * 33 * 4;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM2);
+        attr_done = true;
+    }
+    if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_skinny_bf16");
 }

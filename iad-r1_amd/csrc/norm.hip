@@ -13,7 +13,8 @@ constexpr int MAXC = 8;  // 16-byte chunks per lane -> rows up to 8*64*8 = 4096 
 
 struct RmsFwdArgs {
     const bf16_t* x;      // branch input [T,H] bf16 (or null when x32 is used)
-    float* x32;           // branch input [T,H] fp32 partial sums (decode); zeroed after reading
+    const float* x32;     // branch input: nsplit fp32 partial slabs [nsplit][T][ldx] (decode, split-K skinny GEMM)
+    int nsplit;
     const bf16_t* xbias;  // optional bias [H] added to x32 (e.g. none for o_proj/down)
     const bf16_t* res;    // optional residual [T,H]
     bf16_t* res_out;      // where x+res is written (may alias res); null = do not write
@@ -38,13 +39,14 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(RmsFwdArgs p) {
         const int ch = c * 64 + lane;
         if (ch < nchunk) {
             if (p.x32) {
-                float* src = p.x32 + (long long)row * p.ldx + ch * 8;
-                const f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
-                const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-                *(f32x4_t*)src = z;
-                *(f32x4_t*)(src + 4) = z;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[c][e] = a[e]; v[c][4 + e] = b[e]; }
+                for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+                for (int sp = 0; sp < p.nsplit; ++sp) {
+                    const float* src = p.x32 + ((long long)sp * p.T + row) * p.ldx + ch * 8;
+                    const f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[c][e] += a[e]; v[c][4 + e] += b[e]; }
+                }
                 if (p.xbias) {
                     const u32x4_t bb = *(const u32x4_t*)(p.xbias + ch * 8);
 #pragma unroll
@@ -192,13 +194,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(RmsBwdArgs p) {
         else if (nc_ <= 4) { CALL(4); } else if (nc_ <= 6) { CALL(6); } else { CALL(8); } \
     } while (0)
 
-extern "C" int iadr1_rmsnorm_fwd(const void* x, float* x32, const void* xbias, const void* res, void* res_out, const void* w,
-                                 void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy, float eps,
-                                 hipStream_t stream) {
+extern "C" int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, const void* xbias, const void* res, void* res_out,
+                                 const void* w, void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy,
+                                 float eps, hipStream_t stream) {
     IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0 && H <= MAXC * 512, "rmsnorm_fwd: H=%d must be a multiple of 8 and <= %d", H, MAXC * 512);
     IADR1_REQUIRE((x != nullptr) != (x32 != nullptr), "rmsnorm_fwd: exactly one of x / x32");
     IADR1_REQUIRE((ldx % 8) == 0 && (ldr % 8) == 0 && (ldy % 8) == 0, "rmsnorm_fwd: leading dims must be multiples of 8");
-    RmsFwdArgs p{(const bf16_t*)x, x32, (const bf16_t*)xbias, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (bf16_t*)y, rstd, T, H, ldx, ldr, ldy, eps};
+    IADR1_REQUIRE(x32 == nullptr || nsplit >= 1, "rmsnorm_fwd: nsplit >= 1 with x32");
+    RmsFwdArgs p{(const bf16_t*)x, x32, nsplit, (const bf16_t*)xbias, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (bf16_t*)y, rstd, T, H, ldx, ldr, ldy, eps};
     const dim3 grid((T + 3) / 4), block(256);
 #define CALL(NC) hipLaunchKernelGGL(rmsnorm_fwd_kernel<NC>, grid, block, 0, stream, p)
     DISPATCH_NC(H, CALL);

@@ -23,7 +23,7 @@ def parse_header(path: str = HEADER) -> dict[str, tuple[str, list[tuple[str, str
     """name -> (return type, [(ctype-name, arg-name)])"""
     txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
     protos = {}
-    for m in re.finditer(r"(int|const char\*)\s+(iadr1_\w+)\s*\(([^)]*)\)\s*;", txt):
+    for m in re.finditer(r"(int|long long|const char\*)\s+(iadr1_\w+)\s*\(([^)]*)\)\s*;", txt):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         parsed = []
         if args and args != "void":
@@ -50,7 +50,7 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in PROTOS.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
-            fn.restype = ctypes.c_char_p if ret != "int" else ctypes.c_int
+            fn.restype = {"int": ctypes.c_int, "long long": ctypes.c_longlong}.get(ret, ctypes.c_char_p)
             fn.argtypes = [ctypes.c_void_p if t == "ptr" else _CTYPE[t] for t, _ in args]
         _lib = L
     return _lib

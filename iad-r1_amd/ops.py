@@ -29,13 +29,19 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
-def gemm_skinny(x, w, bias=None, out=None, out_dtype=BF16):
-    """out[M,N] = x[M,K] @ w[N,K]^T + bias   (decode-time, HBM-bound weight stream)"""
+def gemm_skinny(x, w, bias=None, out=None, out_dtype=BF16, ksplit=1):
+    """out[M,N] = x[M,K] @ w[N,K]^T + bias   (decode-time, HBM-bound weight stream).  ksplit > 1: `out` is fp32
+    [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=..., nsplit=ksplit)."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
-        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
-    hip.call("gemm_skinny_bf16", x, w, out, bias, M, N, K, _ld(x), _ld(w), _ld(out), 1 if out.dtype == F32 else 0)
+        out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=x.device)
+    if out.dim() == 3:
+        assert out.dtype == F32 and out.shape[0] == ksplit and out.is_contiguous() and bias is None
+        mode, ldy = 2, N
+    else:
+        mode, ldy = (1 if out.dtype == F32 else 0), _ld(out)
+    hip.call("gemm_skinny_bf16", x, w, out, bias, M, N, K, _ld(x), _ld(w), ldy, mode, ksplit)
     return out
 
 
@@ -53,12 +59,20 @@ def transpose(x, out=None, pad_rows_to=1):
 
 
 def rmsnorm_fwd(x, w, eps, res=None, res_out=None, x32=None, xbias=None, want_rstd=False, out=None):
-    src = x if x is not None else x32
-    T, H = src.shape
-    y = out if out is not None else torch.empty(T, H, dtype=BF16, device=src.device)
-    rstd = torch.empty(T, dtype=F32, device=src.device) if want_rstd else None
+    """x: bf16 [T,H]  or  x32: fp32 [nsplit,T,H] partial slabs (summed in the kernel)."""
+    if x is not None:
+        T, H = x.shape
+        ldx, nsplit = _ld(x), 0
+    else:
+        x32 = x32 if x32.dim() == 3 else x32.unsqueeze(0)
+        nsplit, T, H = x32.shape
+        assert x32.is_contiguous()
+        ldx = H
+    dev = (x if x is not None else x32).device
+    y = out if out is not None else torch.empty(T, H, dtype=BF16, device=dev)
+    rstd = torch.empty(T, dtype=F32, device=dev) if want_rstd else None
     ldr = _ld(res) if res is not None else (_ld(res_out) if res_out is not None else H)
-    hip.call("rmsnorm_fwd", x, x32, xbias, res, res_out, w, y, rstd, T, H, _ld(src), ldr, _ld(y), float(eps))
+    hip.call("rmsnorm_fwd", x, x32, nsplit, xbias, res, res_out, w, y, rstd, T, H, ldx, ldr, _ld(y), float(eps))
     return y, rstd
 
 
@@ -203,11 +217,23 @@ def grpo_loss(logp, ref_logp, adv, mask, beta, n_total_rows=None):
     return dlogp, kl, row_loss, row_kl
 
 
+_sample_ws = {}
+
+
 def sample(logits32, temperature, top_k, top_p, seed, step, suppress_token=-1, step_ptr=None, out=None):
     B, V = logits32.shape
     o = out if out is not None else torch.empty(B, dtype=torch.int64, device=logits32.device)
-    hip.call("sample_topk_topp", logits32, _ld(logits32), o, B, V, float(temperature), int(top_k), float(top_p), int(suppress_token), int(seed), int(step), step_ptr)
+    key = (B, logits32.device)
+    ws = _sample_ws.get(key)
+    if ws is None:
+        ws = torch.empty(hip.lib().iadr1_sample_workspace_bytes(B), dtype=torch.uint8, device=logits32.device)
+        _sample_ws[key] = ws
+    hip.call("sample_topk_topp", logits32, _ld(logits32), o, ws, B, V, float(temperature), int(top_k), float(top_p), int(suppress_token), int(seed), int(step), step_ptr)
     return o
+
+
+def rope_kv_store(qkv, cos, sin, slot, kcache, vcache, Hq, Hkv, D):
+    hip.call("rope_kv_store", qkv, _ld(qkv), cos, sin, slot, kcache, vcache, qkv.shape[0], Hq, Hkv, D)
 
 
 def rope_table(pos, inv_freq, cos, sin):

@@ -34,20 +34,22 @@ const char* iadr1_last_error(void);
  * :1386-1387 (lm_head), and their autograd backward (dgrad / wgrad run on transposed operands). */
 int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
                        long long ldb, long long ldc, int out_mode, int act, iadr1_stream_t stream);
-/* Decode-time skinny GEMM: Y[M,N] = X[M,K] . W[N,K]^T + bias (bf16 out, or fp32 when out_f32), M small
- * (processed 64 rows per pass); HBM-bound weight stream, 4-way in-block split-K, no atomics.  Replaces the
- * same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667 -> llm.generate). */
+/* Decode-time skinny GEMM: Y[M,N] = X[M,K] . W[N,K]^T (M small, 64 rows per pass); HBM-bound weight stream,
+ * K spread over 8-16 waves per block (+ optional grid split `ksplit`), no atomics.  out_mode 0: bf16 + bias;
+ * 1: fp32 (logits); 2: fp32 partial slabs Y[ksplit][M][ldy] summed by iadr1_rmsnorm_fwd (x32 path).
+ * Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667). */
 int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
-                           long long ldw, long long ldy, int out_f32, iadr1_stream_t stream);
+                           long long ldw, long long ldy, int out_mode, int ksplit, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
 
 /* ---- RMSNorm (TF:65-79) --------------------------------------------------------------------------------
- * y = w * bf16((x [+ res]) * rsqrt(mean((x+res)^2) + eps)).  Exactly one of x (bf16) / x32 (fp32 split-K
- * sums, re-zeroed after the read, optional bias xbias) is given.  res_out receives x+res (new residual
- * stream), rstd the per-row statistic for the backward.  Any output pointer may be NULL. */
-int iadr1_rmsnorm_fwd(const void* x, float* x32, const void* xbias, const void* res, void* res_out, const void* w,
-                      void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy, float eps,
-                      iadr1_stream_t stream);
+ * y = w * bf16((x [+ res]) * rsqrt(mean((x+res)^2) + eps)).  Exactly one of x (bf16) / x32 is given; x32 =
+ * `nsplit` fp32 partial slabs [nsplit][T][ldx] from the split-K skinny GEMM (summed here, optional bias xbias).
+ * res_out receives x+res (new residual stream), rstd the per-row statistic for the backward.  Any output
+ * pointer may be NULL. */
+int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, const void* xbias, const void* res, void* res_out,
+                      const void* w, void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy,
+                      float eps, iadr1_stream_t stream);
 /* dx = dres + d rmsnorm / dx ; dw (fp32, may be NULL) += sum_t dy * x * rstd */
 int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                       float* dw, int T, int H, long long ld, iadr1_stream_t stream);
@@ -101,6 +103,9 @@ int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, con
                       iadr1_stream_t stream);
 int iadr1_kv_store(const void* k, long long ldk, const void* v, long long ldv, const long long* slot, void* kcache,
                    void* vcache, int T, int Hkv, int D, iadr1_stream_t stream);
+/* decode-step fusion of iadr1_rope_inplace (q,k heads) + iadr1_kv_store for one new token per sequence */
+int iadr1_rope_kv_store(void* qkv, long long ld, const float* cos_t, const float* sin_t, const long long* slot, void* kcache,
+                        void* vcache, int T, int Hq, int Hkv, int D, iadr1_stream_t stream);
 
 /* ---- log-probs / losses -----------------------------------------------------------------------------------
  * logprob_rows: REF:train/stage_rl/trainer/sc_grpo_trainer.py:510-513 (log_softmax + gather, no temperature)
@@ -121,8 +126,9 @@ int iadr1_adamw_flat(float* master, float* m, float* v, float* grad_zeroed_after
                      const float* norm2, float max_norm, iadr1_stream_t stream);
 
 /* ---- sampler (vLLM SamplingParams(temperature, top_p, top_k), REF:...sc_grpo_trainer.py:353-358) -------------- */
-int iadr1_sample_topk_topp(const float* logits, long long ld, long long* out, int B, int V, float temperature, int top_k,
-                           float top_p, int suppress_token, unsigned long long seed, unsigned step,
+long long iadr1_sample_workspace_bytes(int B);
+int iadr1_sample_topk_topp(const float* logits, long long ld, long long* out, void* workspace, int B, int V, float temperature,
+                           int top_k, float top_p, int suppress_token, unsigned long long seed, unsigned step,
                            const unsigned* step_ptr, iadr1_stream_t stream);
 
 /* ---- device-resident rollout bookkeeping (one decode step = a fixed, graph-replayable launch sequence) ------
