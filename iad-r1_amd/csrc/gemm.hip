@@ -17,6 +17,7 @@
 // output columns of one row: bf16 results are staged through LDS and leave as 16-byte row-contiguous
 // stores; fp32 results (logit chunks, wgrad accumulation) leave as 16-byte stores/RMW per lane.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -255,9 +256,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // packed weights: fragment (n-tile, 32-k step) is 1 KiB contiguous in lane order -> one fully coalesced load
+    const int ksteps = p.K >> 5;
     const bf16_t* wrow[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) wrow[j] = p.W + (long long)min(n0 + j * 16 + lm, p.N - 1) * p.ldw + lq * 8;
+    for (int j = 0; j < NB; ++j) wrow[j] = p.W + ((long long)min(blockIdx.x * NB + j, (p.N >> 4) - 1) * ksteps) * 512 + l * 8;
     const bf16_t* xrow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) xrow[i] = p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     u32x4_t v = {0, 0, 0, 0};
-                    if (ok) v = __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + k));
+                    if (ok) v = __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + (long long)(k >> 5) * 512));
                     wf[u][kk][j] = __builtin_bit_cast(bf16x8_t, v);
                 }
 #pragma unroll
@@ -320,6 +323,117 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     }
 }
 
+// Wide variant (MLP up/down projections, lm_head): one wave owns 16*NB (64/128) columns for its K slabs, so an
+// X fragment fetched from L2 feeds NB MFMA column tiles (vector-memory traffic per weight byte drops from 3-5x
+// to 1.5-2x: the X re-read through L2, not HBM, limited the narrow kernel), and the 32-deep half-slabs are
+// software pipelined: the loads of step j+1 are in flight while the MFMAs of step j run.  K may also be split
+// over grid.z (narrow-N, long-K down projection) -> fp32 partial slabs for the fused residual+RMSNorm.
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs p) {
+    constexpr int RC = 32, RLD = RC + 1;  // columns per reduction round
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = (float*)smem_raw;  // [WAVES][64][RLD]
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int lm = l & 15, lq = l >> 4;
+    const int n0 = blockIdx.x * 16 * NB;
+    const int m_base = blockIdx.y * 64;
+    const int nslab = (p.K + 63) >> 6;
+    const int per_z = (nslab + gridDim.z - 1) / gridDim.z;
+    const int s_begin = blockIdx.z * per_z, s_end = min(nslab, s_begin + per_z);
+
+    f32x4_t acc[4][NB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int ksteps = p.K >> 5;
+    const bf16_t* wbase = p.W + l * 8;
+    long long wrow_off[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wrow_off[j] = ((long long)min(blockIdx.x * NB + j, (p.N >> 4) - 1) * ksteps) * 512;
+    const bf16_t* xrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xrow[i] = p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
+
+    // this wave's steps: step j -> slab s_begin + w + (j>>1)*WAVES, half (j&1)
+    const int my_slabs = (s_end - s_begin - w + WAVES - 1) / WAVES;
+    const int nj = my_slabs > 0 ? 2 * my_slabs : 0;
+    auto load = [&](int j, bf16x8_t (&wf)[NB], bf16x8_t (&xf)[4]) {
+        const int k = (s_begin + w + (j >> 1) * WAVES) * 64 + (j & 1) * 32;
+        const bool ok = k + lq * 8 < p.K;
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (ok) v = __builtin_nontemporal_load((const u32x4_t*)(wbase + wrow_off[jj] + (long long)(k >> 5) * 512));
+            wf[jj] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (ok) v = *(const u32x4_t*)(xrow[i] + k);
+            xf[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    };
+    auto compute = [&](const bf16x8_t (&wf)[NB], const bf16x8_t (&xf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], xf[i], acc[i][jj], 0, 0, 0);
+    };
+    bf16x8_t wA[NB], xA[4], wB[NB], xB[4];
+    if (nj > 0) load(0, wA, xA);
+    for (int j = 0; j < nj; j += 2) {
+        load(j + 1, wB, xB);  // nj is even: step j+1 always exists
+        compute(wA, xA);
+        if (j + 2 < nj) load(j + 2, wA, xA);
+        compute(wB, xB);
+    }
+    float* mine = red + (size_t)w * 64 * RLD;
+#pragma unroll
+    for (int r = 0; r < NB / 2; ++r) {
+        if (r) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + jj * 16 + lq * 4 + e] = acc[i][2 * r + jj][e];
+        __syncthreads();
+        for (int idx = t; idx < 64 * RC; idx += WAVES * 64) {
+            const int m = idx / RC, n = idx - m * RC;
+            const int gm = m_base + m, gn = n0 + r * RC + n;
+            if (gm >= p.M || gn >= p.N) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+            if (p.out_mode == 0) {
+                if (p.bias) v += bf2f(p.bias[gn]);
+                ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
+            } else if (p.out_mode == 1) {
+                ((float*)p.Y)[(long long)gm * p.ldy + gn] = v;
+            } else {
+                ((float*)p.Y)[((long long)blockIdx.z * p.M + gm) * p.ldy + gn] = v;
+            }
+        }
+    }
+}
+
+// Repack W[N,K] (row-major) into MFMA-fragment order for the decode stream:
+//   Wp[n/16][k/32][lane = (n%16) + 16*((k%32)/8)][k%8]
+__global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int N, int K) {
+    const int ksteps = K >> 5;
+    const long long total = (long long)(N >> 4) * ksteps * 64;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long long ts = i >> 6;
+        const int ks = (int)(ts % ksteps);
+        const long long tile = ts / ksteps;
+        const long long n = tile * 16 + (lane & 15);
+        const int k = ks * 32 + (lane >> 4) * 8;
+        *(u32x4_t*)(Wp + i * 8) = *(const u32x4_t*)(W + n * ldw + k);
+    }
+}
+
 __device__ char g_zero16[64] __attribute__((aligned(64)));
 
 }  // namespace
@@ -354,8 +468,9 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
 extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
                                       long long ldw, long long ldy, int out_mode, int ksplit, hipStream_t stream) {
     IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_skinny: empty problem");
-    IADR1_REQUIRE((K % 8) == 0 && (ldx % 8) == 0 && (ldw % 8) == 0, "gemm_skinny: K, ldx, ldw must be multiples of 8");
+    IADR1_REQUIRE((K % 32) == 0 && (N % 16) == 0 && (ldx % 8) == 0, "gemm_skinny: packed weights need K %% 32 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_skinny: X/W must be 16-byte aligned");
+    (void)ldw;
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny: ksplit > 1 needs out_mode 2 (partial slabs)");
     SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, (const bf16_t*)bias, M, N, K, ldx, ldw, ldy, out_mode};
     const int mz = (M + 63) / 64;
@@ -366,7 +481,28 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM2);
         attr_done = true;
     }
-    if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
+    constexpr int SMW = 8 * 64 * 33 * 4;
+    static int wide_nb = 0;
+    if (!wide_nb) {
+        const char* e = getenv("IADR1_SKINNY_WIDE_NB");
+        wide_nb = e ? atoi(e) : 8;
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
+    }
+    // wide kernels: NB=8 (128 columns / block) for the big-N streams (gate|up, lm_head); NB=4 with K split over
+    // grid.z for the long-K narrow-N down projection; the narrow kernel for the small projections (latency-bound)
+    (void)wide_nb;
+    if (N >= 8192 && ksplit == 1) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
+    else if (ksplit > 1 && ((N + 63) / 64) * ksplit >= 192) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3((N + 63) / 64, mz, ksplit), dim3(512), SMW, stream, p);
+    else if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
     else hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_skinny_bf16");
+}
+
+extern "C" int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, hipStream_t stream) {
+    IADR1_REQUIRE(N > 0 && K > 0 && (N % 16) == 0 && (K % 32) == 0 && (ldw % 8) == 0, "pack_weight: need N %% 16 == 0, K %% 32 == 0 (N=%d K=%d)", N, K);
+    long long blocks = ((long long)N * K / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, N, K);
+    return iadr1_check_launch("pack_weight_bf16");
 }

@@ -95,6 +95,75 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(RmsFwdArgs p) {
     }
 }
 
+// Few-row variant (decode: T = sequences in flight): one ROW PER BLOCK, 256 threads, so a 64-row call still
+// spreads over 64 CUs and the per-thread dependent-load chain is 1/4 as long as in the wave-per-row kernel.
+__global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
+    __shared__ float scratch[16];
+    const int row = blockIdx.x, t = threadIdx.x;
+    const int nchunk = p.H >> 3;
+    constexpr int MC = 4;  // H <= 8192
+    float v[MC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        const int ch = c * 256 + t;
+        if (ch < nchunk) {
+            if (p.x32) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+                for (int sp = 0; sp < p.nsplit; ++sp) {
+                    const float* src = p.x32 + ((long long)sp * p.T + row) * p.ldx + ch * 8;
+                    const f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[c][e] += a[e]; v[c][4 + e] += b[e]; }
+                }
+                if (p.xbias) {
+                    const u32x4_t bb = *(const u32x4_t*)(p.xbias + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[c][2 * e] += lo_bf(bb[e]); v[c][2 * e + 1] += hi_bf(bb[e]); }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = bf2f(f2bf(v[c][e]));
+            } else {
+                const u32x4_t a = *(const u32x4_t*)(p.x + (long long)row * p.ldx + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[c][2 * e] = lo_bf(a[e]); v[c][2 * e + 1] = hi_bf(a[e]); }
+            }
+            if (p.res) {
+                const u32x4_t r = *(const u32x4_t*)(p.res + (long long)row * p.ldr + ch * 8);
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = pack2bf(v[c][2 * e] + lo_bf(r[e]), v[c][2 * e + 1] + hi_bf(r[e]));
+                    v[c][2 * e] = lo_bf(o[e]);
+                    v[c][2 * e + 1] = hi_bf(o[e]);
+                }
+                if (p.res_out) *(u32x4_t*)(p.res_out + (long long)row * p.ldr + ch * 8) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[c][e] * v[c][e];
+        }
+    }
+    ss = block_sum<256>(ss, scratch);
+    const float rstd = rsqrtf(ss / (float)p.H + p.eps);
+    if (p.rstd && t == 0) p.rstd[row] = rstd;
+    if (!p.y) return;
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        const int ch = c * 256 + t;
+        if (ch < nchunk) {
+            const u32x4_t g = *(const u32x4_t*)(p.w + ch * 8);
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float n0 = bf2f(f2bf(v[c][2 * e] * rstd)), n1 = bf2f(f2bf(v[c][2 * e + 1] * rstd));
+                o[e] = pack2bf(lo_bf(g[e]) * n0, hi_bf(g[e]) * n1);
+            }
+            *(u32x4_t*)(p.y + (long long)row * p.ldy + ch * 8) = o;
+        }
+    }
+}
+
 struct RmsBwdArgs {
     const bf16_t* dy;    // [T,H]
     const bf16_t* x;     // pre-norm input [T,H]
@@ -202,6 +271,10 @@ extern "C" int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, co
     IADR1_REQUIRE((ldx % 8) == 0 && (ldr % 8) == 0 && (ldy % 8) == 0, "rmsnorm_fwd: leading dims must be multiples of 8");
     IADR1_REQUIRE(x32 == nullptr || nsplit >= 1, "rmsnorm_fwd: nsplit >= 1 with x32");
     RmsFwdArgs p{(const bf16_t*)x, x32, nsplit, (const bf16_t*)xbias, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (bf16_t*)y, rstd, T, H, ldx, ldr, ldy, eps};
+    if (T <= 256) {
+        hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, stream, p);
+        return iadr1_check_launch("rmsnorm_fwd");
+    }
     const dim3 grid((T + 3) / 4), block(256);
 #define CALL(NC) hipLaunchKernelGGL(rmsnorm_fwd_kernel<NC>, grid, block, 0, stream, p)
     DISPATCH_NC(H, CALL);

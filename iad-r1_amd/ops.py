@@ -29,11 +29,20 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
-def gemm_skinny(x, w, bias=None, out=None, out_dtype=BF16, ksplit=1):
-    """out[M,N] = x[M,K] @ w[N,K]^T + bias   (decode-time, HBM-bound weight stream).  ksplit > 1: `out` is fp32
-    [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=..., nsplit=ksplit)."""
+def pack_weight(w, out=None):
+    """[N,K] row-major -> decode-packed fragment order (flat [N*K])."""
+    N, K = w.shape
+    o = out if out is not None else torch.empty(N * K, dtype=BF16, device=w.device)
+    hip.call("pack_weight_bf16", w, _ld(w), o, N, K)
+    return o
+
+
+def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1):
+    """out[M,N] = x[M,K] @ W[N,K]^T + bias with W given decode-packed (`pack_weight`); HBM-bound weight stream.
+    ksplit > 1: `out` is fp32 [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=..., nsplit=ksplit)."""
     M, K = x.shape
-    N = w.shape[0]
+    w = wp
+    assert wp.numel() == N * K
     if out is None:
         out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=x.device)
     if out.dim() == 3:
@@ -41,7 +50,7 @@ def gemm_skinny(x, w, bias=None, out=None, out_dtype=BF16, ksplit=1):
         mode, ldy = 2, N
     else:
         mode, ldy = (1 if out.dtype == F32 else 0), _ld(out)
-    hip.call("gemm_skinny_bf16", x, w, out, bias, M, N, K, _ld(x), _ld(w), ldy, mode, ksplit)
+    hip.call("gemm_skinny_bf16", x, w, out, bias, M, N, K, _ld(x), K, ldy, mode, ksplit)
     return out
 
 

@@ -144,9 +144,10 @@ class _Slot:
 class ParamStore:
     """Flat parameter buffers + named views in the engine's fused layout."""
 
-    def __init__(self, cfg: VLMConfig, device, trainable: bool, with_transposes: bool | None = None):
+    def __init__(self, cfg: VLMConfig, device, trainable: bool, with_transposes: bool | None = None, with_decode_pack: bool | None = None):
         self.cfg, self.device, self.trainable = cfg, torch.device(device), trainable
         self.with_transposes = trainable if with_transposes is None else with_transposes
+        self.with_decode_pack = trainable if with_decode_pack is None else with_decode_pack
         c = cfg
         H, I, D = c.hidden_size, c.intermediate_size, c.head_dim
         vh, vip = c.v_hidden, c.v_inter_pad
@@ -210,6 +211,17 @@ class ParamStore:
             self.v = torch.zeros(self.n_total, dtype=F32, device=self.device)
             self.grad = torch.zeros(self.n_total, dtype=F32, device=self.device)
         self._views, self._tviews, self._gviews = {}, {}, {}
+        # decode-packed (MFMA fragment order) shadows of the weights the rollout streams every step
+        self._pk = {}
+        if self.with_decode_pack:
+            names = [f"layers.{i}.{k}" for i in range(c.num_hidden_layers) for k in ("qkv.w", "o.w", "gu.w", "down.w")] + [self.lm_head_name()]
+            tot = sum(_rup(int(np.prod(self.slots[n].shape)), 64) for n in names)
+            self.flat_pk = torch.zeros(tot, dtype=BF16, device=self.device)
+            o = 0
+            for n in names:
+                k = int(np.prod(self.slots[n].shape))
+                self._pk[n] = self.flat_pk[o: o + k]
+                o += _rup(k, 64)
 
     # ---- views -------------------------------------------------------------------------------------------
     def w(self, name: str) -> torch.Tensor:
@@ -240,6 +252,14 @@ class ParamStore:
 
     def lm_head_name(self):
         return "embed" if self.cfg.tie_word_embeddings else "lm_head"
+
+    def wpk(self, name: str) -> torch.Tensor:
+        """Decode-packed shadow (flat) of GEMM weight `name`."""
+        return self._pk[name]
+
+    def refresh_decode_pack(self):
+        for name, dst in self._pk.items():
+            ops.pack_weight(self.w(name), out=dst)
 
     def refresh_transposes(self):
         if not self.with_transposes:
@@ -308,7 +328,12 @@ class ParamStore:
     def finalize(self):
         if self.trainable:
             self.sync_master_from_bf16()
+        self.refresh_shadows()
+
+    def refresh_shadows(self):
+        """After any change of the bf16 parameters (load / optimizer step): transposed + decode-packed copies."""
         self.refresh_transposes()
+        self.refresh_decode_pack()
 
     def export_named(self, source: str = "param") -> dict:
         """Inverse of load_named (bf16 params, or fp32 `grad` views for tests): checkpoint-name -> CPU tensor."""

@@ -53,7 +53,7 @@ class Rollout:
         self.qkv = torch.empty(N, c.qkv_width, dtype=BF16, device=dev)
         self.o = torch.empty(N, Hq * D, dtype=BF16, device=dev)
         self.br = torch.empty(N, H, dtype=BF16, device=dev)
-        self.ks_o, self.ks_down = (2, 4) if H * Hq * D >= 1 << 20 else (1, 1)   # split-K of the two narrow-N projections
+        self.ks_o, self.ks_down = (2, 8) if H * Hq * D >= 1 << 20 else (1, 1)   # split-K of the two narrow-N projections
         self.part_o = torch.empty(self.ks_o, N, H, dtype=F32, device=dev)
         self.part_d = torch.empty(self.ks_down, N, H, dtype=F32, device=dev)
         self.gu = torch.empty(N, 2 * I, dtype=BF16, device=dev)
@@ -79,17 +79,17 @@ class Rollout:
                 ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h)
             else:
                 ops.rmsnorm_fwd(None, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)
-            ops.gemm_skinny(self.h, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=self.qkv)
+            ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
             ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
             ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o)
-            ops.gemm_skinny(self.o, P.w(b + "o.w"), out=self.part_o, ksplit=self.ks_o)
+            ops.gemm_skinny(self.o, P.wpk(b + "o.w"), c.hidden_size, out=self.part_o, ksplit=self.ks_o)
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h)
-            ops.gemm_skinny(self.h, P.w(b + "gu.w"), out=self.gu)
+            ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.gu)
             ops.swiglu_fwd(self.gu, out=self.a)
-            ops.gemm_skinny(self.a, P.w(b + "down.w"), out=self.part_d, ksplit=self.ks_down)
+            ops.gemm_skinny(self.a, P.wpk(b + "down.w"), c.hidden_size, out=self.part_d, ksplit=self.ks_down)
             have_branch = True
         ops.rmsnorm_fwd(None, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)
-        ops.gemm_skinny(self.h, P.w(P.lm_head_name()), out=self.logits)
+        ops.gemm_skinny(self.h, P.wpk(P.lm_head_name()), c.vocab_size, out=self.logits)
         self._sample_and_advance()
 
     def _sample_and_advance(self):

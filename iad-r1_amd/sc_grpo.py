@@ -273,7 +273,7 @@ class SCGRPOEngine:
             if hi > lo:
                 hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,
                          a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd, self.opt_step, scale, self.norm2, a.max_grad_norm)
-        st.refresh_transposes()
+        st.refresh_shadows()
         self.accum = 0
 
     # ---- the whole micro-step ----------------------------------------------------------------------------------------

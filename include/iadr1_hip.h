@@ -40,6 +40,9 @@ int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, 
  * Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667). */
 int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
                            long long ldw, long long ldy, int out_mode, int ksplit, iadr1_stream_t stream);
+/* W[N,K] row-major -> decode-packed MFMA-fragment order Wp[N/16][K/32][64 lanes][8] (what iadr1_gemm_skinny_bf16 reads:
+ * every wave-level load of the weight stream is then 1 KiB contiguous).  N % 16 == 0, K % 32 == 0. */
+int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
 
 /* ---- RMSNorm (TF:65-79) --------------------------------------------------------------------------------

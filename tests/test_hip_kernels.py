@@ -65,16 +65,17 @@ def test_gemm_nt_strided_views():
     assert float(outbuf[:, :256].abs().sum()) == 0 and float(outbuf[:, 516:].abs().sum()) == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (64, 640, 256), (8, 256, 512), (100, 1000, 1032), (64, 22016, 2048), (64, 2048, 11008)])
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (64, 640, 256), (8, 256, 512), (100, 1008, 1056), (64, 22016, 2048), (64, 2048, 11008)])
 def test_gemm_skinny(M, N, K):
     x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
+    wp = ops.pack_weight(w)
     ref = x.float() @ w.float().t()
-    y = ops.gemm_skinny(x, w, out_dtype=F32)
+    y = ops.gemm_skinny(x, wp, N, out_dtype=F32)
     close(y, ref, 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"skinny f32 {M}x{N}x{K}")
-    yb = ops.gemm_skinny(x, w, bias=bias)
+    yb = ops.gemm_skinny(x, wp, N, bias=bias)
     close(yb, ref + bias.float(), 1e-2, 1e-2 * math.sqrt(K) * 0.3, f"skinny bf16+bias {M}x{N}x{K}")
-    for ks in (1, 2, 4):
-        part = ops.gemm_skinny(x, w, out=torch.full((ks, M, N), 7.0, dtype=F32, device=DEV), ksplit=ks)
+    for ks in (1, 2, 8):
+        part = ops.gemm_skinny(x, wp, N, out=torch.full((ks, M, N), 7.0, dtype=F32, device=DEV), ksplit=ks)
         close(part.sum(0), ref, 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"skinny split-K {ks} {M}x{N}x{K}")
 
 
