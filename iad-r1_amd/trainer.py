@@ -1,0 +1,290 @@
+"""`SCGRPOTrainer`: the drop-in trainer API of the reference's SC-GRPO stage
+(/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:72-90 constructor, :586 compute_loss, :821 log;
+used by /root/reference/train/stage_rl/grpo_ad.py:188-207) on top of the HIP engine.
+
+What is kept: constructor signature and error behaviour, the reward-function plugin signature
+`f(prompts=, completions=, current_step=, **dataset_columns) -> list[float]` (REF:773-781), the metric keys
+(`completion_length`, `rewards/<name>`, `reward`, `reward_std`, `kl`; REF:801-827), `train()`, `save_model()`.
+What is replaced: transformers.Trainer + DeepSpeed ZeRO-3 + the vLLM side GPU -> one process per MI355X with the
+whole model resident, in-process hipGraph rollout, RCCL all-reduce of a flat gradient buffer.
+Host-side tokenisation / image patching stays with the HF processor (CPU plumbing, REF:184-227, 600-622).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import time
+from collections import defaultdict
+from dataclasses import dataclass, field
+from typing import Any, Callable, Optional, Union
+
+import numpy as np
+import torch
+
+from .params import ParamStore, VLMConfig
+from .sc_grpo import GRPOArgs, SCGRPOEngine
+
+
+@dataclass
+class GRPOConfig:
+    """Flag surface of the reference's `GRPOConfig` (train/stage_rl/configs.py:24-42 over trl's GRPOConfig) that
+    the SC-GRPO scripts set (scripts/train/SC_GRPO/*.sh:40-63) or whose defaults matter.  Unknown / unused
+    reference flags are accepted by the CLI and ignored."""
+    output_dir: str = "outputs"
+    per_device_train_batch_size: int = 1
+    gradient_accumulation_steps: int = 1
+    num_generations: int = 8
+    max_prompt_length: Optional[int] = 512
+    max_completion_length: int = 256
+    beta: float = 0.04
+    temperature: float = 0.9
+    learning_rate: float = 1e-6
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 1.0
+    lr_scheduler_type: str = "linear"
+    warmup_steps: int = 0
+    num_train_epochs: float = 1.0
+    max_steps: int = -1
+    logging_steps: int = 1
+    save_steps: int = 100
+    seed: int = 42
+    bf16: bool = True
+    gradient_checkpointing: bool = False   # accepted; 288 GB HBM holds the activations of a micro-batch, nothing is recomputed
+    model_init_kwargs: Optional[dict] = None
+    micro_batch_seqs: int = 16
+    run_name: Optional[str] = None
+    report_to: Any = None
+    push_to_hub: bool = False
+    eval_strategy: str = "no"
+
+
+def load_checkpoint(path: str, device, trainable: bool):
+    """HF Qwen2.5-VL checkpoint directory (config.json + *.safetensors) -> (VLMConfig, ParamStore)."""
+    from safetensors import safe_open
+
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = VLMConfig.from_hf_config(json.load(f))
+    store = ParamStore(cfg, device, trainable=trainable)
+    sd = {}
+    files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    for fn in files:
+        with safe_open(os.path.join(path, fn), framework="pt") as sf:
+            for k in sf.keys():
+                name = k
+                # transformers>=5 layout -> classic checkpoint names
+                if name.startswith("model.visual."):
+                    name = name[len("model."):]
+                elif name.startswith("model.language_model."):
+                    name = "model." + name[len("model.language_model."):]
+                sd[name] = sf.get_tensor(k)
+    store.load_named(sd)
+    return cfg, store
+
+
+def save_checkpoint(store: ParamStore, path: str, hf_config: Optional[dict] = None):
+    """Writes HF-layout safetensors (names as the reference's vLLM eval scripts expect) + config.json."""
+    from safetensors.torch import save_file
+
+    os.makedirs(path, exist_ok=True)
+    sd = {k: v.to(torch.bfloat16).contiguous() for k, v in store.export_named().items()}
+    save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    if hf_config is not None:
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(hf_config, f, indent=2)
+
+
+class SCGRPOTrainer:
+    def __init__(
+        self,
+        model: Union[str, tuple],
+        reward_funcs: Union[Callable, list],
+        args: Optional[GRPOConfig] = None,
+        train_dataset=None,
+        eval_dataset=None,
+        processing_class=None,
+        reward_processing_classes=None,
+        callbacks=None,
+        optimizers=(None, None),
+        peft_config=None,
+        max_pixels: Optional[int] = 12845056,
+        min_pixels: Optional[int] = 3136,
+        attn_implementation: str = "flash_attention_2",
+        use_vllm_for_gen: bool = True,
+    ):
+        if args is None:
+            name = model if isinstance(model, str) else "model"
+            args = GRPOConfig(output_dir=f"{os.path.basename(name.rstrip('/'))}-GRPO")
+        self.args = args
+        mik = args.model_init_kwargs or {}
+        if isinstance(model, str):
+            td = mik.get("torch_dtype")
+            if not (td is None or td == "auto" or isinstance(td, torch.dtype)):
+                if isinstance(td, str) and hasattr(torch, td):
+                    td = getattr(torch, td)
+                else:
+                    raise ValueError("Invalid `torch_dtype` passed to `GRPOConfig`. Expected either 'auto' or a string representing "
+                                     f"a `torch.dtype` (e.g., 'float32'), but got {td}.")  # REF:108-111
+            mid = model.lower()
+            if not any(t in mid for t in ("qwen2.5-vl", "qwen2.5_vl", "qwen2.5vl")):
+                raise ValueError(f"{model}: this engine implements the Qwen2.5-VL family of the reference's model switch "
+                                 "(REF:116-137); Qwen2-VL and LLaVA variants are not built yet")
+        elif mik:
+            raise ValueError("You passed `model_init_kwargs` to the `GRPOConfig`, but your model is already instantiated. "
+                             "This argument can only be used when the `model` argument is a string.")  # REF:141-145
+        if peft_config is not None:
+            raise ValueError("peft_config: LoRA is not part of this path (the reference scripts train full parameters)")
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        self.hf_config = None
+        if isinstance(model, str):
+            self.model_id = model
+            self.cfg, self.policy = load_checkpoint(model, self.device, trainable=True)
+            with open(os.path.join(model, "config.json")) as f:
+                self.hf_config = json.load(f)
+        else:
+            self.model_id = "in-memory-qwen2.5-vl"
+            self.cfg, weights = model
+            self.policy = ParamStore(self.cfg, self.device, trainable=True)
+            self.policy.load_named(weights)
+        # frozen reference = the starting checkpoint (REF:152-182)
+        self.ref = ParamStore(self.cfg, self.device, trainable=False)
+        self.ref.copy_from(self.policy)
+        if processing_class is None:
+            if not isinstance(model, str):
+                raise ValueError("processing_class is required when the model is passed in memory")
+            from transformers import AutoProcessor
+            processing_class = AutoProcessor.from_pretrained(model)
+            if hasattr(processing_class, "image_processor"):
+                processing_class.image_processor.max_pixels = max_pixels  # REF:192-193
+                processing_class.image_processor.min_pixels = min_pixels
+        self.processing_class = processing_class
+        self.reward_funcs = list(reward_funcs) if isinstance(reward_funcs, (list, tuple)) else [reward_funcs]
+        for f in self.reward_funcs:
+            if not callable(f):
+                raise ValueError("reward model checkpoints as reward functions are not part of this path; pass callables")
+        self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
+        self.use_vllm = use_vllm_for_gen
+        group = None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            group = dist.group.WORLD
+        self.engine = SCGRPOEngine(self.cfg, self.policy, self.ref, GRPOArgs(
+            num_generations=args.num_generations, max_prompt_length=args.max_prompt_length, max_completion_length=args.max_completion_length,
+            beta=args.beta, temperature=args.temperature, learning_rate=args.learning_rate, weight_decay=args.weight_decay,
+            adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
+            gradient_accumulation_steps=args.gradient_accumulation_steps, micro_batch_seqs=args.micro_batch_seqs, seed=args.seed), group=group)
+        self.state = type("State", (), {"global_step": 0})()
+        self._metrics = defaultdict(list)
+        self.log_history = []
+
+    # ---- batch construction (host) -------------------------------------------------------------------------------
+    def _prepare(self, inputs: list[dict]):
+        from PIL import Image
+        pc = self.processing_class
+        prompts_text = []
+        for ex in inputs:
+            p = ex["prompt"]
+            if isinstance(p, list):  # conversational -> chat template with generation prompt (trl maybe_apply_chat_template)
+                p = pc.apply_chat_template(p, add_generation_prompt=True, tokenize=False)
+            prompts_text.append(p)
+        images, per_prompt = [], []
+        for ex in inputs:
+            im = ex.get("image")
+            im = im if isinstance(im, list) else ([im] if im is not None else [])
+            per_prompt.append(len(im))
+            images += [Image.open(i) if isinstance(i, str) else i for i in im]
+        enc = pc(text=prompts_text, images=images if images else None, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
+        return {"input_ids": enc["input_ids"].numpy(), "attention_mask": enc["attention_mask"].numpy(), "pixel_values": enc["pixel_values"],
+                "image_grid_thw": enc["image_grid_thw"].numpy().tolist(), "images_per_prompt": per_prompt}
+
+    def _rewards(self, inputs, completion_ids: np.ndarray):
+        G = self.args.num_generations
+        texts = self.processing_class.batch_decode(completion_ids, skip_special_tokens=True)
+        conversational = isinstance(inputs[0]["prompt"], list)
+        completions = [[{"role": "assistant", "content": t}] for t in texts] if conversational else texts
+        prompts = [ex["prompt"] for ex in inputs for _ in range(G)]
+        kw = {k: [ex[k] for ex in inputs for _ in range(G)] for k in inputs[0] if k not in ("prompt", "completion")}
+        cols = []
+        for f in self.reward_funcs:
+            cols.append(np.asarray(f(prompts=prompts, completions=completions, current_step=self.state.global_step, **kw), dtype=np.float32))
+        return np.stack(cols, 1)
+
+    # ---- reference API ---------------------------------------------------------------------------------------------
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, last_micro_step=True):
+        """One SC-GRPO micro-step on `inputs` (list of dataset rows).  Returns the loss value; gradients are
+        accumulated inside the engine (there is no autograd graph to hand back)."""
+        if return_outputs:
+            raise ValueError("The GRPOTrainer does not support returning outputs")  # REF:587-588
+        batch = self._prepare(inputs)
+        vis = self.engine.vision_policy(batch, save=True)
+        comp = self.engine.rollout(batch, vis=vis)
+        rew = self._rewards(inputs, comp)
+        out = self.engine.loss_and_grads(batch, comp, rew, backward=True, last_micro_step=last_micro_step, vis=vis)
+        m = out["metrics"]
+        self._metrics["completion_length"].append(m["completion_length"])
+        rp = out["rewards_per_func"].mean(0)
+        for i, f in enumerate(self.reward_funcs):
+            self._metrics[f"rewards/{f.__name__}"].append(float(rp[i]))
+        self._metrics["reward"].append(m["reward"])
+        self._metrics["reward_std"].append(m["reward_std"])
+        self._metrics["kl"].append(m["kl"])
+        return m["loss"]
+
+    def log(self, logs: dict, start_time=None):
+        metrics = {k: sum(v) / len(v) for k, v in self._metrics.items()}
+        logs = {**logs, **metrics}
+        self.log_history.append(logs)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(logs), flush=True)
+        self._metrics.clear()
+
+    def _lr(self, step, total):
+        a = self.args
+        if a.warmup_steps and step < a.warmup_steps:
+            return a.learning_rate * (step + 1) / a.warmup_steps
+        if a.lr_scheduler_type == "constant":
+            return a.learning_rate
+        frac = (step - a.warmup_steps) / max(1, total - a.warmup_steps)
+        if a.lr_scheduler_type == "cosine":
+            return a.learning_rate * 0.5 * (1 + math.cos(math.pi * frac))
+        return a.learning_rate * max(0.0, 1 - frac)  # HF default: linear decay
+
+    def train(self):
+        a = self.args
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        rows = list(self.train_dataset)
+        rows = rows[rank::world]  # prompts are sharded over ranks; each rank keeps whole groups
+        bs, ga = a.per_device_train_batch_size, a.gradient_accumulation_steps
+        steps_per_epoch = max(1, len(rows) // (bs * ga))
+        total = a.max_steps if a.max_steps > 0 else int(math.ceil(steps_per_epoch * a.num_train_epochs))
+        t0 = time.time()
+        i = 0
+        for step in range(total):
+            self.engine.args.learning_rate = self._lr(step, total)
+            losses = []
+            for k in range(ga):
+                inputs = [rows[(i + j) % len(rows)] for j in range(bs)]
+                i += bs
+                losses.append(self.compute_loss(None, inputs, last_micro_step=(k == ga - 1)))
+            self.engine.optimizer_step()
+            self.state.global_step += 1
+            if self.state.global_step % a.logging_steps == 0:
+                self.log({"loss": float(np.mean(losses)), "learning_rate": self.engine.args.learning_rate, "step": self.state.global_step,
+                          "elapsed_s": round(time.time() - t0, 2)})
+            if a.save_steps and self.state.global_step % a.save_steps == 0 and rank == 0:
+                self.save_model(os.path.join(a.output_dir, f"checkpoint-{self.state.global_step}"))
+        return self.log_history
+
+    def save_model(self, output_dir: Optional[str] = None):
+        save_checkpoint(self.policy, output_dir or self.args.output_dir, self.hf_config)
+        pc = self.processing_class
+        if hasattr(pc, "save_pretrained"):
+            pc.save_pretrained(output_dir or self.args.output_dir)
+
+    def push_to_hub(self, **kw):
+        raise RuntimeError("push_to_hub: no network egress in this environment")

@@ -178,3 +178,47 @@ def test_sft_loss_curve_matches_reference_golden(golden_dir):
         losses.append(eng.loss_and_grads(batch))
         eng.optimizer_step()
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-2, atol=2e-2)
+
+
+class _FakeProcessor:
+    """Stands in for AutoProcessor (no tokenizer files offline): fixed prompt tensors, canned decode strings."""
+
+    def __init__(self, batch, texts):
+        self.batch, self.texts = batch, texts
+
+    def apply_chat_template(self, conv, add_generation_prompt=True, tokenize=False):
+        return "PROMPT"
+
+    def __call__(self, text=None, images=None, **kw):
+        return {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in self.batch.items()}
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return list(self.texts[: len(ids)])
+
+
+def test_trainer_api_runs_two_optimizer_steps():
+    from iadr1_amd import rewards
+    from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
+    grid = (1, 16, 12)
+    ids, mask = fx.left_pad([fx.synth_prompt(grid, 9, fx.TINY, 3)], fx.TINY["pad_token_id"])
+    batch = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "pixel_values": torch.from_numpy(fx.synth_pixel_values([grid], fx.TINY, seed=3)),
+             "image_grid_thw": torch.tensor([grid])}
+    texts = ["<think>a</think><location>upper left</location><type>scratch</type><answer>yes</answer>", "<think>b</think><answer>no</answer>", "junk",
+             "<think>c</think><location>top left</location><type>surface scratch</type><answer>yes</answer>"]
+    rows = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "q"}]}], "image": [object()],
+             "solution": "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"}] * 4
+    cfgT = GRPOConfig(output_dir="/tmp/iadr1_trainer_test", num_generations=4, max_completion_length=8, max_prompt_length=4096, learning_rate=1e-3,
+                      gradient_accumulation_steps=2, max_steps=2, save_steps=0)
+    tr = SCGRPOTrainer((CFG, fx.make_weights(fx.TINY, 0)), [rewards.accuracy_reward, rewards.consistency_reward], args=cfgT, train_dataset=rows,
+                       processing_class=_FakeProcessor(batch, texts))
+    before = tr.policy.flat.clone()
+    hist = tr.train()
+    assert len(hist) == 2 and {"loss", "reward", "reward_std", "kl", "completion_length", "rewards/accuracy_reward", "rewards/consistency_reward"} <= set(hist[-1])
+    assert not torch.equal(before, tr.policy.flat)            # parameters moved
+    assert torch.equal(tr.ref.flat, before)                   # the frozen reference did not
+    with pytest.raises(ValueError, match="does not support returning outputs"):
+        tr.compute_loss(None, rows[:1], return_outputs=True)
+    tr.save_model("/tmp/iadr1_trainer_test/final")
+    from safetensors import safe_open
+    with safe_open("/tmp/iadr1_trainer_test/final/model.safetensors", framework="pt") as sf:
+        assert "model.layers.0.self_attn.q_proj.weight" in sf.keys() and "visual.blocks.0.attn.qkv.weight" in sf.keys()

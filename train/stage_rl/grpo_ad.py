@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""SC-GRPO entry point, CLI-compatible with the reference's `train/stage_rl/grpo_ad.py`
+(/root/reference/train/stage_rl/grpo_ad.py:31-65 script arguments, :72-118 prompt templates, :126-129 reward
+registry, :135-181 dataset row -> conversation, :188-207 trainer construction / train / save), driving the
+MI355X engine.  Launch exactly like the reference scripts do, one process per GPU:
+
+    torchrun --nproc_per_node=8 --master-addr 127.0.0.1 train/stage_rl/grpo_ad.py \
+        --model_name_or_path <Qwen2.5-VL checkpoint dir> --dataset_name data.json --image_path /data \
+        --num_generations 8 --max_prompt_length 4096 --max_completion_length 512 --output_dir out ...
+
+Flags of the reference that configure machinery this engine does not have (DeepSpeed, vLLM placement, wandb,
+gradient checkpointing, attention implementation) are accepted and ignored.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+FORMAT_RULES = (
+    "If you find anomalies in the test image, structure your response with the following format:"
+    "<think>[Your process of observation and reasoning is here]</think>"
+    "<location>[The location of the anomaly in the image]</location>"
+    "<type>[The type of anomaly in the image]</type><answer>[Your final answer is here(yes or no)]</answer>"
+    "If no anomalies are detected in the test image, structure your response with the following format:"
+    "<think>[Your process of observation and reasoning is here]</think>"
+    "<answer>[Your final answer is here(yes or no)]</answer>"
+)
+# 0-shot (single image) and 1-shot (reference + test image) wording of the reference, REF grpo_ad.py:72-118
+PROMPTS = {
+    1: {
+        "system": "You are an expert in detecting anomalies in image. Your task is to detect if there are any anomalies in the test image."
+                  + FORMAT_RULES + "{Question}",
+        "question": "You are an expert in detecting defects in image. Your task is to detect if there are any defects in the test image.{Question}",
+    },
+    0: {
+        "system": "You are an expert in detecting anomalies in images. I will provide you with two images: a reference image (first) showing a normal object without defects, and a test image (second) that needs inspection."
+                  "Your task is to compare these images and determine if there are any anomalies in the test image. Use the reference image as a baseline for what is considered normal."
+                  + FORMAT_RULES +
+                  "Remember that the first image is always the reference (normal) image, and the second image is the test image that needs inspection.{Question}",
+        "question": "You are an expert in detecting defects in image. I will provide you with two images: a reference image (first) showing a normal object without defects, and a test image (second) that needs inspection."
+                    "Your task is to compare these images and determine if there are any anomalies in the test image. Use the reference image as a baseline for what is considered normal.{Question}",
+    },
+}
+
+
+def str2bool(v):
+    return str(v).lower() not in ("false", "0", "no")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(allow_abbrev=False)
+    # GRPOScriptArguments
+    p.add_argument("--dataset_name", required=True)
+    p.add_argument("--dataset_train_split", default="train")
+    p.add_argument("--reward_funcs", nargs="+", default=["accuracy", "format"])
+    p.add_argument("--use_vllm_for_gen", default="true")
+    p.add_argument("--use_system_prompt", default="false")
+    p.add_argument("--image_path", default="/data")
+    p.add_argument("--max_pixels", type=int, default=12845056)
+    p.add_argument("--min_pixels", type=int, default=3136)
+    p.add_argument("--single_img", type=int, default=1)
+    # ModelConfig
+    p.add_argument("--model_name_or_path", required=True)
+    p.add_argument("--attn_implementation", default="flash_attention_2")
+    p.add_argument("--torch_dtype", default=None)
+    # GRPOConfig / TrainingArguments subset
+    p.add_argument("--output_dir", required=True)
+    p.add_argument("--per_device_train_batch_size", type=int, default=1)
+    p.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    p.add_argument("--num_generations", type=int, default=8)
+    p.add_argument("--max_prompt_length", type=int, default=512)
+    p.add_argument("--max_completion_length", type=int, default=256)
+    p.add_argument("--beta", type=float, default=0.04)
+    p.add_argument("--temperature", type=float, default=0.9)
+    p.add_argument("--learning_rate", type=float, default=1e-6)
+    p.add_argument("--weight_decay", type=float, default=0.0)
+    p.add_argument("--max_grad_norm", type=float, default=1.0)
+    p.add_argument("--lr_scheduler_type", default="linear")
+    p.add_argument("--warmup_steps", type=int, default=0)
+    p.add_argument("--num_train_epochs", type=float, default=1.0)
+    p.add_argument("--max_steps", type=int, default=-1)
+    p.add_argument("--logging_steps", type=int, default=1)
+    p.add_argument("--save_steps", type=int, default=100)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--micro_batch_seqs", type=int, default=16)
+    p.add_argument("--run_name", default=None)
+    # accepted for script compatibility, no effect here
+    for flag in ("--deepspeed", "--report_to", "--gradient_checkpointing", "--bf16", "--ddp_timeout", "--push_to_hub", "--config"):
+        p.add_argument(flag, nargs="?", default=None, const=True)
+    return p
+
+
+def make_conversation(example: dict, image_path: str, use_system_prompt: bool, single_img: int) -> dict:
+    """Dataset row {problem, image, solution, ...} -> {"prompt": chat, "image": [abs paths]} (REF grpo_ad.py:135-181)."""
+    img = example.get("image")
+    if not img:
+        raise ValueError("row without an image")
+    items = img if isinstance(img, list) else [img]
+    paths = []
+    for it in items:
+        if isinstance(it, str):
+            paths.append(os.path.join(image_path, it))
+        elif isinstance(it, dict):
+            paths.append(os.path.join(image_path, it["path"]))
+        else:
+            raise TypeError("Unsupported Format.")
+    tmpl = PROMPTS[single_img]
+    pics = [{"type": "image"} for _ in paths]
+    if use_system_prompt:
+        prompt = [{"role": "system", "content": tmpl["system"]}, {"role": "user", "content": pics + [{"type": "text", "text": example["problem"]}]}]
+    else:
+        prompt = [{"role": "user", "content": pics + [{"type": "text", "text": tmpl["question"].format(Question=example["problem"])}]}]
+    out = {k: v for k, v in example.items() if k not in ("messages",)}
+    out.update(prompt=prompt, image=paths)
+    return out
+
+
+def load_rows(path: str):
+    with open(path) as f:
+        txt = f.read().strip()
+    return json.loads(txt) if txt.startswith("[") else [json.loads(l) for l in txt.splitlines() if l.strip()]
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    if a.single_img not in (0, 1):
+        raise ValueError("The single_img parameter can only be 0 or 1")
+    if not a.dataset_name.endswith((".json", ".jsonl")):
+        raise ValueError("dataset_name must be a .json/.jsonl manifest (the reference loads it with load_dataset('json'))")
+    import torch
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.rewards import REWARD_FUNCS
+    from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
+
+    rows = [make_conversation(r, a.image_path, str2bool(a.use_system_prompt), a.single_img) for r in load_rows(a.dataset_name)]
+    cfg = GRPOConfig(**{k: getattr(a, k) for k in GRPOConfig.__dataclass_fields__ if hasattr(a, k) and getattr(a, k) is not None and k not in ("report_to", "gradient_checkpointing", "bf16", "push_to_hub")})
+    trainer = SCGRPOTrainer(model=a.model_name_or_path, reward_funcs=[REWARD_FUNCS[n] for n in a.reward_funcs], args=cfg, train_dataset=rows,
+                            attn_implementation=a.attn_implementation, max_pixels=a.max_pixels, min_pixels=a.min_pixels, use_vllm_for_gen=str2bool(a.use_vllm_for_gen))
+    trainer.train()
+    if int(os.environ.get("RANK", "0")) == 0:
+        trainer.save_model(a.output_dir)
+
+
+if __name__ == "__main__":
+    main()
