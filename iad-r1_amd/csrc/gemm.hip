@@ -218,6 +218,242 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_128(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// gemm_nt_256: 256x256x64 block tile, 8 waves (2 x 4) of 128x64, deep software pipeline ("8 phases per two K
+// tiles"): every K tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64);
+// each phase ds_reads only the operand half it newly needs (A half: 8 x b128, B half: 4 x b128), issues the
+// LDS-DMA of ONE half-tile of the NEXT K tile into the other LDS buffer, and waits with a COUNTED vmcnt so two
+// half-tiles stay in flight across the s_barrier -- the DMA queue is never drained inside the main loop.
+// LDS: 2 buffers x (A 32 KiB + B 32 KiB) = 128 KiB, XOR-swizzled like gemm_nt_128 (source address + read side).
+// Half-tiles are cut so that a phase needs the same half for every wave: A half h = rows {wm*128 + h*64 + 0..63},
+// B half h = cols {wn*64 + h*32 + 0..31}.  Epilogue: each wave stages its 128x64 bf16 result in its own LDS
+// slab and writes full 128-byte row segments.
+// ------------------------------------------------------------------------------------------------------
+constexpr int T2 = 256, NT2 = 512, HALF_BYTES = 128 * 64 * 2;          // 16 KiB per half tile
+constexpr int BUF2_BYTES = 4 * HALF_BYTES;                             // A0 A1 B0 B1
+constexpr int SMEM2_MAIN = 2 * BUF2_BYTES;                             // 128 KiB
+constexpr int EP_LD = 64 + 8;                                          // epilogue slab row stride (elements)
+constexpr int SMEM2_EPI = 8 * 128 * EP_LD * 2;                         // 147456 B
+constexpr int SMEM2_BYTES = SMEM2_EPI > SMEM2_MAIN ? SMEM2_EPI : SMEM2_MAIN;
+
+#define IADR1_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int OUT>
+__global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l = t & 63;
+    const int wm = w >> 2, wn = w & 3;
+
+    const int tiles_m = (p.M + T2 - 1) / T2, tiles_n = (p.N + T2 - 1) / T2;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int band = wg / (4 * tiles_n), in_band = wg - band * 4 * tiles_n;
+    const int band_rows = min(4, tiles_m - band * 4);
+    const int tm = band * 4 + in_band % band_rows, tn = in_band / band_rows;
+    const int m0 = tm * T2, n0 = tn * T2;
+
+    // ---- DMA sources: per half-tile 2 x 16 B per thread ----------------------------------------------------
+    const bf16_t* src[4][2];  // [A0, A1, B0, B1][instr]
+    int chunk_k[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (i * 8 + w) * 64 + l;   // 16-B slot inside the half-tile image
+        const int rl = L >> 3, c = L & 7;
+        const int cs = c ^ ((rl >> 1) & 7);
+        chunk_k[i] = cs * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int arow = (rl >> 6) * 128 + h * 64 + (rl & 63);          // A half h: rows wm*128 + h*64 + ..
+            const int bcol = (rl >> 5) * 64 + h * 32 + (rl & 31);           // B half h: cols wn*64 + h*32 + ..
+            src[h][i] = p.A + (long long)min(m0 + arow, p.M - 1) * p.lda + cs * 8;
+            src[2 + h][i] = p.B + (long long)min(n0 + bcol, p.N - 1) * p.ldb + cs * 8;
+        }
+    }
+    auto stage_half = [&](int buf, int half /*0..3 = A0 A1 B0 B1*/, int kt) {
+        char* base = smem + buf * BUF2_BYTES + half * HALF_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = k0 + chunk_k[i] < p.K;
+            glds16(ok ? (const void*)(src[half][i] + k0) : p.zeros, base + (i * 8 + w) * 1024);
+        }
+    };
+
+    // ---- fragment read offsets inside a half-tile image -------------------------------------------------------
+    int a_off[2], b_off[2];  // per k-step; add mi*2048 / ni*2048
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = kk * 4 + (l >> 4);
+        const int ra = wm * 64 + (l & 15), rb = wn * 32 + (l & 15);
+        a_off[kk] = ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4);
+        b_off[kk] = rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4);
+    }
+
+    f32x4_t acc[8][4];  // [m-tile][n-tile] of the 128x64 wave tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8_t af[4][2], bfr[2][2];  // current A half (4 m-tiles x 2 k-steps), current B half (2 n-tiles x 2 k-steps)
+    auto read_a = [&](int buf, int h) {
+        const char* base = smem + buf * BUF2_BYTES + h * HALF_BYTES;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8_t*)(base + a_off[kk] + mi * 2048);
+    };
+    auto read_b = [&](int buf, int h) {
+        const char* base = smem + buf * BUF2_BYTES + (2 + h) * HALF_BYTES;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bfr[ni][kk] = *(const bf16x8_t*)(base + b_off[kk] + ni * 2048);
+    };
+#define IADR1_QUAD(MH, NH)                                                                                                   \
+    do {                                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                     \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                     \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                     \
+            acc[(MH) * 4 + mi][(NH) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni][kk], af[mi][kk], acc[(MH) * 4 + mi][(NH) * 2 + ni], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                       \
+    } while (0)
+
+    const int nk = (p.K + BK - 1) / BK;
+    // Schedule (u = K tile, buffer u&1).  A half-tile region is re-filled ONE phase after the phase that read it;
+    // that is safe because every phase retires its ds_reads (lgkmcnt(0)) BEFORE its barrier:
+    //   phase 1: read A0,B0(u)  | DMA B0(u+1) -> other buffer   | barrier | quadrant (0,0)
+    //   phase 2: read B1(u)     | DMA A0(u+2) -> this buffer    | barrier | quadrant (0,1)
+    //   phase 3: read A1(u)     | DMA B1(u+2) -> this buffer    | barrier | quadrant (1,1)
+    //   phase 4: read B0(u)     | DMA A1(u+2) -> this buffer    | vmcnt(6): all of tile u+1 landed, three
+    //                                                              half-tiles of u+2 stay in flight | barrier | (1,0)
+    // prologue: tile 0 complete + A0,B1,A1 of tile 1 in flight.
+    stage_half(0, 0, 0);
+    stage_half(0, 2, 0);
+    stage_half(0, 3, 0);
+    stage_half(0, 1, 0);
+    if (nk > 1) {
+        stage_half(1, 0, 1);
+        stage_half(1, 3, 1);
+        stage_half(1, 1, 1);
+        IADR1_VMCNT(6);
+    } else {
+        IADR1_VMCNT(0);
+    }
+    __builtin_amdgcn_s_barrier();
+
+#define IADR1_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1, nxt = cur ^ 1;
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+        read_a(cur, 0);
+        read_b(cur, 0);
+        if (more1) stage_half(nxt, 2, kt + 1);
+        IADR1_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        IADR1_QUAD(0, 0);
+
+        read_b(cur, 1);
+        if (more2) stage_half(cur, 0, kt + 2);
+        IADR1_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        IADR1_QUAD(0, 1);
+
+        read_a(cur, 1);
+        if (more2) stage_half(cur, 3, kt + 2);
+        IADR1_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        IADR1_QUAD(1, 1);
+
+        read_b(cur, 0);
+        if (more2) { stage_half(cur, 1, kt + 2); IADR1_VMCNT(6); } else if (more1) { IADR1_VMCNT(0); }
+        IADR1_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        IADR1_QUAD(1, 0);
+    }
+#undef IADR1_LGKM0
+#undef IADR1_QUAD
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    const int lm = l & 15, lq = l >> 4;
+    if constexpr (OUT == OUT_BF16) {
+        __syncthreads();  // every wave is done with the operand buffers
+        bf16_t* slab = (bf16_t*)smem + (size_t)w * 128 * EP_LD;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = j * 16 + lq * 4;
+            const int gn = n0 + wn * 64 + nl;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = (gn + e < p.N) ? bf2f(p.bias[gn + e]) : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][e] + bv[e];
+                    if (p.act == 1) v[e] = gelu_erf(v[e]);
+                }
+                *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + nl) = (u32x2_t){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            }
+        }
+        // same wave wrote and reads its slab: only its own LDS ops need to retire (compiler inserts lgkmcnt)
+        bf16_t* C = (bf16_t*)p.C;
+        const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + (l >> 3), ch = l & 7;
+            const int gm = m0 + wm * 128 + row, gn = n0 + wn * 64 + ch * 8;
+            if (gm >= p.M || gn >= p.N) continue;
+            bf16_t* dst = C + (long long)gm * p.ldc + gn;
+            if (vec_ok && gn + 8 <= p.N) {
+                *(u32x4_t*)dst = *(const u32x4_t*)(slab + row * EP_LD + ch * 8);
+            } else {
+                const bf16_t* sv = slab + row * EP_LD + ch * 8;
+                for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = sv[e];
+            }
+        }
+    } else {
+        float* C = (float*)p.C;
+        const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int gm = m0 + wm * 128 + i * 16 + lm;
+            if (gm >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + wn * 64 + j * 16 + lq * 4;
+                if (gn >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][e];
+                    if (p.bias && gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
+                    if (p.act == 1) v[e] = gelu_erf(v[e]);
+                }
+                float* dst = C + (long long)gm * p.ldc + gn;
+                if (vec_ok && gn + 4 <= p.N) {
+                    f32x4_t o = {v[0], v[1], v[2], v[3]};
+                    if constexpr (OUT == OUT_F32_ACC) o += *(const f32x4_t*)dst;
+                    *(f32x4_t*)dst = o;
+                } else {
+                    for (int e = 0; e < 4 && gn + e < p.N; ++e) {
+                        if constexpr (OUT == OUT_F32_ACC) dst[e] += v[e];
+                        else dst[e] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Skinny GEMM for the rollout decode step:  Y[M (64 per grid.y), N] = X[M,K] . W[N,K]^T (+ bias).
 // HBM-bound weight stream (6.17 GB of bf16 weights per decode step for 3B), and
 // for the small projections latency-bound: the whole K extent is therefore spread over MANY waves --
@@ -451,14 +687,30 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, "gemm_nt: A/B must be 16-byte aligned");
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2, "gemm_nt: bad out_mode %d", out_mode);
     GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act};
-    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    static int force_tile = -1;
     static bool attr_done = false;
     if (!attr_done) {
+        const char* e = getenv("IADR1_GEMM_TILE");
+        force_tile = e ? atoi(e) : 0;
         (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
         attr_done = true;
     }
+    // 256^2 deep-pipeline kernel when the grid fills the chip with big tiles; 128^2 kernel for small / ragged problems
+    const long long tiles256 = (long long)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
+    const bool big = force_tile == 256 || (force_tile != 128 && M >= 512 && N >= 512 && tiles256 >= 192);
+    if (big) {
+        const int grid = (int)tiles256;
+        if (out_mode == 0) hipLaunchKernelGGL(gemm_nt_256<OUT_BF16>, dim3(grid), dim3(NT2), SMEM2_BYTES, stream, p);
+        else if (out_mode == 1) hipLaunchKernelGGL(gemm_nt_256<OUT_F32>, dim3(grid), dim3(NT2), SMEM2_BYTES, stream, p);
+        else hipLaunchKernelGGL(gemm_nt_256<OUT_F32_ACC>, dim3(grid), dim3(NT2), SMEM2_BYTES, stream, p);
+        return iadr1_check_launch("gemm_nt_bf16");
+    }
+    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (out_mode == 0) hipLaunchKernelGGL(gemm_nt_128<OUT_BF16>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     else if (out_mode == 1) hipLaunchKernelGGL(gemm_nt_128<OUT_F32>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     else hipLaunchKernelGGL(gemm_nt_128<OUT_F32_ACC>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);

@@ -32,7 +32,7 @@ def close(got, ref, rtol, atol, what=""):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (100, 200, 72), (1000, 520, 1216), (333, 324, 160), (64, 1280, 3456), (4096, 2048, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (100, 200, 72), (1000, 520, 1216), (333, 324, 160), (64, 1280, 3456), (4096, 2048, 2048), (4096, 4096, 1024), (3000, 5000, 520)])
 @pytest.mark.parametrize("mode", ["bf16", "bf16_bias", "bf16_bias_gelu", "f32", "f32_acc"])
 def test_gemm_nt(M, N, K, mode):
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.5)
