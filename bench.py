@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--gen-len", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=16)
+    ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -95,15 +95,25 @@ class GemmTimer:
             e0.record()
             r = orig(a, b, bias=bias, out=out, out_dtype=out_dtype, accumulate=accumulate, act=act)
             e1.record()
-            timer.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            timer.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], (a.shape[0], b.shape[0], a.shape[1], 'acc' if accumulate else str(out_dtype if out is None else out.dtype)[6:])))
             return r
 
         ops.gemm_nt = timed
 
     def summary(self):
-        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records) * 1e-3
-        fl = sum(f for _, _, f in self.records)
+        t = sum(r[0].elapsed_time(r[1]) for r in self.records) * 1e-3
+        fl = sum(r[2] for r in self.records)
         return len(self.records), t, fl
+
+    def by_shape(self, top=14):
+        agg = {}
+        for e0, e1, f, key in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+        return [{"MNK_out": list(k), "calls": v[0], "ms": round(v[1] * 1e3, 2), "TF": round(v[2] / max(v[1], 1e-9) / 1e12, 1)} for k, v in rows]
 
 
 def cpu_baseline(cfg_dict_3b, seconds_budget):
@@ -199,6 +209,7 @@ def main():
         eng.step(synth_batch(cfg, a.prompts, a.prompt_len, seed=1234 + 7919 * rank + step_id), reward_fn)
         step_id += 1
     barrier()
+    ms0 = torch.cuda.memory_stats()
     timer.enabled = True
     t0 = time.perf_counter()
     metrics = None
@@ -223,9 +234,14 @@ def main():
             "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}"},
             "samples_per_sec_per_gpu": N * a.steps / dt,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
             "last_step_metrics": metrics,
+            "gemm_by_shape": timer.by_shape(),
+            "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30, "peak_reserved_GB": torch.cuda.max_memory_reserved() / 2**30,
+                    "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0),
+                    "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+                    "device_frees_in_timed_region": torch.cuda.memory_stats().get("num_device_free", 0) - ms0.get("num_device_free", 0)},
         }
         if not a.no_cpu_baseline and a.model == "3b":
             d3 = {"text": {"vocab_size": 151936, "hidden_size": 2048, "intermediate_size": 11008, "num_hidden_layers": 36, "num_attention_heads": 16,

@@ -60,6 +60,15 @@ class Engine:
         vd = c.v_head_dim
         self.v_inv_freq = 1.0 / (10000.0 ** (np.arange(0, vd // 2, 2, dtype=np.float32) / (vd // 2)))
         self.lm_chunk = 4096
+        self._ws = {}
+
+    def _workspace(self, key, shape, dtype):
+        """Persistent scratch (lm_head logit chunks are GBs: re-allocating them per call costs ~100 ms of page mapping)."""
+        t = self._ws.get(key)
+        if t is None or t.shape != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            self._ws[key] = t
+        return t
 
     # ========================================================================================================
     # plans
@@ -206,31 +215,65 @@ class Engine:
     # ========================================================================================================
     # text decoder (TF::790-873; layer ::708-757)
     # ========================================================================================================
+    def _text_buffers(self, T: int, save: bool):
+        """Static activation storage (no allocator traffic in the step; GiB-sized tensors were being hipFree'd and
+        re-mapped by the caching allocator every layer).  save=True: one slab per decoder layer, alive until the
+        backward of this micro-batch; save=False: one scratch slab reused by every layer."""
+        c = self.cfg
+        H, I = c.hidden_size, c.intermediate_size
+        L = c.num_hidden_layers if save else 1
+        key = "act_save" if save else "act_scratch"
+        cur = self._ws.get(key)
+        if cur is None or cur["T"] < T:
+            if cur is not None:
+                self._ws[key] = cur = None  # release before growing
+            mk = lambda w: torch.empty(L, T, w, dtype=BF16, device=self.dev)
+            cur = {"T": T, "x_in": mk(H), "h1": mk(H), "qkv": mk(c.qkv_width), "o": mk(c.num_attention_heads * c.head_dim), "x_mid": mk(H),
+                   "h2": mk(H), "gu": mk(2 * I), "a": mk(I), "rstd1": torch.empty(L, T, dtype=F32, device=self.dev),
+                   "rstd2": torch.empty(L, T, dtype=F32, device=self.dev), "lse": torch.empty(L, c.num_attention_heads, T, dtype=F32, device=self.dev)}
+            self._ws[key] = cur
+        return cur
+
     def text_forward(self, plan: TextPlan, img_embeds, save: bool, kv_sink=None):
         c, P = self.cfg, self.p
         H, D, Hq, Hkv = c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         qw, kw = Hq * D, Hkv * D
         x = ops.embed_fwd(plan.ids, plan.img_index if img_embeds is not None else None, P.w("embed"), img_embeds)
+        T = x.shape[0]
+        B = self._text_buffers(T, save)
+        Tb = B["T"]
         ctx = {"layers": [], "plan": plan} if save else None
         res, branch = x, None
         eps = c.rms_norm_eps
         for i in range(c.num_hidden_layers):
             b = f"layers.{i}."
-            x_in = torch.empty_like(res) if (save and branch is not None) else res
+            li = i if save else 0
+            buf = lambda name: B[name][li, :T]
+            h1 = buf("h1")
+            rstd1 = B["rstd1"][li, :T] if save else None
             if branch is None:
-                h1, rstd1 = ops.rmsnorm_fwd(res, P.w(b + "ln1"), eps, want_rstd=save)
+                x_in = res
+                hip_rstd = rstd1
+                ops.hip.call("rmsnorm_fwd", res, None, 0, None, None, None, P.w(b + "ln1"), h1, hip_rstd, T, H, H, H, H, float(eps))
             else:
-                h1, rstd1 = ops.rmsnorm_fwd(branch, P.w(b + "ln1"), eps, res=res, res_out=x_in, want_rstd=save)
-            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"))
+                x_in = buf("x_in") if save else res
+                ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, rstd1, T, H, H, H, H, float(eps))
+            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=buf("qkv"))
             ops.rope_(qkv, plan.cos, plan.sin, Hq + Hkv, D)
             if kv_sink is not None:
                 kv_sink(i, qkv[:, qw: qw + kw], qkv[:, qw + kw:])
-            o, lse = ops.attn_fwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], plan.seg, Hq, Hkv, D, True, D**-0.5, want_lse=save)
+            o = buf("o")
+            o.zero_()  # rows outside every segment (left / post-EOS padding) must read as zeros downstream (0 x stale NaN in wgrad otherwise)
+            lse = B["lse"][li].view(-1)[: Hq * T].view(Hq, T) if save else None
+            ops.hip.call("attn_fwd", qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, lse, plan.seg.start, plan.seg.end, plan.seg.n, plan.seg.max_len,
+                         T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, float(D**-0.5))
             ab = ops.gemm_nt(o, P.w(b + "o.w"))
-            x_mid = torch.empty_like(x_in) if save else x_in
-            h2, rstd2 = ops.rmsnorm_fwd(ab, P.w(b + "ln2"), eps, res=x_in, res_out=x_mid, want_rstd=save)
-            gu = ops.gemm_nt(h2, P.w(b + "gu.w"))
-            a = ops.swiglu_fwd(gu)
+            x_mid = buf("x_mid") if save else x_in
+            h2 = buf("h2")
+            rstd2 = B["rstd2"][li, :T] if save else None
+            ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, T, H, H, H, H, float(eps))
+            gu = ops.gemm_nt(h2, P.w(b + "gu.w"), out=buf("gu"))
+            a = ops.swiglu_fwd(gu, out=buf("a"))
             branch = ops.gemm_nt(a, P.w(b + "down.w"))
             res = x_mid
             if save:
@@ -285,13 +328,14 @@ class Engine:
         R = rows.numel()
         logp = torch.empty(R, dtype=F32, device=self.dev)
         lse = torch.empty(R, dtype=F32, device=self.dev)
+        V = W.shape[0]
+        lg_buf = self._workspace("lm_logits", (min(R, self.lm_chunk), V), F32)
         for r0 in range(0, R, self.lm_chunk):
             r1 = min(R, r0 + self.lm_chunk)
-            lg = ops.gemm_nt(hsel[r0:r1], W, out_dtype=F32)
+            lg = ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[: r1 - r0])
             lp, ls = ops.logprob_rows(lg, targets[r0:r1])
             logp[r0:r1] = lp
             lse[r0:r1] = ls
-            del lg
         ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0]} if save else None
         return logp, ctx
 
@@ -303,14 +347,23 @@ class Engine:
         hsel, rows, targets, lse = ctx["hsel"], ctx["rows"], ctx["targets"], ctx["lse"]
         R, H = hsel.shape
         dhsel = torch.empty(R, H, dtype=BF16, device=self.dev)
+        V = W.shape[0]
+        nc = min(R, self.lm_chunk)
+        lg_buf = self._workspace("lm_logits", (nc, V), F32)
+        dl_buf = self._workspace("lm_dlogits", (nc, V), BF16)
+        dlT_buf = self._workspace("lm_dlogits_t", (V, (nc + 7) // 8 * 8), BF16)
         for r0 in range(0, R, self.lm_chunk):
             r1 = min(R, r0 + self.lm_chunk)
-            lg = ops.gemm_nt(hsel[r0:r1], W, out_dtype=F32)
-            dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1])
-            del lg
+            n = r1 - r0
+            lg = ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[:n])
+            dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1], out=dl_buf[:n])
             ops.gemm_nt(dl, WT, out=dhsel[r0:r1])
-            self._wgrad(name, dl, hsel[r0:r1])
-            del dl
+            np8 = (n + 7) // 8 * 8
+            dlT = dlT_buf[:, :np8]
+            if np8 != n:
+                dlT[:, n:].zero_()
+            ops.transpose(dl, out=dlT)
+            ops.gemm_nt(dlT, ops.transpose(hsel[r0:r1], pad_rows_to=8), out=self.p.g(name), accumulate=True)
         # scatter rows back: dhf[t] = dhsel[inv[t]] or 0
         inv = torch.full((ctx["T"],), -1, dtype=torch.int32, device=self.dev)
         inv[rows] = torch.arange(R, dtype=torch.int32, device=self.dev)
