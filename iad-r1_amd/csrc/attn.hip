@@ -484,14 +484,22 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
         const int phys = p.block_table[(long long)b * p.max_pages + pg];
         const bf16_t* kp = p.kcache + ((long long)phys * p.Hkv + kvh) * PAGE * D;
         const bf16_t* vp = p.vcache + ((long long)phys * p.Hkv + kvh) * D * PAGE;
-        f32x4_t s[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        // all K and V fragments of the page are requested up front: one memory latency per page, not two
+        bf16x8_t kfr[KS][2], vfr[DT];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int row = (li >> 2) * 8 + (li & 3) + 4 * t;  // perm_row within one 32-key page
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_g(kp + row * D + ks * 32 + g * 8, true), qf[ks], s[t], 0, 0, 0);
+                kfr[ks][t] = ld_frag_g(kp + row * D + ks * 32 + g * 8, true);
             }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vfr[dt] = ld_frag_g(vp + (dt * 16 + li) * PAGE + g * 8, true);
+        f32x4_t s[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[ks][t], qf[ks], s[t], 0, 0, 0);
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             acc[dt] *= alpha;
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_g(vp + (dt * 16 + li) * PAGE + g * 8, true), pf, acc[dt], 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pf, acc[dt], 0, 0, 0);
         }
     }
     lsum += __shfl_xor(lsum, 16, WAVE);

@@ -470,7 +470,7 @@ struct SkinnyArgs {
     const bf16_t* bias;
     int M, N, K;
     long long ldx, ldw, ldy;
-    int out_mode;  // 0 bf16 (+bias), 1 fp32, 2 fp32 partial slabs [gridDim.z][M][ldy]
+    int out_mode;  // 0 bf16 (+bias), 1 fp32, 2 fp32 partial slabs [gridDim.z][M][ldy], 3 fused SwiGLU (wide kernel, gate/up tile pairs)
 };
 
 template <int NB, int WAVES>
@@ -635,6 +635,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
 #pragma unroll
                 for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + jj * 16 + lq * 4 + e] = acc[i][2 * r + jj][e];
         __syncthreads();
+        if (p.out_mode == 3) {
+            // tiles (2r, 2r+1) of this round are the GATE and UP projections of the same 16 output columns
+            // (iadr1_pack_gateup_bf16 interleaves them): a = silu(bf16(gate)) * bf16(up), TF::95-96,552-554
+            for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
+                const int m = idx >> 4, n = idx & 15;
+                const int gm = m_base + m, gn = (n0 >> 1) + r * 16 + n;
+                if (gm >= p.M || gn >= (p.N >> 1)) continue;
+                float g = 0.f, u = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ++ww) {
+                    g += red[((size_t)ww * 64 + m) * RLD + n];
+                    u += red[((size_t)ww * 64 + m) * RLD + 16 + n];
+                }
+                g = bf2f(f2bf(g));
+                u = bf2f(f2bf(u));
+                const float sg = bf2f(f2bf(g / (1.f + __expf(-g))));
+                ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(sg * u);
+            }
+            continue;
+        }
         for (int idx = t; idx < 64 * RC; idx += WAVES * 64) {
             const int m = idx / RC, n = idx - m * RC;
             const int gm = m_base + m, gn = n0 + r * RC + n;
@@ -651,6 +671,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
                 ((float*)p.Y)[((long long)blockIdx.z * p.M + gm) * p.ldy + gn] = v;
             }
         }
+    }
+}
+
+// Decode-packing of a fused gate|up matrix W[2I, K] for the SwiGLU-fused skinny GEMM: packed 16-row tile 2q holds
+// gate rows [16q, 16q+16), tile 2q+1 the matching up rows [I+16q, ...), so one block owns both halves of its columns.
+__global__ __launch_bounds__(256) void pack_gateup_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int I, int K) {
+    const int ksteps = K >> 5;
+    const long long total = (long long)(2 * I >> 4) * ksteps * 64;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long long ts = i >> 6;
+        const int ks = (int)(ts % ksteps);
+        const long long tile = ts / ksteps;
+        const long long n = (tile & 1 ? I : 0) + (tile >> 1) * 16 + (lane & 15);
+        const int k = ks * 32 + (lane >> 4) * 8;
+        *(u32x4_t*)(Wp + i * 8) = *(const u32x4_t*)(W + n * ldw + k);
     }
 }
 
@@ -723,7 +759,8 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     IADR1_REQUIRE((K % 32) == 0 && (N % 16) == 0 && (ldx % 8) == 0, "gemm_skinny: packed weights need K %% 32 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_skinny: X/W must be 16-byte aligned");
     (void)ldw;
-    IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny: ksplit > 1 needs out_mode 2 (partial slabs)");
+    IADR1_REQUIRE(out_mode >= 0 && out_mode <= 3 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny: ksplit > 1 needs out_mode 2 (partial slabs)");
+    IADR1_REQUIRE(out_mode != 3 || (N % 128) == 0, "gemm_skinny: fused SwiGLU needs N (= 2*I) to be a multiple of 128, got %d", N);
     SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, (const bf16_t*)bias, M, N, K, ldx, ldw, ldy, out_mode};
     const int mz = (M + 63) / 64;
     static bool attr_done = false;
@@ -744,7 +781,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     // wide kernels: NB=8 (128 columns / block) for the big-N streams (gate|up, lm_head); NB=4 with K split over
     // grid.z for the long-K narrow-N down projection; the narrow kernel for the small projections (latency-bound)
     (void)wide_nb;
-    if (N >= 8192 && ksplit == 1) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
+    if ((N >= 8192 && ksplit == 1) || out_mode == 3) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
     else if (ksplit > 1 && ((N + 63) / 64) * ksplit >= 192) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3((N + 63) / 64, mz, ksplit), dim3(512), SMW, stream, p);
     else if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
     else hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);
@@ -757,4 +794,12 @@ extern "C" int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, in
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, N, K);
     return iadr1_check_launch("pack_weight_bf16");
+}
+
+extern "C" int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, hipStream_t stream) {
+    IADR1_REQUIRE(I > 0 && K > 0 && (I % 64) == 0 && (K % 32) == 0 && (ldw % 8) == 0, "pack_gateup: need I %% 64 == 0, K %% 32 == 0 (I=%d K=%d)", I, K);
+    long long blocks = ((long long)2 * I * K / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_gateup_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, I, K);
+    return iadr1_check_launch("pack_gateup_bf16");
 }

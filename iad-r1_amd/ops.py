@@ -37,12 +37,25 @@ def pack_weight(w, out=None):
     return o
 
 
-def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1):
+def pack_gateup(w, out=None):
+    """[2I,K] gate|up -> decode-packed with gate/up tiles interleaved (for gemm_skinny(..., swiglu=True))."""
+    N2, K = w.shape
+    o = out if out is not None else torch.empty(N2 * K, dtype=BF16, device=w.device)
+    hip.call("pack_gateup_bf16", w, _ld(w), o, N2 // 2, K)
+    return o
+
+
+def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=False):
     """out[M,N] = x[M,K] @ W[N,K]^T + bias with W given decode-packed (`pack_weight`); HBM-bound weight stream.
     ksplit > 1: `out` is fp32 [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=..., nsplit=ksplit)."""
     M, K = x.shape
     w = wp
     assert wp.numel() == N * K
+    if swiglu:
+        if out is None:
+            out = torch.empty(M, N // 2, dtype=BF16, device=x.device)
+        hip.call("gemm_skinny_bf16", x, w, out, None, M, N, K, _ld(x), K, _ld(out), 3, 1)
+        return out
     if out is None:
         out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=x.device)
     if out.dim() == 3:

@@ -258,8 +258,12 @@ class ParamStore:
         return self._pk[name]
 
     def refresh_decode_pack(self):
+        fuse = self.cfg.intermediate_size % 64 == 0
         for name, dst in self._pk.items():
-            ops.pack_weight(self.w(name), out=dst)
+            if fuse and name.endswith(".gu.w"):
+                ops.pack_gateup(self.w(name), out=dst)   # gate/up tiles interleaved: the decode GEMM applies SwiGLU in its epilogue
+            else:
+                ops.pack_weight(self.w(name), out=dst)
 
     def refresh_transposes(self):
         if not self.with_transposes:

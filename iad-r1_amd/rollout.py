@@ -61,6 +61,7 @@ class Rollout:
         self.logits = torch.empty(N, V, dtype=F32, device=dev)
         self.cos = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
+        self.fuse_swiglu = I % 64 == 0
         self.graph = None
         self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
 
@@ -84,8 +85,11 @@ class Rollout:
             ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o)
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), c.hidden_size, out=self.part_o, ksplit=self.ks_o)
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h)
-            ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.gu)
-            ops.swiglu_fwd(self.gu, out=self.a)
+            if self.fuse_swiglu:
+                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True)
+            else:
+                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.gu)
+                ops.swiglu_fwd(self.gu, out=self.a)
             ops.gemm_skinny(self.a, P.wpk(b + "down.w"), c.hidden_size, out=self.part_d, ksplit=self.ks_down)
             have_branch = True
         ops.rmsnorm_fwd(None, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)

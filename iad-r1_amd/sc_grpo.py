@@ -280,10 +280,26 @@ class SCGRPOEngine:
     def step(self, batch, reward_fn, do_optimizer_step=True):
         """reward_fn(completion_ids: np.ndarray [N,C]) -> [N, n_funcs] rewards (decode + plugin functions live with
         the caller, which owns the tokenizer)."""
+        import os, time
+        timing = os.environ.get("IADR1_TIMING") == "1"
+
+        def mark():
+            if timing:
+                torch.cuda.synchronize()
+            return time.perf_counter()
+
+        t0 = mark()
         vis = self.vision_policy(batch, save=True)
+        t1 = mark()
         comp = self.rollout(batch, vis=vis)
+        t2 = mark()
         rewards = reward_fn(comp)
+        t3 = mark()
         out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=do_optimizer_step, vis=vis)
+        t4 = mark()
         if do_optimizer_step:
             self.optimizer_step()
+        t5 = mark()
+        if timing:
+            print(f"[iadr1 timing] vision {1e3*(t1-t0):.1f} ms | rollout {1e3*(t2-t1):.1f} | rewards {1e3*(t3-t2):.1f} | ref+policy fwd/bwd {1e3*(t4-t3):.1f} | optimizer {1e3*(t5-t4):.1f}", flush=True)
         return out["metrics"]

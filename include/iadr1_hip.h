@@ -36,13 +36,17 @@ int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, 
                        long long ldb, long long ldc, int out_mode, int act, iadr1_stream_t stream);
 /* Decode-time skinny GEMM: Y[M,N] = X[M,K] . W[N,K]^T (M small, 64 rows per pass); HBM-bound weight stream,
  * K spread over 8-16 waves per block (+ optional grid split `ksplit`), no atomics.  out_mode 0: bf16 + bias;
- * 1: fp32 (logits); 2: fp32 partial slabs Y[ksplit][M][ldy] summed by iadr1_rmsnorm_fwd (x32 path).
+ * 1: fp32 (logits); 2: fp32 partial slabs Y[ksplit][M][ldy] summed by iadr1_rmsnorm_fwd (x32 path); 3: fused
+ * SwiGLU over a gate|up matrix packed with iadr1_pack_gateup_bf16 (N = 2*I rows in, Y is [M, I]).
  * Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667). */
 int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
                            long long ldw, long long ldy, int out_mode, int ksplit, iadr1_stream_t stream);
 /* W[N,K] row-major -> decode-packed MFMA-fragment order Wp[N/16][K/32][64 lanes][8] (what iadr1_gemm_skinny_bf16 reads:
  * every wave-level load of the weight stream is then 1 KiB contiguous).  N % 16 == 0, K % 32 == 0. */
 int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, iadr1_stream_t stream);
+/* gate|up matrix W[2I,K] -> decode-packed with gate/up 16-row tiles interleaved, for out_mode 3 (fused SwiGLU) of
+ * iadr1_gemm_skinny_bf16: Y[M, I] = silu(X.Wgate^T) * (X.Wup^T).  I % 64 == 0. */
+int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
 
 /* ---- RMSNorm (TF:65-79) --------------------------------------------------------------------------------

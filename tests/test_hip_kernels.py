@@ -79,6 +79,15 @@ def test_gemm_skinny(M, N, K):
         close(part.sum(0), ref, 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"skinny split-K {ks} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 96)])
+def test_gemm_skinny_fused_swiglu(M, I, K):
+    x, w = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.3)
+    a = ops.gemm_skinny(x, ops.pack_gateup(w), 2 * I, swiglu=True)
+    gu = (x.float() @ w.float().t()).to(BF)
+    ref = torch.nn.functional.silu(gu[:, :I].float()).to(BF).float() * gu[:, I:].float()
+    close(a, ref, 2e-2, 2e-2 * math.sqrt(K) * 0.3, f"skinny swiglu {M}x{I}x{K}")
+
+
 @pytest.mark.parametrize("R,C", [(64, 64), (100, 200), (4096, 2560), (37, 8)])
 def test_transpose(R, C):
     x = rnd(R, ((C + 7) // 8) * 8, seed=3)[:, :C]
