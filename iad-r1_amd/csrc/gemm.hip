@@ -347,6 +347,12 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
 
 #define IADR1_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    // Role split: the two waves of every SIMD (wm = 0 / 1) run half a phase apart -- while one issues its MFMAs the
+    // other does its ds_reads / DMA issue -- by giving the wm=1 half ONE extra barrier here (and the wm=0 half one at
+    // the end).  Each phase therefore has two barriers: [reads, DMA, lgkmcnt(0)] | barrier | [16 MFMA] | barrier.
+    // The region re-fill / landing rules above still hold: a reader always passes one more barrier than the wait or
+    // the last read it depends on.
+    if (wm == 1) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1, nxt = cur ^ 1;
         const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
@@ -356,25 +362,30 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
         IADR1_LGKM0();
         __builtin_amdgcn_s_barrier();
         IADR1_QUAD(0, 0);
+        __builtin_amdgcn_s_barrier();
 
         read_b(cur, 1);
         if (more2) stage_half(cur, 0, kt + 2);
         IADR1_LGKM0();
         __builtin_amdgcn_s_barrier();
         IADR1_QUAD(0, 1);
+        __builtin_amdgcn_s_barrier();
 
         read_a(cur, 1);
         if (more2) stage_half(cur, 3, kt + 2);
         IADR1_LGKM0();
         __builtin_amdgcn_s_barrier();
         IADR1_QUAD(1, 1);
+        __builtin_amdgcn_s_barrier();
 
         read_b(cur, 0);
         if (more2) { stage_half(cur, 1, kt + 2); IADR1_VMCNT(6); } else if (more1) { IADR1_VMCNT(0); }
         IADR1_LGKM0();
         __builtin_amdgcn_s_barrier();
         IADR1_QUAD(1, 0);
+        __builtin_amdgcn_s_barrier();
     }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
 #undef IADR1_LGKM0
 #undef IADR1_QUAD
 
