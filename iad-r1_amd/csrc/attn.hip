@@ -17,6 +17,7 @@
 // Backward = the same trick twice: bwd_dq owns q columns (dQ^T += K^T . dS^T), bwd_dkdv owns key
 // columns (dV^T += dO^T . P, dK^T += Q^T . dS) and loops the GQA group so dK/dV need no atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -76,6 +77,32 @@ __device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long 
         *(u32x4_t*)(dst + r * Cfg<D>::LD + c * 8) = v;
     }
 }
+// Split staging (issue-early / write-late): the global loads of the NEXT tile are issued into registers before the
+// MFMAs of the current tile and written to LDS after the barrier that ends it, so their latency hides under compute.
+template <int D, int ROWS>
+struct TileRegs {
+    static constexpr int CPR = Cfg<D>::DQK / 8;
+    static constexpr int N = (ROWS * CPR + 255) / 256;
+    u32x4_t v[N];
+    __device__ __forceinline__ void load(const bf16_t* src, long long ld, int nvalid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            const int r = idx / CPR, c = idx - r * CPR;
+            v[i] = (u32x4_t){0, 0, 0, 0};
+            if (idx < ROWS * CPR && r < nvalid && c * 8 < D) v[i] = *(const u32x4_t*)(src + (long long)r * ld + c * 8);
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* dst) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            const int r = idx / CPR, c = idx - r * CPR;
+            if (idx < ROWS * CPR) *(u32x4_t*)(dst + r * Cfg<D>::LD + c * 8) = v[i];
+        }
+    }
+};
+
 // Same tile stored TRANSPOSED: dst[d][r], row stride LDT (elements), d in [0, DQK)
 template <int D, int ROWS, int LDT>
 __device__ __forceinline__ void stage_rows_t(bf16_t* dst, const bf16_t* src, long long ld, int nvalid) {
@@ -95,16 +122,33 @@ __device__ __forceinline__ void stage_rows_t(bf16_t* dst, const bf16_t* src, lon
 
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
+// ---- hardware transpose read (gfx950 ds_read_b64_tr_b16) ---------------------------------------------------------------
+// Measured lane map (tools/gpu_probe.py, profiles/r01_tr_read_probe.txt): inside each 16-lane group, lane i receives
+// element (i & 3) of the 8-byte chunk addressed by lane 4*j + (i >> 2), for j = 0..3.  With lane L pointing at
+// tile[k0 + (L >> 2)][m0 + 4*(L & 3)] of a ROW-MAJOR [k][m] LDS tile, lane i therefore gets tile[k0 + 0..3][m0 + i]:
+// four consecutive k of column m0+i == half of an MFMA A/B fragment of the TRANSPOSED tile, without ever storing a
+// transposed copy.  Two reads (k0, k0+4) make the 8-element fragment.  The asm is opaque to hipcc: every use is preceded
+// by an explicit counted s_waitcnt lgkmcnt + sched_barrier (guide 5.7).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ void tr_issue(uint64_t& r, uint32_t byte_addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(byte_addr)); }
+__device__ __forceinline__ bf16x8_t tr_frag(uint64_t lo, uint64_t hi) {
+    u32x4_t v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+#define IADR1_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+// lane-constant part of a tr-read address inside a row-major [rows][LD] tile: row (li>>2) + 8*g, column 4*(li&3)
+__device__ __forceinline__ uint32_t tr_lane_off(int li, int g, int LD) { return (uint32_t)(((g * 8 + (li >> 2)) * LD + 4 * (li & 3)) * 2); }
+
 // =====================================================================================================
 // forward
 // =====================================================================================================
 template <int D, int R>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     using C = Cfg<D>;
-    constexpr int BM = 64 * R, BN = 64, LDT = BN + 8;
+    constexpr int BM = 64 * R, BN = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = (bf16_t*)smem;          // [BN][LD]
-    bf16_t* Vt = Ks + BN * C::LD;        // [DQK][LDT]
+    bf16_t* Vs = Ks + BN * C::LD;        // [BN][LD] row-major; consumed through transpose reads
 
     const int seg = blockIdx.y, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
@@ -138,11 +182,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const float c = p.scale * LOG2E;
     const int kv_end = p.causal ? min(slen, q0 + BM) : slen;
 
+    TileRegs<D, BN> kreg, vreg;
+    kreg.load(p.k + (long long)s0 * p.ldk + kvh * D, p.ldk, slen);
+    vreg.load(p.v + (long long)s0 * p.ldv + kvh * D, p.ldv, slen);
     for (int kv0 = 0; kv0 < kv_end; kv0 += BN) {
+        __syncthreads();           // every wave is done reading the previous tile
+        kreg.store(Ks);
+        vreg.store(Vs);
         __syncthreads();
-        stage_rows<D, BN>(Ks, p.k + (long long)(s0 + kv0) * p.ldk + kvh * D, p.ldk, slen - kv0);
-        stage_rows_t<D, BN, LDT>(Vt, p.v + (long long)(s0 + kv0) * p.ldv + kvh * D, p.ldv, slen - kv0);
-        __syncthreads();
+        if (kv0 + BN < kv_end) {   // next tile's loads fly while this tile is computed
+            kreg.load(p.k + (long long)(s0 + kv0 + BN) * p.ldk + kvh * D, p.ldk, slen - kv0 - BN);
+            vreg.load(p.v + (long long)(s0 + kv0 + BN) * p.ldv + kvh * D, p.ldv, slen - kv0 - BN);
+        }
 
         f32x4_t s[4][R];
 #pragma unroll
@@ -200,14 +251,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < 2; ++j) pf[r][j] = pack_frag(s[2 * j][r], s[2 * j + 1][r]);
+        {
+            // O^T[d,q] += V^T . P^T with V^T fragments produced by transpose reads of the row-major V tile;
+            // reads of d-tile dt+1 are in flight while the MFMAs of d-tile dt run
+            const uint32_t vbase = lds_addr(Vs) + tr_lane_off(li, g, C::LD);
+            uint64_t tr[2][4];
+            auto issue = [&](uint64_t (&dst)[4], int dt) {
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bf16x8_t vf = ld_frag_s(Vt + (dt * 16 + li) * LDT + j * 32 + g * 8);
+                    for (int h = 0; h < 2; ++h) tr_issue(dst[j * 2 + h], vbase + (uint32_t)(((j * 32 + h * 4) * C::LD + dt * 16) * 2));
+            };
+            IADR1_LGKM(0);  // nothing else may be counted against the waits below
+            issue(tr[0], 0);
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[dt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[r][j], acc[dt][r], 0, 0, 0);
+            for (int dt = 0; dt < C::DT; ++dt) {
+                if (dt + 1 < C::DT) { issue(tr[(dt + 1) & 1], dt + 1); IADR1_LGKM(4); } else { IADR1_LGKM(0); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8_t vf = tr_frag(tr[dt & 1][j * 2], tr[dt & 1][j * 2 + 1]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[dt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[r][j], acc[dt][r], 0, 0, 0);
+                }
             }
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -255,11 +323,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, long l
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     using C = Cfg<D>;
-    constexpr int BM = 64, KB = 32, LDT = KB + 8;
+    constexpr int BM = 64, KB = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Ks = (bf16_t*)smem;       // [KB][LD]
+    bf16_t* Ks = (bf16_t*)smem;       // [KB][LD]  (also read transposed for dQ^T += K^T . dS^T)
     bf16_t* Vs = Ks + KB * C::LD;     // [KB][LD]
-    bf16_t* Kt = Vs + KB * C::LD;     // [DQK][LDT]
 
     const int seg = blockIdx.y, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
@@ -291,13 +358,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     for (int dt = 0; dt < C::DT; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int kv_end = p.causal ? min(slen, q0 + BM) : slen;
+    TileRegs<D, KB> kreg, vreg;
+    kreg.load(p.k + (long long)s0 * p.ldk + kvh * D, p.ldk, slen);
+    vreg.load(p.v + (long long)s0 * p.ldv + kvh * D, p.ldv, slen);
     for (int kv0 = 0; kv0 < kv_end; kv0 += KB) {
         __syncthreads();
-        const bf16_t* ksrc = p.k + (long long)(s0 + kv0) * p.ldk + kvh * D;
-        stage_rows<D, KB>(Ks, ksrc, p.ldk, slen - kv0);
-        stage_rows<D, KB>(Vs, p.v + (long long)(s0 + kv0) * p.ldv + kvh * D, p.ldv, slen - kv0);
-        stage_rows_t<D, KB, LDT>(Kt, ksrc, p.ldk, slen - kv0);
+        kreg.store(Ks);
+        vreg.store(Vs);
         __syncthreads();
+        if (kv0 + KB < kv_end) {
+            kreg.load(p.k + (long long)(s0 + kv0 + KB) * p.ldk + kvh * D, p.ldk, slen - kv0 - KB);
+            vreg.load(p.v + (long long)(s0 + kv0 + KB) * p.ldv + kvh * D, p.ldv, slen - kv0 - KB);
+        }
 
         f32x4_t st[2], dpt[2];
 #pragma unroll
@@ -321,9 +393,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
                 ds[kt][e] = pv * (dpt[kt][e] - dl);
             }
         const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
+        {
+            const uint32_t kbase = lds_addr(Ks) + tr_lane_off(li, g, C::LD);
+            uint64_t tr[2][2];
+            auto issue = [&](uint64_t (&dst)[2], int dt) {
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Kt + (dt * 16 + li) * LDT + g * 8), dsf, acc[dt], 0, 0, 0);
+                for (int h = 0; h < 2; ++h) tr_issue(dst[h], kbase + (uint32_t)((h * 4 * C::LD + dt * 16) * 2));
+            };
+            IADR1_LGKM(0);
+            issue(tr[0], 0);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                if (dt + 1 < C::DT) { issue(tr[(dt + 1) & 1], dt + 1); IADR1_LGKM(2); } else { IADR1_LGKM(0); }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(tr[dt & 1][0], tr[dt & 1][1]), dsf, acc[dt], 0, 0, 0);
+            }
+        }
     }
     if (!qok) return;
     bf16_t* dst = p.dq + (long long)(s0 + qrow) * p.lddq + head * D;
@@ -341,13 +426,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     using C = Cfg<D>;
-    constexpr int BN = 64, QB = 32, LDT = QB + 8;
+    constexpr int BN = 64, QB = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Qs = (bf16_t*)smem;        // [QB][LD]
-    bf16_t* dOs = Qs + QB * C::LD;     // [QB][LD]
-    bf16_t* Qt = dOs + QB * C::LD;     // [DQK][LDT]
-    bf16_t* dOt = Qt + C::DQK * LDT;   // [DQK][LDT]
-    float* lse_s = (float*)(dOt + C::DQK * LDT);  // [QB]
+    bf16_t* Qs = (bf16_t*)smem;        // [QB][LD]  (also read transposed: dK^T += Q^T . dS)
+    bf16_t* dOs = Qs + QB * C::LD;     // [QB][LD]  (also read transposed: dV^T += dO^T . P)
+    float* lse_s = (float*)(dOs + QB * C::LD);    // [QB]
     float* del_s = lse_s + QB;                    // [QB]
 
     const int seg = blockIdx.y, kvh = blockIdx.z, group = p.Hq / p.Hkv;
@@ -377,22 +460,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     for (int dt = 0; dt < C::DT; ++dt) { dkacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
     const int q_begin = p.causal ? (kv0 / QB) * QB : 0;
-    for (int hh = 0; hh < group; ++hh) {
-        const int head = kvh * group + hh;
-        for (int q0 = q_begin; q0 < slen; q0 += QB) {
+    const int nq = (slen - q_begin + QB - 1) / QB;         // q blocks per head
+    const int nit = group * nq;                            // flattened (head, q block) iteration space
+    TileRegs<D, QB> qreg, doreg;
+    float lse_r = 0.f, del_r = 0.f;
+    auto prefetch = [&](int it) {
+        const int head = kvh * group + it / nq, q0 = q_begin + (it % nq) * QB;
+        qreg.load(p.q + (long long)(s0 + q0) * p.ldq + head * D, p.ldq, slen - q0);
+        doreg.load(p.dout + (long long)(s0 + q0) * p.lddo + head * D, p.lddo, slen - q0);
+        if (threadIdx.x < QB) {
+            const int qr = q0 + threadIdx.x;
+            lse_r = qr < slen ? p.lse[(long long)head * p.T + s0 + qr] * LOG2E : 0.f;
+            del_r = qr < slen ? p.delta[(long long)head * p.T + s0 + qr] : 0.f;
+        }
+    };
+    if (nit > 0) prefetch(0);
+    for (int it = 0; it < nit; ++it) {
+        {
+            const int q0 = q_begin + (it % nq) * QB;
             __syncthreads();
-            const bf16_t* qsrc = p.q + (long long)(s0 + q0) * p.ldq + head * D;
-            const bf16_t* dsrc = p.dout + (long long)(s0 + q0) * p.lddo + head * D;
-            stage_rows<D, QB>(Qs, qsrc, p.ldq, slen - q0);
-            stage_rows<D, QB>(dOs, dsrc, p.lddo, slen - q0);
-            stage_rows_t<D, QB, LDT>(Qt, qsrc, p.ldq, slen - q0);
-            stage_rows_t<D, QB, LDT>(dOt, dsrc, p.lddo, slen - q0);
-            if (threadIdx.x < QB) {
-                const int qr = q0 + threadIdx.x;
-                lse_s[threadIdx.x] = qr < slen ? p.lse[(long long)head * p.T + s0 + qr] * LOG2E : 0.f;
-                del_s[threadIdx.x] = qr < slen ? p.delta[(long long)head * p.T + s0 + qr] : 0.f;
-            }
+            qreg.store(Qs);
+            doreg.store(dOs);
+            if (threadIdx.x < QB) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
             __syncthreads();
+            if (it + 1 < nit) prefetch(it + 1);
 
             // S[q, key] and dP[q, key]: A = Q / dO rows (permuted so a lane's registers are 8 consecutive q), B = K / V fragments
             f32x4_t s[2], dp[2];
@@ -419,10 +510,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
                     ds[t][e] = pp * (dp[t][e] - del_s[qi]);
                 }
             const bf16x8_t pf = pack_frag(pv[0], pv[1]), dsf = pack_frag(ds[0], ds[1]);
+            {
+                const uint32_t off = tr_lane_off(li, g, C::LD);
+                const uint32_t qbase = lds_addr(Qs) + off, dobase = lds_addr(dOs) + off;
+                uint64_t tr[2][4];  // [buffer][dO lo, dO hi, Q lo, Q hi]
+                auto issue = [&](uint64_t (&dst)[4], int dt) {
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt) {
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(dOt + (dt * 16 + li) * LDT + g * 8), pf, dvacc[dt], 0, 0, 0);
-                dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Qt + (dt * 16 + li) * LDT + g * 8), dsf, dkacc[dt], 0, 0, 0);
+                    for (int h = 0; h < 2; ++h) {
+                        tr_issue(dst[h], dobase + (uint32_t)((h * 4 * C::LD + dt * 16) * 2));
+                        tr_issue(dst[2 + h], qbase + (uint32_t)((h * 4 * C::LD + dt * 16) * 2));
+                    }
+                };
+                IADR1_LGKM(0);
+                issue(tr[0], 0);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    if (dt + 1 < C::DT) { issue(tr[(dt + 1) & 1], dt + 1); IADR1_LGKM(4); } else { IADR1_LGKM(0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(tr[dt & 1][0], tr[dt & 1][1]), pf, dvacc[dt], 0, 0, 0);
+                    dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(tr[dt & 1][2], tr[dt & 1][3]), dsf, dkacc[dt], 0, 0, 0);
+                }
             }
         }
     }
@@ -655,10 +762,13 @@ extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void*
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
     p.seg_start = seg_start; p.seg_end = seg_end; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
-    const bool small = max_seqlen <= 64;  // ViT windows: one 64-row tile per segment
+    static int force_r = -1;
+    if (force_r < 0) { const char* e = getenv("IADR1_ATTN_R"); force_r = e ? atoi(e) : 1; }
+    // 64-row q tiles (R=1, ~180 VGPR, 2 blocks/CU) measured 1.4x faster than 128-row tiles (R=2, 1 block/CU): occupancy wins
+    const bool small = max_seqlen <= 64 || force_r == 1;
 #define LAUNCH_FWD(DD, RR)                                                                                           \
     do {                                                                                                             \
-        const int smem = (64 * Cfg<DD>::LD + Cfg<DD>::DQK * 72) * 2;                                                 \
+        const int smem = (2 * 64 * Cfg<DD>::LD) * 2;                                                                 \
         set_smem(attn_fwd_kernel<DD, RR>, smem);                                                                     \
         const int bm = 64 * RR;                                                                                      \
         hipLaunchKernelGGL((attn_fwd_kernel<DD, RR>), dim3((max_seqlen + bm - 1) / bm, nseg, Hq), dim3(256), smem, stream, p); \
@@ -687,10 +797,10 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
     do {                                                                                                                                 \
         hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)o, ldo,    \
                            (const bf16_t*)dout, lddo, delta, T, Hq);                                                                     \
-        const int smem_dq = (2 * 32 * Cfg<DD>::LD + Cfg<DD>::DQK * 40) * 2;                                                              \
+        const int smem_dq = (2 * 32 * Cfg<DD>::LD) * 2;                                                                                  \
         set_smem(attn_bwd_dq_kernel<DD>, smem_dq);                                                                                       \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hq), dim3(256), smem_dq, stream, p);               \
-        const int smem_kv = (2 * 32 * Cfg<DD>::LD + 2 * Cfg<DD>::DQK * 40) * 2 + 64 * 4;                                                 \
+        const int smem_kv = (2 * 32 * Cfg<DD>::LD) * 2 + 64 * 4;                                                                         \
         set_smem(attn_bwd_dkdv_kernel<DD>, smem_kv);                                                                                     \
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hkv), dim3(256), smem_kv, stream, p);            \
     } while (0)
