@@ -7,7 +7,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n, float* out) {
+// Deterministic two-stage reduction (no float atomics): data-parallel replicas must compute a BIT-IDENTICAL clip
+// coefficient from their identical all-reduced gradients, or they drift apart.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long long n, float* partial) {
     __shared__ float scratch[16];
     float s = 0.f;
     const long long n4 = n >> 2;
@@ -17,7 +19,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n,
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
     s = block_sum<256>(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, int nblocks, float* out) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    s = block_sum<256>(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 struct AdamArgs {
@@ -75,13 +84,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs p) {
 
 }  // namespace
 
-extern "C" int iadr1_sumsq_acc(const float* g, long long n, float* out, hipStream_t stream) {
-    IADR1_REQUIRE(n > 0, "sumsq: empty");
+extern "C" int iadr1_sumsq(const float* g, long long n, float* partials2048, float* out, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0 && partials2048 != nullptr, "sumsq: empty input or missing 2048-float scratch");
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, stream, g, n, out);
-    return iadr1_check_launch("sumsq_acc");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((int)blocks), dim3(256), 0, stream, g, n, partials2048);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)partials2048, (int)blocks, out);
+    return iadr1_check_launch("sumsq");
 }
 
 extern "C" int iadr1_adamw_flat(float* master, float* m, float* v, float* grad, void* param_bf16, long long n, float lr, float beta1,

@@ -140,6 +140,7 @@ class SCGRPOEngine:
         self.accum = 0
         self._rollout = None
         self.norm2 = torch.zeros(1, dtype=F32, device=self.dev)
+        self.norm_scratch = torch.zeros(2048, dtype=F32, device=self.dev)
 
     # ---- vision: once per unique image ---------------------------------------------------------------------
     def _vision(self, batch, want_policy_ctx: bool):
@@ -267,8 +268,7 @@ class SCGRPOEngine:
         self.reducer.finish()
         self.opt_step += 1
         scale = 1.0 / (self.reducer.world * max(1, self.accum))
-        self.norm2.zero_()
-        hip.call("sumsq_acc", st.grad, st.n_total, self.norm2)
+        hip.call("sumsq", st.grad, st.n_total, self.norm_scratch, self.norm2)
         for lo, hi, wd in ((0, st.n_decay, a.weight_decay), (st.n_decay, st.n_total, 0.0)):
             if hi > lo:
                 hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,

@@ -38,6 +38,7 @@ class SFTEngine:
         self.opt_step = 0
         self.accum = 0
         self.norm2 = torch.zeros(1, dtype=F32, device=self.dev)
+        self.norm_scratch = torch.zeros(2048, dtype=F32, device=self.dev)
 
     def loss_and_grads(self, batch, backward=True, num_items_in_batch=None, last_micro_step=True):
         """batch: input_ids, attention_mask, labels [B,S] (numpy), pixel_values [n,patch_dim], image_grid_thw [n_img,3],
@@ -92,8 +93,7 @@ class SFTEngine:
         self.reducer.finish()
         self.opt_step += 1
         scale = 1.0 / (self.reducer.world * max(1, self.accum))
-        self.norm2.zero_()
-        hip.call("sumsq_acc", st.grad, st.n_total, self.norm2)
+        hip.call("sumsq", st.grad, st.n_total, self.norm_scratch, self.norm2)
         for lo, hi, wd in ((0, st.n_decay, a.weight_decay), (st.n_decay, st.n_total, 0.0)):
             if hi > lo:
                 hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,

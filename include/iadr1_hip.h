@@ -127,7 +127,9 @@ int iadr1_grpo_loss(const float* logp, const float* ref_logp, const float* adv, 
                     float* dlogp, float* kl, float* row_loss, float* row_kl, int N, int C, iadr1_stream_t stream);
 
 /* ---- optimizer (HF Trainer default AdamW + clip_grad_norm_, TF:trainer.py:1168) ------------------------------- */
-int iadr1_sumsq_acc(const float* g, long long n, float* out, iadr1_stream_t stream);
+/* out[0] = sum(g^2), deterministic (fixed-order two-stage reduction; scratch = 2048 floats) so that data-parallel
+ * replicas derive a bit-identical clip coefficient */
+int iadr1_sumsq(const float* g, long long n, float* partials2048, float* out, iadr1_stream_t stream);
 int iadr1_adamw_flat(float* master, float* m, float* v, float* grad_zeroed_after, void* param_bf16, long long n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                      const float* norm2, float max_norm, iadr1_stream_t stream);

@@ -346,8 +346,11 @@ def test_adamw_matches_torch():
         torch.nn.utils.clip_grad_norm_([wt], 1.0)
         opt.step()
         grad = g.clone()
-        norm2 = torch.zeros(1, device=DEV)
-        hip.call("sumsq_acc", grad, n, norm2)
+        norm2, scratch = torch.zeros(1, device=DEV), torch.zeros(2048, device=DEV)
+        hip.call("sumsq", grad, n, scratch, norm2)
+        norm2b = torch.zeros(1, device=DEV)
+        hip.call("sumsq", grad, n, scratch, norm2b)
+        assert torch.equal(norm2, norm2b)   # deterministic: replicas must agree bit for bit
         close(norm2[0], (g * g).sum(), 1e-4, 1e-3, "sumsq")
         hip.call("adamw_flat", master, m, v, grad, pb, n, 1e-2, 0.9, 0.999, 1e-8, 0.1, step, 1.0, norm2, 1.0)
         assert float(grad.abs().sum()) == 0.0

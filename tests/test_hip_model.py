@@ -222,3 +222,60 @@ def test_trainer_api_runs_two_optimizer_steps():
     from safetensors import safe_open
     with safe_open("/tmp/iadr1_trainer_test/final/model.safetensors", framework="pt") as sf:
         assert "model.layers.0.self_attn.q_proj.weight" in sf.keys() and "visual.blocks.0.attn.qkv.weight" in sf.keys()
+
+
+def _ddp_worker(rank, world, port, q, hook):
+    import os as _os
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # 2 ranks share the one GPU of the test box: gloo moves the CUDA buffers
+    pol, ref = store(fx.make_weights(fx.TINY, 0), True), store(fx.make_weights(fx.TINY, 0), False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=6, learning_rate=1e-3, micro_batch_seqs=2), group=dist.group.WORLD)
+    if not hook:
+        eng.reducer.layer_ready = lambda i: None   # everything is exchanged in finish(): the buffer still holds LOCAL gradients after backward
+    grid = (1, 16, 12)
+    ids, mask = fx.left_pad([fx.synth_prompt(grid, 9, fx.TINY, 50 + rank)], fx.TINY["pad_token_id"])     # each rank its own prompt
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=50 + rank), "image_grid_thw": [grid]}
+    comps = fx.synth_completions(4, 6, fx.TINY, 70 + rank)
+    rew = np.array([[1.0, 0.0], [0.5, 1.0], [2.0, 1.0], [0.0, 0.0]], dtype=np.float32) * (1 + rank)
+    eng.loss_and_grads(batch, comps, rew, last_micro_step=True)
+    local = pol.grad.clone()
+    eng.optimizer_step()
+    q.put((rank, local.cpu().numpy(), pol.flat.float().cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def _run_ddp(hook):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, hook)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_ddp_two_ranks_match_single_process_average():
+    """world_size 2 (gloo, both ranks on the test GPU).  (1) With the gradient exchange done in one go after backward,
+    both ranks end bit-identical and equal to a single process that averages the two local gradients itself.
+    (2) With per-layer buckets launched from the backward hook (overlap path) the ranks are again bit-identical and
+    land on the same parameters."""
+    (_, g0, w0), (_, g1, w1) = _run_ddp(hook=False)
+    assert np.array_equal(w0, w1)                                   # replicas stay bit-identical
+    pol, ref = store(fx.make_weights(fx.TINY, 0), True), store(fx.make_weights(fx.TINY, 0), False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=6, learning_rate=1e-3))
+    pol.grad.copy_(torch.from_numpy(g0 + g1).to(DEV))               # same fp32 sum the all-reduce forms
+    eng.accum = 2                                                   # scale 1/2 == 1/world
+    eng.optimizer_step()
+    assert np.array_equal(pol.flat.float().cpu().numpy(), w0)
+    (_, _, h0), (_, _, h1) = _run_ddp(hook=True)
+    assert np.array_equal(h0, h1)
+    # local gradients carry atomics-order noise run to run; the update is lr*sign-like for Adam's first step
+    assert np.abs(h0 - w0).max() <= 4e-3
