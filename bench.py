@@ -234,6 +234,15 @@ def main():
     if rank == 0:
         n_launch, t_gemm, fl_gemm = timer.summary()
         ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
+        # HBM-side traffic of the heaviest GEMM shape from the PMC passes recorded under profiles/ (separate rocprofv3 --pmc
+        # runs, gfx950 FETCH_SIZE correction applied there); null when the record is absent
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")))
+            k0 = pmc["kernels"][0]
+            traffic = {"bytes_per_launch": k0["traffic_bytes"], "algorithmic_bytes_per_launch": k0["algorithmic_bytes"], "MNK": k0["MNK"], "source": "profiles/r01_gemm_pmc.json"}
+        except Exception:
+            pass
         out = {
             "metric": "GRPO samples/sec (img448+512tok, group=8) Qwen2.5-VL-3B" if a.model == "3b" else f"GRPO samples/sec {a.model}",
             "value": world * N * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -242,7 +251,7 @@ def main():
                        "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}"},
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
+                         "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
             "last_step_metrics": metrics,
             "gemm_by_shape": timer.by_shape(),
             "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30, "peak_reserved_GB": torch.cuda.max_memory_reserved() / 2**30,
