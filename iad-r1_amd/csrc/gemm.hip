@@ -37,6 +37,7 @@ struct GemmArgs {
     int M, N, K;
     long long lda, ldb, ldc;
     int act;  // 0 none, 1 exact GELU
+    int band;  // tile rows per rasterisation band (gemm_nt_256)
 };
 
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2 };
@@ -251,9 +252,10 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int band = wg / (4 * tiles_n), in_band = wg - band * 4 * tiles_n;
-    const int band_rows = min(4, tiles_m - band * 4);
-    const int tm = band * 4 + in_band % band_rows, tn = in_band / band_rows;
+    const int BR = p.band;
+    const int band = wg / (BR * tiles_n), in_band = wg - band * BR * tiles_n;
+    const int band_rows = min(BR, tiles_m - band * BR);
+    const int tm = band * BR + in_band % band_rows, tn = in_band / band_rows;
     const int m0 = tm * T2, n0 = tn * T2;
 
     // ---- DMA sources: per half-tile 2 x 16 B per thread ----------------------------------------------------
@@ -741,7 +743,9 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     IADR1_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0, "gemm_nt: K, lda, ldb must be multiples of 8 (16-byte chunks); K=%d lda=%lld ldb=%lld", K, lda, ldb);
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, "gemm_nt: A/B must be 16-byte aligned");
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2, "gemm_nt: bad out_mode %d", out_mode);
-    GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act};
+    static int band_rows = 0;
+    if (!band_rows) { const char* e = getenv("IADR1_GEMM_BAND"); band_rows = e ? atoi(e) : 4; if (band_rows < 1) band_rows = 4; }
+    GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act, band_rows};
     static int force_tile = -1;
     static bool attr_done = false;
     if (!attr_done) {

@@ -53,6 +53,16 @@ TINY = {
 }
 
 
+# A second tiny config with the structural differences of Qwen2.5-VL-7B (BASELINE.json config 4): UNTIED lm_head and a
+# GQA group of 7 query heads per kv head (28/4 in the real model), so hidden = 7*128.
+TINY7 = {
+    "text": dict(TINY["text"], hidden_size=896, intermediate_size=1152, num_attention_heads=7, num_key_value_heads=1, vocab_size=768),
+    "vision": dict(TINY["vision"], out_hidden_size=896, depth=2, fullatt_block_indexes=[1]),
+    "image_token_id": 760, "video_token_id": 761, "vision_start_token_id": 758, "vision_end_token_id": 759,
+    "eos_token_id": 1, "pad_token_id": 2, "tie_word_embeddings": False,
+}
+
+
 def param_shapes(cfg: dict) -> dict[str, tuple[int, ...]]:
     """Checkpoint-name -> shape for a Qwen2.5-VL config dict like ``TINY``."""
     t, v = cfg["text"], cfg["vision"]

@@ -133,3 +133,16 @@ def test_sft_loss_curve(golden_dir):
         opt.step()
         losses.append(loss.item())
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
+
+
+def test_forward_7b_like_config(golden_dir):
+    """Untied lm_head + GQA group of 7 (the structural deltas of Qwen2.5-VL-7B, BASELINE config 4)."""
+    g = _load(golden_dir, "logps_7b_like.npz")
+    m = oq.Qwen25VLOracle(fx.TINY7, fx.make_weights(fx.TINY7, 0))
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    grids = [tuple(int(z) for z in r) for r in g["image_grid_thw"]]
+    pv = torch.from_numpy(fx.synth_pixel_values(grids, fx.TINY7, seed=91))
+    with torch.no_grad():
+        lp = m.per_token_logps(ids, mask, pv, grids)
+    valid = (mask[:, 1:] * mask[:, :-1]).bool().numpy()
+    np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=3e-4)

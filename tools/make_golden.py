@@ -445,6 +445,24 @@ def gen_logps_padded(SCGRPOTrainer):
     print("logps_padded.npz:", tuple(logps.shape))
 
 
+def gen_logps_7b_like(SCGRPOTrainer):
+    """Same as logps_padded but on TINY7 (untied lm_head, GQA group 7: the structural deltas of Qwen2.5-VL-7B)."""
+    cfg = fx.TINY7
+    model = build_hf_model(cfg, fx.make_weights(cfg, seed=0)).eval()
+    grids = [(1, 8, 12), (1, 16, 8)]
+    batch = tiny_batch(cfg, grids, [7, 3], seed=91)
+    comp = np.array(fx.synth_completions(2, 5, cfg, 6)).astype(np.int64)
+    ids = torch.cat([batch["input_ids"], torch.from_numpy(comp)], 1)
+    mask = torch.cat([batch["attention_mask"], torch.ones(2, 5, dtype=torch.long)], 1)
+    inputs = dict(batch, input_ids=ids, attention_mask=mask, mm_token_type_ids=(ids == cfg["image_token_id"]).int())
+    holder = types.SimpleNamespace(model_id="tiny-qwen2.5-vl")
+    with torch.no_grad():
+        logps = SCGRPOTrainer._get_per_token_logps(holder, model, **inputs)
+    np.savez_compressed(os.path.join(OUT, "logps_7b_like.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [7, 3], "seed": 91, "config": "fixture_util.TINY7"}),
+                        input_ids=ids.numpy(), attention_mask=mask.numpy(), image_grid_thw=inputs["image_grid_thw"].numpy(), per_token_logps=logps.numpy())
+    print("logps_7b_like.npz:", tuple(logps.shape))
+
+
 def gen_vision_index():
     from transformers import vision_utils as vu
 
@@ -539,6 +557,8 @@ def main():
         gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={0: 11, 2: 3, 5: 7}, name="sc_grpo_g8.npz", seed=22)
     if not only or "logps" in only:
         gen_logps_padded(SCGRPOTrainer)
+    if not only or "logps7" in only:
+        gen_logps_7b_like(SCGRPOTrainer)
     if not only or "greedy" in only:
         gen_greedy()
     if not only or "sft" in only:
