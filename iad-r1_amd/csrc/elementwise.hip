@@ -123,6 +123,38 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* da, const b
     }
 }
 
+// QuickGELU x*sigmoid(1.702x) of the Qwen2-VL vision MLP (hidden_act "quick_gelu", TF:models/qwen2_vl/modeling_qwen2_vl.py:293-301)
+__global__ __launch_bounds__(256) void quick_gelu_fwd_kernel(const bf16_t* z, bf16_t* a, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4_t v = *(const u32x4_t*)(z + i * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = lo_bf(v[e]), a1 = hi_bf(v[e]);
+            o[e] = pack2bf(a0 / (1.f + __expf(-1.702f * a0)), a1 / (1.f + __expf(-1.702f * a1)));
+        }
+        *(u32x4_t*)(a + i * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void quick_gelu_bwd_kernel(const bf16_t* da, const bf16_t* z, bf16_t* dz, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4_t v = *(const u32x4_t*)(z + i * 8), d = *(const u32x4_t*)(da + i * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r[2];
+#pragma unroll
+            for (int hsel = 0; hsel < 2; ++hsel) {
+                const float x = hsel ? hi_bf(v[e]) : lo_bf(v[e]), dv = hsel ? hi_bf(d[e]) : lo_bf(d[e]);
+                const float sg = 1.f / (1.f + __expf(-1.702f * x));
+                r[hsel] = dv * (sg + 1.702f * x * sg * (1.f - sg));
+            }
+            o[e] = pack2bf(r[0], r[1]);
+        }
+        *(u32x4_t*)(dz + i * 8) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column sums of a bf16 matrix into fp32 (bias gradients): out[n] += sum_t dY[t][n].
 // Block = 64 columns x 4 row-lanes... each thread owns 8 columns (16 B) and strides over rows.
@@ -295,6 +327,16 @@ extern "C" int iadr1_gelu_bwd(const void* da, const void* z, void* dz, long long
     IADR1_REQUIRE(n > 0 && (n % 8) == 0, "gelu_bwd: n must be a multiple of 8");
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)da, (const bf16_t*)z, (bf16_t*)dz, n / 8);
     return iadr1_check_launch("gelu_bwd");
+}
+extern "C" int iadr1_quick_gelu_fwd(const void* z, void* a, long long n, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0 && (n % 8) == 0, "quick_gelu_fwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(quick_gelu_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)z, (bf16_t*)a, n / 8);
+    return iadr1_check_launch("quick_gelu_fwd");
+}
+extern "C" int iadr1_quick_gelu_bwd(const void* da, const void* z, void* dz, long long n, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0 && (n % 8) == 0, "quick_gelu_bwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)da, (const bf16_t*)z, (bf16_t*)dz, n / 8);
+    return iadr1_check_launch("quick_gelu_bwd");
 }
 extern "C" int iadr1_colsum_acc(const void* dy, long long ld, float* out, int T, int N, hipStream_t stream) {
     IADR1_REQUIRE(T > 0 && N > 0 && (N % 8) == 0 && (ld % 8) == 0, "colsum: N, ld must be multiples of 8");

@@ -295,3 +295,207 @@ extern "C" int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
 #undef CALL
     return iadr1_check_launch("rmsnorm_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// LayerNorm (with bias) for the Qwen2-VL vision tower (nn.LayerNorm(eps=1e-6) at TF:models/qwen2_vl/modeling_qwen2_vl.py:
+// 281,428-429): same wave-per-row structure as RMSNorm, fused residual add on the way in, mean/rstd saved for backward.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct LnFwdArgs {
+    const bf16_t* x;
+    const bf16_t* res;
+    bf16_t* res_out;
+    const bf16_t* w;
+    const bf16_t* b;
+    bf16_t* y;
+    float* mean;
+    float* rstd;
+    int T, H;
+    long long ldx, ldr, ldy;
+    float eps;
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(LnFwdArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.T) return;
+    const int nchunk = p.H >> 3;
+    float v[NC][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+            const u32x4_t a = *(const u32x4_t*)(p.x + (long long)row * p.ldx + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[c][2 * e] = lo_bf(a[e]); v[c][2 * e + 1] = hi_bf(a[e]); }
+            if (p.res) {
+                const u32x4_t r = *(const u32x4_t*)(p.res + (long long)row * p.ldr + ch * 8);
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = pack2bf(v[c][2 * e] + lo_bf(r[e]), v[c][2 * e + 1] + hi_bf(r[e]));
+                    v[c][2 * e] = lo_bf(o[e]);
+                    v[c][2 * e + 1] = hi_bf(o[e]);
+                }
+                if (p.res_out) *(u32x4_t*)(p.res_out + (long long)row * p.ldr + ch * 8) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1 += v[c][e];
+        }
+    }
+    const float mean = wave_sum(s1) / (float)p.H;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; s2 += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)p.H + p.eps);
+    if (lane == 0) {
+        if (p.mean) p.mean[row] = mean;
+        if (p.rstd) p.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+            const u32x4_t g = *(const u32x4_t*)(p.w + ch * 8), bb = *(const u32x4_t*)(p.b + ch * 8);
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = pack2bf((v[c][2 * e] - mean) * rstd * lo_bf(g[e]) + lo_bf(bb[e]), (v[c][2 * e + 1] - mean) * rstd * hi_bf(g[e]) + hi_bf(bb[e]));
+            *(u32x4_t*)(p.y + (long long)row * p.ldy + ch * 8) = o;
+        }
+    }
+}
+
+struct LnBwdArgs {
+    const bf16_t* dy;
+    const bf16_t* x;
+    const bf16_t* w;
+    const float* mean;
+    const float* rstd;
+    const bf16_t* dres;
+    bf16_t* dx;
+    float* dw;
+    float* db;
+    int T, H;
+    long long ld;
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs p) {
+    extern __shared__ float sred[];  // [2][4][H]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nchunk = p.H >> 3;
+    float dwacc[NC][8], dbacc[NC][8], g[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwacc[c][e] = 0.f; dbacc[c][e] = 0.f; g[c][e] = 0.f; }
+        if (ch < nchunk) {
+            const u32x4_t gg = *(const u32x4_t*)(p.w + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[c][2 * e] = lo_bf(gg[e]); g[c][2 * e + 1] = hi_bf(gg[e]); }
+        }
+    }
+    for (int row = blockIdx.x * 4 + wv; row < p.T; row += gridDim.x * 4) {
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        float n[NC][8], dn[NC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = c * 64 + lane;
+            if (ch < nchunk) {
+                const u32x4_t a = *(const u32x4_t*)(p.x + (long long)row * p.ld + ch * 8);
+                const u32x4_t d = *(const u32x4_t*)(p.dy + (long long)row * p.ld + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    n[c][2 * e] = (lo_bf(a[e]) - mean) * rstd;
+                    n[c][2 * e + 1] = (hi_bf(a[e]) - mean) * rstd;
+                    const float d0 = lo_bf(d[e]), d1 = hi_bf(d[e]);
+                    dwacc[c][2 * e] += d0 * n[c][2 * e];
+                    dwacc[c][2 * e + 1] += d1 * n[c][2 * e + 1];
+                    dbacc[c][2 * e] += d0;
+                    dbacc[c][2 * e + 1] += d1;
+                    dn[c][2 * e] = d0 * g[c][2 * e];
+                    dn[c][2 * e + 1] = d1 * g[c][2 * e + 1];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1 += dn[c][e]; s2 += dn[c][e] * n[c][e]; }
+            }
+        }
+        s1 = wave_sum(s1) / (float)p.H;
+        s2 = wave_sum(s2) / (float)p.H;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = c * 64 + lane;
+            if (ch < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dn[c][e] - s1 - n[c][e] * s2);
+                if (p.dres) {
+                    const u32x4_t r = *(const u32x4_t*)(p.dres + (long long)row * p.ld + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[2 * e] += lo_bf(r[e]); o[2 * e + 1] += hi_bf(r[e]); }
+                }
+                u32x4_t ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = pack2bf(o[2 * e], o[2 * e + 1]);
+                *(u32x4_t*)(p.dx + (long long)row * p.ld + ch * 8) = ov;
+            }
+        }
+    }
+    if (!p.dw) return;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sred[wv * p.H + ch * 8 + e] = dwacc[c][e];
+                sred[(4 + wv) * p.H + ch * 8 + e] = dbacc[c][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.H; i += 256) {
+        atomicAdd(p.dw + i, sred[i] + sred[p.H + i] + sred[2 * p.H + i] + sred[3 * p.H + i]);
+        atomicAdd(p.db + i, sred[4 * p.H + i] + sred[5 * p.H + i] + sred[6 * p.H + i] + sred[7 * p.H + i]);
+    }
+}
+
+}  // namespace
+
+extern "C" int iadr1_layernorm_fwd(const void* x, const void* res, void* res_out, const void* w, const void* b, void* y, float* mean,
+                                   float* rstd, int T, int H, long long ldx, long long ldr, long long ldy, float eps, hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0 && H <= MAXC * 512, "layernorm_fwd: H=%d must be a multiple of 8 and <= %d", H, MAXC * 512);
+    IADR1_REQUIRE((ldx % 8) == 0 && (ldr % 8) == 0 && (ldy % 8) == 0, "layernorm_fwd: leading dims must be multiples of 8");
+    LnFwdArgs p{(const bf16_t*)x, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, T, H, ldx, ldr, ldy, eps};
+    const dim3 grid((T + 3) / 4), block(256);
+#define CALL(NC) hipLaunchKernelGGL(layernorm_fwd_kernel<NC>, grid, block, 0, stream, p)
+    DISPATCH_NC(H, CALL);
+#undef CALL
+    return iadr1_check_launch("layernorm_fwd");
+}
+
+extern "C" int iadr1_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres,
+                                   void* dx, float* dw, float* db, int T, int H, long long ld, hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0 && H <= MAXC * 512, "layernorm_bwd: H=%d must be a multiple of 8 and <= %d", H, MAXC * 512);
+    IADR1_REQUIRE((ld % 8) == 0 && ((dw == nullptr) == (db == nullptr)), "layernorm_bwd: ld multiple of 8; dw and db together");
+    LnBwdArgs p{(const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw, db, T, H, ld};
+    int blocks = (T + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    const dim3 grid(blocks), block(256);
+#define CALL(NC) hipLaunchKernelGGL(layernorm_bwd_kernel<NC>, grid, block, (size_t)(dw ? 8 * H * sizeof(float) : 0), stream, p)
+    DISPATCH_NC(H, CALL);
+#undef CALL
+    return iadr1_check_launch("layernorm_bwd");
+}

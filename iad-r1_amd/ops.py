@@ -139,6 +139,35 @@ def gelu_bwd(da, z):
     return dz
 
 
+def quick_gelu_fwd(z):
+    a = torch.empty_like(z)
+    hip.call("quick_gelu_fwd", z, a, z.numel())
+    return a
+
+
+def quick_gelu_bwd(da, z):
+    dz = torch.empty_like(z)
+    hip.call("quick_gelu_bwd", da, z, dz, z.numel())
+    return dz
+
+
+def layernorm_fwd(x, w, b, eps, res=None, res_out=None, want_stats=False):
+    T, H = x.shape
+    y = torch.empty(T, H, dtype=BF16, device=x.device)
+    mean = torch.empty(T, dtype=F32, device=x.device) if want_stats else None
+    rstd = torch.empty(T, dtype=F32, device=x.device) if want_stats else None
+    ldr = _ld(res) if res is not None else H
+    hip.call("layernorm_fwd", x, res, res_out, w, b, y, mean, rstd, T, H, _ld(x), ldr, _ld(y), float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dres=None, dw=None, db=None):
+    T, H = x.shape
+    dx = torch.empty(T, H, dtype=BF16, device=x.device)
+    hip.call("layernorm_bwd", dy, x, w, mean, rstd, dres, dx, dw, db, T, H, _ld(x))
+    return dx
+
+
 def colsum_acc(dy, out32):
     T, N = dy.shape
     hip.call("colsum_acc", dy, _ld(dy), out32, T, N)

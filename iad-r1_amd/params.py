@@ -55,6 +55,9 @@ class VLMConfig:
     eos_token_id: int
     pad_token_id: int
     tie_word_embeddings: bool
+    # "qwen2_5_vl": RMSNorm + gated SwiGLU MLP + window attention;  "qwen2_vl": LayerNorm(+bias) + fc1/QuickGELU/fc2, full
+    # attention only (TF:models/qwen2_vl/modeling_qwen2_vl.py:418-447) -- the decoder is identical
+    v_arch: str = "qwen2_5_vl"
 
     @property
     def head_dim(self):
@@ -89,7 +92,7 @@ class VLMConfig:
             v_temporal=v["temporal_patch_size"], v_window=v["window_size"], v_fullatt=tuple(v["fullatt_block_indexes"]),
             image_token_id=d["image_token_id"], vision_start_token_id=d["vision_start_token_id"],
             vision_end_token_id=d["vision_end_token_id"], eos_token_id=d["eos_token_id"], pad_token_id=d["pad_token_id"],
-            tie_word_embeddings=d.get("tie_word_embeddings", False),
+            tie_word_embeddings=d.get("tie_word_embeddings", False), v_arch=v.get("arch", "qwen2_5_vl"),
         )
 
     @staticmethod
@@ -99,6 +102,9 @@ class VLMConfig:
         v = c["vision_config"]
         rope = t.get("rope_parameters") or t.get("rope_scaling") or c.get("rope_scaling") or {}
         eos = t.get("eos_token_id", c.get("eos_token_id", 151645))
+        if "embed_dim" in v:  # Qwen2-VL: ViT width is `embed_dim`, vision `hidden_size` is the merger output
+            v = dict(v, hidden_size=v["embed_dim"], intermediate_size=int(v["embed_dim"] * v.get("mlp_ratio", 4)), window_size=0,
+                     fullatt_block_indexes=list(range(v["depth"])), arch="qwen2_vl")
         return VLMConfig(
             vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
             num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
@@ -110,6 +116,7 @@ class VLMConfig:
             image_token_id=c.get("image_token_id", 151655), vision_start_token_id=c.get("vision_start_token_id", 151652),
             vision_end_token_id=c.get("vision_end_token_id", 151653), eos_token_id=eos[0] if isinstance(eos, (list, tuple)) else eos,
             pad_token_id=t.get("pad_token_id") or c.get("pad_token_id") or 151643, tie_word_embeddings=c.get("tie_word_embeddings", False),
+            v_arch=v.get("arch", "qwen2_5_vl"),
         )
 
     @staticmethod
@@ -121,6 +128,17 @@ class VLMConfig:
             v_inter=3420, v_heads=16, v_in_channels=3, v_patch=14, v_merge=2, v_temporal=2, v_window=112, v_fullatt=(7, 15, 23, 31),
             image_token_id=151655, vision_start_token_id=151652, vision_end_token_id=151653, eos_token_id=151645, pad_token_id=151643,
             tie_word_embeddings=True,
+        )
+
+    @staticmethod
+    def qwen2vl_2b() -> "VLMConfig":
+        """Qwen2-VL-2B-Instruct shapes (public config.json; BASELINE.json config 1)."""
+        return VLMConfig(
+            vocab_size=151936, hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12,
+            num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=1e6, mrope_section=(16, 24, 24), v_depth=32, v_hidden=1280,
+            v_inter=5120, v_heads=16, v_in_channels=3, v_patch=14, v_merge=2, v_temporal=2, v_window=0, v_fullatt=tuple(range(32)),
+            image_token_id=151655, vision_start_token_id=151652, vision_end_token_id=151653, eos_token_id=151645, pad_token_id=151643,
+            tie_word_embeddings=True, v_arch="qwen2_vl",
         )
 
     @staticmethod
@@ -156,6 +174,8 @@ class ParamStore:
         def add(name, shape, decay, gemm):
             specs.append((name, tuple(shape), decay, gemm))
 
+        q2 = c.v_arch == "qwen2_vl"
+        assert c.v_arch in ("qwen2_5_vl", "qwen2_vl"), c.v_arch
         add("visual.patch_embed", (vh, c.patch_dim), True, True)
         for i in range(c.v_depth):
             b = f"visual.blocks.{i}."
@@ -165,12 +185,22 @@ class ParamStore:
             add(b + "proj.w", (vh, vh), True, True)
             add(b + "proj.b", (vh,), False, False)
             add(b + "norm2", (vh,), False, False)
+            if q2:
+                add(b + "norm1.b", (vh,), False, False)
+                add(b + "norm2.b", (vh,), False, False)
+                add(b + "fc1.w", (c.v_inter, vh), True, True)
+                add(b + "fc1.b", (c.v_inter,), False, False)
+                add(b + "fc2.w", (vh, c.v_inter), True, True)
+                add(b + "fc2.b", (vh,), False, False)
+                continue
             add(b + "gu.w", (2 * vip, vh), True, True)
             add(b + "gu.b", (2 * vip,), False, False)
             add(b + "down.w", (vh, vip), True, True)
             add(b + "down.b", (vh,), False, False)
         mu = c.v_merge**2
         add("visual.merger.ln_q", (vh,), False, False)
+        if q2:
+            add("visual.merger.ln_q.b", (vh,), False, False)
         add("visual.merger.fc1.w", (vh * mu, vh * mu), True, True)
         add("visual.merger.fc1.b", (vh * mu,), False, False)
         add("visual.merger.fc2.w", (H, vh * mu), True, True)
@@ -297,6 +327,14 @@ class ParamStore:
             self._assign(b + "qkv.b", t(s + "attn.qkv.bias"))
             self._assign(b + "proj.w", t(s + "attn.proj.weight"))
             self._assign(b + "proj.b", t(s + "attn.proj.bias"))
+            if c.v_arch == "qwen2_vl":
+                self._assign(b + "norm1.b", t(s + "norm1.bias"))
+                self._assign(b + "norm2.b", t(s + "norm2.bias"))
+                self._assign(b + "fc1.w", t(s + "mlp.fc1.weight"))
+                self._assign(b + "fc1.b", t(s + "mlp.fc1.bias"))
+                self._assign(b + "fc2.w", t(s + "mlp.fc2.weight"))
+                self._assign(b + "fc2.b", t(s + "mlp.fc2.bias"))
+                continue
             gu = torch.zeros(2 * vip, c.v_hidden)
             gu[:vi] = t(s + "mlp.gate_proj.weight")
             gu[vip: vip + vi] = t(s + "mlp.up_proj.weight")
@@ -310,6 +348,8 @@ class ParamStore:
             self._assign(b + "down.w", dn)
             self._assign(b + "down.b", t(s + "mlp.down_proj.bias"))
         self._assign("visual.merger.ln_q", t("visual.merger.ln_q.weight"))
+        if c.v_arch == "qwen2_vl":
+            self._assign("visual.merger.ln_q.b", t("visual.merger.ln_q.bias"))
         self._assign("visual.merger.fc1.w", t("visual.merger.mlp.0.weight"))
         self._assign("visual.merger.fc1.b", t("visual.merger.mlp.0.bias"))
         self._assign("visual.merger.fc2.w", t("visual.merger.mlp.2.weight"))
@@ -351,11 +391,18 @@ class ParamStore:
             out[s + "norm1.weight"], out[s + "norm2.weight"] = get(b + "norm1"), get(b + "norm2")
             out[s + "attn.qkv.weight"], out[s + "attn.qkv.bias"] = get(b + "qkv.w"), get(b + "qkv.b")
             out[s + "attn.proj.weight"], out[s + "attn.proj.bias"] = get(b + "proj.w"), get(b + "proj.b")
+            if c.v_arch == "qwen2_vl":
+                out[s + "norm1.bias"], out[s + "norm2.bias"] = get(b + "norm1.b"), get(b + "norm2.b")
+                out[s + "mlp.fc1.weight"], out[s + "mlp.fc1.bias"] = get(b + "fc1.w"), get(b + "fc1.b")
+                out[s + "mlp.fc2.weight"], out[s + "mlp.fc2.bias"] = get(b + "fc2.w"), get(b + "fc2.b")
+                continue
             gu, gb, dn = get(b + "gu.w"), get(b + "gu.b"), get(b + "down.w")
             out[s + "mlp.gate_proj.weight"], out[s + "mlp.up_proj.weight"] = gu[:vi].clone(), gu[vip: vip + vi].clone()
             out[s + "mlp.gate_proj.bias"], out[s + "mlp.up_proj.bias"] = gb[:vi].clone(), gb[vip: vip + vi].clone()
             out[s + "mlp.down_proj.weight"], out[s + "mlp.down_proj.bias"] = dn[:, :vi].clone(), get(b + "down.b")
         out["visual.merger.ln_q.weight"] = get("visual.merger.ln_q")
+        if c.v_arch == "qwen2_vl":
+            out["visual.merger.ln_q.bias"] = get("visual.merger.ln_q.b")
         out["visual.merger.mlp.0.weight"], out["visual.merger.mlp.0.bias"] = get("visual.merger.fc1.w"), get("visual.merger.fc1.b")
         out["visual.merger.mlp.2.weight"], out["visual.merger.mlp.2.bias"] = get("visual.merger.fc2.w"), get("visual.merger.fc2.b")
         out["model.embed_tokens.weight"] = get("embed")
@@ -389,7 +436,7 @@ class ParamStore:
             else:
                 v.copy_((torch.randn(v.shape, generator=g, device=self.device, dtype=F32) * std).to(BF16))
         vi, vip = c.v_inter, c.v_inter_pad
-        if vip != vi:
+        if vip != vi and c.v_arch == "qwen2_5_vl":
             for i in range(c.v_depth):
                 b = f"visual.blocks.{i}."
                 self.w(b + "gu.w")[vi:vip].zero_()

@@ -77,6 +77,12 @@ class Engine:
         c = self.cfg
         grids = [tuple(int(z) for z in g) for g in grids]
         m2 = c.v_merge**2
+        if c.v_arch == "qwen2_vl":   # no window reorder, every block attends over the whole image (TF:qwen2_vl ::690-720)
+            cu_full = indexing.vision_cu_seqlens(grids)
+            pos = indexing.vision_position_ids(grids, c.v_merge).astype(np.float32)
+            rot_t = torch.from_numpy((pos[:, :, None] * self.v_inv_freq[None, None, :]).reshape(pos.shape[0], -1)).to(self.dev)
+            seg = ops.Segments.from_cu(cu_full, self.dev)
+            return VisionPlan(pos.shape[0], None, None, seg, seg, rot_t.cos().contiguous(), rot_t.sin().contiguous())
         win, cu_win = indexing.vision_window_index(grids, c.v_merge, c.v_window, c.v_patch)
         cu_full = indexing.vision_cu_seqlens(grids)
         pos = indexing.vision_position_ids(grids, c.v_merge).astype(np.float32)  # [N,2]
@@ -133,6 +139,8 @@ class Engine:
         vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
         N = plan.n_patches
         px = pixel_values if pixel_values.dtype == BF16 else ops.cast_f32_to_bf16(pixel_values)
+        if c.v_arch == "qwen2_vl":
+            return self._vision_forward_q2(px, plan, save)
         x = ops.gemm_nt(px, P.w("visual.patch_embed"))                                   # K1: conv3d(stride==kernel) == GEMM
         x = ops.embed_fwd(plan.win_index, None, x.view(N // m2, m2 * vh), None).view(N, vh)  # K2: window-order gather
         ctx = {"px": px, "layers": []} if save else None
@@ -168,6 +176,79 @@ class Engine:
             ctx.update(x_last=x_last, rstdq=rstdq, hq4=hq4, z=z, ga=ga, plan=plan)
         return out, ctx
 
+    def _vision_forward_q2(self, px, plan: VisionPlan, save: bool):
+        """Qwen2-VL tower (TF:models/qwen2_vl/modeling_qwen2_vl.py:418-447 block, ::293-301 MLP, ::270-290 merger)."""
+        c, P = self.cfg, self.p
+        vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
+        N, seg = plan.n_patches, plan.seg_full
+        res = ops.gemm_nt(px, P.w("visual.patch_embed"))
+        ctx = {"px": px, "layers": []} if save else None
+        branch = None
+        for i in range(c.v_depth):
+            b = f"visual.blocks.{i}."
+            x_in = torch.empty_like(res) if (save and branch is not None) else res
+            h1, mu1, rs1 = ops.layernorm_fwd(res if branch is None else branch, P.w(b + "norm1"), P.w(b + "norm1.b"), 1e-6,
+                                             res=None if branch is None else res, res_out=None if branch is None else x_in, want_stats=save)
+            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"))
+            ops.rope_(qkv, plan.cos, plan.sin, 2 * nh, d)
+            o, lse = ops.attn_fwd(qkv[:, :vh], qkv[:, vh: 2 * vh], qkv[:, 2 * vh:], seg, nh, nh, d, False, d**-0.5, want_lse=save)
+            ab = ops.gemm_nt(o, P.w(b + "proj.w"), bias=P.w(b + "proj.b"))
+            x_mid = torch.empty_like(x_in) if save else x_in
+            h2, mu2, rs2 = ops.layernorm_fwd(ab, P.w(b + "norm2"), P.w(b + "norm2.b"), 1e-6, res=x_in, res_out=x_mid, want_stats=save)
+            z = ops.gemm_nt(h2, P.w(b + "fc1.w"), bias=P.w(b + "fc1.b"))
+            a = ops.quick_gelu_fwd(z)
+            branch = ops.gemm_nt(a, P.w(b + "fc2.w"), bias=P.w(b + "fc2.b"))
+            res = x_mid
+            if save:
+                ctx["layers"].append((x_in, mu1, rs1, h1, qkv, o, lse, x_mid, mu2, rs2, h2, z, a))
+        x_last = torch.empty_like(res) if save else res
+        hq, muq, rsq = ops.layernorm_fwd(branch, P.w("visual.merger.ln_q"), P.w("visual.merger.ln_q.b"), 1e-6, res=res, res_out=x_last, want_stats=save)
+        hq4 = hq.view(N // m2, m2 * vh)
+        z = ops.gemm_nt(hq4, P.w("visual.merger.fc1.w"), bias=P.w("visual.merger.fc1.b"))
+        ga = ops.gelu_fwd(z)
+        out = ops.gemm_nt(ga, P.w("visual.merger.fc2.w"), bias=P.w("visual.merger.fc2.b"))
+        if save:
+            ctx.update(x_last=x_last, muq=muq, rstdq=rsq, hq4=hq4, z=z, ga=ga, plan=plan)
+        return out, ctx
+
+    def _vision_backward_q2(self, d_out, ctx):
+        c, P = self.cfg, self.p
+        vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
+        plan: VisionPlan = ctx["plan"]
+        N, seg = plan.n_patches, plan.seg_full
+        ops.colsum_acc(d_out, P.g("visual.merger.fc2.b"))
+        dga = ops.gemm_nt(d_out, P.wT("visual.merger.fc2.w"))
+        self._wgrad("visual.merger.fc2.w", d_out, ctx["ga"])
+        dz = ops.gelu_bwd(dga, ctx["z"])
+        ops.colsum_acc(dz, P.g("visual.merger.fc1.b"))
+        dhq4 = ops.gemm_nt(dz, P.wT("visual.merger.fc1.w"))
+        self._wgrad("visual.merger.fc1.w", dz, ctx["hq4"])
+        dres = ops.layernorm_bwd(dhq4.view(N, vh), ctx["x_last"], P.w("visual.merger.ln_q"), ctx["muq"], ctx["rstdq"],
+                                 dw=P.g("visual.merger.ln_q"), db=P.g("visual.merger.ln_q.b"))
+        for i in reversed(range(c.v_depth)):
+            b = f"visual.blocks.{i}."
+            x_in, mu1, rs1, h1, qkv, o, lse, x_mid, mu2, rs2, h2, z, a = ctx["layers"][i]
+            ops.colsum_acc(dres, P.g(b + "fc2.b"))
+            da = ops.gemm_nt(dres, P.wT(b + "fc2.w"))
+            self._wgrad(b + "fc2.w", dres, a)
+            dz = ops.quick_gelu_bwd(da, z)
+            ops.colsum_acc(dz, P.g(b + "fc1.b"))
+            dh2 = ops.gemm_nt(dz, P.wT(b + "fc1.w"))
+            self._wgrad(b + "fc1.w", dz, h2)
+            dx_mid = ops.layernorm_bwd(dh2, x_mid, P.w(b + "norm2"), mu2, rs2, dres=dres, dw=P.g(b + "norm2"), db=P.g(b + "norm2.b"))
+            ops.colsum_acc(dx_mid, P.g(b + "proj.b"))
+            do = ops.gemm_nt(dx_mid, P.wT(b + "proj.w"))
+            self._wgrad(b + "proj.w", dx_mid, o)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :vh], qkv[:, vh: 2 * vh], qkv[:, 2 * vh:], o, do, lse, seg, nh, nh, d, False, d**-0.5,
+                         dqkv[:, :vh], dqkv[:, vh: 2 * vh], dqkv[:, 2 * vh:])
+            ops.rope_(dqkv, plan.cos, plan.sin, 2 * nh, d, backward=True)
+            ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
+            dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"))
+            self._wgrad(b + "qkv.w", dqkv, h1)
+            dres = ops.layernorm_bwd(dh1, x_in, P.w(b + "norm1"), mu1, rs1, dres=dx_mid, dw=P.g(b + "norm1"), db=P.g(b + "norm1.b"))
+        self._wgrad("visual.patch_embed", dres, ctx["px"])
+
     def _wgrad(self, name, dy, x):
         """grad[name] ([N,K] fp32) += dy[T,N]^T . x[T,K]   (NT kernel on transposed copies)"""
         ops.gemm_nt(ops.transpose(dy, pad_rows_to=8), ops.transpose(x, pad_rows_to=8), out=self.p.g(name), accumulate=True)
@@ -178,6 +259,8 @@ class Engine:
         vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
         plan: VisionPlan = ctx["plan"]
         N = plan.n_patches
+        if c.v_arch == "qwen2_vl":
+            return self._vision_backward_q2(d_out, ctx)
         dmo = ops.embed_fwd(plan.win_index, None, d_out, None)                          # inverse of the reverse gather
         ops.colsum_acc(dmo, P.g("visual.merger.fc2.b"))
         dga = ops.gemm_nt(dmo, P.wT("visual.merger.fc2.w"))

@@ -61,6 +61,13 @@ int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, const void* x
 int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                       float* dw, int T, int H, long long ld, iadr1_stream_t stream);
 
+/* ---- LayerNorm with bias (Qwen2-VL vision tower: nn.LayerNorm(eps=1e-6), TF:models/qwen2_vl/modeling_qwen2_vl.py:281,428-429)
+ * y = ((x [+ res]) - mean) * rstd * w + b; backward returns dx (+ dres) and accumulates dw, db (fp32). */
+int iadr1_layernorm_fwd(const void* x, const void* res, void* res_out, const void* w, const void* b, void* y, float* mean,
+                        float* rstd, int T, int H, long long ldx, long long ldr, long long ldy, float eps, iadr1_stream_t stream);
+int iadr1_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres,
+                        void* dx, float* dw, float* db, int T, int H, long long ld, iadr1_stream_t stream);
+
 /* ---- rotary embeddings: vision 2-D rotary TF:153-171 and decoder M-RoPE TF:557-599 -----------------------
  * In place on `nheads` consecutive heads of width D per token row; cos/sin fp32 [T, D/2] (the M-RoPE
  * t/h/w section select is folded into the table by the host).  backward != 0 applies the transpose. */
@@ -74,6 +81,9 @@ int iadr1_swiglu_bwd(const void* da, long long lda, const void* gu, long long ld
                      iadr1_stream_t stream);
 int iadr1_gelu_fwd(const void* z, void* a, long long n, iadr1_stream_t stream);
 int iadr1_gelu_bwd(const void* da, const void* z, void* dz, long long n, iadr1_stream_t stream);
+/* QuickGELU x*sigmoid(1.702x): Qwen2-VL vision MLP (TF:models/qwen2_vl/modeling_qwen2_vl.py:293-301) */
+int iadr1_quick_gelu_fwd(const void* z, void* a, long long n, iadr1_stream_t stream);
+int iadr1_quick_gelu_bwd(const void* da, const void* z, void* dz, long long n, iadr1_stream_t stream);
 /* out[n] (fp32) += sum_t dy[t][n]   (bias gradients) */
 int iadr1_colsum_acc(const void* dy, long long ld, float* out, int T, int N, iadr1_stream_t stream);
 

@@ -156,9 +156,44 @@ class Qwen25VLOracle:
                 continue
             yield k, t
 
+    # -- Qwen2-VL vision tower: TF:models/qwen2_vl/modeling_qwen2_vl.py:650-720 (blocks ::418-447, MLP ::293-301,
+    #    merger ::270-290): LayerNorm blocks, fc1 -> QuickGELU -> fc2, full attention per image, LayerNorm merger --------
+    def _visual_qwen2vl(self, pixel_values, grid_thw, return_last_hidden=False):
+        v = self.cfg["vision"]
+        w = self.w
+        vh, nh = v["hidden_size"], v["num_heads"]
+        d = vh // nh
+        m2 = v["spatial_merge_size"] ** 2
+        x = pixel_values.to(w["visual.patch_embed.proj.weight"].dtype) @ w["visual.patch_embed.proj.weight"].reshape(vh, -1).t()
+        n = x.shape[0]
+        cu = vision_cu_seqlens(grid_thw)
+        pos = vision_position_ids(grid_thw, v["spatial_merge_size"])
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, d // 2, 2, dtype=torch.float32) / (d // 2)))
+        rot = (pos.unsqueeze(-1).float() * inv_freq).flatten(1)
+        emb = torch.cat([rot, rot], -1)
+        cos, sin = emb.cos().unsqueeze(1), emb.sin().unsqueeze(1)
+        ln = lambda z, name: F.layer_norm(z, (vh,), w[name + ".weight"], w[name + ".bias"], 1e-6)
+        for i in range(v["depth"]):
+            b = f"visual.blocks.{i}."
+            h = ln(x, b + "norm1")
+            qkv = (h @ w[b + "attn.qkv.weight"].t() + w[b + "attn.qkv.bias"]).view(n, 3, nh, d)
+            q, k, val = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+            q = (q.float() * cos + rotate_half(q.float()) * sin).to(x.dtype)
+            k = (k.float() * cos + rotate_half(k.float()) * sin).to(x.dtype)
+            a = _segment_attention(q, k, val, cu, d**-0.5).reshape(n, vh)
+            x = x + (a @ w[b + "attn.proj.weight"].t() + w[b + "attn.proj.bias"])
+            z = ln(x, b + "norm2") @ w[b + "mlp.fc1.weight"].t() + w[b + "mlp.fc1.bias"]
+            x = x + ((z * torch.sigmoid(1.702 * z)) @ w[b + "mlp.fc2.weight"].t() + w[b + "mlp.fc2.bias"])
+        h = ln(x, "visual.merger.ln_q").view(-1, vh * m2)
+        h = F.gelu(h @ w["visual.merger.mlp.0.weight"].t() + w["visual.merger.mlp.0.bias"])
+        merged = h @ w["visual.merger.mlp.2.weight"].t() + w["visual.merger.mlp.2.bias"]
+        return (merged, x) if return_last_hidden else merged
+
     # -- vision tower: TF::408-471 ---------------------------------------------------------------
     def visual(self, pixel_values, grid_thw, return_last_hidden=False):
         v = self.cfg["vision"]
+        if v.get("arch") == "qwen2_vl":
+            return self._visual_qwen2vl(pixel_values, grid_thw, return_last_hidden)
         w = self.w
         vh, nh = v["hidden_size"], v["num_heads"]
         d = vh // nh

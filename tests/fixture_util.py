@@ -63,6 +63,22 @@ TINY7 = {
 }
 
 
+# Qwen2-VL structure (BASELINE.json config 1, Qwen2-VL-2B PA-SFT): the vision tower uses LayerNorm (with bias), a
+# fc1 -> QuickGELU -> fc2 MLP (mlp_ratio 4), no window attention, and a LayerNorm merger
+# (TF:models/qwen2_vl/modeling_qwen2_vl.py:270-300, 418-447); the decoder is the same as Qwen2.5-VL's.
+# "hidden_size" is the ViT width (HF `embed_dim`), "out_hidden_size" the merger output (HF vision `hidden_size`).
+TINY_Q2 = {
+    "text": dict(TINY["text"]),
+    "vision": {
+        "arch": "qwen2_vl", "depth": 3, "hidden_size": 160, "intermediate_size": 640, "num_heads": 2, "in_channels": 3,
+        "patch_size": 14, "spatial_merge_size": 2, "temporal_patch_size": 2, "window_size": 0, "out_hidden_size": 256,
+        "fullatt_block_indexes": [0, 1, 2],
+    },
+    "image_token_id": 630, "video_token_id": 631, "vision_start_token_id": 628, "vision_end_token_id": 629,
+    "eos_token_id": 1, "pad_token_id": 2, "tie_word_embeddings": True,
+}
+
+
 def param_shapes(cfg: dict) -> dict[str, tuple[int, ...]]:
     """Checkpoint-name -> shape for a Qwen2.5-VL config dict like ``TINY``."""
     t, v = cfg["text"], cfg["vision"]
@@ -82,6 +98,14 @@ def param_shapes(cfg: dict) -> dict[str, tuple[int, ...]]:
         s[b + "attn.qkv.bias"] = (3 * vh,)
         s[b + "attn.proj.weight"] = (vh, vh)
         s[b + "attn.proj.bias"] = (vh,)
+        if v.get("arch") == "qwen2_vl":
+            s[b + "norm1.bias"] = (vh,)
+            s[b + "norm2.bias"] = (vh,)
+            s[b + "mlp.fc1.weight"] = (vi, vh)
+            s[b + "mlp.fc1.bias"] = (vi,)
+            s[b + "mlp.fc2.weight"] = (vh, vi)
+            s[b + "mlp.fc2.bias"] = (vh,)
+            continue
         s[b + "mlp.gate_proj.weight"] = (vi, vh)
         s[b + "mlp.gate_proj.bias"] = (vi,)
         s[b + "mlp.up_proj.weight"] = (vi, vh)
@@ -89,6 +113,8 @@ def param_shapes(cfg: dict) -> dict[str, tuple[int, ...]]:
         s[b + "mlp.down_proj.weight"] = (vh, vi)
         s[b + "mlp.down_proj.bias"] = (vh,)
     s["visual.merger.ln_q.weight"] = (vh,)
+    if v.get("arch") == "qwen2_vl":
+        s["visual.merger.ln_q.bias"] = (vh,)
     s["visual.merger.mlp.0.weight"] = (vh * mu, vh * mu)
     s["visual.merger.mlp.0.bias"] = (vh * mu,)
     s["visual.merger.mlp.2.weight"] = (v["out_hidden_size"], vh * mu)

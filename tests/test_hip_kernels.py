@@ -131,6 +131,42 @@ def test_rmsnorm_fwd_bwd(T, H):
     close(dw, wr.grad, 1e-2, 1e-2 * math.sqrt(T), "rmsnorm dw")
 
 
+@pytest.mark.parametrize("T,H", [(5, 160), (300, 1280), (131, 256)])
+def test_layernorm_fwd_bwd(T, H):
+    """nn.LayerNorm(eps=1e-6) with bias (Qwen2-VL vision tower) vs torch fp32."""
+    x, res = rnd(T, H, seed=1), rnd(T, H, seed=3)
+    w, b = (1 + 0.1 * rnd(H, seed=2).float()).to(BF), (0.1 * rnd(H, seed=6).float()).to(BF)
+    ro = torch.empty_like(x)
+    y, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-6, res=res, res_out=ro, want_stats=True)
+    s = (x.float() + res.float()).to(BF)
+    assert torch.equal(ro, s)
+    sr = s.float().requires_grad_(True)
+    wr, br = w.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(sr, (H,), wr, br, 1e-6)
+    close(y, ref, 2e-2, 1e-2, "layernorm fwd")
+    close(mean, s.float().mean(-1), 1e-5, 1e-5, "mean")
+    close(rstd, torch.rsqrt(s.float().var(-1, unbiased=False) + 1e-6), 1e-4, 1e-5, "rstd")
+    y0, _, _ = ops.layernorm_fwd(s, w, b, 1e-6)
+    assert torch.equal(y0, y)
+    dy, dres = rnd(T, H, seed=4), rnd(T, H, seed=5)
+    ref.backward(dy.float())
+    dw, db = torch.zeros(H, dtype=F32, device=DEV), torch.zeros(H, dtype=F32, device=DEV)
+    dx = ops.layernorm_bwd(dy, s, w, mean, rstd, dres=dres, dw=dw, db=db)
+    close(dx, sr.grad + dres.float(), 2e-2, 2e-2, "layernorm dx")
+    close(dw, wr.grad, 1e-2, 1e-2 * math.sqrt(T), "layernorm dw")
+    close(db, br.grad, 1e-2, 1e-2 * math.sqrt(T), "layernorm db")
+
+
+def test_quick_gelu_fwd_bwd():
+    z = (rnd(50, 640, seed=1).float() * 3).to(BF)
+    zr = z.float().requires_grad_(True)
+    ref = zr * torch.sigmoid(1.702 * zr)
+    close(ops.quick_gelu_fwd(z), ref, 1e-2, 1e-2, "quick_gelu")
+    da = rnd(50, 640, seed=2)
+    ref.backward(da.float())
+    close(ops.quick_gelu_bwd(da, z), zr.grad, 1e-2, 1e-2, "quick_gelu bwd")
+
+
 # ------------------------------------------------------------------------------------------------ rope / act
 @pytest.mark.parametrize("D,nh", [(128, 3), (80, 4)])
 def test_rope(D, nh):

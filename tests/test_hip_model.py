@@ -320,3 +320,39 @@ def test_7b_like_config_forward_and_rollout(golden_dir):
     top2 = np.sort(lg, -1)[..., -2:]
     agree = (lg.argmax(-1) == toks) | ((top2[..., 1] - top2[..., 0]) < 0.05)   # decode and prefill kernels may split a near-tie
     assert agree.all()
+
+
+def test_qwen2vl_variant_matches_reference_golden(golden_dir):
+    """Qwen2-VL structure (BASELINE config 1: PA-SFT on 4 samples): LayerNorm / QuickGELU ViT, no windows.  Image embeds,
+    logps and the 3-step AdamW loss curve vs a tiny HF Qwen2VLForConditionalGeneration (tests/golden/qwen2vl_sft.npz)."""
+    g = load(golden_dir, "qwen2vl_sft.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = VLMConfig.from_dict(fx.TINY_Q2)
+    w = fx.make_weights(fx.TINY_Q2, 0)
+    p = ParamStore(cfg, DEV, trainable=True)
+    p.load_named(w)
+    back = p.export_named()
+    for k, v in w.items():
+        assert np.array_equal(back[k].numpy(), v.reshape(back[k].shape)), k
+    e = Engine(p)
+    grids = [tuple(int(z) for z in r) for r in g["image_grid_thw"]]
+    img, _ = e.vision_forward(torch.from_numpy(g["pixel_values"]).to(DEV), e.vision_plan(grids), save=False)
+    assert relerr(img.float().cpu().numpy(), g["image_embeds"]) < 3e-2          # bf16 ViT vs fp32 reference
+    ids, mask = g["input_ids"], g["attention_mask"]
+    rows = np.cumsum([0] + [t * h * w_ // 4 for t, h, w_ in grids])
+    plan = e.text_plan(ids, mask, [[gr] for gr in grids], [[int(r)] for r in rows[:-1]])
+    hf, _ = e.text_forward(plan, img, save=False)
+    B, S = ids.shape
+    valid = (mask[:, 1:] * mask[:, :-1]).astype(bool)
+    rr = (np.arange(B)[:, None] * S + np.arange(S - 1)[None, :])[valid]
+    lp, _ = e.logprobs(hf, torch.from_numpy(rr).to(DEV), torch.from_numpy(ids[:, 1:][valid].astype(np.int64)).to(DEV), save=False)
+    err = np.abs(lp.cpu().numpy() - g["per_token_logps"][valid]).max()
+    assert err < 0.08, err                                                         # bf16 logits, |logp| ~ 6.5
+    eng = SFTEngine(cfg, p, SFTArgs(learning_rate=meta["lr"], weight_decay=meta["wd"], max_grad_norm=0.0))
+    batch = {k: g[k] for k in ("input_ids", "attention_mask", "labels", "pixel_values")}
+    batch["image_grid_thw"] = grids
+    losses = []
+    for _ in range(3):
+        losses.append(eng.loss_and_grads(batch))
+        eng.optimizer_step()
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-2, atol=2e-2)

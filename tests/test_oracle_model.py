@@ -146,3 +146,31 @@ def test_forward_7b_like_config(golden_dir):
         lp = m.per_token_logps(ids, mask, pv, grids)
     valid = (mask[:, 1:] * mask[:, :-1]).bool().numpy()
     np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=3e-4)
+
+
+def test_qwen2vl_variant(golden_dir):
+    """Qwen2-VL structure (BASELINE config 1: Qwen2-VL-2B PA-SFT on 4 samples): LayerNorm / QuickGELU vision tower without
+    window attention.  Golden from a tiny HF Qwen2VLForConditionalGeneration: image embeds, logps, 3-step loss curve."""
+    g = _load(golden_dir, "qwen2vl_sft.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = fx.TINY_Q2
+    m = oq.Qwen25VLOracle(cfg, fx.make_weights(cfg, 0), requires_grad=True)
+    grids = [tuple(int(z) for z in r) for r in g["image_grid_thw"]]
+    ids, mask, labels = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels"))
+    pv = torch.from_numpy(g["pixel_values"])
+    with torch.no_grad():
+        np.testing.assert_allclose(m.visual(pv, grids).numpy(), g["image_embeds"], rtol=1e-4, atol=2e-4)
+        lp = m.per_token_logps(ids, mask, pv, grids)
+    valid = (mask[:, 1:] * mask[:, :-1]).bool().numpy()
+    np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=3e-4)
+    params = dict(m.parameters())
+    opt = torch.optim.AdamW([{"params": [p for p in params.values() if p.ndim >= 2], "weight_decay": meta["wd"]},
+                             {"params": [p for p in params.values() if p.ndim < 2], "weight_decay": 0.0}], lr=meta["lr"])
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = m.sft_loss(ids, mask, labels, pv, grids)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)

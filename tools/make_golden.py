@@ -216,9 +216,45 @@ def hf_name(name: str) -> str:
     return name
 
 
+def build_hf_model_qwen2vl(cfg: dict, weights: dict[str, np.ndarray]):
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+
+    t, v = cfg["text"], cfg["vision"]
+    hf_cfg = Qwen2VLConfig(
+        text_config=dict(
+            vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
+            num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
+            num_key_value_heads=t["num_key_value_heads"], rms_norm_eps=t["rms_norm_eps"],
+            rope_parameters={"rope_type": "default", "rope_theta": t["rope_theta"], "mrope_section": t["mrope_section"]},
+            pad_token_id=cfg["pad_token_id"], eos_token_id=cfg["eos_token_id"], bos_token_id=None,
+        ),
+        vision_config=dict(
+            depth=v["depth"], embed_dim=v["hidden_size"], hidden_size=v["out_hidden_size"], mlp_ratio=v["intermediate_size"] // v["hidden_size"],
+            num_heads=v["num_heads"], in_channels=v["in_channels"], patch_size=v["patch_size"], spatial_merge_size=v["spatial_merge_size"],
+            temporal_patch_size=v["temporal_patch_size"],
+        ),
+        image_token_id=cfg["image_token_id"], video_token_id=cfg["video_token_id"],
+        vision_start_token_id=cfg["vision_start_token_id"], vision_end_token_id=cfg["vision_end_token_id"],
+        tie_word_embeddings=cfg["tie_word_embeddings"],
+    )
+    hf_cfg._attn_implementation = "eager"
+    model = Qwen2VLForConditionalGeneration(hf_cfg)
+    sd = {hf_name(k): torch.from_numpy(a.copy()) for k, a in weights.items()}
+    if cfg["tie_word_embeddings"]:
+        sd["lm_head.weight"] = sd["model.language_model.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("inv_freq" in m for m in missing), missing
+    model.config._attn_implementation = "eager"
+    model.float()
+    return model
+
+
 def build_hf_model(cfg: dict, weights: dict[str, np.ndarray]):
     from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
 
+    if cfg["vision"].get("arch") == "qwen2_vl":
+        return build_hf_model_qwen2vl(cfg, weights)
     t, v = cfg["text"], cfg["vision"]
     hf_cfg = Qwen2_5_VLConfig(
         text_config=dict(
@@ -540,6 +576,47 @@ def gen_sft():
     print("sft.npz: losses", losses)
 
 
+def gen_qwen2vl(SCGRPOTrainer):
+    """BASELINE.json config 1 (Qwen2-VL PA-SFT, 4 samples): tiny Qwen2VLForConditionalGeneration -- image embeds,
+    per-token logps through the reference's `_get_per_token_logps`, and a 3-step AdamW loss curve on 4 samples."""
+    cfg = fx.TINY_Q2
+    model = build_hf_model(cfg, fx.make_weights(cfg, seed=0)).eval()
+    grids = [(1, 16, 12), (1, 8, 8), (1, 4, 6), (1, 10, 10)]
+    b = tiny_batch(cfg, grids, [5, 17, 9, 2], seed=13)
+    resp = np.array(fx.synth_completions(4, 8, cfg, 10)).astype(np.int64)
+    ids = torch.cat([b["input_ids"], torch.from_numpy(resp)], 1)
+    mask = torch.cat([b["attention_mask"], torch.ones(4, 8, dtype=torch.long)], 1)
+    mm = (ids == cfg["image_token_id"]).int()
+    holder = types.SimpleNamespace(model_id="tiny-qwen2-vl")
+    with torch.no_grad():
+        logps = SCGRPOTrainer._get_per_token_logps(holder, model, input_ids=ids, attention_mask=mask, pixel_values=b["pixel_values"],
+                                                   image_grid_thw=b["image_grid_thw"], mm_token_type_ids=mm)
+        vis = model.model.visual(b["pixel_values"], grid_thw=b["image_grid_thw"])
+        embeds = vis.pooler_output if hasattr(vis, "pooler_output") else vis
+    labels = ids.clone()
+    labels[:, : b["input_ids"].shape[1]] = -100
+    inputs = dict(input_ids=ids, attention_mask=mask, pixel_values=b["pixel_values"], image_grid_thw=b["image_grid_thw"], mm_token_type_ids=mm, labels=labels)
+    model.train()
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        (no_decay if (p.ndim < 2 or "norm" in n or "ln_q" in n or n.endswith(".bias")) else decay).append(p)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = model(**inputs).loss
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    np.savez_compressed(
+        os.path.join(OUT, "qwen2vl_sft.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17, 9, 2], "seed": 13, "lr": 1e-3, "wd": 0.1, "config": "fixture_util.TINY_Q2"}),
+        input_ids=ids.numpy(), attention_mask=mask.numpy(), labels=labels.numpy(), pixel_values=b["pixel_values"].numpy(),
+        image_grid_thw=b["image_grid_thw"].numpy(), losses=np.array(losses, dtype=np.float64), per_token_logps=logps.numpy(),
+        image_embeds=torch.as_tensor(embeds).numpy(),
+    )
+    print("qwen2vl_sft.npz: losses", losses, "logps", tuple(logps.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -563,6 +640,8 @@ def main():
         gen_greedy()
     if not only or "sft" in only:
         gen_sft()
+    if not only or "qwen2vl" in only:
+        gen_qwen2vl(SCGRPOTrainer)
 
 
 if __name__ == "__main__":
