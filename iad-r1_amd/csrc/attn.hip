@@ -661,7 +661,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
             num += f * red_o[ww][d][j];
             den += f * red_l[ww][j];
         }
-        p.o[(long long)b * p.ldo + (kvh * group + j) * D + d] = f2bf(den > 0.f ? num / den : 0.f);
+        p.o[p.ldo ? (long long)b * p.ldo + (kvh * group + j) * D + d : xpk_off(b, (kvh * group + j) * D + d, p.Hq * D)] = f2bf(den > 0.f ? num / den : 0.f);
     }
 }
 

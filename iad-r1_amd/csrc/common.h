@@ -79,3 +79,10 @@ int iadr1_check_launch(const char* what);
             return IADR1_ERR_ARG;             \
         }                                     \
     } while (0)
+
+// Decode-packed activation layout ("leading dimension 0" in the C ABI): X[M,K] stored in MFMA B-fragment order so that the
+// (16 rows x 32 k) fragment a wave feeds to v_mfma_f32_16x16x32_bf16 is ONE contiguous 1 KiB load, like the packed weights:
+//   Xp[m/64][k/32][(m%64)/16][lane = m%16 + 16*((k%32)/8)][k%8];   rows are padded to a multiple of 64.
+__device__ __forceinline__ long long xpk_off(int m, int k, int K) {
+    return (long long)(m >> 6) * K * 64 + (long long)((k >> 5) * 4 + ((m & 63) >> 4)) * 512 + ((m & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
+}

@@ -511,9 +511,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     const bf16_t* wrow[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) wrow[j] = p.W + ((long long)min(blockIdx.x * NB + j, (p.N >> 4) - 1) * ksteps) * 512 + l * 8;
+    const bool xpk = p.ldx == 0;  // decode-packed X (see the wide kernel)
+    const long long xstep = xpk ? 2048 : 32;
     const bf16_t* xrow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xrow[i] = p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
+    for (int i = 0; i < 4; ++i)
+        xrow[i] = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + i * 512 + l * 8 : p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
 
     // unpredicated loads (see the wide kernel): full trips of U slabs, then single-slab tail trips
     auto trip = [&](int sb, auto u_tag) {
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
                 for (int j = 0; j < NB; ++j)
                     wf[u][kk][j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + (long long)(k >> 5) * 512)));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xf[u][kk][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + k));
+                for (int i = 0; i < 4; ++i) xf[u][kk][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + (long long)(k >> 5) * xstep));
             }
 #pragma unroll
         for (int u = 0; u < UU; ++u)
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) wt[j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + (long long)(k >> 5) * 512)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xt[i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + k));
+        for (int i = 0; i < 4; ++i) xt[i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + (long long)(k >> 5) * xstep));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -610,10 +613,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
     const int ksteps = p.K >> 5;
     const long long tile_stride = (long long)ksteps * 512;
     const bf16_t* wbase = p.W + (long long)blockIdx.x * NB * tile_stride + l * 8;
+    // X row-major: lane (lm, lq) reads 16 B of row m_base + 16 i + lm (16 cache lines per wave-load).  X decode-packed
+    // (ldx == 0, common.h xpk_off): fragment (k-step, row group) is 1 KiB contiguous in lane order, rows padded to 64.
+    const bool xpk = p.ldx == 0;
     const int xr0 = min(m_base + lm, p.M - 1);
-    const bf16_t* xbase = p.X + (long long)xr0 * p.ldx + lq * 8;
-    const long long xgroup = 16 * p.ldx;
-    const int xgroups_ok = (p.M - m_base - lm + 15) / 16;  // row groups i < xgroups_ok are real rows for this lane
+    const bf16_t* xbase = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + l * 8 : p.X + (long long)xr0 * p.ldx + lq * 8;
+    const long long xgroup = xpk ? 512 : 16 * p.ldx;
+    const long long xstep = xpk ? 2048 : 32;
+    const int xgroups_ok = xpk ? 4 : (p.M - m_base - lm + 15) / 16;  // row groups i < xgroups_ok are real rows for this lane
 
     // K is walked in 32-deep steps; wave w takes steps s_begin*2 + w, + WAVES, ... and keeps DEPTH steps in flight
     // (all their loads are issued before the first MFMA of the trip).  Measured against slab-wise software pipelining
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
                 wf[d][jj] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wbase + jj * tile_stride + st * 512)));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                xf[d][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + st * 32));
+                xf[d][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + st * xstep));
         }
 #pragma unroll
         for (int d = 0; d < DD; ++d)
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
                 g = bf2f(f2bf(g));
                 u = bf2f(f2bf(u));
                 const float sg = bf2f(f2bf(g / (1.f + __expf(-g))));
-                ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(sg * u);
+                ((bf16_t*)p.Y)[p.ldy ? (long long)gm * p.ldy + gn : xpk_off(gm, gn, p.N >> 1)] = f2bf(sg * u);
             }
             continue;
         }
@@ -724,6 +731,17 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* W, long 
         const long long n = tile * 16 + (lane & 15);
         const int k = ks * 32 + (lane >> 4) * 8;
         *(u32x4_t*)(Wp + i * 8) = *(const u32x4_t*)(W + n * ldw + k);
+    }
+}
+
+// X[M,K] row-major -> decode-packed (common.h xpk_off); pad rows (M..roundup64) are zero-filled
+__global__ __launch_bounds__(256) void pack_act_kernel(const bf16_t* X, long long ldx, bf16_t* Xp, int M, int K) {
+    const int Mp = (M + 63) & ~63;
+    const long long total = (long long)Mp * (K >> 3);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / (K >> 3)), c = (int)(i % (K >> 3));
+        const u32x4_t v = m < M ? *(const u32x4_t*)(X + (long long)m * ldx + c * 8) : (u32x4_t){0, 0, 0, 0};
+        *(u32x4_t*)(Xp + xpk_off(m, c * 8, K)) = v;
     }
 }
 
@@ -780,6 +798,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
                                       long long ldw, long long ldy, int out_mode, int ksplit, hipStream_t stream) {
     IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_skinny: empty problem");
     IADR1_REQUIRE((K % 32) == 0 && (N % 16) == 0 && (ldx % 8) == 0, "gemm_skinny: packed weights need K %% 32 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+    IADR1_REQUIRE(ldy != 0 || (out_mode == 3 && (N % 64) == 0), "gemm_skinny: a decode-packed output (ldy == 0) exists for the fused-SwiGLU mode only");
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_skinny: X/W must be 16-byte aligned");
     (void)ldw;
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 3 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny: ksplit > 1 needs out_mode 2 (partial slabs)");
@@ -797,14 +816,18 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     static int wide_nb = 0;
     if (!wide_nb) {
         const char* e = getenv("IADR1_SKINNY_WIDE_NB");
-        wide_nb = e ? atoi(e) : 8;
+        wide_nb = e ? atoi(e) : -1;  // -1: 4 with packed X, 8 with row-major X
         (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
     }
     // wide kernels: NB=8 (128 columns / block) for the big-N streams (gate|up, lm_head); NB=4 with K split over
     // grid.z for the long-K narrow-N down projection; the narrow kernel for the small projections (latency-bound)
-    (void)wide_nb;
-    if (((N >= 8192 && ksplit == 1) || out_mode == 3) && (N % 128) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
+    // with decode-packed X the X fragments are cheap coalesced L2 reads, and 64-column blocks (two co-resident per CU, 344
+    // blocks on the 3B gate|up) beat 128-column ones: 24.6 vs 33.7 us on the 90 MB gate|up stream (tools/decode_stream.py)
+    const bool big = (N >= 8192 && ksplit == 1) || out_mode == 3;
+    const int nb = (ldx == 0 && wide_nb != 8) || wide_nb == 4 ? 4 : 8;
+    if (big && nb == 4 && (N % 64) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3(N / 64, mz, 1), dim3(512), SMW, stream, p);
+    else if (big && (N % 128) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
     else if (ksplit > 1 && (N % 64) == 0 && (N / 64) * ksplit >= 192) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3((N + 63) / 64, mz, ksplit), dim3(512), SMW, stream, p);
     else if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
     else hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);
@@ -817,6 +840,14 @@ extern "C" int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, in
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, N, K);
     return iadr1_check_launch("pack_weight_bf16");
+}
+
+extern "C" int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, hipStream_t stream) {
+    IADR1_REQUIRE(M > 0 && K > 0 && (K % 32) == 0 && (ldx % 8) == 0, "pack_act: need K %% 32 == 0 (K=%d)", K);
+    long long blocks = ((long long)((M + 63) & ~63) * K / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_act_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)X, ldx, (bf16_t*)Xp, M, K);
+    return iadr1_check_launch("pack_act_bf16");
 }
 
 extern "C" int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, hipStream_t stream) {

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
                 const float n0 = bf2f(f2bf(v[c][2 * e] * rstd)), n1 = bf2f(f2bf(v[c][2 * e + 1] * rstd));
                 o[e] = pack2bf(lo_bf(g[e]) * n0, hi_bf(g[e]) * n1);
             }
-            *(u32x4_t*)(p.y + (long long)row * p.ldy + ch * 8) = o;
+            *(u32x4_t*)(p.y + (p.ldy ? (long long)row * p.ldy + ch * 8 : xpk_off(row, ch * 8, p.H))) = o;   // ldy == 0: decode-packed
         }
     }
 }
@@ -271,6 +271,7 @@ extern "C" int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, co
     IADR1_REQUIRE((ldx % 8) == 0 && (ldr % 8) == 0 && (ldy % 8) == 0, "rmsnorm_fwd: leading dims must be multiples of 8");
     IADR1_REQUIRE(x32 == nullptr || nsplit >= 1, "rmsnorm_fwd: nsplit >= 1 with x32");
     RmsFwdArgs p{(const bf16_t*)x, x32, nsplit, (const bf16_t*)xbias, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (bf16_t*)y, rstd, T, H, ldx, ldr, ldy, eps};
+    IADR1_REQUIRE(ldy != 0 || (T <= 256 && (H % 32) == 0), "rmsnorm_fwd: decode-packed output (ldy == 0) needs T <= 256 and H %% 32 == 0");
     if (T <= 256) {
         hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, stream, p);
         return iadr1_check_launch("rmsnorm_fwd");

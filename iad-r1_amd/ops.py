@@ -45,25 +45,57 @@ def pack_gateup(w, out=None):
     return o
 
 
+class PackedAct:
+    """bf16 activations [M, K] in the decode-packed layout (MFMA B-fragment order, rows padded to 64; C ABI: leading
+    dimension 0).  Producers: pack_act, rmsnorm_fwd(out=PackedAct), attn_decode(out=PackedAct), gemm_skinny(swiglu, out=PackedAct)."""
+
+    def __init__(self, M, K, device):
+        assert K % 32 == 0
+        self.M, self.K = M, K
+        self.buf = torch.zeros((M + 63) // 64 * 64 * K, dtype=BF16, device=device)
+
+    @property
+    def shape(self):
+        return (self.M, self.K)
+
+    def unpack(self):
+        Mp = self.buf.numel() // self.K
+        return self.buf.view(Mp // 64, self.K // 32, 4, 4, 16, 8).permute(0, 2, 4, 1, 3, 5).reshape(Mp, self.K)[: self.M]
+
+
+def pack_act(x, out=None):
+    M, K = x.shape
+    out = out if out is not None else PackedAct(M, K, x.device)
+    hip.call("pack_act_bf16", x, _ld(x), out.buf, M, K)
+    return out
+
+
+def _xarg(x):
+    return (x.buf, 0) if isinstance(x, PackedAct) else (x, _ld(x))
+
+
 def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=False):
     """out[M,N] = x[M,K] @ W[N,K]^T + bias with W given decode-packed (`pack_weight`); HBM-bound weight stream.
-    ksplit > 1: `out` is fp32 [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=..., nsplit=ksplit)."""
+    x may be a PackedAct.  ksplit > 1: `out` is fp32 [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=...)."""
     M, K = x.shape
     w = wp
     assert wp.numel() == N * K
+    xb, ldx = _xarg(x)
+    dev = xb.device
     if swiglu:
         if out is None:
-            out = torch.empty(M, N // 2, dtype=BF16, device=x.device)
-        hip.call("gemm_skinny_bf16", x, w, out, None, M, N, K, _ld(x), K, _ld(out), 3, 1)
+            out = torch.empty(M, N // 2, dtype=BF16, device=dev)
+        ob, ldo = _xarg(out)
+        hip.call("gemm_skinny_bf16", xb, w, ob, None, M, N, K, ldx, K, ldo, 3, 1)
         return out
     if out is None:
-        out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=x.device)
+        out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=dev)
     if out.dim() == 3:
         assert out.dtype == F32 and out.shape[0] == ksplit and out.is_contiguous() and bias is None
         mode, ldy = 2, N
     else:
         mode, ldy = (1 if out.dtype == F32 else 0), _ld(out)
-    hip.call("gemm_skinny_bf16", x, w, out, bias, M, N, K, _ld(x), K, ldy, mode, ksplit)
+    hip.call("gemm_skinny_bf16", xb, w, out, bias, M, N, K, ldx, K, ldy, mode, ksplit)
     return out
 
 
@@ -94,7 +126,8 @@ def rmsnorm_fwd(x, w, eps, res=None, res_out=None, x32=None, xbias=None, want_rs
     y = out if out is not None else torch.empty(T, H, dtype=BF16, device=dev)
     rstd = torch.empty(T, dtype=F32, device=dev) if want_rstd else None
     ldr = _ld(res) if res is not None else (_ld(res_out) if res_out is not None else H)
-    hip.call("rmsnorm_fwd", x, x32, nsplit, xbias, res, res_out, w, y, rstd, T, H, ldx, ldr, _ld(y), float(eps))
+    yb, ldy = _xarg(y)
+    hip.call("rmsnorm_fwd", x, x32, nsplit, xbias, res, res_out, w, yb, rstd, T, H, ldx, ldr, ldy, float(eps))
     return y, rstd
 
 
@@ -234,7 +267,8 @@ def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq
 def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=None):
     B = q.shape[0]
     o = out if out is not None else torch.empty(B, Hq * D, dtype=BF16, device=q.device)
-    hip.call("attn_decode", q, kcache, vcache, block_table, ctx_len, o, B, Hq, Hkv, D, block_table.shape[1], _ld(q), _ld(o), float(scale))
+    ob, ldo = _xarg(o)
+    hip.call("attn_decode", q, kcache, vcache, block_table, ctx_len, ob, B, Hq, Hkv, D, block_table.shape[1], _ld(q), ldo, float(scale))
     return o
 
 

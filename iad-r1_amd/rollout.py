@@ -13,6 +13,8 @@
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -49,19 +51,24 @@ class Rollout:
         self.out_tokens = torch.zeros(N, max_new, dtype=i64, device=dev)
         # activations of one decode step
         self.x = torch.empty(N, H, dtype=BF16, device=dev)
-        self.h = torch.empty(N, H, dtype=BF16, device=dev)
+        # GEMM inputs live in the decode-packed layout (ops.PackedAct: MFMA B-fragment order), written directly by their
+        # producers (RMSNorm, decode attention, the fused SwiGLU epilogue) so that every X fragment load of the skinny GEMMs
+        # is one contiguous 1 KiB read instead of 16 half cache lines.  IADR1_DECODE_PACKED=0 keeps row-major (A/B switch).
+        self.packed = os.environ.get("IADR1_DECODE_PACKED", "1") != "0" and H % 32 == 0 and (Hq * D) % 32 == 0
+        self.fuse_swiglu = I % 64 == 0
+        act = (lambda k: ops.PackedAct(N, k, dev)) if self.packed else (lambda k: torch.empty(N, k, dtype=BF16, device=dev))
+        self.h = act(H)
         self.qkv = torch.empty(N, c.qkv_width, dtype=BF16, device=dev)
-        self.o = torch.empty(N, Hq * D, dtype=BF16, device=dev)
+        self.o = act(Hq * D)
         self.br = torch.empty(N, H, dtype=BF16, device=dev)
         self.ks_o, self.ks_down = (2, 8) if H * Hq * D >= 1 << 20 else (1, 1)   # split-K of the two narrow-N projections
         self.part_o = torch.empty(self.ks_o, N, H, dtype=F32, device=dev)
         self.part_d = torch.empty(self.ks_down, N, H, dtype=F32, device=dev)
         self.gu = torch.empty(N, 2 * I, dtype=BF16, device=dev)
-        self.a = torch.empty(N, I, dtype=BF16, device=dev)
+        self.a = act(I) if self.fuse_swiglu else torch.empty(N, I, dtype=BF16, device=dev)
         self.logits = torch.empty(N, V, dtype=F32, device=dev)
         self.cos = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
-        self.fuse_swiglu = I % 64 == 0
         self.graph = None
         self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
 

@@ -38,6 +38,9 @@ int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, 
  * K spread over 8-16 waves per block (+ optional grid split `ksplit`), no atomics.  out_mode 0: bf16 + bias;
  * 1: fp32 (logits); 2: fp32 partial slabs Y[ksplit][M][ldy] summed by iadr1_rmsnorm_fwd (x32 path); 3: fused
  * SwiGLU over a gate|up matrix packed with iadr1_pack_gateup_bf16 (N = 2*I rows in, Y is [M, I]).
+ * ldx == 0: X is DECODE-PACKED (MFMA B-fragment order, rows padded to 64: Xp[m/64][k/32][(m%64)/16][m%16 + 16*((k%32)/8)][k%8],
+ * see iadr1_pack_act_bf16) -- every X fragment load is then 1 KiB contiguous like the weights; iadr1_rmsnorm_fwd (ldy == 0),
+ * iadr1_attn_decode (ldo == 0) and out_mode 3 here (ldy == 0) emit that layout directly, so the decode step never repacks.
  * Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667). */
 int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
                            long long ldw, long long ldy, int out_mode, int ksplit, iadr1_stream_t stream);
@@ -47,6 +50,8 @@ int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K,
 /* gate|up matrix W[2I,K] -> decode-packed with gate/up 16-row tiles interleaved, for out_mode 3 (fused SwiGLU) of
  * iadr1_gemm_skinny_bf16: Y[M, I] = silu(X.Wgate^T) * (X.Wup^T).  I % 64 == 0. */
 int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, iadr1_stream_t stream);
+/* X[M,K] row-major -> decode-packed activations Xp (buffer of roundup(M,64)*K elements; pad rows zeroed).  K % 32 == 0. */
+int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
 
 /* ---- RMSNorm (TF:65-79) --------------------------------------------------------------------------------

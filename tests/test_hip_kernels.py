@@ -88,6 +88,38 @@ def test_gemm_skinny_fused_swiglu(M, I, K):
     close(a, ref, 2e-2, 2e-2 * math.sqrt(K) * 0.3, f"skinny swiglu {M}x{I}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (8, 256, 512), (100, 1008, 1056), (64, 22016, 2048), (64, 2048, 11008)])
+def test_gemm_skinny_decode_packed_x(M, N, K):
+    """X in the decode-packed layout (C ABI: ldx == 0) gives the same numbers as row-major X: bit-exact where the K split
+    over waves is the same, fp32-rounding-close otherwise."""
+    x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
+    wp = ops.pack_weight(w)
+    xp = ops.pack_act(x)
+    assert torch.equal(xp.unpack(), x)
+    assert xp.buf.numel() == (M + 63) // 64 * 64 * K
+    y0, y1 = ops.gemm_skinny(x, wp, N, out_dtype=F32), ops.gemm_skinny(xp, wp, N, out_dtype=F32)
+    close(y1, y0, 1e-5, 1e-4, "packed X f32")
+    close(ops.gemm_skinny(xp, wp, N, bias=bias), ops.gemm_skinny(x, wp, N, bias=bias), 1e-2, 1e-2, "packed X bf16+bias")
+    for ks in (2, 8):
+        p0 = ops.gemm_skinny(x, wp, N, out=torch.zeros((ks, M, N), dtype=F32, device=DEV), ksplit=ks)
+        p1 = ops.gemm_skinny(xp, wp, N, out=torch.zeros((ks, M, N), dtype=F32, device=DEV), ksplit=ks)
+        close(p1.sum(0), p0.sum(0), 1e-5, 1e-4, f"packed X split-K {ks}")
+
+
+@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 96)])
+def test_decode_packed_producers(M, I, K):
+    """RMSNorm and the fused-SwiGLU epilogue write the decode-packed layout directly (ldy == 0): same values as row-major."""
+    x, w = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.3)
+    wpk = ops.pack_gateup(w)
+    a0 = ops.gemm_skinny(x, wpk, 2 * I, swiglu=True)
+    a1 = ops.gemm_skinny(ops.pack_act(x), wpk, 2 * I, swiglu=True, out=ops.PackedAct(M, I, DEV))
+    close(a1.unpack(), a0, 1e-2, 1e-2, "swiglu packed out")
+    g, res = (1 + 0.1 * rnd(K, seed=4).float()).to(BF), rnd(M, K, seed=5)
+    y0, _ = ops.rmsnorm_fwd(x, g, 1e-6, res=res, res_out=torch.empty_like(x))
+    y1, _ = ops.rmsnorm_fwd(x, g, 1e-6, res=res, res_out=torch.empty_like(x), out=ops.PackedAct(M, K, DEV))
+    assert torch.equal(y1.unpack(), y0)
+
+
 @pytest.mark.parametrize("R,C", [(64, 64), (100, 200), (4096, 2560), (37, 8)])
 def test_transpose(R, C):
     x = rnd(R, ((C + 7) // 8) * 8, seed=3)[:, :C]
@@ -313,6 +345,8 @@ def test_decode_attention_and_kv_store(Hq, Hkv, B, lens):
     ops.kv_store(kall2, vall2, slot_pad, kc, vc, Hkv, D)
     q = rnd(B, Hq * D, seed=5)
     o = ops.attn_decode(q, kc, vc, perm.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), Hq, Hkv, D, D ** -0.5)
+    op = ops.attn_decode(q, kc, vc, perm.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), Hq, Hkv, D, D ** -0.5, out=ops.PackedAct(B, Hq * D, DEV))
+    assert torch.equal(op.unpack(), o)          # decode-packed output (ldo == 0): same values, MFMA-fragment order
     if B == len(lens) and Hq == 16:
         # fused decode-step variant: rope(q,k) + cache append of one new token per sequence == rope_ + kv_store
         qkv = rnd(B, (Hq + 2 * Hkv) * D, seed=7)
