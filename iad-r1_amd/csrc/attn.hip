@@ -552,9 +552,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
 //   4 waves take pages round-robin, each keeps an online-softmax state; combined through LDS at the end.
 //   Sequences of one GRPO group share their prompt pages through the block table (prefill once per prompt).
 // =====================================================================================================
+// K pages are stored in the MFMA A-fragment order attn_decode reads them in: inside one (page, kv head) block of 32 keys x D,
+// element (key r, dim d) sits at kpk_off(r, d), so fragment (ks, t) = keys perm_row(li) + 4t, dims ks*32 + g*8.. is ONE
+// contiguous 1 KiB wave load (a row-major page makes it 16 half cache lines; decode attention is load-throughput bound).
+__device__ __forceinline__ int kpk_off(int r, int d) {
+    const int li = (r >> 3) * 4 + (r & 3), t = (r >> 2) & 1;
+    return ((((d >> 5) * 2 + t) * 64) + ((d >> 3) & 3) * 16 + li) * 8 + (d & 7);
+}
+
 struct DecodeArgs {
     const bf16_t* q;          // [B, Hq*D] (row stride ldq)
-    const bf16_t* kcache;     // [npages][Hkv][32][D]
+    const bf16_t* kcache;     // [npages][Hkv][32 x D in kpk_off order]
     const bf16_t* vcache;     // [npages][Hkv][D][32]
     const int* block_table;   // [B][max_pages]
     const int* ctx_len;       // [B] number of valid keys (including the current token)
@@ -596,10 +604,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = (li >> 2) * 8 + (li & 3) + 4 * t;  // perm_row within one 32-key page
-                kfr[ks][t] = ld_frag_g(kp + row * D + ks * 32 + g * 8, true);
-            }
+            for (int t = 0; t < 2; ++t) kfr[ks][t] = ld_frag_g(kp + ((ks * 2 + t) * 64 + l) * 8, true);  // keys perm_row(li) + 4t (kpk_off)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) vfr[dt] = ld_frag_g(vp + (dt * 16 + li) * PAGE + g * 8, true);
         f32x4_t s[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* k, long lon
         const long long page = sl >> 5;
         const int off = (int)(sl & 31);
         const u32x4_t kv = *(const u32x4_t*)(k + t * ldk + h * D + c * 8);
-        *(u32x4_t*)(kcache + ((page * Hkv + h) * 32 + off) * D + c * 8) = kv;
+        *(u32x4_t*)(kcache + (page * Hkv + h) * 32 * D + kpk_off(off, c * 8)) = kv;
         const u32x4_t vv = *(const u32x4_t*)(v + t * ldv + h * D + c * 8);
         bf16_t* vd = vcache + (page * Hkv + h) * (long long)D * 32 + off;
 #pragma unroll
@@ -723,9 +728,9 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(bf16_t* qkv, long lo
                 *(u32x2_t*)p = va;
                 *(u32x2_t*)(p + HALF) = vb;
             } else if (sl >= 0) {
-                bf16_t* kd = kcache + ((page * Hkv + (h - Hq)) * 32 + off) * D + c * 4;
-                *(u32x2_t*)kd = va;
-                *(u32x2_t*)(kd + HALF) = vb;
+                bf16_t* kd = kcache + (page * Hkv + (h - Hq)) * 32 * D;
+                *(u32x2_t*)(kd + kpk_off(off, c * 4)) = va;
+                *(u32x2_t*)(kd + kpk_off(off, c * 4 + HALF)) = vb;
             }
         } else if (sl >= 0) {
             r -= (Hq + Hkv) * RC;

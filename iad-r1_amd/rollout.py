@@ -62,6 +62,8 @@ class Rollout:
         self.o = act(Hq * D)
         self.br = torch.empty(N, H, dtype=BF16, device=dev)
         self.ks_o, self.ks_down = (2, 8) if H * Hq * D >= 1 << 20 else (1, 1)   # split-K of the two narrow-N projections
+        if os.environ.get("IADR1_DECODE_KS"):
+            self.ks_o, self.ks_down = (int(z) for z in os.environ["IADR1_DECODE_KS"].split(","))
         self.part_o = torch.empty(self.ks_o, N, H, dtype=F32, device=dev)
         self.part_d = torch.empty(self.ks_down, N, H, dtype=F32, device=dev)
         self.gu = torch.empty(N, 2 * I, dtype=BF16, device=dev)

@@ -119,7 +119,8 @@ int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    long long ldo, long long lddo, long long lddq, long long lddk, long long lddv, int causal,
                    float scale, iadr1_stream_t stream);
 /* Paged-KV decode attention + cache writes for the group rollout (vLLM's role at REF:...sc_grpo_trainer.py:
- * 343-358,667).  Pages hold 32 keys: K page [Hkv][32][D], V page [Hkv][D][32].  slot = page*32 + offset. */
+ * 343-358,667).  Pages hold 32 keys: K page [Hkv][32 x D in the MFMA-fragment order
+ * attn_decode reads, private to these three entry points], V page [Hkv][D][32].  slot = page*32 + offset. */
 int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len,
                       void* o, int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale,
                       iadr1_stream_t stream);
