@@ -29,6 +29,11 @@ struct AttnArgs {
     float* lse;             // [Hq, T] natural-log logsumexp of the scaled scores
     const int* seg_start;   // [nseg] first token (flat index) of each segment
     const int* seg_end;     // [nseg] one past the last token
+    // Shared-prefix attention (the G completions of one prompt attend to the prompt's keys, which are computed ONCE):
+    // NULL, or [nseg][4] = {prefix_start, prefix_len, child_first, child_count}.  A segment's keys are the token range
+    // [prefix_start, +prefix_len) (all visible) followed by its own tokens (causal); segments [child_first, +child_count)
+    // are the ones that use THIS segment as their prefix (their queries feed this segment's dK/dV).
+    const int* seg_prefix;
     long long ldq, ldk, ldv, ldo;  // token row strides (elements); head h lives at column h*D
     int T, Hq, Hkv;
     int causal;
@@ -180,19 +185,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int dt = 0; dt < C::DT; ++dt) acc[dt][r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     const float c = p.scale * LOG2E;
-    const int kv_end = p.causal ? min(slen, q0 + BM) : slen;
+    const int ps0 = p.seg_prefix ? p.seg_prefix[seg * 4] : 0, plen = p.seg_prefix ? p.seg_prefix[seg * 4 + 1] : 0;
 
     TileRegs<D, BN> kreg, vreg;
-    kreg.load(p.k + (long long)s0 * p.ldk + kvh * D, p.ldk, slen);
-    vreg.load(p.v + (long long)s0 * p.ldv + kvh * D, p.ldv, slen);
+    // key range 0: the shared prefix (every key visible); key range 1: the segment's own tokens (causal)
+    for (int ph = plen > 0 ? 0 : 1; ph < 2; ++ph) {
+    const int kbase = ph == 0 ? ps0 : s0, klen = ph == 0 ? plen : slen;
+    const bool kcausal = ph == 1 && p.causal;
+    const int kv_end = kcausal ? min(slen, q0 + BM) : klen;
+    kreg.load(p.k + (long long)kbase * p.ldk + kvh * D, p.ldk, klen);
+    vreg.load(p.v + (long long)kbase * p.ldv + kvh * D, p.ldv, klen);
     for (int kv0 = 0; kv0 < kv_end; kv0 += BN) {
         __syncthreads();           // every wave is done reading the previous tile
         kreg.store(Ks);
         vreg.store(Vs);
         __syncthreads();
         if (kv0 + BN < kv_end) {   // next tile's loads fly while this tile is computed
-            kreg.load(p.k + (long long)(s0 + kv0 + BN) * p.ldk + kvh * D, p.ldk, slen - kv0 - BN);
-            vreg.load(p.v + (long long)(s0 + kv0 + BN) * p.ldv + kvh * D, p.ldv, slen - kv0 - BN);
+            kreg.load(p.k + (long long)(kbase + kv0 + BN) * p.ldk + kvh * D, p.ldk, klen - kv0 - BN);
+            vreg.load(p.v + (long long)(kbase + kv0 + BN) * p.ldv + kvh * D, p.ldv, klen - kv0 - BN);
         }
 
         f32x4_t s[4][R];
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 for (int r = 0; r < R; ++r) s[kt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[r][ks], s[kt][r], 0, 0, 0);
         }
         // lane (g, e) of tile kt holds key kv0 + (kt>>1)*32 + g*8 + (kt&1)*4 + e for q column qrow[r]
-        const bool need_mask = (kv0 + BN > slen) || (p.causal && kv0 + BN > q0);
+        const bool need_mask = (kv0 + BN > klen) || (kcausal && kv0 + BN > q0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float mx = -INFINITY;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                     float t = s[kt][r][e] * c;
                     if (need_mask) {
                         const int key = kv0 + (kt >> 1) * 32 + g * 8 + (kt & 1) * 4 + e;
-                        if (key >= slen || (p.causal && key > qrow[r])) t = -INFINITY;
+                        if (key >= klen || (kcausal && key > qrow[r])) t = -INFINITY;
                     }
                     s[kt][r][e] = t;
                     mx = fmaxf(mx, t);
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             }
         }
     }
+    }  // key ranges
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float lt = lsum[r];
@@ -357,18 +368,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int kv_end = p.causal ? min(slen, q0 + BM) : slen;
+    const int ps0 = p.seg_prefix ? p.seg_prefix[seg * 4] : 0, plen = p.seg_prefix ? p.seg_prefix[seg * 4 + 1] : 0;
     TileRegs<D, KB> kreg, vreg;
-    kreg.load(p.k + (long long)s0 * p.ldk + kvh * D, p.ldk, slen);
-    vreg.load(p.v + (long long)s0 * p.ldv + kvh * D, p.ldv, slen);
+    for (int ph = plen > 0 ? 0 : 1; ph < 2; ++ph) {   // key range 0: shared prefix (all visible), 1: own tokens (causal)
+    const int kbase = ph == 0 ? ps0 : s0, klen = ph == 0 ? plen : slen;
+    const bool kcausal = ph == 1 && p.causal;
+    const int kv_end = kcausal ? min(slen, q0 + BM) : klen;
+    kreg.load(p.k + (long long)kbase * p.ldk + kvh * D, p.ldk, klen);
+    vreg.load(p.v + (long long)kbase * p.ldv + kvh * D, p.ldv, klen);
     for (int kv0 = 0; kv0 < kv_end; kv0 += KB) {
         __syncthreads();
         kreg.store(Ks);
         vreg.store(Vs);
         __syncthreads();
         if (kv0 + KB < kv_end) {
-            kreg.load(p.k + (long long)(s0 + kv0 + KB) * p.ldk + kvh * D, p.ldk, slen - kv0 - KB);
-            vreg.load(p.v + (long long)(s0 + kv0 + KB) * p.ldv + kvh * D, p.ldv, slen - kv0 - KB);
+            kreg.load(p.k + (long long)(kbase + kv0 + KB) * p.ldk + kvh * D, p.ldk, klen - kv0 - KB);
+            vreg.load(p.v + (long long)(kbase + kv0 + KB) * p.ldv + kvh * D, p.ldv, klen - kv0 - KB);
         }
 
         f32x4_t st[2], dpt[2];
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = kv0 + g * 8 + kt * 4 + e;
-                const bool ok = qok && key < slen && !(p.causal && key > qrow);
+                const bool ok = qok && key < klen && !(kcausal && key > qrow);
                 const float pv = ok ? exp2f(st[kt][e] * c - lse2) : 0.f;
                 ds[kt][e] = pv * (dpt[kt][e] - dl);
             }
@@ -410,6 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             }
         }
     }
+    }  // key ranges
     if (!qok) return;
     bf16_t* dst = p.dq + (long long)(s0 + qrow) * p.lddq + head * D;
 #pragma unroll
@@ -459,31 +475,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) { dkacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dvacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
+    // q sources of this key block, per q head of the GQA group: the segment's own rows (causal: from q_begin on), then -- when
+    // this segment is the shared prefix of others -- every row of each child segment (no mask: a child sees the whole prefix).
     const int q_begin = p.causal ? (kv0 / QB) * QB : 0;
-    const int nq = (slen - q_begin + QB - 1) / QB;         // q blocks per head
-    const int nit = group * nq;                            // flattened (head, q block) iteration space
+    const int nq_own = (slen - q_begin + QB - 1) / QB;
+    const int child_first = p.seg_prefix ? p.seg_prefix[seg * 4 + 2] : 0, child_count = p.seg_prefix ? p.seg_prefix[seg * 4 + 3] : 0;
+    int nq = nq_own;
+    for (int cidx = 0; cidx < child_count; ++cidx) nq += (p.seg_end[child_first + cidx] - p.seg_start[child_first + cidx] + QB - 1) / QB;
+    const int nit = group * nq;                            // flattened (head, source, q block) iteration space
     TileRegs<D, QB> qreg, doreg;
     float lse_r = 0.f, del_r = 0.f;
-    auto prefetch = [&](int it) {
-        const int head = kvh * group + it / nq, q0 = q_begin + (it % nq) * QB;
-        qreg.load(p.q + (long long)(s0 + q0) * p.ldq + head * D, p.ldq, slen - q0);
-        doreg.load(p.dout + (long long)(s0 + q0) * p.lddo + head * D, p.lddo, slen - q0);
-        if (threadIdx.x < QB) {
-            const int qr = q0 + threadIdx.x;
-            lse_r = qr < slen ? p.lse[(long long)head * p.T + s0 + qr] * LOG2E : 0.f;
-            del_r = qr < slen ? p.delta[(long long)head * p.T + s0 + qr] : 0.f;
+    // cursor of the NEXT block to prefetch, and the descriptor of the block being consumed
+    int c_head = 0, c_src = nq_own > 0 ? -1 : 0, c_qb = 0;
+    int n_base = 0, n_rows = 0, n_rel = 0;                 // prefetched block: first global row, valid rows, causal index of row 0
+    int cur_rows = 0, cur_rel = 0;
+    auto prefetch = [&]() {
+        int base, rows, rel;
+        if (c_src < 0) {
+            const int q0 = q_begin + c_qb * QB;
+            base = s0 + q0; rows = slen - q0; rel = q0;
+            if (++c_qb >= nq_own) { c_qb = 0; c_src = 0; }
+        } else {
+            const int cs = p.seg_start[child_first + c_src], clen = p.seg_end[child_first + c_src] - cs;
+            base = cs + c_qb * QB; rows = clen - c_qb * QB; rel = 1 << 30;
+            if (++c_qb >= (clen + QB - 1) / QB) { c_qb = 0; ++c_src; }
         }
+        const int head = kvh * group + c_head;
+        if (c_src >= child_count) { ++c_head; c_src = nq_own > 0 ? -1 : 0; c_qb = 0; }
+        qreg.load(p.q + (long long)base * p.ldq + head * D, p.ldq, rows);
+        doreg.load(p.dout + (long long)base * p.lddo + head * D, p.lddo, rows);
+        if (threadIdx.x < QB) {
+            const bool okr = (int)threadIdx.x < rows;
+            lse_r = okr ? p.lse[(long long)head * p.T + base + threadIdx.x] * LOG2E : 0.f;
+            del_r = okr ? p.delta[(long long)head * p.T + base + threadIdx.x] : 0.f;
+        }
+        n_base = base; n_rows = rows; n_rel = rel;
     };
-    if (nit > 0) prefetch(0);
+    if (nit > 0) prefetch();
     for (int it = 0; it < nit; ++it) {
         {
-            const int q0 = q_begin + (it % nq) * QB;
+            cur_rows = n_rows; cur_rel = n_rel;
             __syncthreads();
             qreg.store(Qs);
             doreg.store(dOs);
             if (threadIdx.x < QB) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
             __syncthreads();
-            if (it + 1 < nit) prefetch(it + 1);
+            if (it + 1 < nit) prefetch();
 
             // S[q, key] and dP[q, key]: A = Q / dO rows (permuted so a lane's registers are 8 consecutive q), B = K / V fragments
             f32x4_t s[2], dp[2];
@@ -503,8 +540,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int qi = g * 8 + t * 4 + e, qr = q0 + qi;
-                    const bool ok = kok && qr < slen && !(p.causal && key > qr);
+                    const int qi = g * 8 + t * 4 + e;
+                    const bool ok = kok && qi < cur_rows && !(p.causal && key > cur_rel + qi);
                     const float pp = ok ? exp2f(s[t][e] * c - lse_s[qi]) : 0.f;
                     pv[t][e] = pp;
                     ds[t][e] = pp * (dp[t][e] - del_s[qi]);
@@ -759,13 +796,13 @@ static int check_common(int T, int Hq, int Hkv, int D, long long ldq, long long 
 }
 
 extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start, const int* seg_end,
-                              int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
+                              const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
                               long long ldo, int causal, float scale, hipStream_t stream) {
     if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
     IADR1_REQUIRE(nseg > 0 && max_seqlen > 0, "attn_fwd: empty segment list");
     AttnArgs p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
-    p.seg_start = seg_start; p.seg_end = seg_end; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.seg_start = seg_start; p.seg_end = seg_end; p.seg_prefix = seg_prefix; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     static int force_r = -1;
     if (force_r < 0) { const char* e = getenv("IADR1_ATTN_R"); force_r = e ? atoi(e) : 1; }
@@ -785,7 +822,7 @@ extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void*
 }
 
 extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta,
-                              void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end, int nseg, int max_seqlen, int T,
+                              void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T,
                               int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv, long long ldo, long long lddo,
                               long long lddq, long long lddk, long long lddv, int causal, float scale, hipStream_t stream) {
     if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
@@ -793,7 +830,7 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
     IADR1_REQUIRE(nseg > 0 && max_seqlen > 0, "attn_bwd: empty segment list");
     AttnArgs p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.lse = (float*)lse;
-    p.seg_start = seg_start; p.seg_end = seg_end; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.seg_start = seg_start; p.seg_end = seg_end; p.seg_prefix = seg_prefix; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;

@@ -238,11 +238,17 @@ def f32_bias_to_bf16(x32, bias, out=None):
 class Segments:
     """Explicit attention segments on the flat token axis (device int32 arrays)."""
 
-    def __init__(self, starts, ends, device):
+    def __init__(self, starts, ends, device, prefix=None):
+        """prefix: optional [nseg][4] rows {prefix_start, prefix_len, child_first, child_count} (shared-prefix attention,
+        include/iadr1_hip.h iadr1_attn_fwd); segments must then be non-empty."""
         self.n = len(starts)
         self.max_len = max(e - s for s, e in zip(starts, ends)) if self.n else 0
         self.start = torch.tensor(starts, dtype=torch.int32, device=device)
         self.end = torch.tensor(ends, dtype=torch.int32, device=device)
+        self.prefix = None
+        if prefix is not None:
+            assert len(prefix) == self.n and all(e > s for s, e in zip(starts, ends)), "shared-prefix segments must be non-empty"
+            self.prefix = torch.tensor(prefix, dtype=torch.int32, device=device).contiguous()
 
     @staticmethod
     def from_cu(cu, device):
@@ -253,14 +259,14 @@ def attn_fwd(q, k, v, seg: Segments, Hq, Hkv, D, causal, scale, out=None, want_l
     T = q.shape[0]
     o = out if out is not None else torch.zeros(T, Hq * D, dtype=BF16, device=q.device)
     lse = torch.empty(Hq, T, dtype=F32, device=q.device) if want_lse else None
-    hip.call("attn_fwd", q, k, v, o, lse, seg.start, seg.end, seg.n, seg.max_len, T, Hq, Hkv, D, _ld(q), _ld(k), _ld(v), _ld(o), 1 if causal else 0, float(scale))
+    hip.call("attn_fwd", q, k, v, o, lse, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, T, Hq, Hkv, D, _ld(q), _ld(k), _ld(v), _ld(o), 1 if causal else 0, float(scale))
     return o, lse
 
 
 def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq, dk, dv):
     T = q.shape[0]
     delta = torch.empty(Hq, T, dtype=F32, device=q.device)
-    hip.call("attn_bwd", q, k, v, o, dout, lse, delta, dq, dk, dv, seg.start, seg.end, seg.n, seg.max_len, T, Hq, Hkv, D,
+    hip.call("attn_bwd", q, k, v, o, dout, lse, delta, dq, dk, dv, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, T, Hq, Hkv, D,
              _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout), _ld(dq), _ld(dk), _ld(dv), 1 if causal else 0, float(scale))
 
 

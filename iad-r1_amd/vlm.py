@@ -348,7 +348,7 @@ class Engine:
             o = buf("o")
             o.zero_()  # rows outside every segment (left / post-EOS padding) must read as zeros downstream (0 x stale NaN in wgrad otherwise)
             lse = B["lse"][li].view(-1)[: Hq * T].view(Hq, T) if save else None
-            ops.hip.call("attn_fwd", qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, lse, plan.seg.start, plan.seg.end, plan.seg.n, plan.seg.max_len,
+            ops.hip.call("attn_fwd", qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
                          T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, float(D**-0.5))
             ab = ops.gemm_nt(o, P.w(b + "o.w"))
             x_mid = buf("x_mid") if save else x_in

@@ -109,13 +109,19 @@ int iadr1_f32_bias_to_bf16(float* in_zeroed_after, const void* bias, void* out, 
  * Flash-style varlen attention over explicit segments [seg_start[i], seg_end[i]) of the flat token axis;
  * D in {128, 80}; GQA via Hq/Hkv.  Replaces flash-attn / eager attention at TF:186-208,225-291 (ViT,
  * non-causal windows) and TF:641-689 (decoder, causal, left padding = segments that start late).
- * lse: [Hq, T] fp32.  Backward also needs a delta scratch [Hq, T] fp32. */
+ * lse: [Hq, T] fp32.  Backward also needs a delta scratch [Hq, T] fp32.
+ * seg_prefix: NULL, or [nseg][4] int32 {prefix_start, prefix_len, child_first, child_count} for SHARED-PREFIX attention: the
+ * keys of segment i are tokens [prefix_start, +prefix_len) (all visible) followed by its own tokens (causal).  Used for
+ * the SC-GRPO policy / reference passes: the G completions of a prompt (REF:...sc_grpo_trainer.py:705-746 runs the prompt G
+ * times inside [B*G, P+C] rows) attend to ONE copy of the prompt's keys/values -- same math, the prompt tokens go through
+ * every layer once per group instead of G times.  Segments [child_first, +child_count) are those whose prefix is segment i
+ * (their queries contribute to segment i's dK/dV); segments must be non-empty; max_seqlen covers own lengths only. */
 int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start,
-                   const int* seg_end, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq,
+                   const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq,
                    long long ldk, long long ldv, long long ldo, int causal, float scale, iadr1_stream_t stream);
 int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                   float* delta, void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end, int nseg,
-                   int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
+                   float* delta, void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end,
+                   const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
                    long long ldo, long long lddo, long long lddq, long long lddk, long long lddv, int causal,
                    float scale, iadr1_stream_t stream);
 /* Paged-KV decode attention + cache writes for the group rollout (vLLM's role at REF:...sc_grpo_trainer.py:

@@ -325,6 +325,77 @@ def test_attn_fwd_bwd(D, Hq, Hkv, causal, segs):
     close(dqkv[:, (Hq + Hkv) * D:][inside], vr.grad[inside], 3e-2, 2e-2 * mag(vr.grad), "attn dv")
 
 
+PREFIX_CASES = [
+    # Hq, Hkv, prompts [(start, end)], completions per prompt [[(start, end), ...], ...]
+    (4, 2, [(3, 103), (110, 174)], [[(200, 230), (232, 233), (240, 337)], [(340, 404), (404, 450)]]),
+    (16, 2, [(0, 512)], [[(512 + 256 * i, 512 + 256 * i + n) for i, n in enumerate([256, 17, 200, 64])]]),
+    (2, 1, [(0, 37)], [[(40, 41)]]),
+]
+
+
+@pytest.mark.parametrize("Hq,Hkv,prompts,comps", PREFIX_CASES)
+def test_attn_shared_prefix_fwd_bwd(Hq, Hkv, prompts, comps):
+    """Shared-prefix attention (seg_prefix): a completion segment's keys are its prompt's tokens (all visible) + its own tokens
+    (causal).  Reference: per (prompt, completion) pair, plain causal attention over the concatenated row, fp32 autograd --
+    exactly what the reference's [B*G, P+C] batch computes; prompt outputs / gradients from the prompt's own causal pass plus
+    the key/value gradients of every completion."""
+    D, scale = 128, 128 ** -0.5
+    segs = list(prompts) + [c for cs in comps for c in cs]
+    T = max(e for _, e in segs) + 3
+    W = (Hq + 2 * Hkv) * D
+    qkv = rnd(T, W, seed=1)
+    q, k, v = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    prefix, first = [], len(prompts)
+    for cs in comps:
+        prefix.append([0, 0, first, len(cs)])
+        first += len(cs)
+    for (ps, pe), cs in zip(prompts, comps):
+        prefix += [[ps, pe - ps, 0, 0] for _ in cs]
+    seg = ops.Segments([s_ for s_, _ in segs], [e for _, e in segs], DEV, prefix=prefix)
+    o, lse = ops.attn_fwd(q, k, v, seg, Hq, Hkv, D, True, scale)
+    do = rnd(T, Hq * D, seed=2)
+    inside = torch.zeros(T, dtype=torch.bool, device=DEV)
+    for s_, e in segs:
+        inside[s_:e] = True
+    do[~inside] = 0
+    dqkv = torch.zeros(T, W, dtype=BF, device=DEV)
+    ops.attn_bwd(q, k, v, o, do, lse, seg, Hq, Hkv, D, True, scale, dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:])
+    # reference
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    grp = Hq // Hkv
+    ref_o = torch.zeros(T, Hq * D, device=DEV)
+    ref_lse = torch.full((Hq, T), float("-inf"), device=DEV)
+    loss = 0.0
+
+    def causal_rows(idx):  # attention of the token rows `idx` (one concatenated sequence), causal
+        n = len(idx)
+        qs = qr[idx].view(n, Hq, D).transpose(0, 1)
+        ks = kr[idx].view(n, Hkv, D).transpose(0, 1).repeat_interleave(grp, 0)
+        vs = vr[idx].view(n, Hkv, D).transpose(0, 1).repeat_interleave(grp, 0)
+        sc = (qs @ ks.transpose(1, 2)) * scale
+        sc = sc.masked_fill(~torch.ones(n, n, dtype=torch.bool, device=DEV).tril(), float("-inf"))
+        return (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(n, Hq * D), torch.logsumexp(sc, -1)
+
+    for (ps, pe), cs in zip(prompts, comps):
+        pidx = torch.arange(ps, pe, device=DEV)
+        po, pl = causal_rows(pidx)
+        ref_o[ps:pe], ref_lse[:, ps:pe] = po.detach(), pl.detach()
+        loss = loss + (po * do[ps:pe].float()).sum()
+        for cs_, ce in cs:
+            idx = torch.cat([pidx, torch.arange(cs_, ce, device=DEV)])
+            co, cl = causal_rows(idx)
+            n = ce - cs_
+            ref_o[cs_:ce], ref_lse[:, cs_:ce] = co[-n:].detach(), cl[:, -n:].detach()
+            loss = loss + (co[-n:] * do[cs_:ce].float()).sum()
+    loss.backward()
+    close(o[inside], ref_o[inside], 2e-2, 2e-2, "prefix attn o")
+    close(lse[:, inside], ref_lse[:, inside], 1e-3, 1e-2, "prefix attn lse")
+    mag = lambda t: float(t.abs().max())
+    close(dqkv[:, : Hq * D][inside], qr.grad[inside], 3e-2, 2e-2 * mag(qr.grad), "prefix attn dq")
+    close(dqkv[:, Hq * D: (Hq + Hkv) * D][inside], kr.grad[inside], 3e-2, 2e-2 * mag(kr.grad), "prefix attn dk")
+    close(dqkv[:, (Hq + Hkv) * D:][inside], vr.grad[inside], 3e-2, 2e-2 * mag(vr.grad), "prefix attn dv")
+
+
 @pytest.mark.parametrize("Hq,Hkv,B,lens", [(16, 2, 5, [1, 33, 64, 517, 767]), (2, 1, 3, [7, 32, 100]), (28, 4, 2, [300, 31])])
 def test_decode_attention_and_kv_store(Hq, Hkv, B, lens):
     D = 128
