@@ -12,6 +12,8 @@ this at per_device_train_batch_size=1, the only setting its scripts use (SURVEY.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 
 import numpy as np
@@ -47,6 +49,9 @@ class GRPOArgs:
     seed: int = 42
     suppress_eos: bool = False  # benchmark mode: fixed-length completions
     use_hip_graph: bool = True
+    # compute every prompt once per group in the reference / policy passes (shared-prefix attention; same math as the
+    # reference's G-fold repeated rows).  Off: IADR1_SHARE_PREFIX=0 or share_prefix=False.
+    share_prefix: bool = os.environ.get("IADR1_SHARE_PREFIX", "1") != "0"
 
 
 def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.ndarray:
@@ -224,21 +229,31 @@ class SCGRPOEngine:
         row_loss = torch.empty(N, dtype=F32, device=self.dev)
         row_kl = torch.empty(N, dtype=F32, device=self.dev)
         mb = max(1, min(a.micro_batch_seqs, N))
+        # shared-prefix layout (vlm.Engine.text_plan_shared): every prompt runs through the layers once per group instead of
+        # G times -- needs micro-batches made of whole groups.  IADR1_SHARE_PREFIX=0 keeps the reference's [n, P+C] rows.
+        share = a.share_prefix and G > 1 and mb % G == 0
         starts = list(range(0, N, mb))
         col = np.arange(C)
         for si, r0 in enumerate(starts):
             r1 = min(N, r0 + mb)
             n = r1 - r0
-            rows_b = [r // G for r in range(r0, r1)]
-            plan = self.pol.text_plan(ids[r0:r1], mask[r0:r1], [gpr[b] for b in rows_b], [off[b] for b in rows_b])
-            sel = (np.arange(n)[:, None] * S + (P - 1) + col[None, :]).reshape(-1)        # logits rows P-1 .. S-2
+            dup = None
+            if share:
+                b0, b1 = r0 // G, r1 // G
+                plan = self.pol.text_plan_shared(ids_p[b0:b1], mask_p[b0:b1], comp[r0:r1], cmask[r0:r1], G, gpr[b0:b1], off[b0:b1])
+                sel, fsel, fdest, fgroup = self.pol.shared_logit_rows(b1 - b0, P, n, C, G)
+                dup = tuple(torch.from_numpy(z).to(self.dev) for z in (fsel, fdest, fgroup))
+            else:
+                rows_b = [r // G for r in range(r0, r1)]
+                plan = self.pol.text_plan(ids[r0:r1], mask[r0:r1], [gpr[b] for b in rows_b], [off[b] for b in rows_b])
+                sel = (np.arange(n)[:, None] * S + (P - 1) + col[None, :]).reshape(-1)        # logits rows P-1 .. S-2
             rows_d = torch.from_numpy(sel.astype(np.int64)).to(self.dev)
             tgt_d = torch.from_numpy(ids[r0:r1, P:].reshape(-1).astype(np.int64)).to(self.dev)
             hf, _ = self.ref.text_forward(plan, img_ref, save=False)
             rl, _ = self.ref.logprobs(hf, rows_d, tgt_d, save=False)
             del hf
             hf, ctx = self.pol.text_forward(plan, img_pol, save=backward)
-            lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward)
+            lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, dup=dup)
             dlogp, kl, rloss, rkl = ops.grpo_loss(lp.view(n, C), rl.view(n, C), adv_d[r0:r1].contiguous(), cmask_d[r0:r1].contiguous(), a.beta, n_total_rows=N)
             logp_all[r0:r1], ref_all[r0:r1], kl_all[r0:r1] = lp.view(n, C), rl.view(n, C), kl
             row_loss[r0:r1], row_kl[r0:r1] = rloss, rkl

@@ -46,6 +46,7 @@ class TextPlan:
     sin: torch.Tensor
     rope_deltas: np.ndarray      # [B]
     lengths: np.ndarray          # [B] number of real tokens
+    shared: tuple = None         # (ng, P, n, C, G) when built by text_plan_shared
 
 
 class Engine:
@@ -129,6 +130,68 @@ class Engine:
         ang = sel.t().to(F32) * self.inv_freq[None, :]                  # [T, D/2] fp32, as TF::525-538
         return TextPlan(B, S, torch.from_numpy(input_ids.reshape(-1).astype(np.int64)).to(self.dev), torch.from_numpy(img_index.reshape(-1)).to(self.dev),
                         ops.Segments(starts, ends, self.dev), ang.cos().contiguous(), ang.sin().contiguous(), deltas, lengths)
+
+    def text_plan_shared(self, ids_p: np.ndarray, mask_p: np.ndarray, comp: np.ndarray, cmask: np.ndarray, G: int, grids_per_prompt, img_off_per_prompt) -> TextPlan:
+        """Shared-prefix layout of a GRPO micro-batch: the reference feeds [ng*G, P+C] rows whose first P positions are the
+        same prompt G times (REF:train/stage_rl/trainer/sc_grpo_trainer.py:626,705-746).  A causal decoder gives those G
+        copies identical hidden states, so here every prompt goes through the layers ONCE:
+            flat tokens = [ng prompts x P] ++ [ng*G completions x C],
+        and completion segments attend to their prompt's keys through `seg_prefix` (include/iadr1_hip.h).  Positions are the
+        reference's (M-RoPE over the full [P+C] rows); logit rows for completion token j are `logit_rows()`."""
+        c = self.cfg
+        ng, P = ids_p.shape
+        n, C = comp.shape
+        assert n == ng * G
+        ids_full = np.concatenate([np.repeat(ids_p, G, 0), comp], 1)
+        mask_full = np.concatenate([np.repeat(mask_p, G, 0), cmask.astype(mask_p.dtype)], 1)
+        flat_grids = [g for b in range(ng) for _ in range(G) for g in grids_per_prompt[b]]
+        pos, deltas = indexing.mrope_position_ids(ids_full, mask_full, flat_grids, c.image_token_id, c.v_merge)   # [3, n, P+C]
+        pos_flat = np.concatenate([pos[:, ::G, :P].reshape(3, ng * P), pos[:, :, P:].reshape(3, n * C)], 1)
+        T = ng * P + n * C
+        img_index = np.full(T, -1, dtype=np.int32)
+        m2 = c.v_merge**2
+        starts, ends, prefix = [], [], []
+        for b in range(ng):
+            cols = np.flatnonzero((ids_p[b] == c.image_token_id) & (mask_p[b] != 0))
+            k = 0
+            for g, off in zip(grids_per_prompt[b], img_off_per_prompt[b]):
+                cnt = g[0] * g[1] * g[2] // m2
+                img_index[b * P + cols[k: k + cnt]] = off + np.arange(cnt)
+                k += cnt
+            if k != len(cols):
+                raise ValueError(f"prompt {b}: {len(cols)} image tokens but grids supply {k}")
+            nz = np.flatnonzero(mask_p[b])
+            if len(nz) == 0 or int(nz[-1]) + 1 - int(nz[0]) != len(nz):
+                raise ValueError("prompt attention_mask rows must be one non-empty contiguous run of ones")
+            starts.append(b * P + int(nz[0]))
+            ends.append(b * P + int(nz[-1]) + 1)
+            prefix.append([0, 0, ng + b * G, G])
+        base = ng * P
+        clen = cmask.astype(np.int64).sum(1)
+        if not (np.all(clen >= 1) and np.all(cmask[np.arange(n), clen - 1] != 0) and np.all(cmask[:, 0] != 0)):
+            raise ValueError("completion masks must be a non-empty run of ones starting at the first completion token")
+        for r in range(n):
+            b = r // G
+            starts.append(base + r * C)
+            ends.append(base + r * C + int(clen[r]))
+            prefix.append([starts[b], ends[b] - starts[b], 0, 0])
+        ids_flat = np.concatenate([ids_p.reshape(-1), comp.reshape(-1)]).astype(np.int64)
+        pos_t = torch.from_numpy(pos_flat).to(self.dev)
+        ang = pos_t[self.mrope_comp].t().to(F32) * self.inv_freq[None, :]
+        plan = TextPlan(n, P + C, torch.from_numpy(ids_flat).to(self.dev), torch.from_numpy(img_index).to(self.dev),
+                        ops.Segments(starts, ends, self.dev, prefix=prefix), ang.cos().contiguous(), ang.sin().contiguous(), deltas, mask_full.sum(1).astype(np.int64))
+        plan.shared = (ng, P, n, C, G)
+        return plan
+
+    @staticmethod
+    def shared_logit_rows(ng, P, n, C, G):
+        """Flat row whose hidden state predicts completion token j of sequence r: j = 0 -> the prompt's last token (one row
+        shared by the G sequences of the group), j > 0 -> completion row j-1.  Returns (rows [n*C] int64, first_sel [n] indices
+        into rows of the j = 0 entries, first_dest [ng] their flat rows, first_group [n] group of each j = 0 entry)."""
+        r = np.arange(n)[:, None]
+        j = np.arange(C)[None, :]
+        rows = np.where(j == 0, (r // G) * P + (P - 1), ng * P + r * C + j - 1).reshape(-1).astype(np.int64)
+        return rows, (np.arange(n) * C).astype(np.int64), (np.arange(ng) * P + (P - 1)).astype(np.int64), (np.arange(n) // G).astype(np.int64)
 
     # ========================================================================================================
     # vision tower  (TF::408-471)
@@ -402,9 +465,11 @@ class Engine:
     # ========================================================================================================
     # lm_head + log-softmax + gather (REF sc_grpo_trainer.py:505-513), only on the rows that are consumed
     # ========================================================================================================
-    def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool):
+    def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool, dup=None):
         """logp[r] = log_softmax(lm_head(hf[rows[r]]))[targets[r]]  (targets < 0 -> 0).  The [R,V] logits exist
-        only as fp32 chunks of `lm_chunk` rows."""
+        only as fp32 chunks of `lm_chunk` rows.  `rows` may repeat a hidden row only where `dup` = (sel, dest, group) says so:
+        entries rows[sel] all equal dest[group] (shared-prefix layout: the prompt's last token predicts the first token of
+        every completion of its group); the backward sums their gradients."""
         P = self.p
         W = P.w(P.lm_head_name())
         hsel = ops.embed_fwd(rows, None, hf, None)
@@ -419,7 +484,7 @@ class Engine:
             lp, ls = ops.logprob_rows(lg, targets[r0:r1])
             logp[r0:r1] = lp
             lse[r0:r1] = ls
-        ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0]} if save else None
+        ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0], "dup": dup} if save else None
         return logp, ctx
 
     def logprobs_backward(self, g: torch.Tensor, ctx) -> torch.Tensor:
@@ -451,7 +516,12 @@ class Engine:
         inv = torch.full((ctx["T"],), -1, dtype=torch.int32, device=self.dev)
         inv[rows] = torch.arange(R, dtype=torch.int32, device=self.dev)
         zero_row = torch.zeros(1, H, dtype=BF16, device=self.dev)
-        return ops.embed_fwd(torch.zeros(ctx["T"], dtype=torch.int64, device=self.dev), inv, zero_row, dhsel)
+        dhf = ops.embed_fwd(torch.zeros(ctx["T"], dtype=torch.int64, device=self.dev), inv, zero_row, dhsel)
+        if ctx.get("dup") is not None:
+            sel, dest, group = ctx["dup"]
+            acc = torch.zeros(dest.numel(), H, dtype=F32, device=self.dev).index_add_(0, group, dhsel[sel].float())
+            dhf[dest] = acc.to(BF16)
+        return dhf
 
     def logits_rows(self, hf: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
         """fp32 logits of a FEW rows (rollout prefill: last prompt position of each prompt)."""

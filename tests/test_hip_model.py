@@ -130,6 +130,33 @@ def test_micro_batching_does_not_change_gradients(golden_dir):
     assert float((a - b).norm() / b.norm()) < 2e-2
 
 
+def test_shared_prefix_layout_equals_repeated_prompt_rows():
+    """SC-GRPO loss + gradients with every prompt computed once per group (shared-prefix attention) vs the reference's layout of
+    G full [P+C] rows per prompt: two left-padded prompts of different length / image size, ragged completions with EOS."""
+    G, C = 4, 9
+    grids = [(1, 16, 12), (1, 8, 8)]
+    ids, mask = fx.left_pad([fx.synth_prompt(grids[0], 6, fx.TINY, 3), fx.synth_prompt(grids[1], 21, fx.TINY, 4)], fx.TINY["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values(grids, fx.TINY, seed=5), "image_grid_thw": grids}
+    comps = fx.synth_completions(2 * G, C, fx.TINY, 77, {1: 3, 2: 0, 6: 8})
+    rewards = np.random.RandomState(0).rand(2 * G, 2).astype(np.float32)
+    w_ref = fx.make_weights(fx.TINY, 0)
+    res = []
+    for share in (True, False):
+        pol, ref = store(fx.perturb_weights(w_ref, 1), True), store(w_ref, False)
+        eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, micro_batch_seqs=2 * G, share_prefix=share))
+        out = eng.loss_and_grads(batch, comps, rewards)
+        res.append((out, pol.grad.clone()))
+    (o1, g1), (o0, g0) = res
+    m = o0["completion_mask"].astype(bool)
+    assert np.abs(o1["logps"].cpu().numpy()[m] - o0["logps"].cpu().numpy()[m]).max() < 0.03      # bf16 hidden states, different tile orders
+    assert np.abs(o1["ref_logps"].cpu().numpy()[m] - o0["ref_logps"].cpu().numpy()[m]).max() < 0.03
+    assert abs(o1["metrics"]["loss"] - o0["metrics"]["loss"]) < 1e-3
+    a, b = g1.double(), g0.double()
+    assert float((a - b).norm() / b.norm()) < 2e-2
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    assert cos > 0.999, cos
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_greedy_rollout_token_ids_bit_exact(golden_dir, use_graph):
     g = load(golden_dir, "greedy.npz")
