@@ -28,6 +28,24 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
+def decode_roofline(cfg, pol, events, n_seq, gen_len):
+    """HBM roofline of the rollout's decode step (one hipGraph replay = ~250 kernels, 64 live sequences): algorithmic bytes per step
+    = every decode-packed weight once + the K/V of every live context, / the HIP-event time of the replay loop (events on the
+    stream the graph is replayed on)."""
+    if not events:
+        return None
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in events)
+    steps = sum(n for _, _, n, _ in events)
+    w_bytes = pol.flat_pk.numel() * 2
+    kv_tok = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2
+    # context read by decode step j (1-based) = prompt length + j tokens (the new token's own K/V included)
+    kv_bytes = sum(kv_tok * (plen * n + n_seq * n * (n + 1) // 2) for _, _, n, plen in events) / max(steps, 1)
+    ach = (w_bytes + kv_bytes) / (ms / steps * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "decode step (hipGraph: skinny GEMMs on decode-packed weights + paged attention + RMSNorm + sampling)", "achieved": ach,
+            "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "ms_per_decode_step": ms / steps, "decode_steps": steps,
+            "algorithmic_bytes_per_step": {"weights": w_bytes, "kv": kv_bytes}, "traffic": None}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -38,7 +56,8 @@ def parse():
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--gen-len", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--no-repeated-rows-leg", action="store_true", help="skip the extra (untimed) step in the reference's repeated-prompt-rows layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -218,6 +237,7 @@ def main():
     barrier()
     ms0 = torch.cuda.memory_stats()
     timer.enabled = True
+    eng._rollout.decode_events = []
     t0 = time.perf_counter()
     metrics = None
     for _ in range(a.steps):
@@ -226,11 +246,28 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    # one extra step OUTSIDE the timed region in the reference's own layout (every prompt repeated in all G rows of its group,
+    # IADR1_SHARE_PREFIX=0) so the line also says what the dedup of the prompt tokens is worth; N=1 only
+    repeated = None
+    if world == 1 and not a.no_repeated_rows_leg and eng.args.share_prefix and a.group > 1:
+        eng.args.share_prefix, eng.args.micro_batch_seqs = False, min(a.micro_batch, 32)
+        b = synth_batch(cfg, a.prompts, a.prompt_len, seed=99)
+        b["pixel_values"] = b["pixel_values"].to(dev)
+        eng.step(b, reward_fn)          # buffers of this layout
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.step(b, reward_fn)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        repeated = {"samples_per_s": N / d1, "ms_per_step": d1 * 1e3, "micro_batch_seqs": eng.args.micro_batch_seqs, "steps": 1,
+                    "note": "same step with the prompt tokens recomputed in all G rows (the reference's [B*G, P+C] layout); not part of `value`"}
+        eng.args.share_prefix, eng.args.micro_batch_seqs = True, a.micro_batch
     if rank == 0:
         n_launch, t_gemm, fl_gemm = timer.summary()
         ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
@@ -248,10 +285,14 @@ def main():
             "value": world * N * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
-                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}"},
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}",
+                       "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "
+                                 "reference's G repeated rows, parity-tested)") if eng.args.share_prefix else "ViT once per image"},
+            "repeated_rows_layout": repeated,
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
+            "roofline_decode": decode_roofline(cfg, pol, dec_ev, N, a.gen_len),
             "last_step_metrics": metrics,
             "gemm_by_shape": timer.by_shape(),
             "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30, "peak_reserved_GB": torch.cuda.max_memory_reserved() / 2**30,

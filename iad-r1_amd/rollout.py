@@ -72,6 +72,7 @@ class Rollout:
         self.cos = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.graph = None
+        self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
         self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
 
     # ---- one decode step (graph body) -------------------------------------------------------------------------
@@ -196,11 +197,19 @@ class Rollout:
             self._capture()  # warm-up + capture advance the state twice: restore it (K/V written meanwhile are rewritten by the real steps)
             for t, s_ in zip((self.pos, self.ctx_len, self.slot, self.finished, self.step, self.cur_tok, self.out_tokens), saved):
                 t.copy_(s_)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.decode_events is not None else None
+        if ev:
+            ev[0].record()
+        nsteps = 0
         for it in range(1, max_new):
             if self.graph is not None:
                 self.graph.replay()
             else:
                 self._decode_step()
+            nsteps += 1
             if sampling["eos"] >= 0 and it % 32 == 0 and bool(self.finished.all()):
                 break
+        if ev:
+            ev[1].record()
+            self.decode_events.append((ev[0], ev[1], nsteps, int(np.sum(lengths)) * G))
         return self.out_tokens[:, :max_new].clone()

@@ -53,3 +53,25 @@ for N, K, NL in [(22016, 2048, 24)]:
             err = f"relerr {((out - ref).abs().max() / ref.abs().max()).item():.1e}"
         us = timeit(lambda i: L.run_wide(v, ctypes.c_void_p(Wp[i % NL].data_ptr()), ctypes.c_void_p(Xa.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, K, st()), NL)
         print(f"  {v:2d} {nm:22s} {us:8.1f} us {nbytes/us/1e6:6.2f} TB/s  blocks {N//cols:5d} {err}", flush=True)
+
+# ---- MALL experiment: does a plain read of the weights just before the GEMM (a prefetch into the 256 MB memory-side cache)
+# make the GEMM itself faster?  t(prefetch + gemm) - t(prefetch) vs t(gemm)
+if not only or 99 in only:
+    N, K, NL = 22016, 2048, 24
+    Ws = [torch.randn(N, K, device=dev).to(torch.bfloat16) for _ in range(NL)]
+    Wp = [ops.pack_weight(w) for w in Ws]
+    X = torch.randn(64, K, device=dev).to(torch.bfloat16)
+    Xpk = X.view(4, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
+    out = torch.zeros(64, N, device=dev)
+    flag = torch.zeros(4096, dtype=torch.int32, device=dev)
+    nbytes = N * K * 2
+    pre = lambda i, v=2: L.run_pure(v, ctypes.c_void_p(Wp[i % NL].data_ptr()), ctypes.c_longlong(nbytes), ctypes.c_void_p(flag.data_ptr()), st())
+    gem = lambda i: L.run_wide(25, ctypes.c_void_p(Wp[i % NL].data_ptr()), ctypes.c_void_p(Xpk.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, K, st())
+    t_pre = timeit(lambda i: pre(i), NL)
+    t_gem = timeit(lambda i: gem(i), NL)
+    t_both = timeit(lambda i: (pre(i), gem(i)), NL)
+    t_pre_nt = timeit(lambda i: pre(i, 1), NL)
+    t_both_nt = timeit(lambda i: (pre(i, 1), gem(i)), NL)
+    t_gem2 = timeit(lambda i: (gem(i), gem(i)), NL)
+    print(f"== MALL: prefetch(plain) {t_pre:.1f} us | gemm {t_gem:.1f} | prefetch+gemm {t_both:.1f} -> gemm after prefetch {t_both - t_pre:.1f} us")
+    print(f"         prefetch(nt) {t_pre_nt:.1f} us | prefetch(nt)+gemm {t_both_nt:.1f} -> gemm after nt prefetch {t_both_nt - t_pre_nt:.1f} us | gemm twice on same W {t_gem2:.1f}")
