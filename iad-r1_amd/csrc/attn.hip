@@ -45,6 +45,10 @@ struct AttnArgs {
     bf16_t* dk;
     bf16_t* dv;
     long long lddo, lddq, lddk, lddv;
+    // dK/dV with the q heads of a GQA group split over `hs` blocks (balances the long query loops of shared-prefix segments):
+    // fp32 partials dkv_ws[hs][T][Hkv][2][D], summed in a fixed order by attn_dkdv_reduce_kernel (deterministic, no atomics)
+    float* dkv_ws;
+    int hs;
 };
 
 template <int D>
@@ -188,22 +192,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int ps0 = p.seg_prefix ? p.seg_prefix[seg * 4] : 0, plen = p.seg_prefix ? p.seg_prefix[seg * 4 + 1] : 0;
 
     TileRegs<D, BN> kreg, vreg;
-    // key range 0: the shared prefix (every key visible); key range 1: the segment's own tokens (causal)
-    for (int ph = plen > 0 ? 0 : 1; ph < 2; ++ph) {
-    const int kbase = ph == 0 ? ps0 : s0, klen = ph == 0 ? plen : slen;
-    const bool kcausal = ph == 1 && p.causal;
-    const int kv_end = kcausal ? min(slen, q0 + BM) : klen;
-    kreg.load(p.k + (long long)kbase * p.ldk + kvh * D, p.ldk, klen);
-    vreg.load(p.v + (long long)kbase * p.ldv + kvh * D, p.ldv, klen);
-    for (int kv0 = 0; kv0 < kv_end; kv0 += BN) {
+    // One continuous tile stream over the two key ranges -- the shared prefix (every key visible) then the segment's own tokens
+    // (causal) -- so the register prefetch of the next tile also runs across the range boundary (a restart there costs a full
+    // global-load latency per block, as much as several tiles of work).
+    const int np_tiles = (plen + BN - 1) / BN;
+    const int own_end = p.causal ? min(slen, q0 + BM) : slen;
+    const int nt = np_tiles + (own_end + BN - 1) / BN;
+    auto tile_load = [&](int t) {
+        const bool pre = t < np_tiles;
+        const int kv0 = (pre ? t : t - np_tiles) * BN;
+        const int row = (pre ? ps0 : s0) + kv0, valid = (pre ? plen : slen) - kv0;
+        kreg.load(p.k + (long long)row * p.ldk + kvh * D, p.ldk, valid);
+        vreg.load(p.v + (long long)row * p.ldv + kvh * D, p.ldv, valid);
+    };
+    if (nt > 0) tile_load(0);
+    for (int t = 0; t < nt; ++t) {
+        const bool pre = t < np_tiles;
+        const int kv0 = (pre ? t : t - np_tiles) * BN;
+        const int klen = pre ? plen : slen;
+        const bool kcausal = !pre && p.causal;
         __syncthreads();           // every wave is done reading the previous tile
         kreg.store(Ks);
         vreg.store(Vs);
         __syncthreads();
-        if (kv0 + BN < kv_end) {   // next tile's loads fly while this tile is computed
-            kreg.load(p.k + (long long)(kbase + kv0 + BN) * p.ldk + kvh * D, p.ldk, klen - kv0 - BN);
-            vreg.load(p.v + (long long)(kbase + kv0 + BN) * p.ldv + kvh * D, p.ldv, klen - kv0 - BN);
-        }
+        if (t + 1 < nt) tile_load(t + 1);   // next tile's loads fly while this tile is computed
 
         f32x4_t s[4][R];
 #pragma unroll
@@ -287,7 +299,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             }
         }
     }
-    }  // key ranges
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float lt = lsum[r];
@@ -370,21 +381,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 
     const int ps0 = p.seg_prefix ? p.seg_prefix[seg * 4] : 0, plen = p.seg_prefix ? p.seg_prefix[seg * 4 + 1] : 0;
     TileRegs<D, KB> kreg, vreg;
-    for (int ph = plen > 0 ? 0 : 1; ph < 2; ++ph) {   // key range 0: shared prefix (all visible), 1: own tokens (causal)
-    const int kbase = ph == 0 ? ps0 : s0, klen = ph == 0 ? plen : slen;
-    const bool kcausal = ph == 1 && p.causal;
-    const int kv_end = kcausal ? min(slen, q0 + BM) : klen;
-    kreg.load(p.k + (long long)kbase * p.ldk + kvh * D, p.ldk, klen);
-    vreg.load(p.v + (long long)kbase * p.ldv + kvh * D, p.ldv, klen);
-    for (int kv0 = 0; kv0 < kv_end; kv0 += KB) {
+    // one continuous tile stream over [shared prefix (all visible)] ++ [own tokens (causal)], see attn_fwd_kernel
+    const int np_tiles = (plen + KB - 1) / KB;
+    const int own_end = p.causal ? min(slen, q0 + BM) : slen;
+    const int nt = np_tiles + (own_end + KB - 1) / KB;
+    auto tile_load = [&](int t) {
+        const bool pre = t < np_tiles;
+        const int kv0 = (pre ? t : t - np_tiles) * KB;
+        const int row = (pre ? ps0 : s0) + kv0, valid = (pre ? plen : slen) - kv0;
+        kreg.load(p.k + (long long)row * p.ldk + kvh * D, p.ldk, valid);
+        vreg.load(p.v + (long long)row * p.ldv + kvh * D, p.ldv, valid);
+    };
+    if (nt > 0) tile_load(0);
+    for (int t = 0; t < nt; ++t) {
+        const bool pre = t < np_tiles;
+        const int kv0 = (pre ? t : t - np_tiles) * KB;
+        const int klen = pre ? plen : slen;
+        const bool kcausal = !pre && p.causal;
         __syncthreads();
         kreg.store(Ks);
         vreg.store(Vs);
         __syncthreads();
-        if (kv0 + KB < kv_end) {
-            kreg.load(p.k + (long long)(kbase + kv0 + KB) * p.ldk + kvh * D, p.ldk, klen - kv0 - KB);
-            vreg.load(p.v + (long long)(kbase + kv0 + KB) * p.ldv + kvh * D, p.ldv, klen - kv0 - KB);
-        }
+        if (t + 1 < nt) tile_load(t + 1);
 
         f32x4_t st[2], dpt[2];
 #pragma unroll
@@ -425,7 +443,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             }
         }
     }
-    }  // key ranges
     if (!qok) return;
     bf16_t* dst = p.dq + (long long)(s0 + qrow) * p.lddq + head * D;
 #pragma unroll
@@ -449,7 +466,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     float* lse_s = (float*)(dOs + QB * C::LD);    // [QB]
     float* del_s = lse_s + QB;                    // [QB]
 
-    const int seg = blockIdx.y, kvh = blockIdx.z, group = p.Hq / p.Hkv;
+    const int hs = p.hs, kvh = blockIdx.z / hs, part = blockIdx.z % hs;
+    const int seg = blockIdx.y, group = p.Hq / p.Hkv, gph = group / hs;   // gph q heads per block
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
     const int ntile = (slen + BN - 1) / BN;
     const int kt0 = blockIdx.x;  // causal: low kv tiles see the most q rows and are scheduled first
@@ -482,11 +500,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     const int child_first = p.seg_prefix ? p.seg_prefix[seg * 4 + 2] : 0, child_count = p.seg_prefix ? p.seg_prefix[seg * 4 + 3] : 0;
     int nq = nq_own;
     for (int cidx = 0; cidx < child_count; ++cidx) nq += (p.seg_end[child_first + cidx] - p.seg_start[child_first + cidx] + QB - 1) / QB;
-    const int nit = group * nq;                            // flattened (head, source, q block) iteration space
+    const int nit = gph * nq;                              // flattened (head, source, q block) iteration space
     TileRegs<D, QB> qreg, doreg;
     float lse_r = 0.f, del_r = 0.f;
     // cursor of the NEXT block to prefetch, and the descriptor of the block being consumed
-    int c_head = 0, c_src = nq_own > 0 ? -1 : 0, c_qb = 0;
+    int c_head = part * gph, c_src = nq_own > 0 ? -1 : 0, c_qb = 0;
     int n_base = 0, n_rows = 0, n_rel = 0;                 // prefetched block: first global row, valid rows, causal index of row 0
     int cur_rows = 0, cur_rel = 0;
     auto prefetch = [&]() {
@@ -571,6 +589,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
         }
     }
     if (!kok) return;
+    if (hs > 1) {
+        float* wd = p.dkv_ws + ((((long long)part * p.T + s0 + key) * p.Hkv + kvh) * 2) * D;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            *(f32x4_t*)(wd + dt * 16 + g * 4) = dkacc[dt] * p.scale;
+            *(f32x4_t*)(wd + D + dt * 16 + g * 4) = dvacc[dt];
+        }
+        return;
+    }
     bf16_t* dkd = p.dk + (long long)(s0 + key) * p.lddk + kvh * D;
     bf16_t* dvd = p.dv + (long long)(s0 + key) * p.lddv + kvh * D;
 #pragma unroll
@@ -578,6 +605,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
         const f32x4_t a = dkacc[dt] * p.scale, b = dvacc[dt];
         *(u32x2_t*)(dkd + dt * 16 + g * 4) = (u32x2_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
         *(u32x2_t*)(dvd + dt * 16 + g * 4) = (u32x2_t){pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    }
+}
+
+// sum of the `hs` head-split partials of dK/dV (fixed order) -> bf16; one thread per 4 consecutive d of one (token, kv head, k|v)
+template <int D>
+__global__ __launch_bounds__(256) void attn_dkdv_reduce_kernel(AttnArgs p) {
+    const int seg = blockIdx.y;
+    const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
+    const int per_tok = p.Hkv * 2 * (D / 4);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)slen * per_tok; i += (long long)gridDim.x * 256) {
+        const int tok = (int)(i / per_tok), r = (int)(i % per_tok);
+        const int kvh = r / (2 * (D / 4)), which = (r / (D / 4)) & 1, d = (r % (D / 4)) * 4;
+        const long long off = ((((long long)(s0 + tok)) * p.Hkv + kvh) * 2 + which) * D + d;
+        f32x4_t a = *(const f32x4_t*)(p.dkv_ws + off);
+        for (int h = 1; h < p.hs; ++h) a += *(const f32x4_t*)(p.dkv_ws + (long long)h * p.T * p.Hkv * 2 * D + off);
+        bf16_t* dst = which ? p.dv + (long long)(s0 + tok) * p.lddv + kvh * D + d : p.dk + (long long)(s0 + tok) * p.lddk + kvh * D + d;
+        *(u32x2_t*)dst = (u32x2_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
     }
 }
 
@@ -822,7 +866,7 @@ extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void*
 }
 
 extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta,
-                              void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T,
+                              void* dq, void* dk, void* dv, float* dkv_ws, int head_splits, const int* seg_start, const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T,
                               int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv, long long ldo, long long lddo,
                               long long lddq, long long lddk, long long lddv, int causal, float scale, hipStream_t stream) {
     if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
@@ -834,6 +878,9 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    const int hs = (dkv_ws && head_splits > 1) ? head_splits : 1;
+    IADR1_REQUIRE((Hq / Hkv) % hs == 0, "attn_bwd: head_splits=%d must divide the GQA group %d", hs, Hq / Hkv);
+    p.dkv_ws = dkv_ws; p.hs = hs;
     const long long items = (long long)T * Hq * 16;
 #define LAUNCH_BWD(DD)                                                                                                                   \
     do {                                                                                                                                 \
@@ -844,7 +891,8 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
         hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hq), dim3(256), smem_dq, stream, p);               \
         const int smem_kv = (2 * 32 * Cfg<DD>::LD) * 2 + 64 * 4;                                                                         \
         set_smem(attn_bwd_dkdv_kernel<DD>, smem_kv);                                                                                     \
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hkv), dim3(256), smem_kv, stream, p);            \
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hkv * hs), dim3(256), smem_kv, stream, p);       \
+        if (hs > 1) hipLaunchKernelGGL(attn_dkdv_reduce_kernel<DD>, dim3((max_seqlen * Hkv * 2 * (DD / 4) + 255) / 256, nseg), dim3(256), 0, stream, p); \
     } while (0)
     if (D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(80);
 #undef LAUNCH_BWD

@@ -263,10 +263,25 @@ def attn_fwd(q, k, v, seg: Segments, Hq, Hkv, D, causal, scale, out=None, want_l
     return o, lse
 
 
+_DKV_WS = {}
+
+
+def _dkv_workspace(n, device):
+    t = _DKV_WS.get(device)
+    if t is None or t.numel() < n:
+        _DKV_WS[device] = t = torch.empty(n, dtype=F32, device=device)
+    return t
+
+
 def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq, dk, dv):
     T = q.shape[0]
     delta = torch.empty(Hq, T, dtype=F32, device=q.device)
-    hip.call("attn_bwd", q, k, v, o, dout, lse, delta, dq, dk, dv, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, T, Hq, Hkv, D,
+    group = Hq // Hkv
+    hs = 1
+    if seg.prefix is not None:   # shared-prefix segments: split the long query loops of the prefix blocks over the q heads of the group
+        hs = 4 if group % 4 == 0 else (group if 1 < group <= 8 else 1)
+    ws = _dkv_workspace(hs * T * Hkv * 2 * D, q.device) if hs > 1 else None
+    hip.call("attn_bwd", q, k, v, o, dout, lse, delta, dq, dk, dv, ws, hs, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, T, Hq, Hkv, D,
              _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout), _ld(dq), _ld(dk), _ld(dv), 1 if causal else 0, float(scale))
 
 

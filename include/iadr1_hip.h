@@ -115,13 +115,16 @@ int iadr1_f32_bias_to_bf16(float* in_zeroed_after, const void* bias, void* out, 
  * the SC-GRPO policy / reference passes: the G completions of a prompt (REF:...sc_grpo_trainer.py:705-746 runs the prompt G
  * times inside [B*G, P+C] rows) attend to ONE copy of the prompt's keys/values -- same math, the prompt tokens go through
  * every layer once per group instead of G times.  Segments [child_first, +child_count) are those whose prefix is segment i
- * (their queries contribute to segment i's dK/dV); segments must be non-empty; max_seqlen covers own lengths only. */
+ * (their queries contribute to segment i's dK/dV); segments must be non-empty; max_seqlen covers own lengths only.
+ * dkv_ws / head_splits (backward): NULL / 1, or an fp32 scratch of head_splits*T*Hkv*2*D floats: the q heads of each GQA group
+ * are then split over head_splits dK/dV blocks (the query loop of a shared prefix block is G+1 segments long) and the partials
+ * are summed in a fixed order -- deterministic, no atomics. */
 int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start,
                    const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq,
                    long long ldk, long long ldv, long long ldo, int causal, float scale, iadr1_stream_t stream);
 int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                   float* delta, void* dq, void* dk, void* dv, const int* seg_start, const int* seg_end,
-                   const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
+                   float* delta, void* dq, void* dk, void* dv, float* dkv_ws, int head_splits, const int* seg_start,
+                   const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
                    long long ldo, long long lddo, long long lddq, long long lddk, long long lddv, int causal,
                    float scale, iadr1_stream_t stream);
 /* Paged-KV decode attention + cache writes for the group rollout (vLLM's role at REF:...sc_grpo_trainer.py:
