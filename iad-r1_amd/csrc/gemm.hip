@@ -506,6 +506,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // a thread's epilogue column is the same in every round (WAVES*64 is a multiple of BNC): fetch its bias now, not in the tail
+    static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
+    const float bias_pre = (p.out_mode == 0 && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
     // packed weights: fragment (n-tile, 32-k step) is 1 KiB contiguous in lane order -> one fully coalesced load
     const int ksteps = p.K >> 5;
     const bf16_t* wrow[NB];
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
         if (p.out_mode == 0) {
-            if (p.bias) v += bf2f(p.bias[gn]);
+            v += bias_pre;
             ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
         } else if (p.out_mode == 1) {
             ((float*)p.Y)[(long long)gm * p.ldy + gn] = v;

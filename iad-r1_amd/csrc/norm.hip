@@ -41,9 +41,32 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(RmsFwdArgs p) {
             if (p.x32) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
-                for (int sp = 0; sp < p.nsplit; ++sp) {
-                    const float* src = p.x32 + ((long long)sp * p.T + row) * p.ldx + ch * 8;
-                    const f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
+                // slabs are summed in order, four at a time with all eight loads of a group in flight together (a rolled loop over
+                // a run-time slab count issues load -> wait -> add per slab: 8 dependent L2 latencies at ksplit 8)
+                const float* src0 = p.x32 + (long long)row * p.ldx + ch * 8;
+                const long long sstride = (long long)p.T * p.ldx;
+                int sp = 0;
+                for (; sp + 4 <= p.nsplit; sp += 4) {
+                    f32x4_t a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride); b[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride + 4); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[c][e] += a[u][e]; v[c][4 + e] += b[u][e]; }
+                }
+                if (sp + 2 <= p.nsplit) {
+                    f32x4_t a[2], b[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { a[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride); b[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride + 4); }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[c][e] += a[u][e]; v[c][4 + e] += b[u][e]; }
+                    sp += 2;
+                }
+                for (; sp < p.nsplit; ++sp) {
+                    const f32x4_t a = *(const f32x4_t*)(src0 + sp * sstride), b = *(const f32x4_t*)(src0 + sp * sstride + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[c][e] += a[e]; v[c][4 + e] += b[e]; }
                 }
@@ -111,9 +134,32 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
             if (p.x32) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
-                for (int sp = 0; sp < p.nsplit; ++sp) {
-                    const float* src = p.x32 + ((long long)sp * p.T + row) * p.ldx + ch * 8;
-                    const f32x4_t a = *(const f32x4_t*)src, b = *(const f32x4_t*)(src + 4);
+                // slabs are summed in order, four at a time with all eight loads of a group in flight together (a rolled loop over
+                // a run-time slab count issues load -> wait -> add per slab: 8 dependent L2 latencies at ksplit 8)
+                const float* src0 = p.x32 + (long long)row * p.ldx + ch * 8;
+                const long long sstride = (long long)p.T * p.ldx;
+                int sp = 0;
+                for (; sp + 4 <= p.nsplit; sp += 4) {
+                    f32x4_t a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride); b[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride + 4); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[c][e] += a[u][e]; v[c][4 + e] += b[u][e]; }
+                }
+                if (sp + 2 <= p.nsplit) {
+                    f32x4_t a[2], b[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { a[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride); b[u] = *(const f32x4_t*)(src0 + (sp + u) * sstride + 4); }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[c][e] += a[u][e]; v[c][4 + e] += b[u][e]; }
+                    sp += 2;
+                }
+                for (; sp < p.nsplit; ++sp) {
+                    const f32x4_t a = *(const f32x4_t*)(src0 + sp * sstride), b = *(const f32x4_t*)(src0 + sp * sstride + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[c][e] += a[e]; v[c][4 + e] += b[e]; }
                 }
@@ -144,6 +190,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
             for (int e = 0; e < 8; ++e) ss += v[c][e] * v[c][e];
         }
     }
+    // the gains are fetched before the block reduction, not after it (one global latency less on the critical path of a
+    // kernel that is nothing but a latency chain)
+    u32x4_t gw[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) gw[c] = (p.y && c * 256 + t < nchunk) ? *(const u32x4_t*)(p.w + (c * 256 + t) * 8) : (u32x4_t){0, 0, 0, 0};
     ss = block_sum<256>(ss, scratch);
     const float rstd = rsqrtf(ss / (float)p.H + p.eps);
     if (p.rstd && t == 0) p.rstd[row] = rstd;
@@ -152,7 +203,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
     for (int c = 0; c < MC; ++c) {
         const int ch = c * 256 + t;
         if (ch < nchunk) {
-            const u32x4_t g = *(const u32x4_t*)(p.w + ch * 8);
+            const u32x4_t g = gw[c];
             u32x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
