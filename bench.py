@@ -56,8 +56,10 @@ def parse():
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--gen-len", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--micro-batch", type=int, default=0, help="sequences per ref/policy pass; 0 = 64 (3B) / 32 (7B: 20480-token activations of 28 wide layers do not fit next to the fp32 optimizer state)")
     ap.add_argument("--no-repeated-rows-leg", action="store_true", help="skip the extra (untimed) step in the reference's repeated-prompt-rows layout")
+    ap.add_argument("--workload", default="sc_grpo", choices=["sc_grpo", "pa_sft"], help="sc_grpo = the north-star SC-GRPO step (default); pa_sft = BASELINE config 2 (PA-SFT, bs 16, 448^2 image, 512 prompt + 256 supervised tokens)")
+    ap.add_argument("--sft-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -175,6 +177,66 @@ def cpu_baseline(cfg_dict_3b, seconds_budget):
             "sample": f"oracle fp32 fwd+bwd of {G} sequences (S={S}, 448^2 image) through 1 decoder layer + 1 ViT block of the 3B shapes, {reps} reps, {dt:.2f} s each = {tf:.3f} TFLOP/s; scaled to 26.8 TFLOP per sample"}
 
 
+def run_pa_sft(a, cfg, dev, rank, world):
+    """BASELINE.json config 2: one PA-SFT optimizer step = forward(labels) + backward + AdamW on `--sft-batch` sequences of
+    [448^2 image + prompt (512 positions) | 256 supervised response tokens] (llamafactory supervised masking: prompt labels -100)."""
+    from iadr1_amd.params import ParamStore
+    from iadr1_amd.sft import SFTArgs, SFTEngine
+    p = ParamStore(cfg, dev, trainable=True, with_decode_pack=False)
+    p.init_random(seed=0)
+    eng = SFTEngine(cfg, p, SFTArgs(learning_rate=1e-5, weight_decay=0.1, micro_batch_seqs=a.sft_batch))
+    timer = GemmTimer()
+    timer.install()
+    B, P, C = a.sft_batch, a.prompt_len, a.gen_len
+
+    def make(seed):
+        b = synth_batch(cfg, B, P, seed)
+        rs = np.random.RandomState(seed + 1)
+        resp = rs.randint(1000, min(150000, cfg.vision_start_token_id), (B, C)).astype(np.int64)
+        ids = np.concatenate([b["input_ids"], resp], 1)
+        labels = ids.copy()
+        labels[:, :P] = -100
+        return {"input_ids": ids, "attention_mask": np.ones_like(ids), "labels": labels, "pixel_values": b["pixel_values"].to(dev), "image_grid_thw": b["image_grid_thw"]}
+
+    batches = [make(4321 + 7919 * rank + i) for i in range(a.warmup + a.steps)]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k = 0
+    for _ in range(a.warmup):
+        eng.loss_and_grads(batches[k]); eng.optimizer_step(); k += 1
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(a.steps):
+        loss = eng.loss_and_grads(batches[k]); eng.optimizer_step(); k += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+        dist.destroy_process_group()
+    if rank == 0:
+        n_launch, t_gemm, fl_gemm = timer.summary()
+        ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
+        print(json.dumps({
+            "metric": f"PA-SFT samples/sec (bs={B}, img448, {P}+{C} tok) Qwen2.5-VL-{a.model.upper()}", "value": world * B * a.steps / dt, "unit": "samples/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic", "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} PA-SFT step (BASELINE config 2): {B} sequences x (448x448 image + {P} prompt positions + {C} supervised tokens), forward(labels) + backward + AdamW, random-init weights", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
+            "last_loss": loss, "tokens_per_s": world * B * (P + C) * a.steps / dt, "cpu_baseline": None,
+            "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30}}), flush=True)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -198,6 +260,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import fixture_util as fx
         cfg = VLMConfig.from_dict(fx.TINY)
+    if a.workload == "pa_sft":
+        return run_pa_sft(a, cfg, dev, rank, world)
+    if a.micro_batch <= 0:
+        a.micro_batch = 32 if a.model == "7b" else 64
     pol = ParamStore(cfg, dev, trainable=True)
     pol.init_random(seed=0)
     ref = ParamStore(cfg, dev, trainable=False)
