@@ -62,13 +62,14 @@ class GRPOConfig:
     eval_strategy: str = "no"
 
 
-def load_checkpoint(path: str, device, trainable: bool):
-    """HF Qwen2.5-VL checkpoint directory (config.json + *.safetensors) -> (VLMConfig, ParamStore)."""
+def load_checkpoint(path: str, device, trainable: bool, with_decode_pack=None):
+    """HF Qwen2.5-VL / Qwen2-VL checkpoint directory (config.json + *.safetensors) -> (VLMConfig, ParamStore).
+    with_decode_pack=True also builds the decode-packed weights a frozen copy needs to generate (evaluation)."""
     from safetensors import safe_open
 
     with open(os.path.join(path, "config.json")) as f:
         cfg = VLMConfig.from_hf_config(json.load(f))
-    store = ParamStore(cfg, device, trainable=trainable)
+    store = ParamStore(cfg, device, trainable=trainable, with_decode_pack=with_decode_pack)
     sd = {}
     files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
     if not files:

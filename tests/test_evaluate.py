@@ -1,0 +1,41 @@
+"""Evaluation-harness host logic vs golden vectors produced by the reference's own functions (tools/make_golden_eval.py)."""
+import io
+import json
+import os
+
+import iadr1_amd  # noqa: F401
+from iadr1_amd import evaluate
+
+
+def _g(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "eval.json")))
+
+
+def test_get_ans_matches_reference(golden_dir):
+    cases = _g(golden_dir)["get_ans"]
+    assert len(cases) >= 50
+    for c in cases:
+        assert evaluate.get_ans(c["response"], c["options"]) == c["expected"], c
+
+
+def test_parse_conversation_matches_reference(golden_dir):
+    for c in _g(golden_dir)["parse_conversation"]:
+        qs, ans = evaluate.parse_conversation(c["text_gt"])
+        assert qs == c["questions"] and ans == c["answers"]
+
+
+def test_accuracy_table_csv_is_bit_exact(golden_dir):
+    acc = _g(golden_dir)["accuracy"]
+    for flag, key in ((False, "csv"), (True, "csv_overkill_miss")):
+        df, stats = evaluate.accuracy_table(acc["answers"], show_overkill_miss=flag)
+        buf = io.StringIO()
+        df.to_csv(buf)
+        assert buf.getvalue() == acc[key]
+        assert stats == acc["question_stats"]
+
+
+def test_prompt_structure():
+    m = evaluate.build_messages(2)
+    kinds = [p["type"] for p in m[0]["content"]]
+    assert kinds == ["text", "image", "image", "text", "image", "text"] and m[0]["content"][-1]["text"] == "Are there any defects in the test image?"
+    assert [p["type"] for p in evaluate.build_messages(0)[0]["content"]] == ["image", "text"]

@@ -383,3 +383,21 @@ def test_qwen2vl_variant_matches_reference_golden(golden_dir):
         losses.append(eng.loss_and_grads(batch))
         eng.optimizer_step()
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-2, atol=2e-2)
+
+
+def test_eval_harness_greedy_generator_matches_hf_generate(golden_dir):
+    """iadr1_amd.evaluate.GreedyGenerator (the eval scripts' decoding path, G = 1) reproduces HF `generate(do_sample=False)` token ids."""
+    from iadr1_amd.evaluate import GreedyGenerator
+    g = load(golden_dir, "greedy.npz")
+    meta = json.loads(str(g["meta"]))
+    grids = [tuple(x) for x in meta["grids"]]
+    frozen = ParamStore(CFG, DEV, trainable=False, with_decode_pack=True)
+    frozen.load_named(fx.make_weights(fx.TINY, 0))
+    gen = GreedyGenerator(CFG, frozen, max_new_tokens=meta["new_tokens"])
+    gen.cfg.eos_token_id, keep = -1, gen.cfg.eos_token_id       # the golden was generated with eos disabled (min_new_tokens)
+    try:
+        toks = gen.generate({"input_ids": g["prompt_ids"], "attention_mask": g["prompt_mask"], "pixel_values": fx.synth_pixel_values(grids, fx.TINY, seed=meta["seed"]), "image_grid_thw": grids})
+    finally:
+        gen.cfg.eos_token_id = keep
+    P = g["prompt_ids"].shape[1]
+    assert toks.tolist() == g["sequences"][:, P:].tolist()
