@@ -633,13 +633,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_reduce_kernel(AttnArgs p) {
 //   4 waves take pages round-robin, each keeps an online-softmax state; combined through LDS at the end.
 //   Sequences of one GRPO group share their prompt pages through the block table (prefill once per prompt).
 // =====================================================================================================
-// K pages are stored in the MFMA A-fragment order attn_decode reads them in: inside one (page, kv head) block of 32 keys x D,
-// element (key r, dim d) sits at kpk_off(r, d), so fragment (ks, t) = keys perm_row(li) + 4t, dims ks*32 + g*8.. is ONE
-// contiguous 1 KiB wave load (a row-major page makes it 16 half cache lines; decode attention is load-throughput bound).
-__device__ __forceinline__ int kpk_off(int r, int d) {
-    const int li = (r >> 3) * 4 + (r & 3), t = (r >> 2) & 1;
-    return ((((d >> 5) * 2 + t) * 64) + ((d >> 3) & 3) * 16 + li) * 8 + (d & 7);
-}
+// K pages are stored in the MFMA A-fragment order attn_decode reads them in: kpk_off (common.h)
 
 struct DecodeArgs {
     const bf16_t* q;          // [B, Hq*D] (row stride ldq)

@@ -86,3 +86,11 @@ int iadr1_check_launch(const char* what);
 __device__ __forceinline__ long long xpk_off(int m, int k, int K) {
     return (long long)(m >> 6) * K * 64 + (long long)((k >> 5) * 4 + ((m & 63) >> 4)) * 512 + ((m & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
 }
+
+// K cache pages (paged KV of the rollout) are stored in the MFMA A-fragment order attn_decode reads them in: inside one
+// (page, kv head) block of 32 keys x D = 128, element (key r, dim d) sits at kpk_off(r, d), so fragment (ks, t) = keys
+// perm_row(li) + 4t, dims ks*32 + g*8.. is ONE contiguous 1 KiB wave load (a row-major page makes it 16 half cache lines).
+__device__ __forceinline__ int kpk_off(int r, int d) {
+    const int li = (r >> 3) * 4 + (r & 3), t = (r >> 2) & 1;
+    return ((((d >> 5) * 2 + t) * 64) + ((d >> 3) & 3) * 16 + li) * 8 + (d & 7);
+}

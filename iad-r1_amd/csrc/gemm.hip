@@ -484,7 +484,15 @@ struct SkinnyArgs {
     const bf16_t* bias;
     int M, N, K;
     long long ldx, ldw, ldy;
-    int out_mode;  // 0 bf16 (+bias), 1 fp32, 2 fp32 partial slabs [gridDim.z][M][ldy], 3 fused SwiGLU (wide kernel, gate/up tile pairs)
+    int out_mode;  // 0 bf16 (+bias), 1 fp32, 2 fp32 partial slabs [gridDim.z][M][ldy], 3 fused SwiGLU (wide kernel, gate/up tile pairs),
+                   // 4 fused q|k|v epilogue of the decode step (narrow kernel): bias + rotary + K/V cache append
+    // out_mode 4 only: weights packed by iadr1_pack_qkv_rope_bf16 (rotary partners d, d+64 share a 16-column tile)
+    const float* rope_cos;     // [M][D/2]
+    const float* rope_sin;
+    const long long* slot;     // [M] page*32 + offset of the new token, < 0: no cache write
+    bf16_t* kcache;
+    bf16_t* vcache;
+    int Hq, Hkv;
 };
 
 template <int NB, int WAVES>
@@ -508,7 +516,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 
     // a thread's epilogue column is the same in every round (WAVES*64 is a multiple of BNC): fetch its bias now, not in the tail
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
-    const float bias_pre = (p.out_mode == 0 && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
+    const float bias_pre = ((p.out_mode == 0 || p.out_mode == 4) && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
+    const float bias_par = (p.out_mode == 4 && p.bias) ? bf2f(p.bias[min(n0 + ((t % BNC) ^ 8), p.N - 1)]) : 0.f;   // rotary partner's
     // packed weights: fragment (n-tile, 32-k step) is 1 KiB contiguous in lane order -> one fully coalesced load
     const int ksteps = p.K >> 5;
     const bf16_t* wrow[NB];
@@ -570,6 +579,40 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + j * 16 + lq * 4 + e] = acc[i][j][e];
     __syncthreads();
+    if (NB == 1 && p.out_mode == 4) {
+        // Decode-step q|k|v epilogue (replaces the separate rope + kv-store launch): this block owns one 16-column tile = 8
+        // rotary pairs (d, d+64) of one head (q/k heads) or 16 plain dims (v heads).  Same rounding points as the unfused path:
+        // bf16(x.W + b), rotary in fp32 on those bf16 values (TF:153-171), bf16 result.
+        constexpr int D = 128, HALF = 64;
+        const int head = blockIdx.x >> 3, j = blockIdx.x & 7;
+        for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
+            const int m = idx >> 4, n = idx & 15, gm = m_base + m;
+            if (gm >= p.M) continue;
+            float vs = 0.f, vp = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) {
+                vs += red[((size_t)ww * 64 + m) * RLD + n];
+                vp += red[((size_t)ww * 64 + m) * RLD + (n ^ 8)];
+            }
+            vs = bf2f(f2bf(vs + bias_pre));
+            vp = bf2f(f2bf(vp + bias_par));
+            const long long sl = p.slot[gm];
+            const long long page = sl >> 5;
+            const int off = (int)(sl & 31);
+            if (head < p.Hq + p.Hkv) {
+                const int dd = j * 8 + (n & 7);
+                const float cc = p.rope_cos[(long long)gm * HALF + dd], ss = p.rope_sin[(long long)gm * HALF + dd];
+                const float a = n < 8 ? vs : vp, b = n < 8 ? vp : vs;
+                const float r = n < 8 ? a * cc - b * ss : b * cc + a * ss;
+                const int dim = n < 8 ? dd : HALF + dd;
+                if (head < p.Hq) ((bf16_t*)p.Y)[(long long)gm * p.ldy + head * D + dim] = f2bf(r);
+                else if (sl >= 0) p.kcache[(page * p.Hkv + (head - p.Hq)) * 32 * D + kpk_off(off, dim)] = f2bf(r);
+            } else if (sl >= 0) {
+                p.vcache[(page * p.Hkv + (head - p.Hq - p.Hkv)) * (long long)D * 32 + (j * 16 + n) * 32 + off] = f2bf(vs);
+            }
+        }
+        return;
+    }
     for (int idx = t; idx < 64 * BNC; idx += WAVES * 64) {
         const int m = idx / BNC, n = idx - m * BNC;
         const int gm = m_base + m, gn = n0 + n;
@@ -737,6 +780,25 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* W, long 
     }
 }
 
+// Decode-packing of the fused q|k|v matrix for the out_mode-4 epilogue: like pack_weight_kernel, but inside every q and k head
+// the 128 rows are dealt to the 8 column tiles as [8j, 8j+8) ++ [64+8j, 64+8j+8) so a tile holds complete rotary pairs; v heads keep
+// their natural order.  The bias vector is permuted the same way.
+__global__ __launch_bounds__(256) void pack_qkv_rope_kernel(const bf16_t* W, long long ldw, const bf16_t* bias, bf16_t* Wp, bf16_t* bias_p, int n_rope_heads, int N, int K) {
+    const int ksteps = K >> 5;
+    const long long total = (long long)(N >> 4) * ksteps * 64;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long long ts = i >> 6;
+        const int ks = (int)(ts % ksteps);
+        const int tile = (int)(ts / ksteps), lm = lane & 15;
+        const int head = tile >> 3, j = tile & 7;
+        const long long n = head < n_rope_heads ? (long long)head * 128 + (lm < 8 ? 8 * j + lm : 64 + 8 * j + lm - 8) : (long long)tile * 16 + lm;
+        const int k = ks * 32 + (lane >> 4) * 8;
+        *(u32x4_t*)(Wp + i * 8) = *(const u32x4_t*)(W + n * ldw + k);
+        if (ks == 0 && lane < 16 && bias) bias_p[tile * 16 + lm] = bias[n];
+    }
+}
+
 // X[M,K] row-major -> decode-packed (common.h xpk_off); pad rows (M..roundup64) are zero-filled
 __global__ __launch_bounds__(256) void pack_act_kernel(const bf16_t* X, long long ldx, bf16_t* Xp, int M, int K) {
     const int Mp = (M + 63) & ~63;
@@ -806,7 +868,9 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     (void)ldw;
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 3 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny: ksplit > 1 needs out_mode 2 (partial slabs)");
     IADR1_REQUIRE(out_mode != 3 || (N % 128) == 0, "gemm_skinny: fused SwiGLU needs N (= 2*I) to be a multiple of 128, got %d", N);
-    SkinnyArgs p{(const bf16_t*)X, (const bf16_t*)W, Y, (const bf16_t*)bias, M, N, K, ldx, ldw, ldy, out_mode};
+    SkinnyArgs p{};
+    p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
+    p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.out_mode = out_mode;
     const int mz = (M + 63) / 64;
     static bool attr_done = false;
     constexpr int SM1 = 16 * 64 * 17 * 4, SM2 = 8 * 64 * 33 * 4;
@@ -843,6 +907,32 @@ extern "C" int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, in
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, N, K);
     return iadr1_check_launch("pack_weight_bf16");
+}
+
+extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const void* bias_p, void* q_out, const float* rope_cos, const float* rope_sin,
+                                           const long long* slot, void* kcache, void* vcache, int M, int Hq, int Hkv, int D, int K, long long ldx,
+                                           long long ldq, hipStream_t stream) {
+    IADR1_REQUIRE(D == 128, "gemm_qkv_rope_kv: head dim %d not built (128 is)", D);
+    IADR1_REQUIRE(M > 0 && Hq > 0 && Hkv > 0 && (K % 32) == 0 && (ldx % 8) == 0, "gemm_qkv_rope_kv: need K %% 32 == 0 (K=%d)", K);
+    IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wp) & 15) == 0, "gemm_qkv_rope_kv: X/W must be 16-byte aligned");
+    SkinnyArgs p{};
+    p.X = (const bf16_t*)X; p.W = (const bf16_t*)Wp; p.Y = q_out; p.bias = (const bf16_t*)bias_p; p.M = M; p.N = (Hq + 2 * Hkv) * D; p.K = K;
+    p.ldx = ldx; p.ldw = K; p.ldy = ldq; p.out_mode = 4;
+    p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.slot = slot; p.kcache = (bf16_t*)kcache; p.vcache = (bf16_t*)vcache; p.Hq = Hq; p.Hkv = Hkv;
+    constexpr int SM1 = 16 * 64 * 17 * 4;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1); attr_done = true; }
+    hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3(p.N / 16, (M + 63) / 64, 1), dim3(1024), SM1, stream, p);
+    return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
+}
+
+extern "C" int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, void* Wp, void* bias_p, int Hq, int Hkv, int D, int K, hipStream_t stream) {
+    IADR1_REQUIRE(D == 128 && K > 0 && (K % 32) == 0 && (ldw % 8) == 0, "pack_qkv_rope: need D == 128, K %% 32 == 0 (D=%d K=%d)", D, K);
+    const int N = (Hq + 2 * Hkv) * D;
+    long long blocks = ((long long)N * K / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_qkv_rope_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)Wp, (bf16_t*)bias_p, Hq + Hkv, N, K);
+    return iadr1_check_launch("pack_qkv_rope_bf16");
 }
 
 extern "C" int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, hipStream_t stream) {

@@ -99,6 +99,23 @@ def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=
     return out
 
 
+def pack_qkv_rope(w, bias, Hq, Hkv, D, out=None, out_bias=None):
+    """q|k|v weight [N, K] (+ bias [N]) -> decode-packed with rotary partners sharing a tile (for gemm_qkv_rope_kv)."""
+    N, K = w.shape
+    out = out if out is not None else torch.empty(N * K, dtype=BF16, device=w.device)
+    out_bias = out_bias if out_bias is not None else torch.empty(N, dtype=BF16, device=w.device)
+    hip.call("pack_qkv_rope_bf16", w, _ld(w), bias, out, out_bias, Hq, Hkv, D, K)
+    return out, out_bias
+
+
+def gemm_qkv_rope_kv(x, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, Hq, Hkv, D):
+    """Decode step: q_out[:, :Hq*D] = rope(x.Wq^T + bq); K / V rows of the new token appended to the paged cache."""
+    M, K = x.shape
+    xb, ldx = _xarg(x)
+    hip.call("gemm_qkv_rope_kv_bf16", xb, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, M, Hq, Hkv, D, K, ldx, _ld(q_out))
+    return q_out
+
+
 def transpose(x, out=None, pad_rows_to=1):
     """out[C, Rp] = x[R, C]^T; Rp = R rounded up to `pad_rows_to` (extra columns zero) so the result can be a
     K-contiguous GEMM operand (K must be a multiple of 8)."""

@@ -252,6 +252,7 @@ class ParamStore:
                 k = int(np.prod(self.slots[n].shape))
                 self._pk[n] = self.flat_pk[o: o + k]
                 o += _rup(k, 64)
+            self._pkb = {f"layers.{i}.qkv.w": torch.zeros(c.qkv_width, dtype=BF16, device=self.device) for i in range(c.num_hidden_layers)}
 
     # ---- views -------------------------------------------------------------------------------------------
     def w(self, name: str) -> torch.Tensor:
@@ -287,10 +288,22 @@ class ParamStore:
         """Decode-packed shadow (flat) of GEMM weight `name`."""
         return self._pk[name]
 
+    def wpk_bias(self, name: str) -> torch.Tensor:
+        """Bias permuted like the rope-ordered decode pack of q|k|v weight `name`."""
+        return self._pkb[name]
+
+    @property
+    def qkv_rope_packed(self) -> bool:
+        return self.cfg.head_dim == 128
+
     def refresh_decode_pack(self):
         fuse = self.cfg.intermediate_size % 64 == 0
+        c = self.cfg
         for name, dst in self._pk.items():
-            if fuse and name.endswith(".gu.w"):
+            if self.qkv_rope_packed and name.endswith(".qkv.w"):
+                # rotary partners share a tile: the decode q|k|v GEMM applies rope and appends K/V in its epilogue
+                ops.pack_qkv_rope(self.w(name), self.w(name[:-1] + "b"), c.num_attention_heads, c.num_key_value_heads, c.head_dim, out=dst, out_bias=self._pkb[name])
+            elif fuse and name.endswith(".gu.w"):
                 ops.pack_gateup(self.w(name), out=dst)   # gate/up tiles interleaved: the decode GEMM applies SwiGLU in its epilogue
             else:
                 ops.pack_weight(self.w(name), out=dst)

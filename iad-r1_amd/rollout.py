@@ -90,8 +90,11 @@ class Rollout:
                 ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h)
             else:
                 ops.rmsnorm_fwd(None, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)
-            ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
-            ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
+            if P.qkv_rope_packed:   # q|k|v projection + rotary + K/V cache append in one launch
+                ops.gemm_qkv_rope_kv(self.h, P.wpk(b + "qkv.w"), P.wpk_bias(b + "qkv.w"), self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
+            else:
+                ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
+                ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
             ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o)
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), c.hidden_size, out=self.part_o, ksplit=self.ks_o)
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h)

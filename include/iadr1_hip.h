@@ -50,6 +50,15 @@ int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K,
 /* gate|up matrix W[2I,K] -> decode-packed with gate/up 16-row tiles interleaved, for out_mode 3 (fused SwiGLU) of
  * iadr1_gemm_skinny_bf16: Y[M, I] = silu(X.Wgate^T) * (X.Wup^T).  I % 64 == 0. */
 int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, iadr1_stream_t stream);
+/* Decode-step fusion of the q|k|v projection with iadr1_rope_kv_store: Y = X.Wqkv^T + b, rotary on the q and k heads (fp32 on the
+ * bf16-rounded projections, TF:153-171), q heads -> q_out[M, >= Hq*D] (row stride ldq), new K / V rows -> the paged cache at slot[m]
+ * (< 0: skipped).  Wp / bias_p come from iadr1_pack_qkv_rope_bf16: decode-packed with the rotary partners (d, d+64) of every q / k
+ * head dealt into the same 16-column tile.  ldx == 0: X decode-packed.  One launch instead of two per layer of the rollout. */
+int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const void* bias_p, void* q_out, const float* rope_cos,
+                                const float* rope_sin, const long long* slot, void* kcache, void* vcache, int M, int Hq, int Hkv,
+                                int D, int K, long long ldx, long long ldq, iadr1_stream_t stream);
+int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, void* Wp, void* bias_p, int Hq, int Hkv, int D, int K,
+                             iadr1_stream_t stream);
 /* X[M,K] row-major -> decode-packed activations Xp (buffer of roundup(M,64)*K elements; pad rows zeroed).  K % 32 == 0. */
 int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);

@@ -439,6 +439,33 @@ def test_decode_attention_and_kv_store(Hq, Hkv, B, lens):
         close(o[b], ref, 2e-2, 2e-2, f"decode b={b} n={n}")
 
 
+@pytest.mark.parametrize("Hq,Hkv,M", [(16, 2, 64), (2, 1, 5), (28, 4, 33)])
+def test_fused_qkv_rope_kv_equals_gemm_then_rope_kv_store(Hq, Hkv, M):
+    """Decode-step fusion (iadr1_gemm_qkv_rope_kv_bf16) == skinny GEMM + bias, then rope_kv_store: q values and both cache pages."""
+    D, K = 128, 256
+    N = (Hq + 2 * Hkv) * D
+    x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
+    ang = torch.rand(M, D // 2, generator=torch.Generator().manual_seed(3)) * 6.28
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    npages = M + 2
+    slot = (torch.arange(M) * 32 + (torch.arange(M) * 7) % 32 + 32).to(DEV)
+    slot[M // 2] = -1                                                        # a finished sequence: no cache write
+    kc0, vc0 = rnd(npages, Hkv, 32, D, seed=4), rnd(npages, Hkv, D, 32, seed=5)
+    # unfused
+    qkv = ops.gemm_skinny(x, ops.pack_weight(w), N, bias=bias)
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    ops.rope_kv_store(qkv, cos, sin, slot, kc1, vc1, Hq, Hkv, D)
+    # fused, X both row-major and decode-packed
+    wp, bp = ops.pack_qkv_rope(w, bias, Hq, Hkv, D)
+    for xin in (x, ops.pack_act(x)):
+        kc2, vc2 = kc0.clone(), vc0.clone()
+        q2 = torch.zeros(M, N, dtype=BF, device=DEV)
+        ops.gemm_qkv_rope_kv(xin, wp, bp, q2, cos, sin, slot, kc2, vc2, Hq, Hkv, D)
+        close(q2[:, : Hq * D], qkv[:, : Hq * D], 1e-2, 1e-2, "fused q")       # fp32 rotary may contract differently: <= 1 bf16 ulp
+        close(kc2, kc1, 1e-2, 1e-2, "fused K cache")
+        assert torch.equal(vc2, vc1)                                          # V is a plain copy of the bf16 projection
+
+
 # ------------------------------------------------------------------------------------------------ losses
 def test_logprob_dlogits_grpo():
     R, V = 37, 1288
