@@ -28,6 +28,15 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
+def _skinny_pmc():
+    """HBM-side bytes of the decode step's heaviest kernel (gate|up stream) from the PMC passes recorded under profiles/."""
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r01_skinny_pmc.json")))
+        return {"kernel": k["kernel"], "bytes_per_launch": k["traffic_bytes"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"], "MNK": k["MNK"], "source": "profiles/r01_skinny_pmc.json"}
+    except Exception:
+        return None
+
+
 def decode_roofline(cfg, pol, events, n_seq, gen_len):
     """HBM roofline of the rollout's decode step (one hipGraph replay = ~250 kernels, 64 live sequences): algorithmic bytes per step
     = every decode-packed weight once + the K/V of every live context, / the HIP-event time of the replay loop (events on the
@@ -43,7 +52,7 @@ def decode_roofline(cfg, pol, events, n_seq, gen_len):
     ach = (w_bytes + kv_bytes) / (ms / steps * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "decode step (hipGraph: skinny GEMMs on decode-packed weights + paged attention + RMSNorm + sampling)", "achieved": ach,
             "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "ms_per_decode_step": ms / steps, "decode_steps": steps,
-            "algorithmic_bytes_per_step": {"weights": w_bytes, "kv": kv_bytes}, "traffic": None}
+            "algorithmic_bytes_per_step": {"weights": w_bytes, "kv": kv_bytes}, "traffic": _skinny_pmc()}
 
 
 def parse():
