@@ -650,8 +650,11 @@ struct DecodeArgs {
 template <int D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
     constexpr int KS = D / 32, DT = D / 16, PAGE = 32;
-    __shared__ float red_m[WAVES][16], red_l[WAVES][16];
-    __shared__ float red_o[WAVES][D][16 + 1];
+    extern __shared__ float dsm[];
+    const int GS = (p.Hq / p.Hkv <= 8) ? 9 : 17;      // q-head columns kept per d (+1 pad): only `group` of the 16 MFMA columns are real
+    float* red_m = dsm;                                // [WAVES][16]
+    float* red_l = dsm + WAVES * 16;                   // [WAVES][16]
+    float* red_o = dsm + 2 * WAVES * 16;               // [WAVES][D][GS]
     const int b = blockIdx.x, kvh = blockIdx.y, group = p.Hq / p.Hkv;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
     const int n = p.ctx_len[b];
@@ -722,24 +725,26 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
     }
     lsum += __shfl_xor(lsum, 16, WAVE);
     lsum += __shfl_xor(lsum, 32, WAVE);
-    if (g == 0) { red_m[w][li] = m; red_l[w][li] = lsum; }
+    if (g == 0) { red_m[w * 16 + li] = m; red_l[w * 16 + li] = lsum; }
+    if (li < GS - 1) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red_o[w][dt * 16 + g * 4 + e][li] = acc[dt][e];
+            for (int e = 0; e < 4; ++e) red_o[(w * D + dt * 16 + g * 4 + e) * GS + li] = acc[dt][e];
+    }
     __syncthreads();
     // combine the 4 partial states: thread -> (q head j, d)
     for (int idx = threadIdx.x; idx < group * D; idx += WAVES * 64) {
         const int j = idx / D, d = idx - j * D;
-        float M = red_m[0][j];
+        float M = red_m[j];
 #pragma unroll
-        for (int ww = 1; ww < WAVES; ++ww) M = fmaxf(M, red_m[ww][j]);
+        for (int ww = 1; ww < WAVES; ++ww) M = fmaxf(M, red_m[ww * 16 + j]);
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) {
-            const float f = (red_m[ww][j] == -INFINITY) ? 0.f : exp2f(red_m[ww][j] - M);
-            num += f * red_o[ww][d][j];
-            den += f * red_l[ww][j];
+            const float f = (red_m[ww * 16 + j] == -INFINITY) ? 0.f : exp2f(red_m[ww * 16 + j] - M);
+            num += f * red_o[(ww * D + d) * GS + j];
+            den += f * red_l[ww * 16 + j];
         }
         p.o[p.ldo ? (long long)b * p.ldo + (kvh * group + j) * D + d : xpk_off(b, (kvh * group + j) * D + d, p.Hq * D)] = f2bf(den > 0.f ? num / den : 0.f);
     }
@@ -899,7 +904,20 @@ extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* 
     IADR1_REQUIRE(B > 0 && Hq % Hkv == 0 && Hq / Hkv <= 16, "attn_decode: GQA group must be <= 16");
     IADR1_REQUIRE((ldq % 8) == 0, "attn_decode: ldq must be a multiple of 8");
     DecodeArgs p{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale};
-    hipLaunchKernelGGL((attn_decode_kernel<128, 8>), dim3(B, Hkv), dim3(512), 0, stream, p);
+    // 16 waves per (sequence, kv head) block: a wave then walks ~1.5 pages instead of ~3 at ctx ~ 640 (the kernel is a chain of dependent
+    // page loads on only B*Hkv = 128 CUs); IADR1_DECODE_ATTN_WAVES=8 keeps the 8-wave form
+    static int waves = 0;
+    if (!waves) { const char* e = getenv("IADR1_DECODE_ATTN_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 16; }
+    const int gs = (Hq / Hkv <= 8) ? 9 : 17;
+    if (waves == 16) {
+        const int smem = (2 * 16 * 16 + 16 * 128 * gs) * 4;
+        set_smem(attn_decode_kernel<128, 16>, smem);
+        hipLaunchKernelGGL((attn_decode_kernel<128, 16>), dim3(B, Hkv), dim3(1024), smem, stream, p);
+    } else {
+        const int smem = (2 * 8 * 16 + 8 * 128 * gs) * 4;
+        set_smem(attn_decode_kernel<128, 8>, smem);
+        hipLaunchKernelGGL((attn_decode_kernel<128, 8>), dim3(B, Hkv), dim3(512), smem, stream, p);
+    }
     return iadr1_check_launch("attn_decode");
 }
 
