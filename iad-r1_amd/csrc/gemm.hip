@@ -748,6 +748,104 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
     }
 }
 
+// Persistent variant for the big decode streams (gate|up, down, lm_head): ONE block per CU stays resident, keeps the X fragments of
+// its waves' k-steps in VGPRs for the whole launch (X is read once per CU instead of once per 64-column block: the X re-read was
+// 3 us of the 24.6 us gate|up call) and walks groups of two column tiles; the W loads of the next group are issued BEFORE the LDS
+// reduction of the current one, so the weight stream does not stop during epilogues (with one-shot blocks every block of the grid
+// streams, then every block reduces).  tools/decode_stream.py on weights that really come from HBM: 19.8 vs 24.9 us on the 90 MB
+// gate|up stream (4.55 TB/s; a plain read of the same bytes runs at 5.4).  grid.x = nz * bps blocks: slice z = blockIdx.x / bps of K
+// (split-K partial slabs, out_mode 2), block b = blockIdx.x % bps takes tile groups b, b + bps, ...
+template <int WAVES, int KSW>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs p) {
+    constexpr int TPI = 2, RLD = 16 * TPI + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = (float*)smem_raw;  // [WAVES][64][RLD]
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
+    const int b = blockIdx.x, bps = gridDim.x;
+    const int m_base = blockIdx.y * 64;
+    const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks)
+    // X fragments of this wave's k-steps w + j*WAVES: loaded once, resident for the whole launch
+    const bool xpk = p.ldx == 0;
+    const bf16_t* xbase = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + l * 8 : p.X + (long long)min(m_base + lm, p.M - 1) * p.ldx + lq * 8;
+    const long long xgroup = xpk ? 512 : 16 * p.ldx, xstep = xpk ? 2048 : 32;
+    const int xgroups_ok = xpk ? 4 : (p.M - m_base - lm + 15) / 16;
+    bf16x8_t xf[KSW][4];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xf[j][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)(w + j * WAVES) * xstep));
+    const bf16_t* wlane = p.W + (long long)w * 512 + l * 8;
+    const int ngroups = p.N / (16 * TPI);
+    bf16x8_t wf[KSW][TPI];
+    auto loadw = [&](int g) {
+        const bf16_t* wb = wlane + (long long)g * TPI * tile_stride;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j)
+#pragma unroll
+            for (int tt = 0; tt < TPI; ++tt) wf[j][tt] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + tt * tile_stride + j * (WAVES * 512))));
+    };
+    int g = b;
+    if (g < ngroups) loadw(g);
+    float* mine = red + (size_t)w * 64 * RLD;
+    for (; g < ngroups; g += bps) {
+        f32x4_t acc[4][TPI];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KSW; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][tt], xf[j][i], acc[i][tt], 0, 0, 0);
+        if (g + bps < ngroups) loadw(g + bps);   // in flight during the reduction below
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tt = 0; tt < TPI; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + tt * 16 + lq * 4 + e] = acc[i][tt][e];
+        __syncthreads();
+        const int n0 = g * 16 * TPI;
+        if (p.out_mode == 3) {
+            // tiles (2g, 2g+1) are the GATE and UP projections of the same 16 output columns (iadr1_pack_gateup_bf16)
+            for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
+                const int m = idx >> 4, n = idx & 15, gm = m_base + m, gn = g * 16 + n;
+                if (gm >= p.M) continue;
+                float gsum = 0.f, usum = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ++ww) {
+                    gsum += red[((size_t)ww * 64 + m) * RLD + n];
+                    usum += red[((size_t)ww * 64 + m) * RLD + 16 + n];
+                }
+                gsum = bf2f(f2bf(gsum));
+                usum = bf2f(f2bf(usum));
+                const float sg = bf2f(f2bf(gsum / (1.f + __expf(-gsum))));
+                ((bf16_t*)p.Y)[p.ldy ? (long long)gm * p.ldy + gn : xpk_off(gm, gn, p.N >> 1)] = f2bf(sg * usum);
+            }
+        } else {
+            for (int idx = t; idx < 64 * 16 * TPI; idx += WAVES * 64) {
+                const int m = idx / (16 * TPI), n = idx - m * (16 * TPI), gm = m_base + m, gn = n0 + n;
+                if (gm >= p.M) continue;
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+                if (p.out_mode == 0) {
+                    if (p.bias) v += bf2f(p.bias[gn]);
+                    ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
+                } else if (p.out_mode == 1) {
+                    ((float*)p.Y)[(long long)gm * p.ldy + gn] = v;
+                } else {
+                    ((float*)p.Y)[(long long)gm * p.ldy + gn] = v;   // out_mode 2 with a single K slice
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Decode-packing of a fused gate|up matrix W[2I, K] for the SwiGLU-fused skinny GEMM: packed 16-row tile 2q holds
 // gate rows [16q, 16q+16), tile 2q+1 the matching up rows [I+16q, ...), so one block owns both halves of its columns.
 __global__ __launch_bounds__(256) void pack_gateup_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int I, int K) {
@@ -889,6 +987,31 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     }
     // wide kernels: NB=8 (128 columns / block) for the big-N streams (gate|up, lm_head); NB=4 with K split over
     // grid.z for the long-K narrow-N down projection; the narrow kernel for the small projections (latency-bound)
+    // persistent X-resident kernel for the big un-split streams (gate|up, lm_head): K = 32 * 8 waves * KSW exactly, >= 2 tile groups per CU.
+    // Not for the split-K down projection (2 groups per block: two exposed memory latencies, 18.9 vs 14.2 us measured).
+    {
+        static int pers = -1, ncu = 0;
+        constexpr int SMP = 8 * 64 * 33 * 4;
+        if (pers < 0) {
+            const char* e = getenv("IADR1_SKINNY_PERS");
+            pers = e ? atoi(e) : 1;
+            int dev = 0;
+            hipDeviceProp_t prop;
+            (void)hipGetDevice(&dev);
+            ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
+            (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
+            (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
+        }
+        const int ksw = K / 256;
+        if (pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu) {
+            const dim3 grid(ncu, mz, 1), block(512);
+            if (ksw == 8) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 8>), grid, block, SMP, stream, p);
+            else if (ksw == 6) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 6>), grid, block, SMP, stream, p);
+            else hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 4>), grid, block, SMP, stream, p);
+            return iadr1_check_launch("gemm_skinny_bf16");
+        }
+    }
     // with decode-packed X the X fragments are cheap coalesced L2 reads, and 64-column blocks (two co-resident per CU, 344
     // blocks on the 3B gate|up) beat 128-column ones: 24.6 vs 33.7 us on the 90 MB gate|up stream (tools/decode_stream.py)
     const bool big = (N >= 8192 && ksplit == 1) || out_mode == 3;

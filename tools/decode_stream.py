@@ -20,6 +20,7 @@ wide_names = {0: "wide NB8 W8 d2 Wonly", 1: "wide NB8 W8 d2 W+X", 2: "wide NB8 W
               6: "wide NB4 W8 d4 Wonly", 7: "wide NB4 W8 d4 full", 8: "wide NB2 W8 d4 Wonly", 9: "wide NB2 W8 d4 full", 10: "wide NB4 W4 d4 Wonly", 11: "wide NB4 W4 d4 full",
               20: "pkx NB8 W8 d2 W+X", 21: "pkx NB8 W8 d2 +mfma", 22: "pkx NB8 W8 d2 full", 23: "pkx NB4 W8 d2 W+X", 24: "pkx NB4 W8 d2 +mfma", 25: "pkx NB4 W8 d2 full",
               26: "pkx NB4 W8 d1 full", 27: "pkx NB4 W8 d4 full", 28: "pkx NB2 W8 d2 full", 29: "pkx NB2 W8 d4 full", 30: "pkx NB4 W4 d2 full", 31: "pkx NB4 W4 d4 full", 32: "pkx NB8 W4 d2 full", 33: "pkx NB8 W8 d1 full",
+              40: "pkx pers W8 T2 g256", 41: "pkx pers W8 T1 g256", 42: "pkx pers W8 T2 g512", 43: "pkx pers W16 T1 g256", 44: "pkx pers W16 T2 g256", 45: "pkx pers W8 T4 g256", 46: "pkx pers W8 T1 g512", 47: "pkx pers W16 T1 g512", 48: "pkx pers W4 T2 g256", 49: "pkx pers W4 T4 g256", 50: "pkx pers W4 T1 g256",
               12: "ldsx W4 T1 KC256 d4", 13: "ldsx W4 T1 KC256 d8", 14: "ldsx W8 T1 KC256 d8", 15: "ldsx W4 T2 KC256 d4", 16: "ldsx W2 T2 KC256 d4", 17: "ldsx W4 T1 KC512 d8", 18: "ldsx W2 T1 KC256 d8"}
 only = [int(a) for a in sys.argv[1:]]
 for N, K, NL in [(22016, 2048, 24)]:
@@ -42,14 +43,14 @@ for N, K, NL in [(22016, 2048, 24)]:
     ref = X.float() @ Ws[0].float().t()
     for v, nm in wide_names.items():
         if only and v not in only: continue
-        cols = {0: 128, 1: 128, 2: 128, 3: 128, 4: 64, 5: 64, 6: 64, 7: 64, 8: 32, 9: 32, 10: 64, 11: 64, 20: 128, 21: 128, 22: 128, 23: 64, 24: 64, 25: 64, 26: 64, 27: 64, 28: 32, 29: 32, 30: 64, 31: 64, 32: 128, 33: 128, 12: 64, 13: 64, 14: 128, 15: 128, 16: 64, 17: 64, 18: 32}[v]
+        cols = {0: 128, 1: 128, 2: 128, 3: 128, 4: 64, 5: 64, 6: 64, 7: 64, 8: 32, 9: 32, 10: 64, 11: 64, 40: 32, 41: 16, 42: 32, 43: 16, 44: 32, 45: 64, 46: 16, 47: 16, 48: 32, 49: 64, 50: 16, 20: 128, 21: 128, 22: 128, 23: 64, 24: 64, 25: 64, 26: 64, 27: 64, 28: 32, 29: 32, 30: 64, 31: 64, 32: 128, 33: 128, 12: 64, 13: 64, 14: 128, 15: 128, 16: 64, 17: 64, 18: 32}[v]
         if N % cols: continue
         out.zero_()
         Xa = Xpk if nm.startswith("pkx") else X
         L.run_wide(v, ctypes.c_void_p(Wp[0].data_ptr()), ctypes.c_void_p(Xa.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, K, st())
         torch.cuda.synchronize()
         err = ""
-        if "full" in nm or "ldsx" in nm:
+        if "full" in nm or "ldsx" in nm or "pers" in nm:
             err = f"relerr {((out - ref).abs().max() / ref.abs().max()).item():.1e}"
         us = timeit(lambda i: L.run_wide(v, ctypes.c_void_p(Wp[i % NL].data_ptr()), ctypes.c_void_p(Xa.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, K, st()), NL)
         print(f"  {v:2d} {nm:22s} {us:8.1f} us {nbytes/us/1e6:6.2f} TB/s  blocks {N//cols:5d} {err}", flush=True)

@@ -145,6 +145,64 @@ __global__ __launch_bounds__(WAVES * 64) void ldsx_k(const uint16_t* __restrict_
             for (int e = 0; e < 4; ++e) out[(long long)(i * 16 + lm) * N + (tile0 + j) * 16 + lq * 4 + e] = acc[i][j][e];
 }
 
+// ---- 4. persistent blocks, X register-resident: one block per CU keeps the X fragments of its waves' k-steps in VGPRs for the
+// whole kernel and walks column-tile groups; the W loads of the next group are issued before the LDS reduction of the current one.
+template <int WAVES, int TPI, int KSW>
+__global__ __launch_bounds__(WAVES * 64) void pers_k(const uint16_t* __restrict__ Wp, const uint16_t* __restrict__ Xp, float* out, int N, int K) {
+    extern __shared__ float red[];   // [WAVES][64][16*TPI + 1]
+    constexpr int RLD = 16 * TPI + 1;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
+    const int ksteps = K >> 5;
+    const long long tile_stride = (long long)ksteps * 512;
+    u32x4_t xf[KSW][4];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[j][i] = *(const u32x4_t*)(Xp + (((long long)(w + j * WAVES) * 4 + i) * 64 + l) * 8);
+    const int ngroups = N / (16 * TPI);
+    u32x4_t wf[KSW][TPI];
+    auto loadw = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < KSW; ++j)
+#pragma unroll
+            for (int tt = 0; tt < TPI; ++tt)
+                wf[j][tt] = __builtin_nontemporal_load((const u32x4_t*)(Wp + ((long long)g * TPI + tt) * tile_stride + (long long)(w + j * WAVES) * 512 + l * 8));
+    };
+    int g = blockIdx.x;
+    if (g < ngroups) loadw(g);
+    float* mine = red + (size_t)w * 64 * RLD;
+    for (; g < ngroups; g += gridDim.x) {
+        f32x4_t acc[4][TPI];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = (f32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < KSW; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int tt = 0; tt < TPI; ++tt)
+                    acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j][tt]), __builtin_bit_cast(bf16x8_t, xf[j][i]), acc[i][tt], 0, 0, 0);
+        if (g + (int)gridDim.x < ngroups) loadw(g + gridDim.x);   // flies during the reduction below
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tt = 0; tt < TPI; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + tt * 16 + lq * 4 + e] = acc[i][tt][e];
+        __syncthreads();
+        for (int idx = t; idx < 64 * 16 * TPI; idx += WAVES * 64) {
+            const int m = idx / (16 * TPI), n = idx - m * (16 * TPI);
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+            out[(long long)m * N + g * 16 * TPI + n] = v;
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int run_pure(int variant, const void* p, long long bytes, uint32_t* out, hipStream_t st) {
     const long long n16 = bytes / 16;
     switch (variant) {
@@ -192,6 +250,20 @@ extern "C" int run_wide(int variant, const void* Wp, const void* X, float* out, 
         case 31: LW(4, 4, 4, 6); break;
         case 32: LW(8, 4, 2, 6); break;
         case 33: LW(8, 8, 1, 6); break;
+#define LP(WV, TPI, KSW, GRID) do { constexpr int SM = WV * 64 * (16 * TPI + 1) * 4; \
+    if (SM > 48 * 1024) (void)hipFuncSetAttribute((const void*)pers_k<WV, TPI, KSW>, hipFuncAttributeMaxDynamicSharedMemorySize, SM); \
+    hipLaunchKernelGGL((pers_k<WV, TPI, KSW>), dim3(GRID), dim3(WV * 64), SM, st, (const uint16_t*)Wp, (const uint16_t*)X, out, N, K); } while (0)
+        case 40: LP(8, 2, 8, 256); break;
+        case 41: LP(8, 1, 8, 256); break;
+        case 42: LP(8, 2, 8, 512); break;
+        case 43: LP(16, 1, 4, 256); break;
+        case 44: LP(16, 2, 4, 256); break;
+        case 45: LP(8, 4, 8, 256); break;
+        case 46: LP(8, 1, 8, 512); break;
+        case 47: LP(16, 1, 4, 512); break;
+        case 48: LP(4, 2, 16, 256); break;
+        case 49: LP(4, 4, 16, 256); break;
+        case 50: LP(4, 1, 16, 256); break;
         case 12: LX(4, 1, 256, 4); break;   // 64 cols / block
         case 13: LX(4, 1, 256, 8); break;
         case 14: LX(8, 1, 256, 8); break;   // 128 cols / block
