@@ -518,6 +518,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
     const float bias_pre = ((p.out_mode == 0 || p.out_mode == 4) && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
     const float bias_par = (p.out_mode == 4 && p.bias) ? bf2f(p.bias[min(n0 + ((t % BNC) ^ 8), p.N - 1)]) : 0.f;   // rotary partner's
+    // out_mode 4 (one output per thread when WAVES*64 == 64*16): rotary factors and the cache slot are fetched up front as well
+    float pre_cos = 1.f, pre_sin = 0.f;
+    long long pre_slot = -1;
+    if (NB == 1 && p.out_mode == 4) {
+        const int gm0 = min(m_base + (t >> 4), p.M - 1), dd0 = (blockIdx.x & 7) * 8 + (t & 7);
+        pre_slot = p.slot[gm0];
+        if ((int)(blockIdx.x >> 3) < p.Hq + p.Hkv) { pre_cos = p.rope_cos[(long long)gm0 * 64 + dd0]; pre_sin = p.rope_sin[(long long)gm0 * 64 + dd0]; }
+    }
     // packed weights: fragment (n-tile, 32-k step) is 1 KiB contiguous in lane order -> one fully coalesced load
     const int ksteps = p.K >> 5;
     const bf16_t* wrow[NB];
@@ -596,12 +604,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             }
             vs = bf2f(f2bf(vs + bias_pre));
             vp = bf2f(f2bf(vp + bias_par));
-            const long long sl = p.slot[gm];
+            const bool first = idx == t && WAVES * 64 == 64 * 16;   // the prefetched values belong to this (m, n)
+            const long long sl = first ? pre_slot : p.slot[gm];
             const long long page = sl >> 5;
             const int off = (int)(sl & 31);
             if (head < p.Hq + p.Hkv) {
                 const int dd = j * 8 + (n & 7);
-                const float cc = p.rope_cos[(long long)gm * HALF + dd], ss = p.rope_sin[(long long)gm * HALF + dd];
+                const float cc = first ? pre_cos : p.rope_cos[(long long)gm * HALF + dd], ss = first ? pre_sin : p.rope_sin[(long long)gm * HALF + dd];
                 const float a = n < 8 ? vs : vp, b = n < 8 ? vp : vs;
                 const float r = n < 8 ? a * cc - b * ss : b * cc + a * ss;
                 const int dim = n < 8 ? dd : HALF + dd;
