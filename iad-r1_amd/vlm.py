@@ -61,6 +61,7 @@ class Engine:
         vd = c.v_head_dim
         self.v_inv_freq = 1.0 / (10000.0 ** (np.arange(0, vd // 2, 2, dtype=np.float32) / (vd // 2)))
         self.lm_chunk = 4096
+        self.keep_logits_bytes = 24 << 30
         self._ws = {}
 
     def _workspace(self, key, shape, dtype):
@@ -477,14 +478,18 @@ class Engine:
         logp = torch.empty(R, dtype=F32, device=self.dev)
         lse = torch.empty(R, dtype=F32, device=self.dev)
         V = W.shape[0]
-        lg_buf = self._workspace("lm_logits", (min(R, self.lm_chunk), V), F32)
+        # with `save`, the fp32 logits of all R rows are kept for the backward (10 GB for 16384 x 151936: nothing on a 288 GB part)
+        # instead of being recomputed chunk by chunk; without it only one chunk is ever alive
+        keep = save and R * V * 4 <= self.keep_logits_bytes
+        lg_all = self._workspace("lm_logits_all", (R, V), F32) if keep else None
+        lg_buf = None if keep else self._workspace("lm_logits", (min(R, self.lm_chunk), V), F32)
         for r0 in range(0, R, self.lm_chunk):
             r1 = min(R, r0 + self.lm_chunk)
-            lg = ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[: r1 - r0])
+            lg = ops.gemm_nt(hsel[r0:r1], W, out=lg_all[r0:r1] if keep else lg_buf[: r1 - r0])
             lp, ls = ops.logprob_rows(lg, targets[r0:r1])
             logp[r0:r1] = lp
             lse[r0:r1] = ls
-        ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0], "dup": dup} if save else None
+        ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0], "dup": dup, "logits": lg_all} if save else None
         return logp, ctx
 
     def logprobs_backward(self, g: torch.Tensor, ctx) -> torch.Tensor:
@@ -497,13 +502,14 @@ class Engine:
         dhsel = torch.empty(R, H, dtype=BF16, device=self.dev)
         V = W.shape[0]
         nc = min(R, self.lm_chunk)
-        lg_buf = self._workspace("lm_logits", (nc, V), F32)
+        kept = ctx.get("logits")
+        lg_buf = None if kept is not None else self._workspace("lm_logits", (nc, V), F32)
         dl_buf = self._workspace("lm_dlogits", (nc, V), BF16)
         dlT_buf = self._workspace("lm_dlogits_t", (V, (nc + 7) // 8 * 8), BF16)
         for r0 in range(0, R, self.lm_chunk):
             r1 = min(R, r0 + self.lm_chunk)
             n = r1 - r0
-            lg = ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[:n])
+            lg = kept[r0:r1] if kept is not None else ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[:n])
             dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1], out=dl_buf[:n])
             ops.gemm_nt(dl, WT, out=dhsel[r0:r1])
             np8 = (n + 7) // 8 * 8
