@@ -155,6 +155,7 @@ struct SampleArgs {
     int suppress;       // token id forced to -inf (e.g. EOS for fixed-length benchmarking), -1 = none
     uint32_t seed_lo, seed_hi, step;
     const unsigned* step_ptr;  // optional device-resident step counter (hipGraph replays freeze kernel arguments)
+    const unsigned long long* seed_ptr;  // optional device-resident seed, same reason: a new seed per rollout must not force a re-capture
 };
 
 __device__ __forceinline__ int eff_k(const SampleArgs& p) {
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(NT) void sample_stage2(SampleArgs p) {
             ++nk;
         }
         const uint32_t step = p.step_ptr ? *p.step_ptr : p.step;
-        const float u = philox_uniform(p.seed_lo, p.seed_hi, (uint32_t)row, step) * kept;
+        const unsigned long long sd = p.seed_ptr ? *p.seed_ptr : (((unsigned long long)p.seed_hi << 32) | p.seed_lo);
+        const float u = philox_uniform((uint32_t)sd, (uint32_t)(sd >> 32), (uint32_t)row, step) * kept;
         float cum = 0.f;
         int pick = nk - 1;
         for (int j = 0; j < nk; ++j) {
@@ -256,14 +258,14 @@ extern "C" long long iadr1_sample_workspace_bytes(int B) { return (long long)B *
 
 extern "C" int iadr1_sample_topk_topp(const float* logits, long long ld, long long* out, void* workspace, int B, int V, float temperature,
                                       int top_k, float top_p, int suppress_token, unsigned long long seed, unsigned step,
-                                      const unsigned* step_ptr, hipStream_t stream) {
+                                      const unsigned* step_ptr, const unsigned long long* seed_ptr, hipStream_t stream) {
     IADR1_REQUIRE(B > 0 && V > 0 && workspace != nullptr, "sample: empty problem or missing workspace (iadr1_sample_workspace_bytes)");
     IADR1_REQUIRE(V <= NCHUNK * NT * ITEMS, "sample: V=%d exceeds the built maximum %d", V, NCHUNK * NT * ITEMS);
     IADR1_REQUIRE(top_k <= MAXK, "sample: top_k=%d exceeds the built maximum %d", top_k, MAXK);
     IADR1_REQUIRE(top_p > 0.f && top_p <= 1.f, "sample: top_p must be in (0,1]");
     float* cv = (float*)workspace;
     int* ci = (int*)(cv + (long long)B * NCHUNK * MAXK);
-    SampleArgs p{logits, ld, out, cv, ci, B, V, temperature, top_p, top_k, suppress_token, (uint32_t)seed, (uint32_t)(seed >> 32), step, step_ptr};
+    SampleArgs p{logits, ld, out, cv, ci, B, V, temperature, top_p, top_k, suppress_token, (uint32_t)seed, (uint32_t)(seed >> 32), step, step_ptr, seed_ptr};
     hipLaunchKernelGGL(sample_stage1, dim3(NCHUNK, B), dim3(NT), 0, stream, p);
     hipLaunchKernelGGL(sample_stage2, dim3(B), dim3(NT), 0, stream, p);
     return iadr1_check_launch("sample_topk_topp");

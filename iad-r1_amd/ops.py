@@ -343,7 +343,7 @@ def grpo_loss(logp, ref_logp, adv, mask, beta, n_total_rows=None):
 _sample_ws = {}
 
 
-def sample(logits32, temperature, top_k, top_p, seed, step, suppress_token=-1, step_ptr=None, out=None):
+def sample(logits32, temperature, top_k, top_p, seed, step, suppress_token=-1, step_ptr=None, out=None, seed_ptr=None):
     B, V = logits32.shape
     o = out if out is not None else torch.empty(B, dtype=torch.int64, device=logits32.device)
     key = (B, logits32.device)
@@ -351,7 +351,7 @@ def sample(logits32, temperature, top_k, top_p, seed, step, suppress_token=-1, s
     if ws is None:
         ws = torch.empty(hip.lib().iadr1_sample_workspace_bytes(B), dtype=torch.uint8, device=logits32.device)
         _sample_ws[key] = ws
-    hip.call("sample_topk_topp", logits32, _ld(logits32), o, ws, B, V, float(temperature), int(top_k), float(top_p), int(suppress_token), int(seed), int(step), step_ptr)
+    hip.call("sample_topk_topp", logits32, _ld(logits32), o, ws, B, V, float(temperature), int(top_k), float(top_p), int(suppress_token), int(seed), int(step), step_ptr, seed_ptr)
     return o
 
 

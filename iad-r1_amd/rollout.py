@@ -73,7 +73,8 @@ class Rollout:
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.graph = None
         self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
-        self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
 
     # ---- one decode step (graph body) -------------------------------------------------------------------------
     def _decode_step(self):
@@ -111,7 +112,7 @@ class Rollout:
 
     def _sample_and_advance(self):
         s = self.sampling
-        ops.sample(self.logits, s["temperature"], s["top_k"], s["top_p"], s["seed"], 0, suppress_token=s["suppress"], step_ptr=self.step, out=self.sampled)
+        ops.sample(self.logits, s["temperature"], s["top_k"], s["top_p"], 0, 0, suppress_token=s["suppress"], step_ptr=self.step, out=self.sampled, seed_ptr=self.seed_dev)
         ops.decode_advance(self.sampled, self.cur_tok, self.out_tokens, self.pos, self.ctx_len, self.slot, self.block_table, self.finished, self.step, s["eos"], s["pad"])
 
     def _capture(self):
@@ -138,7 +139,8 @@ class Rollout:
         N = Bp * G
         assert N == self.N, f"rollout was built for {self.N} sequences, got {N}"
         assert max_new <= self.max_new
-        sampling = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p), seed=int(seed),
+        self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)   # device-resident: a new seed per rollout does not invalidate the captured graph
+        sampling = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p),
                         suppress=c.eos_token_id if suppress_eos else -1, eos=c.eos_token_id if stop_at_eos and not suppress_eos else -1, pad=c.pad_token_id)
         if sampling != self.sampling:
             self.sampling = sampling

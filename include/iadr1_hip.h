@@ -172,7 +172,9 @@ int iadr1_adamw_flat(float* master, float* m, float* v, float* grad_zeroed_after
 long long iadr1_sample_workspace_bytes(int B);
 int iadr1_sample_topk_topp(const float* logits, long long ld, long long* out, void* workspace, int B, int V, float temperature,
                            int top_k, float top_p, int suppress_token, unsigned long long seed, unsigned step,
-                           const unsigned* step_ptr, iadr1_stream_t stream);
+                           const unsigned* step_ptr, const unsigned long long* seed_ptr, iadr1_stream_t stream);
+/* step_ptr / seed_ptr: optional device-resident step counter / seed that replace the scalar arguments (a captured hipGraph freezes
+ * kernel arguments: the rollout replays one graph for every decode step of every optimizer step). */
 
 /* ---- device-resident rollout bookkeeping (one decode step = a fixed, graph-replayable launch sequence) ------
  * rope_table: cos/sin [B, half] for the current text positions (TF:1165-1176: pos = kv_len + rope_delta).

@@ -552,3 +552,5 @@ def test_sampler_greedy_and_topk_topp(V):
     # device-resident step counter gives the same stream as the argument
     sp = torch.tensor([7], dtype=torch.int32, device=DEV)
     assert torch.equal(ops.sample(lg, 0.9, 50, 0.9, seed=5, step=0, step_ptr=sp), ops.sample(lg, 0.9, 50, 0.9, seed=5, step=7))
+    sd = torch.tensor([1234567890123], dtype=torch.int64, device=DEV)     # device-resident seed (graph replays): same stream as the scalar
+    assert torch.equal(ops.sample(lg, 0.9, 50, 0.9, seed=0, step=3, seed_ptr=sd), ops.sample(lg, 0.9, 50, 0.9, seed=1234567890123, step=3))
