@@ -855,6 +855,76 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     }
 }
 
+// Split-K form of the persistent kernel for the long-K narrow-N down projection (out_mode 2, fp32 partial slabs): grid.x = nz * bps,
+// slice z = blockIdx.x / bps owns k-steps [z*per_z, ...), its bps blocks walk 16-column tiles b, b + bps, ... (one tile per iteration so
+// that a block has >= 4 iterations to pipeline: with two-tile groups it had 2 and ran slower than the one-shot kernel).  A wave's steps
+// past the end of the slice get a zero X fragment and a clamped (valid, redundant) W address: no predicated loads in the loop.
+template <int WAVES, int KSW>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(SkinnyArgs p, int nz, int bps) {
+    constexpr int RLD = 16 + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = (float*)smem_raw;  // [WAVES][64][RLD]
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
+    const int z = blockIdx.x / bps, b = blockIdx.x - z * bps;
+    const int m_base = blockIdx.y * 64;
+    const int ksteps = p.K >> 5;
+    const int per_z = (ksteps + nz - 1) / nz;
+    const int st_begin = z * per_z, st_end = min(ksteps, st_begin + per_z);
+    const long long tile_stride = (long long)ksteps * 512;
+    const bool xpk = p.ldx == 0;
+    const bf16_t* xbase = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + l * 8 : p.X + (long long)min(m_base + lm, p.M - 1) * p.ldx + lq * 8;
+    const long long xgroup = xpk ? 512 : 16 * p.ldx, xstep = xpk ? 2048 : 32;
+    const int xgroups_ok = xpk ? 4 : (p.M - m_base - lm + 15) / 16;
+    bf16x8_t xf[KSW][4];
+    int woff[KSW];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        const int st = st_begin + w + j * WAVES;
+        const bool ok = st < st_end;
+        woff[j] = min(st, st_end - 1) * 512 + l * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (ok) v = *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)st * xstep);
+            xf[j][i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    const int ntiles = p.N >> 4;
+    bf16x8_t wf[KSW];
+    auto loadw = [&](int g) {
+        const bf16_t* wb = p.W + (long long)g * tile_stride;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + woff[j])));
+    };
+    int g = b;
+    if (g < ntiles) loadw(g);
+    float* mine = red + (size_t)w * 64 * RLD;
+    for (; g < ntiles; g += bps) {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KSW; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[j][i], acc[i], 0, 0, 0);
+        if (g + bps < ntiles) loadw(g + bps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + lq * 4 + e] = acc[i][e];
+        __syncthreads();
+        for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
+            const int m = idx >> 4, n = idx & 15, gm = m_base + m;
+            if (gm >= p.M) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+            ((float*)p.Y)[((long long)z * p.M + gm) * p.ldy + g * 16 + n] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // Decode-packing of a fused gate|up matrix W[2I, K] for the SwiGLU-fused skinny GEMM: packed 16-row tile 2q holds
 // gate rows [16q, 16q+16), tile 2q+1 the matching up rows [I+16q, ...), so one block owns both halves of its columns.
 __global__ __launch_bounds__(256) void pack_gateup_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int I, int K) {
@@ -1011,6 +1081,16 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
             (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
             (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
             (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
+        }
+        {   // split-K slabs (down projection): <= 6 k-steps per wave in a slice, >= 4 tiles per block
+            const int kst = K >> 5, per_z = (kst + ksplit - 1) / ksplit, bps = ksplit > 0 ? ncu / ksplit : 0;
+            static bool attr2 = false;
+            constexpr int SMS = 8 * 64 * 17 * 4;
+            if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS); attr2 = true; }
+            if (pers && ksplit > 1 && out_mode == 2 && per_z <= 48 && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
+                hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 6>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
+                return iadr1_check_launch("gemm_skinny_bf16");
+            }
         }
         const int ksw = K / 256;
         if (pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu) {
