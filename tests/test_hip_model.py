@@ -430,7 +430,9 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
             eng2 = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=512, max_completion_length=C, use_hip_graph=False, suppress_eos=True))
             assert np.array_equal(toks, eng2.rollout(batch, greedy=True))                         # (3)
             assert toks.shape == (Bp * G, C) and (toks >= 0).all() and (toks < cfg.vocab_size).all()
-            comp = toks
+        # distinct completions for the gradient comparison: the G greedy completions of a prompt are identical, and with zero-sum group
+        # advantages their exact gradient is 0 (both layouts then return rounding noise only)
+        comp = np.random.RandomState(3).randint(1000, 100000, (Bp * G, C))
         rewards = np.random.RandomState(1).rand(Bp * G, 2).astype(np.float32)
         out = eng.loss_and_grads(batch, comp, rewards)
         res[share] = (out, pol.grad.clone())
@@ -438,16 +440,6 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
     for o in (o1, o0):
         assert torch.equal(o["logps"], o["ref_logps"]) and float(o["kl"].abs().max()) == 0.0        # (1)
     assert float((o1["logps"] - o0["logps"]).abs().max()) < 0.05                                      # (2) bf16 hidden states, different tile orders
-    # gradients, per decoder weight.  This comparison is ill-conditioned on purpose-built random weights: group advantages sum to zero and the
-    # G completions pull on the shared prompt tokens almost identically (near-uniform attention at init), so the prompt-token gradient is a
-    # small residual of cancelling terms -- summed in fp32 before ONE bf16 rounding in the shared layout, after G separate bf16 roundings in
-    # the repeated one -- and that noise grows along the backward chain (measured cosines: last down_proj 0.998 ... first qkv 0.964).
-    # Well-conditioned checks: test_shared_prefix_layout_equals_repeated_prompt_rows (cos > 0.999) and the reference's own goldens.
-    cos = {}
-    for name, sl in pol.slots.items():
-        if name.startswith("layers.") and name.endswith(".w"):
-            n = int(np.prod(sl.shape))
-            a, b = g1[sl.offset: sl.offset + n].double(), g0[sl.offset: sl.offset + n].double()
-            cos[name] = float((a @ b) / (a.norm() * b.norm() + 1e-300))
-    assert cos["layers.1.down.w"] > 0.995 and min(cos.values()) > 0.95, cos
+    a, b = g1.double(), g0.double()
+    assert float((a @ b) / (a.norm() * b.norm())) > 0.999
     assert torch.isfinite(g1).all() and torch.isfinite(g0).all()
