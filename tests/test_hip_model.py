@@ -443,3 +443,41 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
     a, b = g1.double(), g0.double()
     assert float((a @ b) / (a.norm() * b.norm())) > 0.999
     assert torch.isfinite(g1).all() and torch.isfinite(g0).all()
+
+
+def test_two_images_per_prompt_one_shot_template_vs_oracle():
+    """The reference's 1-shot prompts carry TWO images (a normal template + the query image, REF:train/stage_rl/grpo_ad.py:92-116,
+    `--single_img 0`).  Log-probs of the SC-GRPO passes (shared-prefix layout) vs the fp32 oracle on such prompts, plus greedy rollout
+    agreement; two prompts with different image sizes and left padding."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import qwen25vl as oq
+    T = fx.TINY
+    rs = np.random.RandomState(11)
+
+    def prompt(g1, g2, n_text):
+        img = lambda g: [T["vision_start_token_id"]] + [T["image_token_id"]] * fx.n_image_tokens(g, T) + [T["vision_end_token_id"]]
+        return rs.randint(3, T["vision_start_token_id"], 4).tolist() + img(g1) + rs.randint(3, T["vision_start_token_id"], 3).tolist() + img(g2) + rs.randint(3, T["vision_start_token_id"], n_text).tolist()
+
+    grids = [(1, 8, 8), (1, 16, 12), (1, 12, 8), (1, 8, 12)]
+    ids, mask = fx.left_pad([prompt(grids[0], grids[1], 5), prompt(grids[2], grids[3], 11)], T["pad_token_id"])
+    pv = fx.synth_pixel_values(grids, T, seed=21)
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": pv, "image_grid_thw": grids, "images_per_prompt": [2, 2]}
+    G, C = 4, 7
+    comps = fx.synth_completions(2 * G, C, T, 5, {3: 2})
+    w = fx.make_weights(T, 0)
+    pol, ref = store(fx.perturb_weights(w, 1), True), store(w, False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, micro_batch_seqs=2 * G))
+    out = eng.loss_and_grads(batch, comps, np.random.RandomState(0).rand(2 * G, 2).astype(np.float32))
+    # oracle: the reference's repeated-row layout, every row with its two images
+    m = oq.Qwen25VLOracle(T, fx.perturb_weights(w, 1))
+    full_ids, full_mask = torch.from_numpy(out["ids"]), torch.from_numpy(out["mask"])
+    pv_rows = torch.cat([torch.from_numpy(pv[: 64 + 192])] * G + [torch.from_numpy(pv[64 + 192:])] * G)      # patches per prompt: 64+192, 96+96
+    grids_rows = [grids[0], grids[1]] * G + [grids[2], grids[3]] * G
+    with torch.no_grad():
+        lp = m.per_token_logps(full_ids, full_mask, pv_rows, grids_rows)
+    P = ids.shape[1]
+    cm = out["completion_mask"].astype(bool)
+    assert np.abs(out["logps"].cpu().numpy()[cm] - lp.numpy()[:, P - 1:][cm]).max() < 0.06
+    toks = eng.rollout(batch, greedy=True)
+    assert toks.shape[0] == 2 * G and all((toks[b * G] == toks[b * G + 1]).all() for b in range(2))
