@@ -430,6 +430,20 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
             eng2 = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=512, max_completion_length=C, use_hip_graph=False, suppress_eos=True))
             assert np.array_equal(toks, eng2.rollout(batch, greedy=True))                         # (3)
             assert toks.shape == (Bp * G, C) and (toks >= 0).all() and (toks < cfg.vocab_size).all()
+            # decode kernels (persistent / fused skinny GEMMs, paged attention) vs training kernels on the same weights: the logits the last
+            # decode step produced == teacher-forced logits of [prompt | tokens] at that position
+            dec = eng._rollout.logits.float().cpu().numpy()
+            ids_p, mask_p = np.asarray(batch["input_ids"]), np.asarray(batch["attention_mask"])
+            full = np.concatenate([np.repeat(ids_p, G, 0), toks[:, : C - 1]], 1)
+            fmask = np.ones_like(full)
+            e_pol = eng.pol
+            vis = eng.vision_policy(batch, save=False)
+            gpr, off = eng._per_row_images(batch, vis["grids"], vis["rows"])
+            plan = e_pol.text_plan(full, fmask, [gpr[r // G] for r in range(Bp * G)], [off[r // G] for r in range(Bp * G)])
+            hf, _ = e_pol.text_forward(plan, vis["img"], save=False)
+            S2 = full.shape[1]
+            tf = e_pol.logits_rows(hf, torch.arange(Bp * G, device=DEV) * S2 + (S2 - 1)).float().cpu().numpy()
+            assert np.abs(dec - tf).max() < 0.03 * np.abs(tf).max(), (np.abs(dec - tf).max(), np.abs(tf).max())
         # distinct completions for the gradient comparison: the G greedy completions of a prompt are identical, and with zero-sum group
         # advantages their exact gradient is 0 (both layouts then return rounding noise only)
         comp = np.random.RandomState(3).randint(1000, 100000, (Bp * G, C))
