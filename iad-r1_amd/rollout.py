@@ -130,7 +130,7 @@ class Rollout:
 
     # ---- public ---------------------------------------------------------------------------------------------------
     def generate(self, plan: TextPlan, img_embeds, G: int, max_new: int, temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress_eos=False,
-                 stop_at_eos=True) -> torch.Tensor:
+                 stop_at_eos=True, train_carry=None) -> torch.Tensor:
         """plan: the Bp left-padded prompts.  Returns completion ids [Bp*G, max_new] (prompt-major order: p0 x G,
         p1 x G, ...), pad after the first EOS."""
         e, c = self.e, self.e.cfg
@@ -182,7 +182,13 @@ class Rollout:
                     ops.kv_store(k, v, slot_tail_d[gi], self.kc[i], self.vc[i], Hkv, D)
 
         # ---- prefill (once per prompt) ----------------------------------------------------------------------
-        hf, _ = e.text_forward(plan, img_embeds, save=False, kv_sink=kv_sink)
+        if train_carry is not None:
+            # the prefill doubles as the prompt part of the policy's training forward (Engine.text_forward two-phase mode): activations
+            # saved in the training arena, rows [0, Bp*S) of the shared-prefix batch of T_total = Bp*S + N*max_new rows
+            hf, _ = e.text_forward(plan, img_embeds, save=True, kv_sink=kv_sink, rows=(0, Bp * S, Bp * S + N * max_new), carry=train_carry)
+            hf = hf[: Bp * S]
+        else:
+            hf, _ = e.text_forward(plan, img_embeds, save=False, kv_sink=kv_sink)
         last_rows = torch.arange(Bp, device=dev, dtype=torch.int64) * S + (S - 1)
         lg = e.logits_rows(hf, last_rows)                                    # [Bp, V] fp32
         self.logits.copy_(lg.repeat_interleave(G, 0))

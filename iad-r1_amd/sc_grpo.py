@@ -52,6 +52,8 @@ class GRPOArgs:
     # compute every prompt once per group in the reference / policy passes (shared-prefix attention; same math as the
     # reference's G-fold repeated rows).  Off: IADR1_SHARE_PREFIX=0 or share_prefix=False.
     share_prefix: bool = os.environ.get("IADR1_SHARE_PREFIX", "1") != "0"
+    # let the rollout's prefill double as the prompt part of the policy's training forward (needs share_prefix and one whole-batch micro-batch)
+    reuse_prefill: bool = os.environ.get("IADR1_REUSE_PREFILL", "1") != "0"
 
 
 def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.ndarray:
@@ -174,7 +176,7 @@ class SCGRPOEngine:
         img, vctx = self.pol.vision_forward(px, plan_v, save=save)
         return {"grids": grids, "plan": plan_v, "px": px, "rows": rows, "img": img, "ctx": vctx}
 
-    def rollout(self, batch, vis=None, greedy=False) -> np.ndarray:
+    def rollout(self, batch, vis=None, greedy=False, train_carry=None) -> np.ndarray:
         """Completion ids [Bp*G, <=C] (numpy, right-padded with pad after EOS like REF:680-683)."""
         a = self.args
         ids, mask = np.asarray(batch["input_ids"]), np.asarray(batch["attention_mask"])
@@ -189,11 +191,12 @@ class SCGRPOEngine:
         if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_pages * 32 < ids.shape[1] + a.max_completion_length:
             self._rollout = Rollout(self.pol, N, ids.shape[1], a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph)
         toks = self._rollout.generate(plan, img_pol, a.num_generations, a.max_completion_length, temperature=0.0 if greedy else a.temperature,
-                                      top_k=a.top_k, top_p=a.top_p, seed=a.seed + 1000003 * self.opt_step + 7919 * self.accum, suppress_eos=a.suppress_eos)
+                                      top_k=a.top_k, top_p=a.top_p, seed=a.seed + 1000003 * self.opt_step + 7919 * self.accum, suppress_eos=a.suppress_eos,
+                                      train_carry=train_carry)
         return toks.cpu().numpy()
 
     # ---- loss + gradients for given completions ------------------------------------------------------------------
-    def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None):
+    def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None, train_carry=None):
         """completions: list of Bp*G id lists (prompt-major) or an [N,C] array already padded;
         rewards_per_func: [N, n_funcs] float tensor/array.  Accumulates gradients into policy.grad."""
         a, c = self.args, self.cfg
@@ -259,7 +262,13 @@ class SCGRPOEngine:
             hf, _ = self.ref.text_forward(plan, img_ref, save=False)
             rl, _ = self.ref.logprobs(hf, rows_d, tgt_d, save=False)
             del hf
-            hf, ctx = self.pol.text_forward(plan, img_pol, save=backward)
+            if train_carry is not None and "x0" in train_carry and share and backward and n == N and C == a.max_completion_length and vis is not None and vis["ctx"] is not None:
+                # the rollout's prefill already ran (and saved) the prompt rows of this batch: only the completion rows go through the layers
+                T_all = plan.ids.numel()
+                train_carry["full_plan"] = plan
+                hf, ctx = self.pol.text_forward(plan.tail, None, save=True, rows=((b1 - b0) * P, T_all, T_all), carry=train_carry)
+            else:
+                hf, ctx = self.pol.text_forward(plan, img_pol, save=backward)
             lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, dup=dup)
             adv_d = advantages()["adv_d"]
             dlogp, kl, rloss, rkl = ops.grpo_loss(lp.view(n, C), rl.view(n, C), adv_d[r0:r1].contiguous(), cmask_d[r0:r1].contiguous(), a.beta, n_total_rows=N)
@@ -315,13 +324,18 @@ class SCGRPOEngine:
         t0 = mark()
         vis = self.vision_policy(batch, save=True)
         t1 = mark()
-        comp = self.rollout(batch, vis=vis)
+        # two-phase policy forward: with one whole-batch micro-batch in the shared-prefix layout the rollout's prefill IS the prompt part of
+        # the training forward (saved in the training arena), so the policy forward after the rollout only runs the completion rows
+        a = self.args
+        N = len(batch["input_ids"]) * a.num_generations
+        carry = {} if (a.share_prefix and a.reuse_prefill and a.num_generations > 1 and a.micro_batch_seqs >= N and N % a.num_generations == 0) else None
+        comp = self.rollout(batch, vis=vis, train_carry=carry)
         t2 = mark()
         # rewards are computed on the host inside loss_and_grads, after the first forward passes are in the GPU queue (in the
         # phase-timing mode they are evaluated here so that they get their own column)
         rewards = reward_fn(comp) if timing else (lambda: reward_fn(comp))
         t3 = mark()
-        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=do_optimizer_step, vis=vis)
+        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=do_optimizer_step, vis=vis, train_carry=carry)
         t4 = mark()
         if do_optimizer_step:
             self.optimizer_step()

@@ -47,6 +47,7 @@ class TextPlan:
     rope_deltas: np.ndarray      # [B]
     lengths: np.ndarray          # [B] number of real tokens
     shared: tuple = None         # (ng, P, n, C, G) when built by text_plan_shared
+    tail: "TextPlan" = None      # completion rows only (two-phase forward), set by text_plan_shared
 
 
 class Engine:
@@ -187,6 +188,10 @@ class Engine:
         plan = TextPlan(n, P + C, torch.from_numpy(ids_flat).to(self.dev), torch.from_numpy(img_index).to(self.dev),
                         ops.Segments(starts, ends, self.dev, prefix=prefix), ang.cos().contiguous(), ang.sin().contiguous(), deltas, mask_full.sum(1).astype(np.int64))
         plan.shared = (ng, P, n, C, G)
+        # the completion rows alone (two-phase forward: the prompt rows were already run by the rollout's prefill); segment indices stay absolute
+        T0 = ng * P
+        plan.tail = TextPlan(n, P + C, plan.ids[T0:], plan.img_index[T0:], ops.Segments(starts[ng:], ends[ng:], self.dev, prefix=prefix[ng:]),
+                             plan.cos[T0:], plan.sin[T0:], deltas, plan.lengths)
         return plan
 
     @staticmethod
@@ -386,30 +391,43 @@ class Engine:
             self._ws[key] = cur
         return cur
 
-    def text_forward(self, plan: TextPlan, img_embeds, save: bool, kv_sink=None):
+    def text_forward(self, plan: TextPlan, img_embeds, save: bool, kv_sink=None, rows=None, carry=None):
+        """Decoder forward over the flat token rows of `plan`.
+
+        rows = (r0, r1, T_total), carry = dict: TWO-PHASE use (save=True only).  This call covers rows [r0, r1) of a T_total-row batch whose
+        other rows are produced by another call sharing `carry` and the same activation arena: the rollout's prefill runs the prompt rows
+        [0, ng*P) with save=True (they are exactly the prompt region of the shared-prefix training batch, same kernels, same inputs), and
+        after the rollout only the completion rows [ng*P, T) go through the layers -- the policy forward no longer recomputes the prompts.
+        `plan` then describes the rows of this call (ids / img_index / cos / sin have r1-r0 rows) with ABSOLUTE segment indices; the call
+        that completes the batch sets carry["full_plan"] first and gets the ctx for text_backward over all T_total rows."""
         c, P = self.cfg, self.p
         H, D, Hq, Hkv = c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         qw, kw = Hq * D, Hkv * D
-        x = ops.embed_fwd(plan.ids, plan.img_index if img_embeds is not None else None, P.w("embed"), img_embeds)
-        T = x.shape[0]
+        Tl = plan.ids.numel()
+        r0, r1, T = (0, Tl, Tl) if rows is None else rows
+        assert r1 - r0 == Tl and (rows is None or (save and carry is not None))
+        part = rows is not None
+        if part and "x0" not in carry:
+            carry.update(x0=torch.empty(T, H, dtype=BF16, device=self.dev), hf=torch.empty(T, H, dtype=BF16, device=self.dev),
+                         x_last=torch.empty(T, H, dtype=BF16, device=self.dev), rstdf=torch.empty(T, dtype=F32, device=self.dev))
+        x = ops.embed_fwd(plan.ids, plan.img_index if img_embeds is not None else None, P.w("embed"), img_embeds, out=carry["x0"][r0:r1] if part else None)
         B = self._text_buffers(T, save)
-        Tb = B["T"]
-        ctx = {"layers": [], "plan": plan} if save else None
+        ctx = {"layers": [], "plan": carry.get("full_plan", plan) if part else plan} if save else None
         res, branch = x, None
         eps = c.rms_norm_eps
         for i in range(c.num_hidden_layers):
             b = f"layers.{i}."
             li = i if save else 0
-            buf = lambda name: B[name][li, :T]
+            buf = lambda name: B[name][li, r0:r1]
+            full = lambda name: B[name][li, :T]
             h1 = buf("h1")
-            rstd1 = B["rstd1"][li, :T] if save else None
+            rstd1 = B["rstd1"][li, r0:r1] if save else None
             if branch is None:
                 x_in = res
-                hip_rstd = rstd1
-                ops.hip.call("rmsnorm_fwd", res, None, 0, None, None, None, P.w(b + "ln1"), h1, hip_rstd, T, H, H, H, H, float(eps))
+                ops.hip.call("rmsnorm_fwd", res, None, 0, None, None, None, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps))
             else:
                 x_in = buf("x_in") if save else res
-                ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, rstd1, T, H, H, H, H, float(eps))
+                ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps))
             qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=buf("qkv"))
             ops.rope_(qkv, plan.cos, plan.sin, Hq + Hkv, D)
             if kv_sink is not None:
@@ -417,19 +435,30 @@ class Engine:
             o = buf("o")
             o.zero_()  # rows outside every segment (left / post-EOS padding) must read as zeros downstream (0 x stale NaN in wgrad otherwise)
             lse = B["lse"][li].view(-1)[: Hq * T].view(Hq, T) if save else None
-            ops.hip.call("attn_fwd", qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
+            # attention addresses rows absolutely: the keys of a completion segment live in the prompt rows written by the other phase
+            qkv_all, o_all = full("qkv"), full("o")
+            ops.hip.call("attn_fwd", qkv_all[:, :qw], qkv_all[:, qw: qw + kw], qkv_all[:, qw + kw:], o_all, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
                          T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, float(D**-0.5))
             ab = ops.gemm_nt(o, P.w(b + "o.w"))
             x_mid = buf("x_mid") if save else x_in
             h2 = buf("h2")
-            rstd2 = B["rstd2"][li, :T] if save else None
-            ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, T, H, H, H, H, float(eps))
+            rstd2 = B["rstd2"][li, r0:r1] if save else None
+            ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, Tl, H, H, H, H, float(eps))
             gu = ops.gemm_nt(h2, P.w(b + "gu.w"), out=buf("gu"))
             a = ops.swiglu_fwd(gu, out=buf("a"))
             branch = ops.gemm_nt(a, P.w(b + "down.w"))
             res = x_mid
             if save:
-                ctx["layers"].append((x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a))
+                if not part:
+                    ctx["layers"].append((x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a))
+                else:   # views over ALL rows of the batch (the other phase fills / has filled the rest)
+                    ctx["layers"].append((carry["x0"] if i == 0 else full("x_in"), B["rstd1"][li, :T], full("h1"), qkv_all, o_all, lse, full("x_mid"),
+                                          B["rstd2"][li, :T], full("h2"), full("gu"), full("a")))
+        if part:
+            hf, x_last, rstdf = carry["hf"], carry["x_last"], carry["rstdf"]
+            ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_last[r0:r1], P.w("norm"), hf[r0:r1], rstdf[r0:r1], Tl, H, H, H, H, float(eps))
+            ctx.update(x_last=x_last, rstdf=rstdf)
+            return hf, ctx
         x_last = torch.empty_like(res) if save else res
         hf, rstdf = ops.rmsnorm_fwd(branch, P.w("norm"), eps, res=res, res_out=x_last, want_rstd=save)
         if save:

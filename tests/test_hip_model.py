@@ -495,3 +495,23 @@ def test_two_images_per_prompt_one_shot_template_vs_oracle():
     assert np.abs(out["logps"].cpu().numpy()[cm] - lp.numpy()[:, P - 1:][cm]).max() < 0.06
     toks = eng.rollout(batch, greedy=True)
     assert toks.shape[0] == 2 * G and all((toks[b * G] == toks[b * G + 1]).all() for b in range(2))
+
+
+def test_prefill_reused_as_prompt_part_of_the_policy_forward():
+    """Two-phase policy forward: the rollout's prefill (saved in the training arena) is the prompt region of the shared-prefix batch, the
+    forward after the rollout runs the completion rows only.  Same completions, same loss, same gradients as the one-shot forward."""
+    G, C = 4, 9
+    grids = [(1, 16, 12), (1, 8, 8)]
+    ids, mask = fx.left_pad([fx.synth_prompt(grids[0], 6, fx.TINY, 3), fx.synth_prompt(grids[1], 21, fx.TINY, 4)], fx.TINY["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values(grids, fx.TINY, seed=5), "image_grid_thw": grids}
+    w = fx.make_weights(fx.TINY, 0)
+    reward_fn = lambda comp: np.stack([(comp[:, 0] % 3).astype(np.float32), (comp[:, 1] % 2).astype(np.float32)], 1)
+    res = []
+    for reuse in (True, False):
+        pol, ref = store(fx.perturb_weights(w, 1), True), store(w, False)
+        eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, micro_batch_seqs=2 * G, reuse_prefill=reuse, suppress_eos=True))
+        m = eng.step(batch, reward_fn, do_optimizer_step=False)
+        res.append((m, pol.grad.clone()))
+    (m1, g1), (m0, g0) = res
+    assert abs(m1["loss"] - m0["loss"]) < 1e-6 and m1["reward"] == m0["reward"] and abs(m1["kl"] - m0["kl"]) < 1e-6
+    assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max()) + 1e-12
