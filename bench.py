@@ -52,7 +52,7 @@ def decode_roofline(cfg, pol, events, n_seq, gen_len):
     ach = (w_bytes + kv_bytes) / (ms / steps * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "decode step (hipGraph: skinny GEMMs on decode-packed weights + paged attention + RMSNorm + sampling)", "achieved": ach,
             "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "ms_per_decode_step": ms / steps, "decode_steps": steps,
-            "algorithmic_bytes_per_step": {"weights": w_bytes, "kv": kv_bytes}, "traffic": _skinny_pmc()}
+            "algorithmic_bytes_per_step": {"weights": w_bytes, "kv": kv_bytes}, "traffic": (_skinny_pmc() or {}).get("bytes_per_launch"), "traffic_detail": _skinny_pmc()}
 
 
 def parse():
@@ -370,7 +370,8 @@ def main():
             "repeated_rows_layout": repeated,
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
+                         "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+                         "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
             "roofline_decode": decode_roofline(cfg, pol, dec_ev, N, a.gen_len),
             "last_step_metrics": metrics,
             "gemm_by_shape": timer.by_shape(),
