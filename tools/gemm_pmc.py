@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """Launch the dominant GEMM shapes of the SC-GRPO step a few times (for rocprofv3 --pmc passes)."""
-import os, sys, torch
+import os, sys
+if len(sys.argv) >= 4 and sys.argv[1] == "--parse":     # python tools/gemm_pmc.py --parse <rocpd db> <counter>: avg counter value per gemm_nt grid
+    import sqlite3, json
+    db = sqlite3.connect(sys.argv[2])
+    rows = db.execute("select kernel_name, grid_size, avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like '%gemm_nt%' group by kernel_name, grid_size order by grid_size desc", (sys.argv[3],)).fetchall()
+    print(json.dumps([{"kernel": r[0][:70], "grid": r[1], "avg_value": r[2], "launches": r[3]} for r in rows], indent=1))
+    sys.exit(0)
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import iadr1_amd
 from iadr1_amd import ops
 dev = "cuda"
-for M, N, K in [(24576, 22016, 2048), (24576, 2048, 11008), (22016, 2048, 24576)]:
+for M, N, K in [(20480, 22016, 2048), (20480, 2048, 11008), (22016, 2048, 20480)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); b = torch.randn(N, K, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB: evicts the 256 MiB Infinity Cache between launches
