@@ -63,3 +63,18 @@ def test_trainer_constructor_errors_match_reference():
         SCGRPOTrainer((None, {}), [], args=GRPOConfig(model_init_kwargs={"a": 1}))
     with pytest.raises(ValueError, match="Qwen2.5-VL"):
         SCGRPOTrainer("/x/llava-1.5-7b", [], args=GRPOConfig())
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for sub in ("iad-r1_amd", "train", "scripts"):
+        for dp, _, files in os.walk(os.path.join(root, sub)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h")):
+                    txt = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M):
+                        offenders.append(os.path.join(dp, f))
+    assert not offenders, offenders
