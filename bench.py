@@ -233,13 +233,17 @@ def run_pa_sft(a, cfg, dev, rank, world):
 
     k = 0
     for _ in range(a.warmup):
-        eng.loss_and_grads(batches[k]); eng.optimizer_step(); k += 1
+        eng.loss_and_grads(batches[k])
+        eng.optimizer_step()
+        k += 1
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()
     loss = None
     for _ in range(a.steps):
-        loss = eng.loss_and_grads(batches[k]); eng.optimizer_step(); k += 1
+        loss = eng.loss_and_grads(batches[k])
+        eng.optimizer_step()
+        k += 1
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False

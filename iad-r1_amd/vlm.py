@@ -10,6 +10,7 @@ ONCE per unique image per step and its output rows are fanned out to every seque
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -62,7 +63,6 @@ class Engine:
         vd = c.v_head_dim
         self.v_inv_freq = 1.0 / (10000.0 ** (np.arange(0, vd // 2, 2, dtype=np.float32) / (vd // 2)))
         self.lm_chunk = 4096
-        import os
         self.wgrad_stream = torch.cuda.Stream() if (self.dev.type == "cuda" and os.environ.get("IADR1_WGRAD_STREAM", "1") != "0") else None
         self.keep_logits_bytes = 24 << 30
         self._ws = {}
