@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="3b", choices=["3b", "7b", "tiny"])
+    ap.add_argument("--model", default="3b", choices=["3b", "7b", "qwen2vl_2b", "tiny"])
     ap.add_argument("--prompts", type=int, default=8)
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=512)
@@ -213,6 +213,7 @@ def run_pa_sft(a, cfg, dev, rank, world):
     timer = GemmTimer()
     timer.install()
     B, P, C = a.sft_batch, a.prompt_len, a.gen_len
+    model_name = "Qwen2-VL-2B" if a.model == "qwen2vl_2b" else f"Qwen2.5-VL-{a.model.upper()}"
 
     def make(seed):
         b = synth_batch(cfg, B, P, seed)
@@ -257,9 +258,9 @@ def run_pa_sft(a, cfg, dev, rank, world):
         n_launch, t_gemm, fl_gemm = timer.summary()
         ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
         print(json.dumps({
-            "metric": f"PA-SFT samples/sec (bs={B}, img448, {P}+{C} tok) Qwen2.5-VL-{a.model.upper()}", "value": world * B * a.steps / dt, "unit": "samples/s", "n_gpus": world,
+            "metric": f"PA-SFT samples/sec (bs={B}, img448, {P}+{C} tok) {model_name}", "value": world * B * a.steps / dt, "unit": "samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic", "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} PA-SFT step (BASELINE config 2): {B} sequences x (448x448 image + {P} prompt positions + {C} supervised tokens), forward(labels) + backward + AdamW, random-init weights", "parallelism": f"dp{world}"},
+            "data": "synthetic", "config": {"workload": f"{model_name} PA-SFT step (BASELINE config {1 if a.model == 'qwen2vl_2b' else 2}): {B} sequences x (448x448 image + {P} prompt positions + {C} supervised tokens), forward(labels) + backward + AdamW, random-init weights", "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
             "last_loss": loss, "tokens_per_s": world * B * (P + C) * a.steps / dt, "cpu_baseline": None,
@@ -285,6 +286,8 @@ def main():
         cfg = VLMConfig.qwen25vl_3b()
     elif a.model == "7b":
         cfg = VLMConfig.qwen25vl_7b()
+    elif a.model == "qwen2vl_2b":
+        cfg = VLMConfig.qwen2vl_2b()      # BASELINE config 1 (Qwen2-VL-2B PA-SFT): LayerNorm / QuickGELU ViT, no window attention
     else:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import fixture_util as fx
