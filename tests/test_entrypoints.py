@@ -41,6 +41,36 @@ def test_pa_sft_cli_accepts_reference_flags():
     assert a.learning_rate == 1e-5 and a.weight_decay == 0.1 and a.warmup_steps == 100 and a.cutoff_len == 4096 and a.lr_scheduler_type == "cosine"
 
 
+class _CharProcessor:
+    """ChatML rendering with one token per character: enough to exercise encode_example's turn splitting without a tokenizer download."""
+
+    def apply_chat_template(self, msgs, tokenize=False, add_generation_prompt=False):
+        s = "".join("<%s>%s</>" % (m["role"][0], "".join(p.get("text", "@") for p in m["content"])) for m in msgs)
+        return s + ("<a>" if add_generation_prompt else "")
+
+    def __call__(self, text, images=None, return_tensors="pt", add_special_tokens=False):
+        import torch
+        return {"input_ids": torch.tensor([[ord(c) for c in text[0]]])}
+
+
+def test_pa_sft_encode_example_masks_and_truncates_per_turn():
+    m = _load("train/stage_sft/train.py")
+    row = {"messages": [{"from": "human", "value": "what is this"}, {"from": "gpt", "value": "a nut"}, {"from": "human", "value": "broken?"},
+                        {"from": "gpt", "value": "yes, scratched"}], "images": []}
+    ids, labels, pix, grids = m.encode_example(_CharProcessor(), row, 4096)
+    text = "".join(map(chr, ids))
+    assert text == "<u>what is this</><a>a nut</><u>broken?</><a>yes, scratched</>" and pix is None and grids == []
+    assert "".join(chr(l) for l in labels if l != -100) == "a nut</>yes, scratched</>"
+    assert all(l == -100 or l == i for i, l in zip(ids, labels))
+    ids2, labels2, _, _ = m.encode_example(_CharProcessor(), row, 4096, mask_history=True)
+    assert ids2 == ids and "".join(chr(l) for l in labels2 if l != -100) == "yes, scratched</>"
+    # the budget is spent turn by turn (reference infer_seqlen), not by chopping the tail of the concatenation: a short answer survives whole and
+    # its prompt is trimmed from the right
+    ids3, labels3, _, _ = m.encode_example(_CharProcessor(), row, 20)
+    assert "".join(map(chr, ids3)) == "<u>what is ta nut</>"
+    assert "".join(chr(l) for l in labels3 if l != -100) == "a nut</>"
+
+
 def test_make_conversation_structure():
     m = _load("train/stage_rl/grpo_ad.py")
     row = {"problem": "Is there any defect?", "image": "a/b.png", "solution": "<answer>no</answer>"}

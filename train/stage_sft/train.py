@@ -45,6 +45,8 @@ def build_parser():
     p.add_argument("--save_steps", type=int, default=500)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--micro_batch_seqs", type=int, default=16)
+    p.add_argument("--train_on_prompt", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
+    p.add_argument("--mask_history", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     for flag in ("--deepspeed", "--bf16", "--plot_loss", "--overwrite_cache", "--overwrite_output_dir", "--ddp_timeout", "--preprocessing_num_workers",
                  "--report_to", "--gradient_checkpointing", "--flash_attn", "--image_max_pixels", "--image_min_pixels"):
         p.add_argument(flag, nargs="?", default=None, const=True)
@@ -63,8 +65,10 @@ def load_sharegpt(name: str, dataset_dir: str):
     return [{"messages": r[cols["messages"]], "images": r.get(cols["images"], [])} for r in rows]
 
 
-def encode_example(proc, row, cutoff_len):
-    """-> (input_ids, labels, pixel_values, grids): every assistant turn is supervised, everything else is -100."""
+def encode_example(proc, row, cutoff_len, train_on_prompt=False, mask_history=False, image_token_id=151655):
+    """-> (input_ids, labels, pixel_values, grids).  Per-turn truncation and masking are iadr1_amd.sft_data.supervised_labels (the reference's
+    _encode_supervised_example, llamafactory/data/processors/supervised.py:33-87): answers supervised, prompts -100, turns trimmed against cutoff_len."""
+    from iadr1_amd.sft_data import supervised_labels
     from PIL import Image
     msgs = []
     for m in row["messages"]:
@@ -78,9 +82,7 @@ def encode_example(proc, row, cutoff_len):
                 parts.append({"type": "text", "text": s})
         msgs.append({"role": role, "content": parts})
     images = [Image.open(p) if isinstance(p, str) else p for p in row["images"]]
-    ids, labels = [], []
-    prev = 0
-    full = None
+    turns, prev, full = [], 0, None      # (prompt_ids, answer_ids) per turn, the unit the reference truncates and masks by
     for t in range(len(msgs)):
         if msgs[t]["role"] != "assistant":
             continue
@@ -89,10 +91,11 @@ def encode_example(proc, row, cutoff_len):
         full = proc(text=[upto], images=images or None, return_tensors="pt", add_special_tokens=False)
         n_before = proc(text=[before], images=images or None, return_tensors="pt", add_special_tokens=False)["input_ids"].shape[1]
         cur = full["input_ids"][0].tolist()
-        labels += [-100] * (n_before - prev) + cur[n_before:]
+        turns.append((cur[prev:n_before], cur[n_before:]))
         prev = len(cur)
-        ids = cur
-    ids, labels = ids[:cutoff_len], labels[:cutoff_len]
+    ids, labels = supervised_labels(turns, cutoff_len, train_on_prompt=train_on_prompt, mask_history=mask_history)
+    if images and ids.count(image_token_id) != sum(1 for tn in turns for part in tn for x in part if x == image_token_id):
+        raise ValueError("cutoff_len=%d truncates image placeholder tokens; raise --cutoff_len" % cutoff_len)
     return ids, labels, (full["pixel_values"] if images else None), (full["image_grid_thw"].tolist() if images else [])
 
 
@@ -133,7 +136,7 @@ def main(argv=None):
         eng.args.learning_rate = lr
         losses = []
         for k in range(ga):
-            enc = [encode_example(proc, rows[(i + j) % len(rows)], a.cutoff_len) for j in range(bs)]
+            enc = [encode_example(proc, rows[(i + j) % len(rows)], a.cutoff_len, a.train_on_prompt, a.mask_history, cfg.image_token_id) for j in range(bs)]
             i += bs
             S = (max(len(e[0]) for e in enc) + 7) // 8 * 8  # pad_to_multiple_of=8 (sft/workflow.py:60), right padding
             ids = np.full((bs, S), pad, dtype=np.int64)
