@@ -4,7 +4,10 @@ Host-side integer logic, no device work.  Follows the reference's LLaMA-Factory 
   * `turn_budget`       <- infer_seqlen, train/stage_sft/llamafactory/data/processors/processor_utils.py:51-65
   * `supervised_labels` <- _encode_supervised_example, train/stage_sft/llamafactory/data/processors/supervised.py:33-87
 Pinned bit-exactly against those two functions by tests/golden/sft_data.json (tools/make_golden_sft_data.py)."""
-from typing import List, Sequence, Tuple
+import math
+import os
+from dataclasses import dataclass, fields
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 IGNORE_INDEX = -100
 
@@ -59,3 +62,154 @@ def supervised_labels(turns: Sequence[Tuple[Sequence[int], Sequence[int]]], cuto
         ids.append(eos_token_id)
         labels.append(eos_token_id)
     return ids, labels
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# Dataset rows -> conversation turns -> text (the part of a22 in front of the tokenizer).  Follows
+#   * `ShareGPTSchema` / `align_sharegpt`    <- DatasetAttr + get_dataset_list + convert_sharegpt + _convert_images,
+#                                               llamafactory/data/parser.py:27-162, aligner.py:33-54,137-232
+#   * `regular_image_size`                   <- BasePlugin._preprocess_image + Qwen2vlPlugin._preprocess_image, mm_plugin.py:108-123,810-824
+#   * `expand_image_placeholders`            <- Qwen2vlPlugin.process_messages, mm_plugin.py:850-896
+#   * `qwen2_vl_turn_texts` / `encode_turns` <- template "qwen2_vl" (template.py:1120-1133) through Template._encode / encode_multiturn /
+#                                               _convert_elements_to_ids (template.py:85-160)
+# Pinned by tests/golden/sft_text.json (tools/make_golden_sft_data.py drives the reference's own functions).
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+IMAGE_PLACEHOLDER = "<image>"
+QWEN2_VL_DEFAULT_SYSTEM = "You are a helpful assistant."
+
+
+@dataclass
+class ShareGPTSchema:
+    """Column and tag names of a sharegpt-format dataset: the `columns` / `tags` objects of a dataset_info.json entry, with LLaMA-Factory's defaults."""
+    messages: str = "conversations"
+    images: Optional[str] = None
+    system: Optional[str] = None
+    role_tag: str = "from"
+    content_tag: str = "value"
+    user_tag: str = "human"
+    assistant_tag: str = "gpt"
+    observation_tag: str = "observation"
+    function_tag: str = "function_call"
+    system_tag: Optional[str] = "system"
+
+    @classmethod
+    def from_dataset_info(cls, entry: Dict[str, Any]) -> "ShareGPTSchema":
+        if entry.get("formatting", "alpaca") != "sharegpt":
+            raise ValueError("only sharegpt-format datasets are part of the PA-SFT path (dataset_info.json: \"formatting\": \"sharegpt\")")
+        s = cls()
+        for f in fields(cls):       # a present `columns` / `tags` object resets every name it does not mention to None (parser.py:134-155)
+            key = "tags" if f.name.endswith("_tag") else "columns"
+            if key in entry:
+                setattr(s, f.name, entry[key].get(f.name))
+        return s
+
+
+def align_sharegpt(example: Dict[str, Any], schema: ShareGPTSchema, image_dir: Optional[str] = None) -> Dict[str, Any]:
+    """One dataset row -> {"prompt": [...], "response": [...], "system": str, "images": list | None} with roles user / assistant / observation /
+    function.  A leading system-tagged message becomes `system`.  Rows whose roles do not alternate (user|observation, assistant|function, ...) or
+    whose turn count is odd are dropped the way the reference drops them: empty prompt and response."""
+    role_of = {schema.user_tag: "user", schema.assistant_tag: "assistant", schema.observation_tag: "observation", schema.function_tag: "function",
+               schema.system_tag: "system"}
+    allowed = ((schema.user_tag, schema.observation_tag), (schema.assistant_tag, schema.function_tag))
+    msgs = example[schema.messages]
+    if schema.system_tag and len(msgs) and msgs[0][schema.role_tag] == schema.system_tag:
+        system, msgs = msgs[0][schema.content_tag], msgs[1:]
+    else:
+        system = example[schema.system] if schema.system else ""
+    broken = len(msgs) % 2 != 0
+    turns = []
+    for i, m in enumerate(msgs):
+        if m[schema.role_tag] not in allowed[i % 2]:
+            broken = True
+        turns.append({"role": role_of[m[schema.role_tag]], "content": m[schema.content_tag]})
+    images = None
+    if schema.images:
+        images = example[schema.images]
+        if not isinstance(images, list):
+            images = [images]
+        elif not images:
+            images = None
+        else:
+            images = list(images)
+        if images is not None and image_dir is not None:
+            images = [os.path.join(image_dir, im) if isinstance(im, str) and os.path.isfile(os.path.join(image_dir, im)) else im for im in images]
+    return {"prompt": [] if broken else turns[:-1], "response": [] if broken else turns[-1:], "system": system, "images": images}
+
+
+def _regular_size_steps(width: int, height: int, max_pixels: int):
+    """The successive (width, height) targets of the reference's resizes, in order; empty when the image is left alone."""
+    if width * height > max_pixels:
+        f = math.sqrt(max_pixels / (width * height))
+        width, height = int(width * f), int(height * f)
+        yield width, height
+    if min(width, height) < 28:
+        width, height = max(width, 28), max(height, 28)
+        yield width, height
+    if width / height > 200:
+        width = height * 180
+        yield width, height
+    if height / width > 200:
+        height = width * 180
+        yield width, height
+
+
+def regular_image_size(width: int, height: int, max_pixels: int = 512 * 512):
+    """(width, height) an image has when the HF image processor sees it: area capped at `max_pixels` (both sides scaled by the same factor,
+    truncated), sides at least 28, aspect ratio cut back to 180 when it exceeds 200."""
+    for width, height in _regular_size_steps(width, height, max_pixels):
+        pass
+    return width, height
+
+
+def regularize_image(image, max_pixels: int = 512 * 512):
+    """PIL image -> RGB PIL image of `regular_image_size`, through the same sequence of nearest-neighbour resizes as the reference."""
+    from PIL import Image
+    for size in _regular_size_steps(image.width, image.height, max_pixels):
+        image = image.resize(size, resample=Image.Resampling.NEAREST)
+    return image if image.mode == "RGB" else image.convert("RGB")
+
+
+def expand_image_placeholders(messages, grids, merge_size: int = 2, image_token: str = "<|image_pad|>"):
+    """Every "<image>" in the message contents, in order, becomes <|vision_start|> + t*h*w / merge_size^2 image tokens + <|vision_end|> for the
+    corresponding entry of `grids` ([t, h, w] patch grids).  Counts must match exactly."""
+    out, used = [], 0
+    for m in messages:
+        content = m["content"]
+        while IMAGE_PLACEHOLDER in content:
+            if used >= len(grids):
+                raise ValueError("`len(images)` is less than the number of %s tokens." % IMAGE_PLACEHOLDER)
+            t, h, w = (int(v) for v in grids[used])
+            content = content.replace(IMAGE_PLACEHOLDER, "<|vision_start|>" + image_token * (t * h * w // (merge_size * merge_size)) + "<|vision_end|>", 1)
+            used += 1
+        out.append({**m, "content": content})
+    if used != len(grids):
+        raise ValueError("The number of images does not match the number of %s tokens." % IMAGE_PLACEHOLDER)
+    return out
+
+
+def qwen2_vl_turn_texts(messages, system: Optional[str] = None):
+    """ChatML rendering of the "qwen2_vl" template as [(prompt_pieces, answer_pieces)] per turn; every piece is tokenised on its own (that is what the
+    reference does, so the system block and the user block never merge across their boundary).  Turn 0 carries the system block; the assistant's
+    closing "<|im_end|>\\n" belongs to the answer and is therefore supervised."""
+    if len(messages) % 2:
+        raise ValueError("a conversation is user / assistant pairs")
+    system = system or QWEN2_VL_DEFAULT_SYSTEM
+    rendered = []
+    for i, m in enumerate(messages):
+        pieces = ["<|im_start|>system\n" + system + "<|im_end|>\n"] if i == 0 and system else []
+        if m["role"] == "user":
+            pieces.append("<|im_start|>user\n" + m["content"] + "<|im_end|>\n<|im_start|>assistant\n")
+        elif m["role"] == "assistant":
+            pieces.append(m["content"] + "<|im_end|>\n")
+        elif m["role"] == "observation":
+            pieces.append("<|im_start|>user\n<tool_response>\n" + m["content"] + "\n</tool_response><|im_end|>\n<|im_start|>assistant\n")
+        else:
+            raise NotImplementedError("Unexpected role: %s (tool calls are not part of the IAD-R1 data)" % m["role"])
+        rendered.append(pieces)
+    return [(rendered[i], rendered[i + 1]) for i in range(0, len(rendered), 2)]
+
+
+def encode_turns(tokenizer, turn_texts):
+    """[(prompt_pieces, answer_pieces)] -> [(prompt_ids, answer_ids)], each piece through tokenizer.encode(piece, add_special_tokens=False)."""
+    enc = lambda pieces: [t for p in pieces if p for t in tokenizer.encode(p, add_special_tokens=False)]
+    return [(enc(s), enc(t)) for s, t in turn_texts]

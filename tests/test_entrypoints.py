@@ -2,6 +2,7 @@
 dataset rows are turned into the same conversation structure, and the trainer reproduces the reference's
 constructor error behaviour (/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:108-111,141-145,587-588)."""
 import importlib.util
+import json
 import os
 
 import pytest
@@ -42,33 +43,42 @@ def test_pa_sft_cli_accepts_reference_flags():
 
 
 class _CharProcessor:
-    """ChatML rendering with one token per character: enough to exercise encode_example's turn splitting without a tokenizer download."""
+    """One token per character, no images: enough to run encode_example without a tokenizer download."""
 
-    def apply_chat_template(self, msgs, tokenize=False, add_generation_prompt=False):
-        s = "".join("<%s>%s</>" % (m["role"][0], "".join(p.get("text", "@") for p in m["content"])) for m in msgs)
-        return s + ("<a>" if add_generation_prompt else "")
+    class tokenizer:
+        @staticmethod
+        def encode(text, add_special_tokens=False):
+            return [ord(c) for c in text]
 
-    def __call__(self, text, images=None, return_tensors="pt", add_special_tokens=False):
-        import torch
-        return {"input_ids": torch.tensor([[ord(c) for c in text[0]]])}
+    image_processor = None
 
 
-def test_pa_sft_encode_example_masks_and_truncates_per_turn():
+def test_pa_sft_encode_example_masks_and_truncates_per_turn(tmp_path):
     m = _load("train/stage_sft/train.py")
-    row = {"messages": [{"from": "human", "value": "what is this"}, {"from": "gpt", "value": "a nut"}, {"from": "human", "value": "broken?"},
-                        {"from": "gpt", "value": "yes, scratched"}], "images": []}
-    ids, labels, pix, grids = m.encode_example(_CharProcessor(), row, 4096)
-    text = "".join(map(chr, ids))
-    assert text == "<u>what is this</><a>a nut</><u>broken?</><a>yes, scratched</>" and pix is None and grids == []
-    assert "".join(chr(l) for l in labels if l != -100) == "a nut</>yes, scratched</>"
+    data = [{"messages": [{"role": "user", "content": "what is this"}, {"role": "assistant", "content": "a nut"}, {"role": "user", "content": "broken?"},
+                          {"role": "assistant", "content": "yes, scratched"}], "images": []},
+            {"messages": [{"role": "user", "content": "dangling"}], "images": []}]
+    (tmp_path / "d.json").write_text(json.dumps(data))
+    rows = m.load_sharegpt(str(tmp_path / "d.json"), str(tmp_path))
+    assert len(rows) == 1 and rows[0]["images"] is None          # the odd-length row is dropped, as the reference's aligner + filter do
+    (tmp_path / "dataset_info.json").write_text(json.dumps({"ead": {"file_name": "d.json", "formatting": "sharegpt", "columns": {"messages": "messages", "images": "images"},
+                                                                    "tags": {"role_tag": "role", "content_tag": "content", "user_tag": "user", "assistant_tag": "assistant"}}}))
+    assert m.load_sharegpt("ead", str(tmp_path)) == rows
+    with pytest.raises(ValueError, match="Undefined dataset"):
+        m.load_sharegpt("nope", str(tmp_path))
+    sys_block = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n"
+    ids, labels, pix, grids = m.encode_example(_CharProcessor(), rows[0], 4096)
+    assert "".join(map(chr, ids)) == (sys_block + "<|im_start|>user\nwhat is this<|im_end|>\n<|im_start|>assistant\na nut<|im_end|>\n"
+                                      "<|im_start|>user\nbroken?<|im_end|>\n<|im_start|>assistant\nyes, scratched<|im_end|>\n") and pix is None and grids == []
+    assert "".join(chr(l) for l in labels if l != -100) == "a nut<|im_end|>\nyes, scratched<|im_end|>\n"
     assert all(l == -100 or l == i for i, l in zip(ids, labels))
-    ids2, labels2, _, _ = m.encode_example(_CharProcessor(), row, 4096, mask_history=True)
-    assert ids2 == ids and "".join(chr(l) for l in labels2 if l != -100) == "yes, scratched</>"
+    ids2, labels2, _, _ = m.encode_example(_CharProcessor(), rows[0], 4096, mask_history=True)
+    assert ids2 == ids and "".join(chr(l) for l in labels2 if l != -100) == "yes, scratched<|im_end|>\n"
     # the budget is spent turn by turn (reference infer_seqlen), not by chopping the tail of the concatenation: a short answer survives whole and
     # its prompt is trimmed from the right
-    ids3, labels3, _, _ = m.encode_example(_CharProcessor(), row, 20)
-    assert "".join(map(chr, ids3)) == "<u>what is ta nut</>"
-    assert "".join(chr(l) for l in labels3 if l != -100) == "a nut</>"
+    ids3, labels3, _, _ = m.encode_example(_CharProcessor(), rows[0], 60)
+    assert "".join(map(chr, ids3)) == (sys_block + "<|im_start|>user\nwhat is this<|im_end|>\n<|im_start|>assistant\n")[:44] + "a nut<|im_end|>\n"
+    assert "".join(chr(l) for l in labels3 if l != -100) == "a nut<|im_end|>\n"
 
 
 def test_make_conversation_structure():

@@ -15,7 +15,7 @@ def timeit(fn, n):
         for i in range(n): fn(i)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (3 * n) * 1e3
-H, I, V, NL = 2048, 11008, 151936, 16
+H, I, V, NL = 2048, 11008, 151936, int(os.environ.get("NL", "16"))   # NL=1: the same 90 MB every launch (memory-side cache hits)
 x = ops.pack_act(torch.randn(64, H, device=dev).to(torch.bfloat16))
 gu = [ops.pack_gateup(torch.randn(2 * I, H, device=dev).to(torch.bfloat16)) for _ in range(NL)]
 a = ops.PackedAct(64, I, dev)
@@ -28,6 +28,8 @@ part = torch.empty(8, 64, H, dtype=torch.float32, device=dev)
 us = timeit(lambda i: ops.gemm_skinny(ain, dn[i % (2 * NL)], H, out=part, ksplit=8), 2 * NL)
 print(f"PERS={os.environ.get('IADR1_SKINNY_PERS','1')} down ks8        {us:7.1f} us  {I*H*2/us/1e6:5.2f} TB/s", flush=True)
 del dn
+if NL < 3:
+    sys.exit(0)
 lm = [ops.pack_weight(torch.randn(V, H, device=dev).to(torch.bfloat16)) for _ in range(3)]
 lg = torch.empty(64, V, dtype=torch.float32, device=dev)
 us = timeit(lambda i: ops.gemm_skinny(x, lm[i % 3], V, out=lg), 3)

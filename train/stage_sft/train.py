@@ -3,10 +3,9 @@
 run_sft, train/sft/workflow.py:40-132), accepting the LLaMA-Factory flags the reference's PA_SFT_*.sh scripts pass
 (scripts/train/PA_SFT/*.sh:25-50) and driving the MI355X SFT engine (iadr1_amd.sft).
 
-Data: the `sharegpt` manifests registered in data/dataset_info.json (columns `messages` / `images`); rendering goes
-through the checkpoint's own chat template (the `qwen2_vl` template of the reference expands `<image>` to
-<|vision_start|><|image_pad|>xN<|vision_end|>, llamafactory/data/mm_plugin.py:850-896 -- the HF processor does the
-same expansion), prompt turns are masked with -100 (processors/supervised.py:34-87), cutoff_len truncation, loss
+Data: the `sharegpt` manifests registered in data/dataset_info.json; alignment, image regularisation, `<image>` expansion, the `qwen2_vl`
+template, per-turn truncation and label masking are the reference's, restated in iadr1_amd.sft_data and pinned by goldens produced by the
+reference's own functions (tests/golden/sft_data.json, sft_text.json); the HF processor supplies the tokenizer and the image processor.  Loss
 curve written to <output_dir>/trainer_log.jsonl (train/callbacks.py:279-318)."""
 from __future__ import annotations
 
@@ -45,6 +44,7 @@ def build_parser():
     p.add_argument("--save_steps", type=int, default=500)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--micro_batch_seqs", type=int, default=16)
+    p.add_argument("--image_resolution", type=int, default=512 * 512)
     p.add_argument("--train_on_prompt", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     p.add_argument("--mask_history", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     for flag in ("--deepspeed", "--bf16", "--plot_loss", "--overwrite_cache", "--overwrite_output_dir", "--ddp_timeout", "--preprocessing_num_workers",
@@ -54,49 +54,44 @@ def build_parser():
 
 
 def load_sharegpt(name: str, dataset_dir: str):
-    path = name
-    cols = {"messages": "messages", "images": "images"}
+    """Rows of a sharegpt-format dataset, aligned the way the reference aligns them (iadr1_amd.sft_data.align_sharegpt).  `name` is an entry of
+    <dataset_dir>/dataset_info.json (file_name / formatting / columns / tags, LLaMA-Factory schema) or, failing that, a path to a json file in the
+    README's Expert-AD layout (README.md:71-99: "messages" with role / content, "images")."""
+    from iadr1_amd.sft_data import ShareGPTSchema, align_sharegpt
     info_p = os.path.join(dataset_dir, "dataset_info.json")
-    if not os.path.exists(path) and os.path.exists(info_p):
-        info = json.load(open(info_p))[name]
-        path = info["file_name"] if os.path.isabs(info["file_name"]) else os.path.join(dataset_dir, info["file_name"])
-        cols.update(info.get("columns", {}))
-    rows = json.load(open(path))
-    return [{"messages": r[cols["messages"]], "images": r.get(cols["images"], [])} for r in rows]
+    if not os.path.exists(name) and os.path.exists(info_p):
+        info = json.load(open(info_p))
+        if name not in info:
+            raise ValueError("Undefined dataset %s in dataset_info.json." % name)
+        entry = info[name]
+        path = entry["file_name"] if os.path.isabs(entry["file_name"]) else os.path.join(dataset_dir, entry["file_name"])
+        schema = ShareGPTSchema.from_dataset_info(entry)
+    else:
+        path = name
+        schema = ShareGPTSchema(messages="messages", images="images", role_tag="role", content_tag="content", user_tag="user", assistant_tag="assistant")
+    rows = [align_sharegpt(r, schema, image_dir=dataset_dir) for r in json.load(open(path))]
+    return [r for r in rows if r["prompt"]]      # the reference filters out the rows its aligner emptied (odd turn counts, roles out of order)
 
 
-def encode_example(proc, row, cutoff_len, train_on_prompt=False, mask_history=False, image_token_id=151655):
-    """-> (input_ids, labels, pixel_values, grids).  Per-turn truncation and masking are iadr1_amd.sft_data.supervised_labels (the reference's
-    _encode_supervised_example, llamafactory/data/processors/supervised.py:33-87): answers supervised, prompts -100, turns trimmed against cutoff_len."""
-    from iadr1_amd.sft_data import supervised_labels
-    from PIL import Image
-    msgs = []
-    for m in row["messages"]:
-        role = {"human": "user", "gpt": "assistant"}.get(m.get("from", m.get("role")), m.get("from", m.get("role")))
-        text = m.get("value", m.get("content"))
-        parts, segs = [], text.split("<image>")
-        for i, s in enumerate(segs):
-            if i:
-                parts.append({"type": "image"})
-            if s:
-                parts.append({"type": "text", "text": s})
-        msgs.append({"role": role, "content": parts})
-    images = [Image.open(p) if isinstance(p, str) else p for p in row["images"]]
-    turns, prev, full = [], 0, None      # (prompt_ids, answer_ids) per turn, the unit the reference truncates and masks by
-    for t in range(len(msgs)):
-        if msgs[t]["role"] != "assistant":
-            continue
-        upto = proc.apply_chat_template(msgs[: t + 1], tokenize=False)
-        before = proc.apply_chat_template(msgs[:t], tokenize=False, add_generation_prompt=True)
-        full = proc(text=[upto], images=images or None, return_tensors="pt", add_special_tokens=False)
-        n_before = proc(text=[before], images=images or None, return_tensors="pt", add_special_tokens=False)["input_ids"].shape[1]
-        cur = full["input_ids"][0].tolist()
-        turns.append((cur[prev:n_before], cur[n_before:]))
-        prev = len(cur)
+def encode_example(proc, row, cutoff_len, train_on_prompt=False, mask_history=False, image_token_id=151655, image_resolution=512 * 512):
+    """Aligned row -> (input_ids, labels, pixel_values, grids), the reference's supervised preprocessing end to end (iadr1_amd.sft_data): images
+    regularised (mm_plugin.py:108-123,810-824), "<image>" expanded to the vision tokens of its patch grid (mm_plugin.py:850-896), "qwen2_vl" ChatML
+    turns tokenised piecewise (template.py:85-160,1120-1133), per-turn budget and label mask (processors/supervised.py:33-87)."""
+    from iadr1_amd.sft_data import encode_turns, expand_image_placeholders, qwen2_vl_turn_texts, regularize_image, supervised_labels
+    images = []
+    for im in row["images"] or []:
+        if isinstance(im, str):
+            from PIL import Image
+            im = Image.open(im)
+        images.append(regularize_image(im, image_resolution))
+    feats = proc.image_processor(images=images, return_tensors="pt") if images else None
+    grids = feats["image_grid_thw"].tolist() if images else []
+    msgs = expand_image_placeholders(row["prompt"] + row["response"], grids, merge_size=getattr(proc.image_processor, "merge_size", 2))
+    turns = encode_turns(proc.tokenizer, qwen2_vl_turn_texts(msgs, row["system"]))
     ids, labels = supervised_labels(turns, cutoff_len, train_on_prompt=train_on_prompt, mask_history=mask_history)
-    if images and ids.count(image_token_id) != sum(1 for tn in turns for part in tn for x in part if x == image_token_id):
+    if images and ids.count(image_token_id) != sum(part.count(image_token_id) for tn in turns for part in tn):
         raise ValueError("cutoff_len=%d truncates image placeholder tokens; raise --cutoff_len" % cutoff_len)
-    return ids, labels, (full["pixel_values"] if images else None), (full["image_grid_thw"].tolist() if images else [])
+    return ids, labels, (feats["pixel_values"] if images else None), grids
 
 
 def main(argv=None):
@@ -136,7 +131,7 @@ def main(argv=None):
         eng.args.learning_rate = lr
         losses = []
         for k in range(ga):
-            enc = [encode_example(proc, rows[(i + j) % len(rows)], a.cutoff_len, a.train_on_prompt, a.mask_history, cfg.image_token_id) for j in range(bs)]
+            enc = [encode_example(proc, rows[(i + j) % len(rows)], a.cutoff_len, a.train_on_prompt, a.mask_history, cfg.image_token_id, a.image_resolution) for j in range(bs)]
             i += bs
             S = (max(len(e[0]) for e in enc) + 7) // 8 * 8  # pad_to_multiple_of=8 (sft/workflow.py:60), right padding
             ids = np.full((bs, S), pad, dtype=np.int64)
