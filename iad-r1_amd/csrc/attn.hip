@@ -66,6 +66,9 @@ __device__ __forceinline__ bf16x8_t ld_frag_g(const bf16_t* p, bool ok) {
 }
 __device__ __forceinline__ bf16x8_t ld_frag_s(const bf16_t* p) { return *(const bf16x8_t*)p; }
 
+// v_exp_f32 directly: exp2f() wraps it in a denormal-range rescale (~5 extra VALU instructions per call); softmax terms that small are zero anyway
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t a, const f32x4_t b) {
     u32x4_t v = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
     return __builtin_bit_cast(bf16x8_t, v);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = s[kt][r][e] * c;
+                    float t = s[kt][r][e];
                     if (need_mask) {
                         const int key = kv0 + (kt >> 1) * 32 + g * 8 + (kt & 1) * 4 + e;
                         if (key >= klen || (kcausal && key > qrow[r])) t = -INFINITY;
@@ -251,15 +254,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
             mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
-            const float mn = fmaxf(m[r], mx);
-            const float alpha = (mn == -INFINITY) ? 1.f : exp2f(m[r] - mn);
+            const float mn = fmaxf(m[r], mx * c);     // the running max lives in scaled (log2) units; the scale rides in the fma below
+            const float alpha = (mn == -INFINITY) ? 1.f : fast_exp2(m[r] - mn);
             const float mref = (mn == -INFINITY) ? 0.f : mn;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pv = exp2f(s[kt][r][e] - mref);
+                    const float pv = fast_exp2(__builtin_fmaf(s[kt][r][e], c, -mref));
                     s[kt][r][e] = pv;
                     ps += pv;
                 }
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             for (int e = 0; e < 4; ++e) {
                 const int key = kv0 + g * 8 + kt * 4 + e;
                 const bool ok = qok && key < klen && !(kcausal && key > qrow);
-                const float pv = ok ? exp2f(st[kt][e] * c - lse2) : 0.f;
+                const float pv = ok ? fast_exp2(__builtin_fmaf(st[kt][e], c, -lse2)) : 0.f;
                 ds[kt][e] = pv * (dpt[kt][e] - dl);
             }
         const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     const int qi = g * 8 + t * 4 + e;
                     const bool ok = kok && qi < cur_rows && !(p.causal && key > cur_rel + qi);
-                    const float pp = ok ? exp2f(s[t][e] * c - lse_s[qi]) : 0.f;
+                    const float pp = ok ? fast_exp2(__builtin_fmaf(s[t][e], c, -lse_s[qi])) : 0.f;
                     pv[t][e] = pp;
                     ds[t][e] = pp * (dp[t][e] - del_s[qi]);
                 }
@@ -703,14 +706,14 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
         mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
         mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
         const float mn = fmaxf(m, mx);
-        const float alpha = (mn == -INFINITY) ? 1.f : exp2f(m - mn);
+        const float alpha = (mn == -INFINITY) ? 1.f : fast_exp2(m - mn);
         const float mref = (mn == -INFINITY) ? 0.f : mn;
         float ps = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pv = exp2f(s[t][e] - mref);
+                const float pv = fast_exp2(s[t][e] - mref);
                 s[t][e] = pv;
                 ps += pv;
             }

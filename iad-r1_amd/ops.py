@@ -260,12 +260,19 @@ class Segments:
         include/iadr1_hip.h iadr1_attn_fwd); segments must then be non-empty."""
         self.n = len(starts)
         self.max_len = max(e - s for s, e in zip(starts, ends)) if self.n else 0
+        # rows the (disjoint) segments hold and the range they span: callers skip zero-filling outputs when every row belongs to a segment
+        self.rows = int(sum(e - s for s, e in zip(starts, ends)))
+        self.lo, self.hi = (int(min(starts)), int(max(ends))) if self.n else (0, 0)
         self.start = torch.tensor(starts, dtype=torch.int32, device=device)
         self.end = torch.tensor(ends, dtype=torch.int32, device=device)
         self.prefix = None
         if prefix is not None:
             assert len(prefix) == self.n and all(e > s for s, e in zip(starts, ends)), "shared-prefix segments must be non-empty"
             self.prefix = torch.tensor(prefix, dtype=torch.int32, device=device).contiguous()
+
+    def covers(self, r0, r1):
+        """True when every row of [r0, r1) lies in a segment (no left / post-EOS padding rows)."""
+        return self.rows == r1 - r0 and self.lo >= r0 and self.hi <= r1
 
     @staticmethod
     def from_cu(cu, device):

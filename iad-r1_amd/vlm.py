@@ -19,6 +19,10 @@ import torch
 from . import indexing, ops
 from .params import ParamStore, VLMConfig
 
+# IADR1_POISON=1: outputs that skip their zero fill (every row is written by the kernel) start as NaN instead of stale memory, so a row the kernel
+# does not write shows up in the tests instead of passing on a lucky allocation
+_POISON = bool(os.environ.get("IADR1_POISON"))
+
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -453,7 +457,10 @@ class Engine:
             if kv_sink is not None:
                 kv_sink(i, qkv[:, qw: qw + kw], qkv[:, qw + kw:])
             o = buf("o")
-            o.zero_()  # rows outside every segment (left / post-EOS padding) must read as zeros downstream (0 x stale NaN in wgrad otherwise)
+            if _POISON:
+                o.fill_(float("nan"))
+            if not plan.seg.covers(r0, r1):
+                o.zero_()  # rows outside every segment (left / post-EOS padding) must read as zeros downstream (0 x stale NaN in wgrad otherwise)
             lse = B["lse"][li].view(-1)[: Hq * T].view(Hq, T) if save else None
             # attention addresses rows absolutely: the keys of a completion segment live in the prompt rows written by the other phase
             qkv_all, o_all = full("qkv"), full("o")
@@ -504,7 +511,10 @@ class Engine:
             dx_mid = ops.rmsnorm_bwd(dh2, x_mid, P.w(b + "ln2"), rstd2, dres=dres, dw=P.g(b + "ln2"))
             self._wgrad(b + "o.w", dx_mid, o)
             do = ops.gemm_nt(dx_mid, P.wT(b + "o.w"))
-            dqkv = torch.zeros_like(qkv)  # rows of left padding belong to no segment: their gradient is exactly 0
+            # rows of left padding belong to no segment: their gradient is exactly 0 (attn_bwd writes every row that is in a segment)
+            dqkv = torch.empty_like(qkv) if plan.seg.covers(0, qkv.shape[0]) else torch.zeros_like(qkv)
+            if _POISON and plan.seg.covers(0, qkv.shape[0]):
+                dqkv.fill_(float("nan"))
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, do, lse, plan.seg, Hq, Hkv, D, True, D**-0.5,
                          dqkv[:, :qw], dqkv[:, qw: qw + kw], dqkv[:, qw + kw:])
             ops.rope_(dqkv, plan.cos, plan.sin, Hq + Hkv, D, backward=True)
