@@ -268,8 +268,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 }
             lsum[r] = lsum[r] * alpha + ps;
             m[r] = mn;
+            // after the first tiles the running max rarely moves: skip the rescale of the 32 accumulator registers (they live in AGPRs, so each
+            // multiply is a read + multiply + write) when no lane of the wave needs it -- multiplying by 1 is the identity, the result is unchanged
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt) acc[dt][r] *= alpha;
+                for (int dt = 0; dt < C::DT; ++dt) acc[dt][r] *= alpha;
+            }
         }
         bf16x8_t pf[R][2];
 #pragma unroll

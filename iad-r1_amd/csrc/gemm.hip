@@ -167,6 +167,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_128(GemmArgs p) {
         __syncthreads();
         bf16_t* C = (bf16_t*)p.C;
         const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+        if (vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {   // interior tile: 8 slab reads, then 8 unpredicated 16-byte stores
+            u32x4_t rv[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) rv[it] = *(const u32x4_t*)(cs + ((it * NTHREADS + t) >> 4) * C_LD + (t & 15) * 8);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) *(u32x4_t*)(C + (long long)(m0 + ((it * NTHREADS + t) >> 4)) * p.ldc + n0 + (t & 15) * 8) = rv[it];
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = it * NTHREADS + t;
@@ -185,6 +193,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_128(GemmArgs p) {
     } else {
         float* C = (float*)p.C;
         const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+        if (vec_ok && !p.bias && p.act == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {   // interior tile, plain store / accumulate (see gemm_nt_256)
+            float* base = C + (long long)(m0 + wm * 64 + lm) * p.ldc + n0 + wn * 64 + lq * 4;
+#pragma unroll
+            for (int i0 = 0; i0 < 4; i0 += 2) {
+                f32x4_t old[2][4];
+                if constexpr (OUT == OUT_F32_ACC) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) old[u][j] = *(const f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + j * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4_t o = acc[i0 + u][j];
+                        if constexpr (OUT == OUT_F32_ACC) o += old[u][j];
+                        *(f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + j * 16) = o;
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = m0 + wm * 64 + i * 16 + lm;
@@ -406,20 +436,39 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[e] = (gn + e < p.N) ? bf2f(p.bias[gn + e]) : 0.f;
             }
+            if (p.act == 1) {       // one uniform branch per column group, not one per element
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v[4];
+                for (int i = 0; i < 8; ++i) {
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][j][e] + bv[e];
-                    if (p.act == 1) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(acc[i][j][e] + bv[e]);
+                    *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + nl) = (u32x2_t){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
                 }
-                *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + nl) = (u32x2_t){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
+                    *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + nl) = (u32x2_t){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                }
             }
         }
         // same wave wrote and reads its slab: only its own LDS ops need to retire (compiler inserts lgkmcnt)
         bf16_t* C = (bf16_t*)p.C;
         const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+        if (vec_ok && m0 + wm * 128 + 128 <= p.M && n0 + wn * 64 + 64 <= p.N) {
+            // interior sub-tile (all of them on the hot shapes): 16 slab reads, then 16 row-contiguous 16-byte stores, no per-store predicate
+            // (a predicated store is a branch; 16 of them serialise the slab reads behind the stores)
+            bf16_t* dst0 = C + (long long)(m0 + wm * 128 + (l >> 3)) * p.ldc + n0 + wn * 64 + (l & 7) * 8;
+            const bf16_t* src0 = slab + (l >> 3) * EP_LD + (l & 7) * 8;
+            u32x4_t rv[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) rv[it] = *(const u32x4_t*)(src0 + it * 8 * EP_LD);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) *(u32x4_t*)(dst0 + (long long)it * 8 * p.ldc) = rv[it];
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = it * 8 + (l >> 3), ch = l & 7;
@@ -436,6 +485,30 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     } else {
         float* C = (float*)p.C;
         const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+        if (vec_ok && !p.bias && p.act == 0 && m0 + wm * 128 + 128 <= p.M && n0 + wn * 64 + 64 <= p.N) {
+            // interior sub-tile, plain store / accumulate (every wgrad and the lm_head): no predicates, and for the accumulate form the 8 loads
+            // of two row groups are in flight together instead of one load -> add -> store round trip per 16 bytes
+            float* base = C + (long long)(m0 + wm * 128 + lm) * p.ldc + n0 + wn * 64 + lq * 4;
+#pragma unroll
+            for (int i0 = 0; i0 < 8; i0 += 2) {
+                f32x4_t old[2][4];
+                if constexpr (OUT == OUT_F32_ACC) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) old[u][j] = *(const f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + j * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4_t o = acc[i0 + u][j];
+                        if constexpr (OUT == OUT_F32_ACC) o += old[u][j];
+                        *(f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + j * 16) = o;
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int gm = m0 + wm * 128 + i * 16 + lm;
