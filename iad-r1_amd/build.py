@@ -12,6 +12,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libiadr1_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+# per-file additions.  attn.hip: MFMA results in ordinary VGPRs -- the softmax / dS arithmetic works on the accumulators, and with them in AGPRs
+# every such operation is a v_accvgpr_read + op + v_accvgpr_write (2-3 moves per MFMA in these kernels); none of them needs more than 256 registers
+EXTRA_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+if os.environ.get("IADR1_NO_EXTRA_FLAGS"):
+    EXTRA_FLAGS = {}
 
 
 def sources():
@@ -23,6 +28,7 @@ def _digest():
     for f in sources() + [os.path.join(CSRC, "common.h")]:
         h.update(open(f, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -38,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([hipcc, *FLAGS, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((src, subprocess.Popen([hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
