@@ -749,7 +749,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) {
-            const float f = (red_m[ww * 16 + j] == -INFINITY) ? 0.f : exp2f(red_m[ww * 16 + j] - M);
+            const float f = (red_m[ww * 16 + j] == -INFINITY) ? 0.f : fast_exp2(red_m[ww * 16 + j] - M);
             num += f * red_o[(ww * D + d) * GS + j];
             den += f * red_l[ww * 16 + j];
         }
