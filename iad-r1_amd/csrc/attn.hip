@@ -141,13 +141,19 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 // four consecutive k of column m0+i == half of an MFMA A/B fragment of the TRANSPOSED tile, without ever storing a
 // transposed copy.  Two reads (k0, k0+4) make the 8-element fragment.  The asm is opaque to hipcc: every use is preceded
 // by an explicit counted s_waitcnt lgkmcnt + sched_barrier (guide 5.7).
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
-__device__ __forceinline__ void tr_issue(uint64_t& r, uint32_t byte_addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(byte_addr)); }
-__device__ __forceinline__ bf16x8_t tr_frag(uint64_t lo, uint64_t hi) {
-    u32x4_t v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-    return __builtin_bit_cast(bf16x8_t, v);
+// Through the compiler builtin, not inline asm: the two 8-byte results land in adjacent registers (the MFMA operand needs four consecutive
+// VGPRs; asm outputs had to be copied: 64 v_mov per 64-key tile in attn_fwd), byte offsets fold into the instruction's immediate field, and the
+// compiler counts lgkmcnt itself.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ lds_char_t* lds_ptr(const void* p) { return (lds_char_t*)p; }
+// fragment of the TRANSPOSED tile: k0..k0+3 from `lo`, k0+4..k0+7 from `hi` (both are this lane's tr-read addresses, see above)
+__device__ __forceinline__ bf16x8_t tr_frag_ld(lds_char_t* lo, lds_char_t* hi) {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)lo), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)hi);
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-#define IADR1_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 // lane-constant part of a tr-read address inside a row-major [rows][LD] tile: row (li>>2) + 8*g, column 4*(li&3)
 __device__ __forceinline__ uint32_t tr_lane_off(int li, int g, int LD) { return (uint32_t)(((g * 8 + (li >> 2)) * LD + 4 * (li & 3)) * 2); }
 
@@ -283,26 +289,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         {
             // O^T[d,q] += V^T . P^T with V^T fragments produced by transpose reads of the row-major V tile;
             // reads of d-tile dt+1 are in flight while the MFMAs of d-tile dt run
-            const uint32_t vbase = lds_addr(Vs) + tr_lane_off(li, g, C::LD);
-            uint64_t tr[2][4];
-            auto issue = [&](uint64_t (&dst)[4], int dt) {
+            lds_char_t* vbase = lds_ptr(Vs) + tr_lane_off(li, g, C::LD);
+            // the reads of d-tile dt+1 are issued before the MFMAs of d-tile dt
+            bf16x8_t vf[2][2];
+            auto fetch = [&](bf16x8_t (&dst)[2], int dt) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dst[j] = tr_frag_ld(vbase + ((j * 32) * C::LD + dt * 16) * 2, vbase + ((j * 32 + 4) * C::LD + dt * 16) * 2);
+            };
+            fetch(vf[0], 0);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                if (dt + 1 < C::DT) fetch(vf[(dt + 1) & 1], dt + 1);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) tr_issue(dst[j * 2 + h], vbase + (uint32_t)(((j * 32 + h * 4) * C::LD + dt * 16) * 2));
-            };
-            IADR1_LGKM(0);  // nothing else may be counted against the waits below
-            issue(tr[0], 0);
-#pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt) {
-                if (dt + 1 < C::DT) { issue(tr[(dt + 1) & 1], dt + 1); IADR1_LGKM(4); } else { IADR1_LGKM(0); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16x8_t vf = tr_frag(tr[dt & 1][j * 2], tr[dt & 1][j * 2 + 1]);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) acc[dt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[r][j], acc[dt][r], 0, 0, 0);
-                }
+                    for (int r = 0; r < R; ++r) acc[dt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt & 1][j], pf[r][j], acc[dt][r], 0, 0, 0);
             }
         }
     }
@@ -434,19 +435,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             }
         const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
         {
-            const uint32_t kbase = lds_addr(Ks) + tr_lane_off(li, g, C::LD);
-            uint64_t tr[2][2];
-            auto issue = [&](uint64_t (&dst)[2], int dt) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) tr_issue(dst[h], kbase + (uint32_t)((h * 4 * C::LD + dt * 16) * 2));
-            };
-            IADR1_LGKM(0);
-            issue(tr[0], 0);
+            lds_char_t* kbase = lds_ptr(Ks) + tr_lane_off(li, g, C::LD);
+            bf16x8_t kf[2];
+            kf[0] = tr_frag_ld(kbase, kbase + 4 * C::LD * 2);
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) {
-                if (dt + 1 < C::DT) { issue(tr[(dt + 1) & 1], dt + 1); IADR1_LGKM(2); } else { IADR1_LGKM(0); }
-                __builtin_amdgcn_sched_barrier(0);
-                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(tr[dt & 1][0], tr[dt & 1][1]), dsf, acc[dt], 0, 0, 0);
+                if (dt + 1 < C::DT) kf[(dt + 1) & 1] = tr_frag_ld(kbase + (dt + 1) * 32, kbase + (4 * C::LD + (dt + 1) * 16) * 2);
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[dt & 1], dsf, acc[dt], 0, 0, 0);
             }
         }
     }
@@ -574,23 +569,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
             const bf16x8_t pf = pack_frag(pv[0], pv[1]), dsf = pack_frag(ds[0], ds[1]);
             {
                 const uint32_t off = tr_lane_off(li, g, C::LD);
-                const uint32_t qbase = lds_addr(Qs) + off, dobase = lds_addr(dOs) + off;
-                uint64_t tr[2][4];  // [buffer][dO lo, dO hi, Q lo, Q hi]
-                auto issue = [&](uint64_t (&dst)[4], int dt) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        tr_issue(dst[h], dobase + (uint32_t)((h * 4 * C::LD + dt * 16) * 2));
-                        tr_issue(dst[2 + h], qbase + (uint32_t)((h * 4 * C::LD + dt * 16) * 2));
-                    }
-                };
-                IADR1_LGKM(0);
-                issue(tr[0], 0);
+                lds_char_t* qbase = lds_ptr(Qs) + off;
+                lds_char_t* dobase = lds_ptr(dOs) + off;
+                bf16x8_t dof[2], qf2[2];
+                dof[0] = tr_frag_ld(dobase, dobase + 4 * C::LD * 2);
+                qf2[0] = tr_frag_ld(qbase, qbase + 4 * C::LD * 2);
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
-                    if (dt + 1 < C::DT) { issue(tr[(dt + 1) & 1], dt + 1); IADR1_LGKM(4); } else { IADR1_LGKM(0); }
-                    __builtin_amdgcn_sched_barrier(0);
-                    dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(tr[dt & 1][0], tr[dt & 1][1]), pf, dvacc[dt], 0, 0, 0);
-                    dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(tr[dt & 1][2], tr[dt & 1][3]), dsf, dkacc[dt], 0, 0, 0);
+                    if (dt + 1 < C::DT) {
+                        dof[(dt + 1) & 1] = tr_frag_ld(dobase + (dt + 1) * 32, dobase + (4 * C::LD + (dt + 1) * 16) * 2);
+                        qf2[(dt + 1) & 1] = tr_frag_ld(qbase + (dt + 1) * 32, qbase + (4 * C::LD + (dt + 1) * 16) * 2);
+                    }
+                    dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[dt & 1], pf, dvacc[dt], 0, 0, 0);
+                    dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf2[dt & 1], dsf, dkacc[dt], 0, 0, 0);
                 }
             }
         }
