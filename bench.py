@@ -254,6 +254,10 @@ def run_pa_sft(a, cfg, dev, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
         dist.destroy_process_group()
+    elif os.environ.get("IADR1_FORCE_REDUCE"):
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
     if rank == 0:
         n_launch, t_gemm, fl_gemm = timer.summary()
         ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
@@ -274,7 +278,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("IADR1_FORCE_REDUCE"):   # IADR1_FORCE_REDUCE=1 under torchrun --nproc-per-node 1: the RCCL exchange path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     import iadr1_amd  # noqa: F401
@@ -417,9 +421,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or os.environ.get("IADR1_FORCE_REDUCE"):
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

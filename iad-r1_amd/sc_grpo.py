@@ -92,7 +92,9 @@ class GradReducer:
         self.dist, self.store, self.group = dist, store, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.cuda = store.grad.is_cuda
-        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        # IADR1_FORCE_REDUCE=1: run the exchange even in a one-rank group (exercises the side-stream / bucket / RCCL path on a single GPU)
+        self.active = self.world > 1 or (bool(os.environ.get("IADR1_FORCE_REDUCE")) and dist.is_available() and dist.is_initialized())
+        self.stream = torch.cuda.Stream() if (self.cuda and self.active) else None
         c = store.cfg
         s = store.slots
         self.layer_range = []
@@ -108,7 +110,7 @@ class GradReducer:
         self.work = []
 
     def _reduce(self, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         buf = self.store.grad[lo:hi]
         if self.stream is not None:

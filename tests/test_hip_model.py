@@ -308,6 +308,51 @@ def test_ddp_two_ranks_match_single_process_average():
     assert np.abs(h0 - w0).max() <= 4e-3
 
 
+def _rccl_one_rank_worker(port, q):
+    import os as _os
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", IADR1_FORCE_REDUCE="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    pol, ref = store(fx.make_weights(fx.TINY, 0), True), store(fx.make_weights(fx.TINY, 0), False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=6, learning_rate=1e-3, micro_batch_seqs=2))
+    assert eng.reducer.active and eng.reducer.stream is not None
+    grid = (1, 16, 12)
+    ids, mask = fx.left_pad([fx.synth_prompt(grid, 9, fx.TINY, 50)], fx.TINY["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=50), "image_grid_thw": [grid]}
+    comps = fx.synth_completions(4, 6, fx.TINY, 70)
+    rew = np.array([[1.0, 0.0], [0.5, 1.0], [2.0, 1.0], [0.0, 0.0]], dtype=np.float32)
+    eng.loss_and_grads(batch, comps, rew, last_micro_step=True)
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    q.put(pol.flat.float().cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_rccl_exchange_path_on_one_rank():
+    """The RCCL leg of the data-parallel exchange (per-layer buckets from the backward hook on a side stream, remainder in finish()) run in a
+    one-rank group on the test GPU: it must leave the step where a step without any process group leaves it."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_one_rank_worker, args=(port, q))
+    pr.start()
+    w_rccl = q.get(timeout=300)
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+    pol, ref = store(fx.make_weights(fx.TINY, 0), True), store(fx.make_weights(fx.TINY, 0), False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=6, learning_rate=1e-3, micro_batch_seqs=2))
+    grid = (1, 16, 12)
+    ids, mask = fx.left_pad([fx.synth_prompt(grid, 9, fx.TINY, 50)], fx.TINY["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=50), "image_grid_thw": [grid]}
+    eng.loss_and_grads(batch, fx.synth_completions(4, 6, fx.TINY, 70), np.array([[1.0, 0.0], [0.5, 1.0], [2.0, 1.0], [0.0, 0.0]], dtype=np.float32), last_micro_step=True)
+    eng.optimizer_step()
+    # atomics-order noise of the local gradients only (see the two-rank test)
+    assert np.abs(pol.flat.float().cpu().numpy() - w_rccl).max() <= 4e-3
+
+
 def test_7b_like_config_forward_and_rollout(golden_dir):
     """Untied lm_head, GQA group 7 (Qwen2.5-VL-7B structure): log-probs vs the reference golden, and the decode path
     (skinny GEMMs with N=768 / group-7 paged attention) agrees with the training-kernel forward on greedy tokens."""
