@@ -129,6 +129,18 @@ class GemmTimer:
             return r
 
         ops.gemm_nt = timed
+        orig_f = ops.gemm_swiglu_fused
+
+        def timed_f(x, w_gu, gu, a_out):      # gate|up GEMM with the SwiGLU epilogue: the same gemm_nt_256 main loop, 2*T*2I*K FLOPs
+            if not timer.enabled:
+                return orig_f(x, w_gu, gu, a_out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_f(x, w_gu, gu, a_out)
+            e1.record()
+            timer.records.append((e0, e1, 2.0 * x.shape[0] * w_gu.shape[0] * x.shape[1], (x.shape[0], w_gu.shape[0], x.shape[1], 'bfloat16+swiglu' if gu is not None else 'swiglu only')))
+
+        ops.gemm_swiglu_fused = timed_f
 
     def summary(self):
         t = sum(r[0].elapsed_time(r[1]) for r in self.records) * 1e-3

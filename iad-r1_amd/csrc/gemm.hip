@@ -38,9 +38,11 @@ struct GemmArgs {
     long long lda, ldb, ldc;
     int act;  // 0 none, 1 exact GELU
     int band;  // tile rows per rasterisation band (gemm_nt_256)
+    bf16_t* C2;      // OUT_SWIGLU: a[M, N/2] = silu(gate) * up (C = the gate|up matrix itself, or null when only `a` is wanted)
+    long long ldc2;
 };
 
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_SWIGLU = 3 };
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -302,7 +304,14 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
             const int arow = (rl >> 6) * 128 + h * 64 + (rl & 63);          // A half h: rows wm*128 + h*64 + ..
             const int bcol = (rl >> 5) * 64 + h * 32 + (rl & 31);           // B half h: cols wn*64 + h*32 + ..
             src[h][i] = p.A + (long long)min(m0 + arow, p.M - 1) * p.lda + cs * 8;
-            src[2 + h][i] = p.B + (long long)min(n0 + bcol, p.N - 1) * p.ldb + cs * 8;
+            if constexpr (OUT == OUT_SWIGLU) {
+                // fused SwiGLU: B = [gate rows 0..I) | up rows I..2I).  The block's 256 columns are 128 gate + 128 up columns of the SAME 128 outputs,
+                // arranged so that B half 0 of every wave is gate and half 1 is up: a lane then holds gate (n-tiles 0,1) and up (n-tiles 2,3) of the
+                // same (row, column) and the activation is computed in registers.
+                src[2 + h][i] = p.B + (long long)(h * (p.N >> 1) + (n0 >> 1) + (rl >> 5) * 32 + (rl & 31)) * p.ldb + cs * 8;
+            } else {
+                src[2 + h][i] = p.B + (long long)min(n0 + bcol, p.N - 1) * p.ldb + cs * 8;
+            }
         }
     }
     auto stage_half = [&](int buf, int half /*0..3 = A0 A1 B0 B1*/, int kt) {
@@ -424,7 +433,52 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     const int lm = l & 15, lq = l >> 4;
-    if constexpr (OUT == OUT_BF16) {
+    if constexpr (OUT == OUT_SWIGLU) {
+        // interior tiles only (the launcher guarantees M % 256 == 0, N % 256 == 0, 16-byte aligned outputs)
+        __syncthreads();  // every wave is done with the operand buffers
+        bf16_t* slab = (bf16_t*)smem + (size_t)w * 128 * EP_LD;
+        const int I = p.N >> 1;
+        const long long row0 = m0 + wm * 128;
+        const int ca = (n0 >> 1) + wn * 32;           // first of this wave's 32 output columns
+        if (p.C) {   // the gate|up matrix itself (backward needs it): slab columns 0..31 = gate, 32..63 = up
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + j * 16 + lq * 4) = (u32x2_t){pack2bf(acc[i][j][0], acc[i][j][1]), pack2bf(acc[i][j][2], acc[i][j][3])};
+            bf16_t* C = (bf16_t*)p.C;
+            const int ch = l & 7;
+            bf16_t* dst0 = C + (row0 + (l >> 3)) * p.ldc + (ch < 4 ? ca + ch * 8 : I + ca + (ch - 4) * 8);
+            const bf16_t* src0 = slab + (l >> 3) * EP_LD + ch * 8;
+            u32x4_t rv[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) rv[it] = *(const u32x4_t*)(src0 + it * 8 * EP_LD);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) *(u32x4_t*)(dst0 + (long long)it * 8 * p.ldc) = rv[it];
+        }
+        // a = bf16(silu(bf16 gate)) * bf16 up, the arithmetic of swiglu_fwd_kernel on the rounded gate|up values
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float av[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gq = bf2f(f2bf(acc[i][j][e])), uq = bf2f(f2bf(acc[i][j + 2][e]));
+                    av[e] = bf2f(f2bf(gq / (1.f + __expf(-gq)))) * uq;
+                }
+                *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + j * 16 + lq * 4) = (u32x2_t){pack2bf(av[0], av[1]), pack2bf(av[2], av[3])};
+            }
+        {
+            bf16_t* dst0 = p.C2 + (row0 + (l >> 2)) * p.ldc2 + ca + (l & 3) * 8;      // 4 lanes per 64-byte row segment, 16 rows per instruction
+            const bf16_t* src0 = slab + (l >> 2) * EP_LD + (l & 3) * 8;
+            u32x4_t rv[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) rv[it] = *(const u32x4_t*)(src0 + it * 16 * EP_LD);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) *(u32x4_t*)(dst0 + (long long)it * 16 * p.ldc2) = rv[it];
+        }
+    } else if constexpr (OUT == OUT_BF16) {
         __syncthreads();  // every wave is done with the operand buffers
         bf16_t* slab = (bf16_t*)smem + (size_t)w * 128 * EP_LD;
 #pragma unroll
@@ -1078,7 +1132,7 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2, "gemm_nt: bad out_mode %d", out_mode);
     static int band_rows = 0;
     if (!band_rows) { const char* e = getenv("IADR1_GEMM_BAND"); band_rows = e ? atoi(e) : 4; if (band_rows < 1) band_rows = 4; }
-    GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act, band_rows};
+    GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act, band_rows, nullptr, 0};
     static int force_tile = -1;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1107,6 +1161,23 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     else if (out_mode == 1) hipLaunchKernelGGL(gemm_nt_128<OUT_F32>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     else hipLaunchKernelGGL(gemm_nt_128<OUT_F32_ACC>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     return iadr1_check_launch("gemm_nt_bf16");
+}
+
+// gate|up projection with the SwiGLU fused into the epilogue of gemm_nt_256 (training / prefill shapes): GU[M, 2I] = A . W^T (stored when GU != null:
+// the backward pass needs it) and Aout[M, I] = bf16(silu(GU[:, :I])) * GU[:, I:], bit-identical to iadr1_gemm_nt_bf16 + iadr1_swiglu_fwd.
+extern "C" int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, void* Aout, int M, int I, int K, long long lda, long long ldw,
+                                      long long ldgu, long long ldaout, hipStream_t stream) {
+    IADR1_REQUIRE(M > 0 && I > 0 && K > 0 && Aout != nullptr, "gemm_swiglu: empty problem");
+    IADR1_REQUIRE((M % 256) == 0 && (I % 128) == 0 && (K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldaout % 8) == 0 && (GU == nullptr || (ldgu % 8) == 0),
+                  "gemm_swiglu: needs M %% 256 == 0, I %% 128 == 0 and 16-byte row strides (M=%d I=%d K=%d); use gemm_nt + swiglu_fwd otherwise", M, I, K);
+    IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)GU) & 15) == 0 && (((uintptr_t)Aout) & 15) == 0, "gemm_swiglu: operands must be 16-byte aligned");
+    static int band_rows = 0;
+    if (!band_rows) { const char* e = getenv("IADR1_GEMM_BAND"); band_rows = e ? atoi(e) : 4; if (band_rows < 1) band_rows = 4; }
+    GemmArgs p{(const bf16_t*)A, (const bf16_t*)W, GU, nullptr, zeros_ptr(), M, 2 * I, K, lda, ldw, ldgu, 0, band_rows, (bf16_t*)Aout, ldaout};
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); attr_done = true; }
+    hipLaunchKernelGGL(gemm_nt_256<OUT_SWIGLU>, dim3((M / 256) * (I / 128)), dim3(NT2), SMEM2_BYTES, stream, p);
+    return iadr1_check_launch("gemm_swiglu_bf16");
 }
 
 extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,

@@ -3,6 +3,8 @@ torch's job, arithmetic is not) and launch on torch's current HIP stream.  2-D t
 views; a non-unit inner stride is an error, an outer stride is passed through as `ld`."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip
@@ -13,6 +15,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 def _ld(x: torch.Tensor) -> int:
     assert x.dim() == 2 and x.stride(1) == 1, f"need a row-major 2-D view, got shape {tuple(x.shape)} stride {x.stride()}"
     return x.stride(0)
+
+
+_FUSE_SWIGLU = os.environ.get("IADR1_FUSE_SWIGLU", "1") != "0"
 
 
 def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
@@ -161,6 +166,27 @@ def rope_(x, cos, sin, nheads, D, backward=False):
     assert cos.dtype == F32 and cos.shape == (T, D // 2) and cos.is_contiguous() and sin.is_contiguous()
     hip.call("rope_inplace", x, _ld(x), cos, sin, T, nheads, D, 1 if backward else 0)
     return x
+
+
+def gemm_swiglu_fused(x, w_gu, gu, a):
+    """The single-launch form (include/iadr1_hip.h iadr1_gemm_swiglu_bf16); gu may be None.  Shape requirements are the caller's (gemm_swiglu)."""
+    T, K = x.shape
+    I = w_gu.shape[0] // 2
+    hip.call("gemm_swiglu_bf16", x, w_gu, gu, a, T, I, K, _ld(x), _ld(w_gu), _ld(gu) if gu is not None else 0, _ld(a))
+
+
+def gemm_swiglu(x, w_gu, gu_out=None, a_out=None, keep_gu=True):
+    """(gu, a) with gu = x @ w_gu^T ([T, 2I], None when keep_gu is False and the fused launch ran) and a = swiglu(gu) ([T, I]).  One launch when the
+    shape allows (T % 256 == 0, I % 128 == 0, enough tiles for the 256x256 kernel), gemm_nt + swiglu_fwd otherwise -- same bits either way."""
+    T, K = x.shape
+    I = w_gu.shape[0] // 2
+    a = a_out if a_out is not None else torch.empty(T, I, dtype=BF16, device=x.device)
+    if _FUSE_SWIGLU and T % 256 == 0 and I % 128 == 0 and (T // 256) * (I // 128) >= 192 and _ld(x) % 8 == 0:
+        gu = (gu_out if gu_out is not None else torch.empty(T, 2 * I, dtype=BF16, device=x.device)) if keep_gu else None
+        gemm_swiglu_fused(x, w_gu, gu, a)
+        return gu, a
+    gu = gemm_nt(x, w_gu, out=gu_out)
+    return gu, swiglu_fwd(gu, out=a)
 
 
 def swiglu_fwd(gu, out=None):

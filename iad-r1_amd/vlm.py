@@ -471,8 +471,8 @@ class Engine:
             h2 = buf("h2")
             rstd2 = B["rstd2"][li, r0:r1] if save else None
             ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, Tl, H, H, H, H, float(eps))
-            gu = ops.gemm_nt(h2, P.w(b + "gu.w"), out=buf("gu"))
-            a = ops.swiglu_fwd(gu, out=buf("a"))
+            # gate|up projection with the activation in its epilogue; the gate|up matrix itself is written only when backward will read it
+            gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=buf("gu"), a_out=buf("a"), keep_gu=save)
             branch = ops.gemm_nt(a, P.w(b + "down.w"))
             res = x_mid
             if save:

@@ -34,6 +34,12 @@ const char* iadr1_last_error(void);
  * :1386-1387 (lm_head), and their autograd backward (dgrad / wgrad run on transposed operands). */
 int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
                        long long ldb, long long ldc, int out_mode, int act, iadr1_stream_t stream);
+/* gate|up projection + SwiGLU in one launch (training / prefill shapes): GU[M, 2I] = A[M,K] . W[2I,K]^T is stored when GU != NULL (the backward
+ * pass reads it), Aout[M, I] = bf16(silu(gate)) * up with gate = GU[:, :I], up = GU[:, I:], computed in the GEMM epilogue from the rounded gate|up
+ * values: bit-identical to iadr1_gemm_nt_bf16 followed by iadr1_swiglu_fwd.  M %% 256 == 0, I %% 128 == 0.  Replaces TF:552-554
+ * (down_proj(act_fn(gate_proj(x)) * up_proj(x))) up to the down projection. */
+int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, void* Aout, int M, int I, int K, long long lda, long long ldw,
+                           long long ldgu, long long ldaout, iadr1_stream_t stream);
 /* Decode-time skinny GEMM: Y[M,N] = X[M,K] . W[N,K]^T (M small, 64 rows per pass); HBM-bound weight stream,
  * K spread over 8-16 waves per block (+ optional grid split `ksplit`), no atomics.  out_mode 0: bf16 + bias;
  * 1: fp32 (logits); 2: fp32 partial slabs Y[ksplit][M][ldy] summed by iadr1_rmsnorm_fwd (x32 path); 3: fused

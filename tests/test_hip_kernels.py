@@ -554,3 +554,26 @@ def test_sampler_greedy_and_topk_topp(V):
     assert torch.equal(ops.sample(lg, 0.9, 50, 0.9, seed=5, step=0, step_ptr=sp), ops.sample(lg, 0.9, 50, 0.9, seed=5, step=7))
     sd = torch.tensor([1234567890123], dtype=torch.int64, device=DEV)     # device-resident seed (graph replays): same stream as the scalar
     assert torch.equal(ops.sample(lg, 0.9, 50, 0.9, seed=0, step=3, seed_ptr=sd), ops.sample(lg, 0.9, 50, 0.9, seed=1234567890123, step=3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,I,K,keep", [(2048, 3072, 256, True), (2048, 3072, 256, False), (4096, 1664, 512, True), (768, 11008, 2048, True)])
+def test_gemm_swiglu_is_bit_identical_to_gemm_then_swiglu(M, I, K, keep):
+    """Fused gate|up GEMM + SwiGLU epilogue (iadr1_gemm_swiglu_bf16) vs the two separate launches, bit for bit, incl. the stored gate|up matrix."""
+    g = torch.Generator(device="cpu").manual_seed(M + I + K)
+    x = (torch.randn(M, K, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    w = (torch.randn(2 * I, K, generator=g) * K ** -0.5 * 2.0).to(torch.bfloat16).cuda()
+    gu_ref = ops.gemm_nt(x, w)
+    a_ref = ops.swiglu_fwd(gu_ref)
+    assert (M // 256) * (I // 128) >= 192          # the fused kernel is what runs
+    gu_buf = torch.full((M, 2 * I), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gu, a = ops.gemm_swiglu(x, w, gu_out=gu_buf, keep_gu=keep)
+    assert torch.equal(a.view(torch.int16), a_ref.view(torch.int16))
+    if keep:
+        assert gu.data_ptr() == gu_buf.data_ptr() and torch.equal(gu.view(torch.int16), gu_ref.view(torch.int16))
+    else:
+        assert gu is None and bool(torch.isnan(gu_buf.float()).all())     # nothing was written
+    # shapes the fused kernel does not take fall back to the two launches
+    x2 = x[:300].contiguous()
+    gu2, a2 = ops.gemm_swiglu(x2, w)
+    assert torch.equal(a2.view(torch.int16), ops.swiglu_fwd(ops.gemm_nt(x2, w)).view(torch.int16)) and gu2 is not None
