@@ -134,26 +134,7 @@ __device__ __forceinline__ void stage_rows_t(bf16_t* dst, const bf16_t* src, lon
 
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-// ---- hardware transpose read (gfx950 ds_read_b64_tr_b16) ---------------------------------------------------------------
-// Measured lane map (tools/gpu_probe.py, profiles/r01_tr_read_probe.txt): inside each 16-lane group, lane i receives
-// element (i & 3) of the 8-byte chunk addressed by lane 4*j + (i >> 2), for j = 0..3.  With lane L pointing at
-// tile[k0 + (L >> 2)][m0 + 4*(L & 3)] of a ROW-MAJOR [k][m] LDS tile, lane i therefore gets tile[k0 + 0..3][m0 + i]:
-// four consecutive k of column m0+i == half of an MFMA A/B fragment of the TRANSPOSED tile, without ever storing a
-// transposed copy.  Two reads (k0, k0+4) make the 8-element fragment.  The asm is opaque to hipcc: every use is preceded
-// by an explicit counted s_waitcnt lgkmcnt + sched_barrier (guide 5.7).
-// Through the compiler builtin, not inline asm: the two 8-byte results land in adjacent registers (the MFMA operand needs four consecutive
-// VGPRs; asm outputs had to be copied: 64 v_mov per 64-key tile in attn_fwd), byte offsets fold into the instruction's immediate field, and the
-// compiler counts lgkmcnt itself.
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-typedef __attribute__((address_space(3))) char lds_char_t;
-__device__ __forceinline__ lds_char_t* lds_ptr(const void* p) { return (lds_char_t*)p; }
-// fragment of the TRANSPOSED tile: k0..k0+3 from `lo`, k0+4..k0+7 from `hi` (both are this lane's tr-read addresses, see above)
-__device__ __forceinline__ bf16x8_t tr_frag_ld(lds_char_t* lo, lds_char_t* hi) {
-    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)lo), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)hi);
-    return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-}
+// hardware transpose reads: tr_frag_ld (common.h)
 // lane-constant part of a tr-read address inside a row-major [rows][LD] tile: row (li>>2) + 8*g, column 4*(li&3)
 __device__ __forceinline__ uint32_t tr_lane_off(int li, int g, int LD) { return (uint32_t)(((g * 8 + (li >> 2)) * LD + 4 * (li & 3)) * 2); }
 
