@@ -100,6 +100,60 @@ def save_checkpoint(store: ParamStore, path: str, hf_config: Optional[dict] = No
             json.dump(hf_config, f, indent=2)
 
 
+def _layout_digest(store: ParamStore) -> str:
+    import hashlib
+    h = hashlib.sha1()
+    for name in sorted(store.slots):
+        sl = store.slots[name]
+        h.update(f"{name}:{sl.offset}:{tuple(sl.shape)};".encode())
+    h.update(str(store.n_total).encode())
+    return h.hexdigest()
+
+
+def save_training_state(store: ParamStore, path: str, opt_step: int, global_step: int, extra: Optional[dict] = None):
+    """What a run needs to continue bit-exactly, next to the HF-layout weights of `save_checkpoint`: the fp32 master weights and both Adam moments
+    (flat, in the ParamStore layout) as optimizer.safetensors, and trainer_state.json (global_step, the optimizer's step counter -- bias correction and
+    the rollout seed derive from it -- and the layout digest the tensors are only valid for).  The reference gets this from transformers.Trainer
+    (_save_checkpoint TF:trainer.py:3079: optimizer.pt, scheduler.pt, trainer_state.json); the LR schedule here is a pure function of global_step."""
+    from safetensors.torch import save_file
+
+    os.makedirs(path, exist_ok=True)
+    save_file({"master": store.master.detach().cpu(), "exp_avg": store.m.detach().cpu(), "exp_avg_sq": store.v.detach().cpu()},
+              os.path.join(path, "optimizer.safetensors"), metadata={"format": "pt", "layout": _layout_digest(store)})
+    with open(os.path.join(path, "trainer_state.json"), "w") as f:
+        json.dump({"global_step": int(global_step), "opt_step": int(opt_step), "layout": _layout_digest(store), "n_total": int(store.n_total), **(extra or {})}, f, indent=2)
+
+
+def load_training_state(store: ParamStore, path: str) -> dict:
+    """Inverse of save_training_state on a ParamStore of the same configuration: restores master weights / moments, re-derives the bf16 parameters and
+    their transposed / decode-packed copies from the masters, returns the trainer_state.json dict."""
+    from safetensors import safe_open
+
+    with open(os.path.join(path, "trainer_state.json")) as f:
+        state = json.load(f)
+    if state.get("layout") != _layout_digest(store) or state.get("n_total") != store.n_total:
+        raise ValueError(f"{path}: optimizer state was written for a different parameter layout")
+    with safe_open(os.path.join(path, "optimizer.safetensors"), framework="pt") as sf:
+        store.master.copy_(sf.get_tensor("master"))
+        store.m.copy_(sf.get_tensor("exp_avg"))
+        store.v.copy_(sf.get_tensor("exp_avg_sq"))
+    store.flat.copy_(store.master.to(torch.bfloat16))      # round-to-nearest-even, as the optimizer kernel writes them
+    store.refresh_shadows()
+    return state
+
+
+def last_checkpoint(output_dir: str) -> Optional[str]:
+    """Highest-numbered <output_dir>/checkpoint-N that holds a training state (the reference's auto-resume rule, llamafactory hparams/parser.py:332-354
+    -> transformers.trainer_utils.get_last_checkpoint)."""
+    best = None
+    if os.path.isdir(output_dir):
+        for d in os.listdir(output_dir):
+            if d.startswith("checkpoint-") and d[11:].isdigit() and os.path.exists(os.path.join(output_dir, d, "trainer_state.json")):
+                if best is None or int(d[11:]) > int(best[11:]):
+                    best = d
+    return os.path.join(output_dir, best) if best else None
+
+
 class SCGRPOTrainer:
     def __init__(
         self,
@@ -255,17 +309,26 @@ class SCGRPOTrainer:
             return a.learning_rate * 0.5 * (1 + math.cos(math.pi * frac))
         return a.learning_rate * max(0.0, 1 - frac)  # HF default: linear decay
 
-    def train(self):
+    def train(self, resume_from_checkpoint: Optional[str] = None):
+        """resume_from_checkpoint: a checkpoint-N directory written by this trainer (weights + optimizer.safetensors + trainer_state.json), or True for
+        the last one under output_dir (transformers.Trainer.train semantics)."""
         a = self.args
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        start = 0
+        if resume_from_checkpoint:
+            ck = last_checkpoint(a.output_dir) if resume_from_checkpoint is True else resume_from_checkpoint
+            if ck is None:
+                raise ValueError(f"No valid checkpoint found in output directory ({a.output_dir})")
+            st = load_training_state(self.policy, ck)
+            self.engine.opt_step, self.state.global_step, start = st["opt_step"], st["global_step"], st["global_step"]
         rows = list(self.train_dataset)
         rows = rows[rank::world]  # prompts are sharded over ranks; each rank keeps whole groups (SURVEY.md section 8(e))
         bs, ga = a.per_device_train_batch_size, a.gradient_accumulation_steps
         steps_per_epoch = max(1, len(rows) // (bs * ga))
         total = a.max_steps if a.max_steps > 0 else int(math.ceil(steps_per_epoch * a.num_train_epochs))
         t0 = time.time()
-        i = 0
-        for step in range(total):
+        i = start * bs * ga
+        for step in range(start, total):
             self.engine.args.learning_rate = self._lr(step, total)
             losses = []
             for k in range(ga):
@@ -278,7 +341,9 @@ class SCGRPOTrainer:
                 self.log({"loss": float(np.mean(losses)), "learning_rate": self.engine.args.learning_rate, "step": self.state.global_step,
                           "elapsed_s": round(time.time() - t0, 2)})
             if a.save_steps and self.state.global_step % a.save_steps == 0 and rank == 0:
-                self.save_model(os.path.join(a.output_dir, f"checkpoint-{self.state.global_step}"))
+                ck = os.path.join(a.output_dir, f"checkpoint-{self.state.global_step}")
+                self.save_model(ck)
+                save_training_state(self.policy, ck, self.engine.opt_step, self.state.global_step)
         return self.log_history
 
     def save_model(self, output_dir: Optional[str] = None):

@@ -560,3 +560,51 @@ def test_prefill_reused_as_prompt_part_of_the_policy_forward():
     (m1, g1), (m0, g0) = res
     assert abs(m1["loss"] - m0["loss"]) < 1e-6 and m1["reward"] == m0["reward"] and abs(m1["kl"] - m0["kl"]) < 1e-6
     assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max()) + 1e-12
+
+
+def test_training_state_resume(tmp_path):
+    """Save after 2 SFT steps, load into a store initialised differently: master weights, Adam moments and bf16 parameters come back bit for bit and the
+    optimizer's step counter travels in trainer_state.json; 2 more steps then land where 4 straight steps land (up to the atomics-order noise of the
+    gradients, see the two-rank test); a state written for another layout is refused."""
+    from iadr1_amd.sft import SFTArgs, SFTEngine
+    from iadr1_amd.trainer import last_checkpoint, load_training_state, save_training_state
+
+    def batch(seed):
+        grid = (1, 16, 12)
+        ids, mask = fx.left_pad([fx.synth_prompt(grid, 9, fx.TINY, seed)], fx.TINY["pad_token_id"])
+        ids, mask = np.asarray(ids)[:, ::1], np.asarray(mask)
+        # right-aligned prompt of the fixture works as an SFT row: supervise the last 6 positions
+        labels = np.where(np.arange(ids.shape[1])[None, :] >= ids.shape[1] - 6, ids, -100)
+        return {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=seed), "image_grid_thw": [grid]}
+
+    def run(eng, lo, hi):
+        for st in range(lo, hi):
+            eng.args.learning_rate = 1e-3 * (st + 1)
+            eng.loss_and_grads(batch(100 + st))
+            eng.optimizer_step()
+
+    s4 = store(fx.make_weights(fx.TINY, 0), True)
+    e4 = SFTEngine(CFG, s4, SFTArgs(learning_rate=1e-3))
+    run(e4, 0, 4)
+    s2 = store(fx.make_weights(fx.TINY, 0), True)
+    e2 = SFTEngine(CFG, s2, SFTArgs(learning_rate=1e-3))
+    run(e2, 0, 2)
+    ck = str(tmp_path / "checkpoint-2")
+    save_training_state(s2, ck, e2.opt_step, 2)
+    assert last_checkpoint(str(tmp_path)) == ck
+    s3 = store(fx.make_weights(fx.TINY, 1), True)          # different weights: everything must come from the checkpoint
+    e3 = SFTEngine(CFG, s3, SFTArgs(learning_rate=1e-3))
+    state = load_training_state(s3, ck)
+    assert state["global_step"] == 2 and state["opt_step"] == 2
+    e3.opt_step = state["opt_step"]
+    for name in ("master", "m", "v", "flat", "flat_t"):
+        assert torch.equal(getattr(s3, name), getattr(s2, name)), name
+    run(e3, 2, 4)
+    run(e2, 2, 4)                                            # the run that never stopped
+    assert (s3.master - s4.master).abs().max().item() <= 4e-3 and (s2.master - s4.master).abs().max().item() <= 4e-3
+    import json as _json
+    st_path = os.path.join(ck, "trainer_state.json")
+    bad = _json.load(open(st_path)); bad["layout"] = "0" * 40
+    _json.dump(bad, open(st_path, "w"))
+    with pytest.raises(ValueError, match="different parameter layout"):
+        load_training_state(s3, ck)

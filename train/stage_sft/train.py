@@ -45,6 +45,7 @@ def build_parser():
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--micro_batch_seqs", type=int, default=16)
     p.add_argument("--image_resolution", type=int, default=512 * 512)
+    p.add_argument("--resume_from_checkpoint", default=None, help="checkpoint-N directory with a training state; default: the last one under output_dir unless --overwrite_output_dir")
     p.add_argument("--train_on_prompt", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     p.add_argument("--mask_history", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     for flag in ("--deepspeed", "--bf16", "--plot_loss", "--overwrite_cache", "--overwrite_output_dir", "--ddp_timeout", "--preprocessing_num_workers",
@@ -112,7 +113,7 @@ def main(argv=None):
     from transformers import AutoProcessor
 
     from iadr1_amd.sft import SFTArgs, SFTEngine
-    from iadr1_amd.trainer import load_checkpoint, save_checkpoint
+    from iadr1_amd.trainer import last_checkpoint, load_checkpoint, load_training_state, save_checkpoint, save_training_state
 
     cfg, store = load_checkpoint(a.model_name_or_path, dev, trainable=True)
     proc = AutoProcessor.from_pretrained(a.model_name_or_path)
@@ -124,8 +125,15 @@ def main(argv=None):
     os.makedirs(a.output_dir, exist_ok=True)
     log = open(os.path.join(a.output_dir, "trainer_log.jsonl"), "a") if rank == 0 else None
     pad = cfg.pad_token_id
-    i, t0 = 0, time.time()
-    for step in range(total):
+    # resume (reference: llamafactory hparams/parser.py:332-354 picks the last checkpoint of an existing output_dir unless --overwrite_output_dir)
+    ck = a.resume_from_checkpoint or (None if a.overwrite_output_dir else last_checkpoint(a.output_dir))
+    start = 0
+    if ck:
+        st = load_training_state(store, ck)
+        eng.opt_step, start = st["opt_step"], st["global_step"]
+        print(f"resuming from {ck} at step {start}", flush=True)
+    i, t0 = start * bs * ga, time.time()
+    for step in range(start, total):
         lr = a.learning_rate * (step + 1) / a.warmup_steps if step < a.warmup_steps else (
             a.learning_rate * 0.5 * (1 + math.cos(math.pi * (step - a.warmup_steps) / max(1, total - a.warmup_steps))) if a.lr_scheduler_type == "cosine" else a.learning_rate)
         eng.args.learning_rate = lr
@@ -150,6 +158,7 @@ def main(argv=None):
             log.flush()
         if rank == 0 and a.save_steps and (step + 1) % a.save_steps == 0:
             save_checkpoint(store, os.path.join(a.output_dir, f"checkpoint-{step + 1}"), json.load(open(os.path.join(a.model_name_or_path, "config.json"))))
+            save_training_state(store, os.path.join(a.output_dir, f"checkpoint-{step + 1}"), eng.opt_step, step + 1)
     if rank == 0:
         save_checkpoint(store, a.output_dir, json.load(open(os.path.join(a.model_name_or_path, "config.json"))))
         proc.save_pretrained(a.output_dir)
