@@ -304,12 +304,17 @@ class SCGRPOEngine:
         self.opt_step += 1
         scale = 1.0 / (self.reducer.world * max(1, self.accum))
         hip.call("sumsq", st.grad, st.n_total, self.norm_scratch, self.norm2)
+        self.grad_scale = scale          # grad_norm() = sqrt(norm2) * scale: the norm of the averaged gradient, before clipping (HF's `grad_norm` log key)
         for lo, hi, wd in ((0, st.n_decay, a.weight_decay), (st.n_decay, st.n_total, 0.0)):
             if hi > lo:
                 hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,
                          a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd, self.opt_step, scale, self.norm2, a.max_grad_norm)
         st.refresh_shadows()
         self.accum = 0
+
+    def grad_norm(self) -> float:
+        """Global L2 norm of the last optimizer step's (averaged, unclipped) gradient; synchronises the device."""
+        return float(self.norm2.sqrt().item()) * getattr(self, "grad_scale", 1.0)
 
     # ---- the whole micro-step ----------------------------------------------------------------------------------------
     def step(self, batch, reward_fn, do_optimizer_step=True):

@@ -338,7 +338,7 @@ class SCGRPOTrainer:
             self.engine.optimizer_step()
             self.state.global_step += 1
             if self.state.global_step % a.logging_steps == 0:
-                self.log({"loss": float(np.mean(losses)), "learning_rate": self.engine.args.learning_rate, "step": self.state.global_step,
+                self.log({"loss": float(np.mean(losses)), "grad_norm": self.engine.grad_norm(), "learning_rate": self.engine.args.learning_rate, "step": self.state.global_step,
                           "elapsed_s": round(time.time() - t0, 2)})
             if a.save_steps and self.state.global_step % a.save_steps == 0 and rank == 0:
                 ck = os.path.join(a.output_dir, f"checkpoint-{self.state.global_step}")

@@ -240,7 +240,8 @@ def test_trainer_api_runs_two_optimizer_steps():
                        processing_class=_FakeProcessor(batch, texts))
     before = tr.policy.flat.clone()
     hist = tr.train()
-    assert len(hist) == 2 and {"loss", "reward", "reward_std", "kl", "completion_length", "rewards/accuracy_reward", "rewards/consistency_reward"} <= set(hist[-1])
+    assert len(hist) == 2 and {"loss", "grad_norm", "learning_rate", "reward", "reward_std", "kl", "completion_length", "rewards/accuracy_reward", "rewards/consistency_reward"} <= set(hist[-1])
+    assert all(np.isfinite(h["grad_norm"]) and h["grad_norm"] > 0 for h in hist)
     assert not torch.equal(before, tr.policy.flat)            # parameters moved
     assert torch.equal(tr.ref.flat, before)                   # the frozen reference did not
     with pytest.raises(ValueError, match="does not support returning outputs"):
