@@ -13,6 +13,8 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 import torch
 
@@ -388,9 +390,24 @@ class ParamStore:
         self.refresh_shadows()
 
     def refresh_shadows(self):
-        """After any change of the bf16 parameters (load / optimizer step): transposed + decode-packed copies."""
-        self.refresh_transposes()
-        self.refresh_decode_pack()
+        """After any change of the bf16 parameters (load / optimizer step): transposed + decode-packed copies.
+        For a trainable store on the GPU the ~450 small launches (one per tensor) are captured into a hipGraph at the first call and replayed: every
+        pointer is fixed for the life of the store, and the host time of launching them one by one (about 20 ms for the 3B model) is what kept the
+        optimizer tail from overlapping with the next step (sc_grpo.optimizer_step(overlap=True))."""
+        if not (self.trainable and self.device.type == "cuda" and os.environ.get("IADR1_SHADOW_GRAPH", "1") != "0"):
+            self.refresh_transposes()
+            self.refresh_decode_pack()
+            return
+        if getattr(self, "_shadow_graph", None) is None:
+            self.refresh_transposes()          # eager once: first-use initialisation (function attributes, lazily built buffers) must not happen under capture
+            self.refresh_decode_pack()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.refresh_transposes()
+                self.refresh_decode_pack()
+            self._shadow_graph = g
+        self._shadow_graph.replay()
 
     def export_named(self, source: str = "param") -> dict:
         """Inverse of load_named (bf16 params, or fp32 `grad` views for tests): checkpoint-name -> CPU tensor."""

@@ -83,6 +83,20 @@ class Engine:
     # plans
     # ========================================================================================================
     def vision_plan(self, grids) -> VisionPlan:
+        """Host-side index plan of the vision tower for a list of (t, h, w) patch grids.  Plans are immutable and depend on the grids only, so the last few
+        are kept: with a pixel cap most batches repeat a handful of grid lists, and building one (window order, rotary table, segment lists, their
+        host-to-device copies) costs ~15 ms of host time at the start of a step, when the GPU has nothing else queued."""
+        key = tuple(tuple(int(z) for z in g) for g in grids)
+        cache = self.__dict__.setdefault("_vision_plans", {})
+        plan = cache.get(key)
+        if plan is None:
+            plan = self._vision_plan_build(list(key))
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            cache[key] = plan
+        return plan
+
+    def _vision_plan_build(self, grids) -> VisionPlan:
         c = self.cfg
         grids = [tuple(int(z) for z in g) for g in grids]
         m2 = c.v_merge**2
