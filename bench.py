@@ -403,7 +403,7 @@ def main():
             "metric": "GRPO samples/sec (img448+512tok, group=8) Qwen2.5-VL-3B" if a.model == "3b" else f"GRPO samples/sec {a.model}",
             "value": world * N * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
+            "config": {"workload": f"{'Qwen2-VL-2B' if a.model == 'qwen2vl_2b' else 'Qwen2.5-VL-' + a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}",
                        "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "
                                  "reference's G repeated rows, parity-tested); the rollout's prefill is the prompt part of the policy's training forward") if eng.args.share_prefix else "ViT once per image"},

@@ -186,9 +186,9 @@ class SCGRPOTrainer:
                     raise ValueError("Invalid `torch_dtype` passed to `GRPOConfig`. Expected either 'auto' or a string representing "
                                      f"a `torch.dtype` (e.g., 'float32'), but got {td}.")  # REF:108-111
             mid = model.lower()
-            if not any(t in mid for t in ("qwen2.5-vl", "qwen2.5_vl", "qwen2.5vl")):
-                raise ValueError(f"{model}: this engine implements the Qwen2.5-VL family of the reference's model switch "
-                                 "(REF:116-137); Qwen2-VL and LLaVA variants are not built yet")
+            if not any(t in mid for t in ("qwen2.5-vl", "qwen2.5_vl", "qwen2.5vl", "qwen2-vl", "qwen2_vl", "qwen2vl")):
+                raise ValueError(f"{model}: this engine implements the Qwen2-VL and Qwen2.5-VL branches of the reference's model switch "
+                                 "(REF:116-137; which of the two is read from the checkpoint's config.json, not from the path); the LLaVA variants are not built yet")
         elif mik:
             raise ValueError("You passed `model_init_kwargs` to the `GRPOConfig`, but your model is already instantiated. "
                              "This argument can only be used when the `model` argument is a string.")  # REF:141-145

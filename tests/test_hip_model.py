@@ -609,3 +609,46 @@ def test_training_state_resume(tmp_path):
     _json.dump(bad, open(st_path, "w"))
     with pytest.raises(ValueError, match="different parameter layout"):
         load_training_state(s3, ck)
+
+
+def test_sc_grpo_on_the_qwen2vl_structure():
+    """SC-GRPO on the Qwen2-VL structure (the reference's SC_GRPO_Qwen_Instruct_2_VL.sh: LayerNorm / QuickGELU ViT without windows in front of the
+    same decoder): policy == reference => per-token KL exactly 0 and a loss of exactly 0 with zero-mean advantages over identical log-probs is not
+    required -- what is: finite loss, gradients on both towers, graph and eager rollouts identical, and the greedy tokens are the arg-max of the
+    training kernels' logits at every generated position (decode path vs training path on the same weights)."""
+    cfg = VLMConfig.from_dict(fx.TINY_Q2)
+    w = fx.make_weights(fx.TINY_Q2, 0)
+    pol = ParamStore(cfg, DEV, trainable=True); pol.load_named(w)
+    ref = ParamStore(cfg, DEV, trainable=False); ref.load_named(w)
+    grids = [(1, 16, 12), (1, 8, 8)]
+    rows = [fx.synth_prompt(gr, n, fx.TINY_Q2, 31 + i) for i, (gr, n) in enumerate(zip(grids, [7, 12]))]
+    ids, mask = fx.left_pad(rows, fx.TINY_Q2["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values(grids, fx.TINY_Q2, seed=31), "image_grid_thw": grids}
+    G, C = 4, 10
+    eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, suppress_eos=True))
+    toks = eng.rollout(batch, greedy=True)
+    eager = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, suppress_eos=True, use_hip_graph=False))
+    assert np.array_equal(toks, eager.rollout(batch, greedy=True)) and toks.shape == (2 * G, C)
+    assert all(np.array_equal(toks[b * G], toks[b * G + g]) for b in range(2) for g in range(G))       # greedy: the G rows of a prompt agree
+    # teacher-forced training forward over [prompt | greedy tokens]: its arg-max reproduces the tokens (top-2 margin permitting)
+    e = eng.pol
+    full = np.concatenate([np.repeat(ids, G, 0), toks], 1)
+    fmask = np.concatenate([np.repeat(mask, G, 0), np.ones_like(toks)], 1)
+    img, _ = e.vision_forward(torch.from_numpy(batch["pixel_values"]).to(DEV), e.vision_plan(grids), save=False)
+    off = np.cumsum([0] + [t * h * w_ // 4 for t, h, w_ in grids])
+    plan = e.text_plan(full, fmask, [[grids[r // G]] for r in range(2 * G)], [[int(off[r // G])] for r in range(2 * G)])
+    hf, _ = e.text_forward(plan, img, save=False)
+    S, P = full.shape[1], ids.shape[1]
+    rr = (np.arange(2 * G)[:, None] * S + np.arange(P - 1, S - 1)[None, :]).reshape(-1)
+    logits = (hf[torch.from_numpy(rr).to(DEV)].float() @ pol.w("embed").float().t() if cfg.tie_word_embeddings else hf[torch.from_numpy(rr).to(DEV)].float() @ pol.w("lm_head").float().t())
+    top2 = logits.topk(2, -1)
+    sure = (top2.values[:, 0] - top2.values[:, 1]) > 0.05
+    assert sure.float().mean() > 0.5 and torch.equal(top2.indices[:, 0][sure].cpu(), torch.from_numpy(toks.reshape(-1))[sure.cpu()])
+    # one full step with distinct sampled completions: finite loss, both towers receive gradient, KL == 0 exactly because policy == reference
+    comps = fx.synth_completions(2 * G, C, fx.TINY_Q2, 5)
+    rew = np.random.RandomState(0).rand(2 * G, 2).astype(np.float32)
+    out = eng.loss_and_grads(batch, comps, rew)
+    assert np.isfinite(out["metrics"]["loss"]) and out["metrics"]["kl"] == 0.0 and torch.equal(out["logps"], out["ref_logps"])
+    assert float(pol.g("visual.blocks.0.fc1.w").abs().max()) > 0 and float(pol.g("layers.0.qkv.w").abs().max()) > 0
+    eng.optimizer_step()
+    assert np.isfinite(eng.grad_norm()) and eng.grad_norm() > 0
