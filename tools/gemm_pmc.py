@@ -21,3 +21,12 @@ for M, N, K in [(20480, 22016, 2048), (20480, 2048, 11008), (22016, 2048, 20480)
         ops.gemm_nt(a, b, out=out)
     torch.cuda.synchronize()
     del a, b, out, flush
+# the gate|up projection as the reference pass runs it: SwiGLU in the epilogue, only the activation [M, I] is written (gemm_nt_256<3>)
+M, I, K = 20480, 11008, 2048
+a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(2 * I, K, device=dev).to(torch.bfloat16)
+act = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+for _ in range(3):
+    flush.zero_()
+    ops.gemm_swiglu_fused(a, w, None, act)
+torch.cuda.synchronize()
