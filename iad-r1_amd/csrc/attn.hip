@@ -627,7 +627,7 @@ struct DecodeArgs {
 };
 
 template <int D, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, SideOut so) {
     constexpr int KS = D / 32, DT = D / 16, PAGE = 32;
     extern __shared__ float dsm[];
     const int GS = (p.Hq / p.Hkv <= 8) ? 9 : 17;      // q-head columns kept per d (+1 pad): only `group` of the 16 MFMA columns are real
@@ -636,6 +636,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
     float* red_o = dsm + 2 * WAVES * 16;               // [WAVES][D][GS]
     const int b = blockIdx.x, kvh = blockIdx.y, group = p.Hq / p.Hkv;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
+    const long long sb = side_base(so);
     const int n = p.ctx_len[b];
     const int npage = (n + PAGE - 1) / PAGE;
 
@@ -725,7 +726,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p) {
             num += f * red_o[(ww * D + d) * GS + j];
             den += f * red_l[ww * 16 + j];
         }
-        p.o[p.ldo ? (long long)b * p.ldo + (kvh * group + j) * D + d : xpk_off(b, (kvh * group + j) * D + d, p.Hq * D)] = f2bf(den > 0.f ? num / den : 0.f);
+        const bf16_t ov = f2bf(den > 0.f ? num / den : 0.f);
+        p.o[p.ldo ? (long long)b * p.ldo + (kvh * group + j) * D + d : xpk_off(b, (kvh * group + j) * D + d, p.Hq * D)] = ov;
+        if (sb >= 0) {      // the row the attention backward of the policy reads, and its log-sum-exp (natural log, as attn_fwd stores it)
+            const long long r = sb + (long long)b * so.seq_stride;
+            ((bf16_t*)so.p0)[r * so.ld0 + (kvh * group + j) * D + d] = ov;
+            if (d == 0) ((float*)so.p1)[(long long)(kvh * group + j) * so.ld1 + r] = den > 0.f ? (M + log2f(den)) * LN2 : -INFINITY;
+        }
     }
 }
 
@@ -888,14 +895,15 @@ extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* 
     static int waves = 0;
     if (!waves) { const char* e = getenv("IADR1_DECODE_ATTN_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 16; }
     const int gs = (Hq / Hkv <= 8) ? 9 : 17;
+    const SideOut so = iadr1_take_side_out(stream);
     if (waves == 16) {
         const int smem = (2 * 16 * 16 + 16 * 128 * gs) * 4;
         set_smem(attn_decode_kernel<128, 16>, smem);
-        hipLaunchKernelGGL((attn_decode_kernel<128, 16>), dim3(B, Hkv), dim3(1024), smem, stream, p);
+        hipLaunchKernelGGL((attn_decode_kernel<128, 16>), dim3(B, Hkv), dim3(1024), smem, stream, p, so);
     } else {
         const int smem = (2 * 8 * 16 + 8 * 128 * gs) * 4;
         set_smem(attn_decode_kernel<128, 8>, smem);
-        hipLaunchKernelGGL((attn_decode_kernel<128, 8>), dim3(B, Hkv), dim3(512), smem, stream, p);
+        hipLaunchKernelGGL((attn_decode_kernel<128, 8>), dim3(B, Hkv), dim3(512), smem, stream, p, so);
     }
     return iadr1_check_launch("attn_decode");
 }

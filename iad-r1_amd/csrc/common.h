@@ -81,6 +81,22 @@ int iadr1_check_launch(const char* what);
         }                                     \
     } while (0)
 
+// Side outputs of the decode step (rollout -> training hand-over): the kernels of a decode step can ALSO write what they compute into the row-major
+// activation arena the policy's backward pass reads, at row  base + s * seq_stride + *step  for sequence s.  Decode step t processes completion token
+// t of every sequence, which is exactly row (s, t) of the completion block of the shared-prefix training batch, so the teacher-forced policy forward
+// over the completions does not have to be run again.  iadr1_decode_side_outputs() arms the NEXT launch on a stream of one of: iadr1_rmsnorm_fwd
+// (T <= 256; p0 = residual stream rows, p1 = normalised rows, p2 = rstd fp32 [rows]), iadr1_gemm_qkv_rope_kv_bf16 (p0 = roped q|k|v rows),
+// iadr1_attn_decode (p0 = attention output rows, p1 = log-sum-exp fp32 [Hq][ld1]), iadr1_gemm_skinny_bf16 out_mode 3 (p0 = gate|up rows, p1 = SwiGLU rows).
+struct SideOut {
+    void* p0; void* p1; void* p2;
+    long long ld0, ld1, ld2;
+    const unsigned* step;          // device-resident decode step counter; nullptr = side outputs off
+    long long base, seq_stride;
+};
+SideOut iadr1_take_side_out(hipStream_t stream);   // returns and clears what is armed for `stream` (all-zero if nothing)
+// read the step counter ONCE, at kernel entry (a dependent global load in an epilogue is a memory latency on the critical path of a latency-bound kernel)
+__device__ __forceinline__ long long side_base(const SideOut& so) { return so.step ? so.base + (long long)*so.step : -1; }
+
 // Decode-packed activation layout ("leading dimension 0" in the C ABI): X[M,K] stored in MFMA B-fragment order so that the
 // (16 rows x 32 k) fragment a wave feeds to v_mfma_f32_16x16x32_bf16 is ONE contiguous 1 KiB load, like the packed weights:
 //   Xp[m/64][k/32][(m%64)/16][lane = m%16 + 16*((k%32)/8)][k%8];   rows are padded to a multiple of 64.

@@ -620,6 +620,7 @@ struct SkinnyArgs {
     bf16_t* kcache;
     bf16_t* vcache;
     int Hq, Hkv;
+    SideOut so;                // out_mode 4: p0 = roped q|k|v rows; out_mode 3 (persistent kernel): p0 = gate|up rows, p1 = SwiGLU rows (common.h)
 };
 
 template <int NB, int WAVES>
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
     const float bias_pre = ((p.out_mode == 0 || p.out_mode == 4) && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
     const float bias_par = (p.out_mode == 4 && p.bias) ? bf2f(p.bias[min(n0 + ((t % BNC) ^ 8), p.N - 1)]) : 0.f;   // rotary partner's
+    const long long side0 = (NB == 1 && p.out_mode == 4) ? side_base(p.so) : -1;
     // out_mode 4 (one output per thread when WAVES*64 == 64*16): rotary factors and the cache slot are fetched up front as well
     float pre_cos = 1.f, pre_sin = 0.f;
     long long pre_slot = -1;
@@ -743,8 +745,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
                 const int dim = n < 8 ? dd : HALF + dd;
                 if (head < p.Hq) ((bf16_t*)p.Y)[(long long)gm * p.ldy + head * D + dim] = f2bf(r);
                 else if (sl >= 0) p.kcache[(page * p.Hkv + (head - p.Hq)) * 32 * D + kpk_off(off, dim)] = f2bf(r);
-            } else if (sl >= 0) {
-                p.vcache[(page * p.Hkv + (head - p.Hq - p.Hkv)) * (long long)D * 32 + (j * 16 + n) * 32 + off] = f2bf(vs);
+                if (side0 >= 0) ((bf16_t*)p.so.p0)[(side0 + (long long)gm * p.so.seq_stride) * p.so.ld0 + head * D + dim] = f2bf(r);   // training layout: [q heads | k heads | v heads]
+            } else {
+                if (sl >= 0) p.vcache[(page * p.Hkv + (head - p.Hq - p.Hkv)) * (long long)D * 32 + (j * 16 + n) * 32 + off] = f2bf(vs);
+                if (side0 >= 0) ((bf16_t*)p.so.p0)[(side0 + (long long)gm * p.so.seq_stride) * p.so.ld0 + head * D + j * 16 + n] = f2bf(vs);
             }
         }
         return;
@@ -899,6 +903,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
     const int b = blockIdx.x, bps = gridDim.x;
     const int m_base = blockIdx.y * 64;
+    const long long sb = p.out_mode == 3 ? side_base(p.so) : -1;
     const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks)
     // X fragments of this wave's k-steps w + j*WAVES: loaded once, resident for the whole launch
     const bool xpk = p.ldx == 0;
@@ -960,6 +965,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
                 usum = bf2f(f2bf(usum));
                 const float sg = bf2f(f2bf(gsum / (1.f + __expf(-gsum))));
                 ((bf16_t*)p.Y)[p.ldy ? (long long)gm * p.ldy + gn : xpk_off(gm, gn, p.N >> 1)] = f2bf(sg * usum);
+                if (sb >= 0) {      // the same values in the training layout: gate|up row [gate | up] and the activation row
+                    const long long r = sb + (long long)gm * p.so.seq_stride;
+                    bf16_t* gu = (bf16_t*)p.so.p0 + r * p.so.ld0;
+                    gu[gn] = f2bf(gsum);
+                    gu[(p.N >> 1) + gn] = f2bf(usum);
+                    ((bf16_t*)p.so.p1)[r * p.so.ld1 + gn] = f2bf(sg * usum);
+                }
             }
         } else {
             for (int idx = t; idx < 64 * 16 * TPI; idx += WAVES * 64) {
@@ -1237,7 +1249,12 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
             }
         }
         const int ksw = K / 256;
-        if (pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu) {
+        const bool pers_ok = pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu;
+        if (out_mode == 3) {
+            p.so = iadr1_take_side_out(stream);
+            IADR1_REQUIRE(!p.so.step || pers_ok, "gemm_skinny: side outputs of the fused-SwiGLU projection exist in the persistent kernel only (N=%d K=%d)", N, K);
+        }
+        if (pers_ok) {
             const dim3 grid(ncu, mz, 1), block(512);
             if (ksw == 8) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 8>), grid, block, SMP, stream, p);
             else if (ksw == 6) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 6>), grid, block, SMP, stream, p);
@@ -1275,6 +1292,7 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)Wp; p.Y = q_out; p.bias = (const bf16_t*)bias_p; p.M = M; p.N = (Hq + 2 * Hkv) * D; p.K = K;
     p.ldx = ldx; p.ldw = K; p.ldy = ldq; p.out_mode = 4;
     p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.slot = slot; p.kcache = (bf16_t*)kcache; p.vcache = (bf16_t*)vcache; p.Hq = Hq; p.Hkv = Hkv;
+    p.so = iadr1_take_side_out(stream);
     constexpr int SM1 = 16 * 64 * 17 * 4;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1); attr_done = true; }

@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(RmsFwdArgs p) {
 
 // Few-row variant (decode: T = sequences in flight): one ROW PER BLOCK, 256 threads, so a 64-row call still
 // spreads over 64 CUs and the per-thread dependent-load chain is 1/4 as long as in the wave-per-row kernel.
-__global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
+__global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p, SideOut so) {
     __shared__ float scratch[16];
     const int row = blockIdx.x, t = threadIdx.x;
+    const long long sb = side_base(so), srow = sb + (long long)row * so.seq_stride;
     const int nchunk = p.H >> 3;
     constexpr int MC = 4;  // H <= 8192
     float v[MC][8];
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
                     v[c][2 * e + 1] = hi_bf(o[e]);
                 }
                 if (p.res_out) *(u32x4_t*)(p.res_out + (long long)row * p.ldr + ch * 8) = o;
+                if (sb >= 0 && so.p0) *(u32x4_t*)((bf16_t*)so.p0 + srow * so.ld0 + ch * 8) = o;   // residual stream row for the backward pass
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss += v[c][e] * v[c][e];
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
     ss = block_sum<256>(ss, scratch);
     const float rstd = rsqrtf(ss / (float)p.H + p.eps);
     if (p.rstd && t == 0) p.rstd[row] = rstd;
+    if (sb >= 0 && so.p2 && t == 0) ((float*)so.p2)[srow] = rstd;
     if (!p.y) return;
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p) {
                 o[e] = pack2bf(lo_bf(g[e]) * n0, hi_bf(g[e]) * n1);
             }
             *(u32x4_t*)(p.y + (p.ldy ? (long long)row * p.ldy + ch * 8 : xpk_off(row, ch * 8, p.H))) = o;   // ldy == 0: decode-packed
+            if (sb >= 0 && so.p1) *(u32x4_t*)((bf16_t*)so.p1 + srow * so.ld1 + ch * 8) = o;
         }
     }
 }
@@ -324,7 +328,7 @@ extern "C" int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, co
     RmsFwdArgs p{(const bf16_t*)x, x32, nsplit, (const bf16_t*)xbias, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (bf16_t*)y, rstd, T, H, ldx, ldr, ldy, eps};
     IADR1_REQUIRE(ldy != 0 || (T <= 256 && (H % 32) == 0), "rmsnorm_fwd: decode-packed output (ldy == 0) needs T <= 256 and H %% 32 == 0");
     if (T <= 256) {
-        hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, stream, p, iadr1_take_side_out(stream));
         return iadr1_check_launch("rmsnorm_fwd");
     }
     const dim3 grid((T + 3) / 4), block(256);

@@ -335,6 +335,13 @@ def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq
              _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout), _ld(dq), _ld(dk), _ld(dv), 1 if causal else 0, float(scale))
 
 
+def decode_side_outputs(step, base, seq_stride, p0=None, p1=None, p2=None, ld1=None):
+    """Arms the next decode-step kernel on the current stream to also write row-major training rows (include/iadr1_hip.h iadr1_decode_side_outputs).
+    p0 / p1 are [rows, width] tensors (ld = row stride) except where the header says otherwise (ld1 overrides, e.g. the [Hq][T] log-sum-exp)."""
+    ld = lambda t: 0 if t is None else (t.stride(0) if t.dim() > 1 else 1)
+    hip.call("decode_side_outputs", p0, ld(p0), p1, ld(p1) if ld1 is None else ld1, p2, ld(p2), step, int(base), int(seq_stride))
+
+
 def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=None):
     B = q.shape[0]
     o = out if out is not None else torch.empty(B, Hq * D, dtype=BF16, device=q.device)

@@ -72,6 +72,7 @@ class Rollout:
         self.cos = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.graph = None
+        self.trace = None           # training arena filled by the decode steps (generate(train_trace=...)); part of the captured graph
         self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
@@ -79,6 +80,12 @@ class Rollout:
     # ---- one decode step (graph body) -------------------------------------------------------------------------
     def _decode_step(self):
         e, c, P = self.e, self.e.cfg, self.e.p
+        tr = self.trace      # None, or the training arena the step also fills (Rollout.generate(train_trace=...))
+
+        def side(**kw):
+            if tr is not None:
+                ops.decode_side_outputs(self.step, tr["base"], tr["stride"], **kw)
+
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         qw, kw = Hq * D, Hkv * D
         s = self.sampling
@@ -88,17 +95,29 @@ class Rollout:
         for i in range(c.num_hidden_layers):
             b = f"layers.{i}."
             if not have_branch:
+                if tr is not None:
+                    side(p1=tr["h1"][i], p2=tr["rstd1"][i])          # layer 0 enters with the embedding rows (filled after the rollout)
                 ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h)
             else:
+                if tr is not None:
+                    side(p0=tr["x_in"][i], p1=tr["h1"][i], p2=tr["rstd1"][i])
                 ops.rmsnorm_fwd(None, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)
+            if tr is not None:
+                side(p0=tr["qkv"][i])
             if P.qkv_rope_packed:   # q|k|v projection + rotary + K/V cache append in one launch
                 ops.gemm_qkv_rope_kv(self.h, P.wpk(b + "qkv.w"), P.wpk_bias(b + "qkv.w"), self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
             else:
                 ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
                 ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
+            if tr is not None:
+                side(p0=tr["o"][i], p1=tr["lse"][i], ld1=tr["lse"][i].stride(0))
             ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o)
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), c.hidden_size, out=self.part_o, ksplit=self.ks_o)
+            if tr is not None:
+                side(p0=tr["x_mid"][i], p1=tr["h2"][i], p2=tr["rstd2"][i])
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h)
+            if tr is not None:
+                side(p0=tr["gu"][i], p1=tr["a"][i])
             if self.fuse_swiglu:
                 ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True)
             else:
@@ -106,6 +125,8 @@ class Rollout:
                 ops.swiglu_fwd(self.gu, out=self.a)
             ops.gemm_skinny(self.a, P.wpk(b + "down.w"), c.hidden_size, out=self.part_d, ksplit=self.ks_down)
             have_branch = True
+        if tr is not None:
+            side(p0=tr["x_last"], p1=tr["hf"], p2=tr["rstdf"])
         ops.rmsnorm_fwd(None, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)
         ops.gemm_skinny(self.h, P.wpk(P.lm_head_name()), c.vocab_size, out=self.logits)
         self._sample_and_advance()
@@ -130,7 +151,7 @@ class Rollout:
 
     # ---- public ---------------------------------------------------------------------------------------------------
     def generate(self, plan: TextPlan, img_embeds, G: int, max_new: int, temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress_eos=False,
-                 stop_at_eos=True, train_carry=None) -> torch.Tensor:
+                 stop_at_eos=True, train_carry=None, train_trace=False) -> torch.Tensor:
         """plan: the Bp left-padded prompts.  Returns completion ids [Bp*G, max_new] (prompt-major order: p0 x G,
         p1 x G, ...), pad after the first EOS."""
         e, c = self.e, self.e.cfg
@@ -145,6 +166,9 @@ class Rollout:
         if sampling != self.sampling:
             self.sampling = sampling
             self.graph = None  # sampling parameters are kernel arguments frozen in the graph
+        want_trace = bool(train_trace and train_carry is not None)
+        if not want_trace and self.trace is not None:
+            self.trace, self.graph = None, None
         lengths = plan.lengths
         # ---- page tables ------------------------------------------------------------------------------------
         next_page = 1  # page 0 is a scratch page for unused table entries
@@ -187,6 +211,27 @@ class Rollout:
             # saved in the training arena, rows [0, Bp*S) of the shared-prefix batch of T_total = Bp*S + N*max_new rows
             hf, _ = e.text_forward(plan, img_embeds, save=True, kv_sink=kv_sink, rows=(0, Bp * S, Bp * S + N * max_new), carry=train_carry)
             hf = hf[: Bp * S]
+            if want_trace:
+                # the decode steps also fill the completion rows of the training arena: decode replay k processes completion token k of every
+                # sequence = row Bp*S + s*max_new + k; the step counter reads k + 1 during that replay (it counts sampled tokens)
+                T_all = Bp * S + N * max_new
+                A = e._text_buffers(T_all, True)
+                L = c.num_hidden_layers
+                tr = {k: [A[k][i, :T_all] for i in range(L)] for k in ("x_in", "h1", "qkv", "o", "x_mid", "h2", "gu", "a")}
+                tr.update(rstd1=[A["rstd1"][i, :T_all] for i in range(L)], rstd2=[A["rstd2"][i, :T_all] for i in range(L)],
+                          lse=[A["lse"][i].view(-1)[: c.num_attention_heads * T_all].view(c.num_attention_heads, T_all) for i in range(L)],
+                          x_last=train_carry["x_last"], hf=train_carry["hf"], rstdf=train_carry["rstdf"], base=Bp * S - 1, stride=max_new)
+                key = (A["x_in"].data_ptr(), train_carry["hf"].data_ptr(), T_all, max_new)
+                if self.trace is None or self.trace.get("key") != key:
+                    self.graph = None       # the arena pointers are kernel arguments frozen in the graph
+                    # the LAST completion token of a sequence is never a decode input (it is only sampled): its rows are not written by the steps and
+                    # nothing in the loss depends on them, but backward reads them -- they must be finite.  Zero the completion block once.
+                    for k, v in tr.items():
+                        for t_ in (v if isinstance(v, list) else [v]):
+                            if isinstance(t_, torch.Tensor):
+                                (t_[:, Bp * S:] if (t_.dim() == 2 and t_.shape[0] == c.num_attention_heads and k == "lse") else t_[Bp * S:]).zero_()
+                tr["key"] = key
+                self.trace = tr
         else:
             hf, _ = e.text_forward(plan, img_embeds, save=False, kv_sink=kv_sink)
         last_rows = torch.arange(Bp, device=dev, dtype=torch.int64) * S + (S - 1)

@@ -54,6 +54,9 @@ class GRPOArgs:
     share_prefix: bool = os.environ.get("IADR1_SHARE_PREFIX", "1") != "0"
     # let the rollout's prefill double as the prompt part of the policy's training forward (needs share_prefix and one whole-batch micro-batch)
     reuse_prefill: bool = os.environ.get("IADR1_REUSE_PREFILL", "1") != "0"
+    # the rollout's decode steps also write the completion rows of the policy's activation arena, so the policy forward over the completions is not
+    # run before backward (needs reuse_prefill's conditions and the fused decode kernels)
+    reuse_decode: bool = os.environ.get("IADR1_REUSE_DECODE", "1") != "0"
 
 
 def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.ndarray:
@@ -192,10 +195,24 @@ class SCGRPOEngine:
         N = Bp * a.num_generations
         if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_pages * 32 < ids.shape[1] + a.max_completion_length:
             self._rollout = Rollout(self.pol, N, ids.shape[1], a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph)
+        c, st = self.cfg, self.pol.p
+        # decode steps that also fill the training arena (no policy forward over the completions afterwards): needs the fused decode kernels that carry
+        # the side outputs (q|k|v + rotary + cache append, persistent fused-SwiGLU gate|up GEMM)
+        trace = (train_carry is not None and a.reuse_decode and st.qkv_rope_packed and self._rollout_fuses_swiglu(N))
         toks = self._rollout.generate(plan, img_pol, a.num_generations, a.max_completion_length, temperature=0.0 if greedy else a.temperature,
                                       top_k=a.top_k, top_p=a.top_p, seed=a.seed + 1000003 * self.opt_step + 7919 * self.accum, suppress_eos=a.suppress_eos,
-                                      train_carry=train_carry)
+                                      train_carry=train_carry, train_trace=trace)
+        if trace:
+            train_carry["traced"] = True
         return toks.cpu().numpy()
+
+    def _rollout_fuses_swiglu(self, N) -> bool:
+        """True when the decode gate|up projection runs on the persistent fused-SwiGLU kernel (the one with side outputs): include/iadr1_hip.h."""
+        c = self.cfg
+        ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        K, N2 = c.hidden_size, 2 * c.intermediate_size
+        return (self._rollout.fuse_swiglu and os.environ.get("IADR1_SKINNY_PERS", "1") != "0" and K % 256 == 0 and K // 256 in (4, 6, 8)
+                and N2 % 128 == 0 and N2 // 32 >= 2 * ncu and N <= 256)
 
     # ---- loss + gradients for given completions ------------------------------------------------------------------
     def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None, train_carry=None):
@@ -268,7 +285,10 @@ class SCGRPOEngine:
                 # the rollout's prefill already ran (and saved) the prompt rows of this batch: only the completion rows go through the layers
                 T_all = plan.ids.numel()
                 train_carry["full_plan"] = plan
-                hf, ctx = self.pol.text_forward(plan.tail, None, save=True, rows=((b1 - b0) * P, T_all, T_all), carry=train_carry)
+                if train_carry.get("traced"):      # ... and its decode steps wrote the completion rows: nothing to run at all
+                    hf, ctx = self.pol.text_context_from_trace(plan.tail, ((b1 - b0) * P, T_all, T_all), train_carry)
+                else:
+                    hf, ctx = self.pol.text_forward(plan.tail, None, save=True, rows=((b1 - b0) * P, T_all, T_all), carry=train_carry)
             else:
                 hf, ctx = self.pol.text_forward(plan, img_pol, save=backward)
             lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, dup=dup)
@@ -342,6 +362,7 @@ class SCGRPOEngine:
         # phase-timing mode they are evaluated here so that they get their own column)
         rewards = reward_fn(comp) if timing else (lambda: reward_fn(comp))
         t3 = mark()
+        self.last_step_traced = bool(carry and carry.get("traced"))     # the decode steps filled the completion rows of the training arena
         out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=do_optimizer_step, vis=vis, train_carry=carry)
         t4 = mark()
         if do_optimizer_step:

@@ -446,8 +446,12 @@ class Engine:
         assert r1 - r0 == Tl and (rows is None or (save and carry is not None))
         part = rows is not None
         if part and "x0" not in carry:
-            carry.update(x0=torch.empty(T, H, dtype=BF16, device=self.dev), hf=torch.empty(T, H, dtype=BF16, device=self.dev),
-                         x_last=torch.empty(T, H, dtype=BF16, device=self.dev), rstdf=torch.empty(T, dtype=F32, device=self.dev))
+            # persistent like the activation arena: the decode graph may hold these pointers (rollout side outputs)
+            cb = self._ws.get("carry")
+            if cb is None or cb["T"] != T:
+                cb = self._ws["carry"] = {"T": T, "x0": torch.empty(T, H, dtype=BF16, device=self.dev), "hf": torch.empty(T, H, dtype=BF16, device=self.dev),
+                                          "x_last": torch.empty(T, H, dtype=BF16, device=self.dev), "rstdf": torch.empty(T, dtype=F32, device=self.dev)}
+            carry.update(x0=cb["x0"], hf=cb["hf"], x_last=cb["x_last"], rstdf=cb["rstdf"])
         x = ops.embed_fwd(plan.ids, plan.img_index if img_embeds is not None else None, P.w("embed"), img_embeds, out=carry["x0"][r0:r1] if part else None)
         B = self._text_buffers(T, save)
         ctx = {"layers": [], "plan": carry.get("full_plan", plan) if part else plan} if save else None
@@ -505,6 +509,24 @@ class Engine:
         if save:
             ctx.update(x_last=x_last, rstdf=rstdf)
         return hf, ctx
+
+    def text_context_from_trace(self, plan: TextPlan, rows, carry):
+        """The (hf, ctx) pair text_forward(plan, None, save=True, rows=rows, carry=carry) would return for the completion rows [r0, r1), WITHOUT running
+        the layers: the rollout's decode steps already wrote those rows of the activation arena (Rollout side outputs, include/iadr1_hip.h
+        iadr1_decode_side_outputs).  Only the embedding rows of the completion tokens (layer 0's residual input) are gathered here."""
+        c, P = self.cfg, self.p
+        Hq, D, Hkv = c.num_attention_heads, c.head_dim, c.num_key_value_heads
+        r0, r1, T = rows
+        ops.embed_fwd(plan.ids, None, P.w("embed"), None, out=carry["x0"][r0:r1])
+        B = self._text_buffers(T, True)
+        ctx = {"layers": [], "plan": carry["full_plan"]}
+        for i in range(c.num_hidden_layers):
+            full = lambda name: B[name][i, :T]
+            lse = B["lse"][i].view(-1)[: Hq * T].view(Hq, T)
+            ctx["layers"].append((carry["x0"] if i == 0 else full("x_in"), B["rstd1"][i, :T], full("h1"), full("qkv"), full("o"), lse, full("x_mid"),
+                                  B["rstd2"][i, :T], full("h2"), full("gu"), full("a")))
+        ctx.update(x_last=carry["x_last"], rstdf=carry["rstdf"])
+        return carry["hf"], ctx
 
     def text_backward(self, dhf: torch.Tensor, ctx, dimg32=None, layer_done=None):
         """dhf: gradient of the final-norm output [T,H] bf16.  Accumulates parameter grads; image-embed

@@ -25,6 +25,16 @@ typedef void* iadr1_stream_t; /* hipStream_t */
 
 int iadr1_version(void);
 const char* iadr1_last_error(void);
+/* Rollout -> training hand-over.  Arms the NEXT launch on `stream` (by this thread) of one decode-step kernel to ALSO write what it computes into
+ * row-major training buffers, at row  base + s * seq_stride + *step  for sequence s (`step`: device-resident decode step counter):
+ *   iadr1_rmsnorm_fwd (T <= 256)        p0 = residual stream rows [.., ld0] (bf16), p1 = normalised rows [.., ld1], p2 = rstd (fp32, one per row)
+ *   iadr1_gemm_qkv_rope_kv_bf16         p0 = roped q|k|v rows [.., ld0]
+ *   iadr1_attn_decode                   p0 = attention output rows [.., ld0], p1 = log-sum-exp fp32 [Hq][ld1]
+ *   iadr1_gemm_skinny_bf16 out_mode 3   p0 = gate|up rows [.., ld0], p1 = SwiGLU rows [.., ld1]   (persistent kernel shapes only)
+ * Decode step t processes completion token t of every sequence = row (s, t) of the completion block of the shared-prefix training batch, so the
+ * policy's teacher-forced forward over the completions (REF:505-513 on the policy model) need not be run again before backward.  Unused p*: NULL. */
+int iadr1_decode_side_outputs(void* p0, long long ld0, void* p1, long long ld1, void* p2, long long ld2, const unsigned* step, long long base,
+                              long long seq_stride, iadr1_stream_t stream);
 
 /* ---- dense contractions ----------------------------------------------------------------------------
  * C[M,N] (+)= act(A[M,K] . B[N,K]^T + bias[N]).  out_mode: 0 = bf16 store, 1 = fp32 store, 2 = fp32

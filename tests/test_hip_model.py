@@ -652,3 +652,42 @@ def test_sc_grpo_on_the_qwen2vl_structure():
     assert float(pol.g("visual.blocks.0.fc1.w").abs().max()) > 0 and float(pol.g("layers.0.qkv.w").abs().max()) > 0
     eng.optimizer_step()
     assert np.isfinite(eng.grad_norm()) and eng.grad_norm() > 0
+
+
+def test_decode_steps_fill_the_training_arena():
+    """Rollout -> training hand-over at BASELINE widths (depth-reduced 3B shapes): with reuse_decode the decode steps write the completion rows of the
+    policy's activation arena (side outputs of the decode kernels) and no policy forward runs over the completions before backward.  Against the step
+    that does run that forward: same tokens and rewards, loss and KL within the bf16 noise of decode-vs-training kernels, gradient cosine > 0.999."""
+    import dataclasses
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
+    pol = ParamStore(cfg, DEV, trainable=True)
+    pol.init_random(seed=0)
+    ref = ParamStore(cfg, DEV, trainable=False)
+    ref.copy_from(pol)
+    G, C, Bp = 8, 32, 2
+    batch = bench.synth_batch(cfg, Bp, 512, seed=5)
+    seen = {}
+
+    def rew(comp):
+        seen.setdefault("comp", []).append(np.asarray(comp).copy())
+        return np.random.RandomState(0).rand(len(comp), 2).astype(np.float32)
+
+    res = {}
+    for mode in (False, True):
+        pol.grad.zero_()
+        eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=512, max_completion_length=C, micro_batch_seqs=Bp * G, suppress_eos=True,
+                                                   reuse_decode=mode, seed=3))
+        m = eng.step(batch, rew, do_optimizer_step=False)
+        torch.cuda.synchronize()
+        assert eng.last_step_traced == mode
+        res[mode] = (m, pol.grad.clone())
+    assert np.array_equal(seen["comp"][0], seen["comp"][1])                       # the same rollout either way
+    (m0, g0), (m1, g1) = res[False], res[True]
+    assert m0["kl"] == 0.0 and 0.0 <= m1["kl"] < 1e-3                              # policy == reference: exactly 0 on the training kernels, ~1e-5 through the decode kernels
+    assert abs(m0["loss"] - m1["loss"]) < 1e-4 and m0["reward"] == m1["reward"]
+    assert bool(torch.isfinite(g1).all())
+    cos = float((g0 @ g1) / (g0.norm() * g1.norm()))
+    assert cos > 0.999 and float((g0 - g1).norm() / g0.norm()) < 0.03, cos
