@@ -406,7 +406,11 @@ def main():
             "config": {"workload": f"{'Qwen2-VL-2B' if a.model == 'qwen2vl_2b' else 'Qwen2.5-VL-' + a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}",
                        "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "
-                                 "reference's G repeated rows, parity-tested); the rollout's prefill is the prompt part of the policy's training forward") if eng.args.share_prefix else "ViT once per image"},
+                                 "reference's G repeated rows, parity-tested); the rollout's prefill is the prompt part of the policy's training forward"
+                                 + ("; the rollout's decode steps write the completion rows of the policy's activation arena (side outputs of the decode kernels), so the "
+                                    "policy's forward over the completions is the decode itself and is not run a second time before backward (gradient cosine 0.9999 "
+                                    "against running it, tests/test_hip_model.py::test_decode_steps_fill_the_training_arena)" if getattr(eng, "last_step_traced", False) else ""))
+                       if eng.args.share_prefix else "ViT once per image"},
             "repeated_rows_layout": repeated,
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
