@@ -182,8 +182,9 @@ class Rollout:
             shared = list(range(next_page, next_page + full))
             next_page += full
             first = S - n  # left padding
-            for j in range(full * PAGE):
-                slot_shared[b * S + first + j] = shared[j // PAGE] * PAGE + j % PAGE
+            if full:
+                jj = np.arange(full * PAGE)
+                slot_shared[b * S + first + jj] = np.asarray(shared, dtype=np.int64)[jj // PAGE] * PAGE + jj % PAGE
             priv = (n - full * PAGE + max_new + PAGE - 1) // PAGE + 1
             for gi in range(G):
                 r = b * G + gi
