@@ -46,6 +46,16 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(RmsFwdArgs p) {
                 const float* src0 = p.x32 + (long long)row * p.ldx + ch * 8;
                 const long long sstride = (long long)p.T * p.ldx;
                 int sp = 0;
+                if (p.nsplit == 8) {      // the down projection's eight slabs: all sixteen loads in flight at once (one memory latency instead of two)
+                    f32x4_t a[8], b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a[u] = *(const f32x4_t*)(src0 + u * sstride); b[u] = *(const f32x4_t*)(src0 + u * sstride + 4); }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[c][e] += a[u][e]; v[c][4 + e] += b[u][e]; }
+                    sp = 8;
+                }
                 for (; sp + 4 <= p.nsplit; sp += 4) {
                     f32x4_t a[4], b[4];
 #pragma unroll
@@ -140,6 +150,16 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p, Side
                 const float* src0 = p.x32 + (long long)row * p.ldx + ch * 8;
                 const long long sstride = (long long)p.T * p.ldx;
                 int sp = 0;
+                if (p.nsplit == 8) {      // the down projection's eight slabs: all sixteen loads in flight at once (one memory latency instead of two)
+                    f32x4_t a[8], b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a[u] = *(const f32x4_t*)(src0 + u * sstride); b[u] = *(const f32x4_t*)(src0 + u * sstride + 4); }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[c][e] += a[u][e]; v[c][4 + e] += b[u][e]; }
+                    sp = 8;
+                }
                 for (; sp + 4 <= p.nsplit; sp += 4) {
                     f32x4_t a[4], b[4];
 #pragma unroll
