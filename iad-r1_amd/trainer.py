@@ -100,6 +100,20 @@ def save_checkpoint(store: ParamStore, path: str, hf_config: Optional[dict] = No
             json.dump(hf_config, f, indent=2)
 
 
+def average_over_ranks(values: dict) -> dict:
+    """Mean over the ranks of a data-parallel job of a small {name: float} dict (sorted keys, one all-reduce); identity in a single process.
+    The second (and last) collective of the path next to the gradient exchange."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not values:
+        return dict(values)
+    keys = sorted(values)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    t /= dist.get_world_size()
+    return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+
 def _layout_digest(store: ParamStore) -> str:
     import hashlib
     h = hashlib.sha1()
@@ -292,6 +306,9 @@ class SCGRPOTrainer:
 
     def log(self, logs: dict, start_time=None):
         metrics = {k: sum(v) / len(v) for k, v in self._metrics.items()}
+        metrics = average_over_ranks(metrics)      # the reference logs rank-averaged metrics (REF:821-827 over accelerator.gather_for_metrics values)
+        if "loss" in logs:
+            logs = {**logs, **average_over_ranks({"loss": logs["loss"]})}
         logs = {**logs, **metrics}
         self.log_history.append(logs)
         if int(os.environ.get("RANK", "0")) == 0:

@@ -52,7 +52,11 @@ def _worker(rank, world, port, q):
     st.grad.copy_(mine)
     red.finish()
     ok2 = torch.allclose(st.grad, want, rtol=0, atol=1e-6)
-    q.put((rank, bool(ok), bool(ok2), red.layer_range[0][0] > 0))
+    # the other collective of the path: rank-averaged metrics for the log line
+    from iadr1_amd.trainer import average_over_ranks
+    avg = average_over_ranks({"reward": 1.0 + rank, "kl": 0.5 * rank, "completion_length": 10.0})
+    ok3 = avg == {"reward": 1.0 + (world - 1) / 2, "kl": 0.25 * (world - 1), "completion_length": 10.0}
+    q.put((rank, bool(ok), bool(ok2) and bool(ok3), red.layer_range[0][0] > 0))
     dist.destroy_process_group()
 
 
