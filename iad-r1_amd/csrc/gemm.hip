@@ -645,7 +645,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     // a thread's epilogue column is the same in every round (WAVES*64 is a multiple of BNC): fetch its bias now, not in the tail
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
     const float bias_pre = ((p.out_mode == 0 || p.out_mode == 4) && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
-    const float bias_par = (p.out_mode == 4 && p.bias) ? bf2f(p.bias[min(n0 + ((t % BNC) ^ 8), p.N - 1)]) : 0.f;   // rotary partner's
     const long long side0 = (NB == 1 && p.out_mode == 4) ? side_base(p.so) : -1;
     // out_mode 4 (one output per thread when WAVES*64 == 64*16): rotary factors and the cache slot are fetched up front as well
     float pre_cos = 1.f, pre_sin = 0.f;
@@ -725,14 +724,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
             const int m = idx >> 4, n = idx & 15, gm = m_base + m;
             if (gm >= p.M) continue;
-            float vs = 0.f, vp = 0.f;
+            float vs = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < WAVES; ++ww) {
-                vs += red[((size_t)ww * 64 + m) * RLD + n];
-                vp += red[((size_t)ww * 64 + m) * RLD + (n ^ 8)];
-            }
+            for (int ww = 0; ww < WAVES; ++ww) vs += red[((size_t)ww * 64 + m) * RLD + n];
             vs = bf2f(f2bf(vs + bias_pre));
-            vp = bf2f(f2bf(vp + bias_par));
+            // the rotary partner (column n ^ 8 of the same row) is finished by lane ^ 8 of this wave: take its value instead of summing it again
+            const float vp = __shfl_xor(vs, 8, WAVE);
             const bool first = idx == t && WAVES * 64 == 64 * 16;   // the prefetched values belong to this (m, n)
             const long long sl = first ? pre_slot : p.slot[gm];
             const long long page = sl >> 5;
