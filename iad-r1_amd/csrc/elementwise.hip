@@ -240,6 +240,24 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* in, lon
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* in, float* out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = bf2f(in[i]);
 }
+// contiguous forms, 8 elements per thread and step: one 16-byte access on the bf16 side, two on the fp32 side (the gradient exchange casts
+// GB-sized buckets: HBM-bound, 6 B per element)
+__global__ __launch_bounds__(256) void cast_f32_bf16_vec_kernel(const float* in, bf16_t* out, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4_t a = ((const f32x4_t*)in)[2 * i], b = ((const f32x4_t*)in)[2 * i + 1];
+        u32x4_t o;
+        o.x = pack2bf(a.x, a.y); o.y = pack2bf(a.z, a.w); o.z = pack2bf(b.x, b.y); o.w = pack2bf(b.z, b.w);
+        ((u32x4_t*)out)[i] = o;
+    }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_vec_kernel(const bf16_t* in, float* out, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4_t v = ((const u32x4_t*)in)[i];
+        const f32x4_t a = {lo_bf(v.x), hi_bf(v.x), lo_bf(v.y), hi_bf(v.y)}, b = {lo_bf(v.z), hi_bf(v.z), lo_bf(v.w), hi_bf(v.w)};
+        ((f32x4_t*)out)[2 * i] = a;
+        ((f32x4_t*)out)[2 * i + 1] = b;
+    }
+}
 __global__ __launch_bounds__(256) void add_f32_to_bf16_kernel(const float* in, const bf16_t* bias, bf16_t* out, long long R, int C) {
     // out = bf16(in + bias)  ([R,C] fp32 split-K sums -> bf16 activation); `in` is re-zeroed
     const long long total = R * C;
@@ -359,11 +377,24 @@ extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const
 }
 extern "C" int iadr1_cast_f32_to_bf16(const float* in, long long ldi, void* out, long long ldo, int R, int C, int Cpad, hipStream_t stream) {
     IADR1_REQUIRE(R > 0 && C > 0 && Cpad >= C, "cast_f32_to_bf16: bad shape");
+    const long long tot = (long long)R * Cpad;
+    if (C == Cpad && (R == 1 || (ldi == Cpad && ldo == Cpad)) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && tot >= 8) {   // contiguous: vector form + scalar tail
+        const long long n8 = tot / 8;
+        hipLaunchKernelGGL(cast_f32_bf16_vec_kernel, dim3(grid_for(n8)), dim3(256), 0, stream, in, (bf16_t*)out, n8);
+        if (tot % 8) hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(1), dim3(64), 0, stream, in + n8 * 8, (long long)(tot % 8), (bf16_t*)out + n8 * 8, (long long)(tot % 8), 1, (int)(tot % 8), (int)(tot % 8));
+        return iadr1_check_launch("cast_f32_to_bf16");
+    }
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((long long)R * Cpad)), dim3(256), 0, stream, in, ldi, (bf16_t*)out, ldo, R, C, Cpad);
     return iadr1_check_launch("cast_f32_to_bf16");
 }
 extern "C" int iadr1_cast_bf16_to_f32(const void* in, float* out, long long n, hipStream_t stream) {
     IADR1_REQUIRE(n > 0, "cast_bf16_to_f32: empty");
+    if ((((uintptr_t)in | (uintptr_t)out) & 15) == 0 && n >= 8) {
+        const long long n8 = n / 8;
+        hipLaunchKernelGGL(cast_bf16_f32_vec_kernel, dim3(grid_for(n8)), dim3(256), 0, stream, (const bf16_t*)in, out, n8);
+        if (n % 8) hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(1), dim3(64), 0, stream, (const bf16_t*)in + n8 * 8, out + n8 * 8, n % 8);
+        return iadr1_check_launch("cast_bf16_to_f32");
+    }
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const bf16_t*)in, out, n);
     return iadr1_check_launch("cast_bf16_to_f32");
 }

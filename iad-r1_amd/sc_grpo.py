@@ -85,12 +85,19 @@ def group_advantages(rewards: torch.Tensor, G: int):
 
 
 class GradReducer:
-    """Data-parallel gradient exchange: the ONLY collective of the path.  The flat fp32
-    gradient buffer is all-reduced in large contiguous buckets on a side stream; decoder-layer buckets are
-    launched as soon as the last micro-batch's backward has left that layer, so the exchange overlaps the
-    rest of backward.  Works on CPU/gloo too (tests)."""
+    """Data-parallel gradient exchange: the ONLY collective of the data path.  The flat fp32 gradient buffer is
+    all-reduced in contiguous buckets of at most `bucket_bytes` on the wire (256 MB: large enough to run at link rate, small enough that the
+    first bucket leaves while backward is still producing the next) on a side stream; decoder-layer ranges are launched as soon as the last
+    micro-batch's backward has left that layer, so the exchange overlaps the rest of backward.
 
-    def __init__(self, store: ParamStore, group=None):
+    Wire type: bf16 by default -- what the reference moves (DeepSpeed ZeRO-3 reduce-scatters the bf16 gradients of a bf16 model,
+    scripts/train/zero3.json + `--bf16`) and half the bytes over xGMI (7.5 GB instead of 15 GB for the 3B model): each bucket is cast into a bf16
+    staging buffer, summed there by RCCL, and cast back into the fp32 gradient buffer, all stream-ordered on the side stream.
+    IADR1_REDUCE_DTYPE=fp32 (or wire="fp32") sums the fp32 buffer in place.  Ring / tree all-reduce leaves bit-identical sums on every rank
+    either way, so the replicas' parameters stay bit-identical.  The bucket sequence depends on the parameter layout only, never on a rank's
+    data.  Works on CPU / gloo too (tests)."""
+
+    def __init__(self, store: ParamStore, group=None, bucket_bytes: int = 256 << 20, wire: str | None = None):
         import torch.distributed as dist
         self.dist, self.store, self.group = dist, store, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -98,6 +105,13 @@ class GradReducer:
         # IADR1_FORCE_REDUCE=1: run the exchange even in a one-rank group (exercises the side-stream / bucket / RCCL path on a single GPU)
         self.active = self.world > 1 or (bool(os.environ.get("IADR1_FORCE_REDUCE")) and dist.is_available() and dist.is_initialized())
         self.stream = torch.cuda.Stream() if (self.cuda and self.active) else None
+        self.wire = (wire or os.environ.get("IADR1_REDUCE_DTYPE", "bf16")).lower()
+        if self.wire not in ("bf16", "fp32"):
+            raise ValueError("IADR1_REDUCE_DTYPE must be bf16 or fp32")
+        self.bucket_elems = max(1, int(bucket_bytes) // (2 if self.wire == "bf16" else 4))
+        self.stage = torch.empty(store.n_total, dtype=BF16, device=store.grad.device) if (self.active and self.wire == "bf16") else None
+        self.bytes_on_wire = 0          # per step, for the bench line
+        self.n_buckets = 0
         c = store.cfg
         s = store.slots
         self.layer_range = []
@@ -110,36 +124,70 @@ class GradReducer:
 
     def reset(self):
         self.done = []
-        self.work = []
+
+    def _bucket(self, lo, hi):
+        g = self.store.grad[lo:hi]
+        if self.stage is None:
+            self.dist.all_reduce(g, group=self.group)
+            return
+        st = self.stage[lo:hi]
+        if self.cuda:   # fp32 -> bf16 (round to nearest even) and back through the library's cast kernels
+            hip.call("cast_f32_to_bf16", g, hi - lo, st, hi - lo, 1, hi - lo, hi - lo)
+        else:
+            st.copy_(g)
+        self.dist.all_reduce(st, group=self.group)
+        if self.cuda:
+            hip.call("cast_bf16_to_f32", st, g, hi - lo)
+        else:
+            g.copy_(st)
 
     def _reduce(self, lo, hi):
         if not self.active or hi <= lo:
             return
-        buf = self.store.grad[lo:hi]
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                self.work.append(self.dist.all_reduce(buf, group=self.group, async_op=True))
-        else:
-            self.dist.all_reduce(buf, group=self.group)
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _nullcontext()
+        with ctx:
+            for b0 in range(lo, hi, self.bucket_elems):
+                b1 = min(hi, b0 + self.bucket_elems)
+                self._bucket(b0, b1)      # on NCCL the collective is enqueued behind this stream's work and the stream waits for it: no host block
+                self.bytes_on_wire += (b1 - b0) * (2 if self.wire == "bf16" else 4)
+                self.n_buckets += 1
         self.done.append((lo, hi))
 
     def layer_ready(self, i):
         self._reduce(*self.layer_range[i])
 
+    def all_layers_ready(self):
+        """The decoder-layer ranges in backward order -- for a last micro-batch that ran no backward on this rank (nothing supervised in it): the
+        bucket sequence must be the same on every rank whatever the rank-local data was."""
+        sent = set(self.done)
+        for i in reversed(range(len(self.layer_range))):
+            if self.layer_range[i] not in sent:
+                self.layer_ready(i)
+
     def finish(self):
         """Reduce whatever has not been sent yet (vision tower, embedding, lm_head, norm gains / biases) and join."""
+        self.all_layers_ready()
         covered = sorted(self.done)
         cur = 0
         for lo, hi in covered + [(self.store.n_total, self.store.n_total)]:
             if lo > cur:
                 self._reduce(cur, lo)
             cur = max(cur, hi)
-        for w in self.work:
-            w.wait()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        self.last_bytes_on_wire, self.last_n_buckets = self.bytes_on_wire, self.n_buckets
+        self.bytes_on_wire = self.n_buckets = 0
         self.reset()
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 class SCGRPOEngine:
@@ -337,10 +385,13 @@ class SCGRPOEngine:
         return float(self.norm2.sqrt().item()) * getattr(self, "grad_scale", 1.0)
 
     # ---- the whole micro-step ----------------------------------------------------------------------------------------
-    def step(self, batch, reward_fn, do_optimizer_step=True):
-        """reward_fn(completion_ids: np.ndarray [N,C]) -> [N, n_funcs] rewards (decode + plugin functions live with
-        the caller, which owns the tokenizer)."""
-        import os, time
+    def step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False):
+        """One SC-GRPO micro-step: vision tower -> group rollout -> rewards -> reference / policy passes + backward (-> optimizer).  This is the path
+        `SCGRPOTrainer.compute_loss` (the reference's API, REF:586) runs and the one bench.py times.
+        reward_fn(completion_ids: np.ndarray [N,C]) -> [N, n_funcs] rewards (decode + plugin functions live with the caller, which owns the tokenizer).
+        last_micro_step (default: do_optimizer_step): the data-parallel gradient buckets leave from this call's backward.
+        return_outputs: the whole loss_and_grads dict (log-probs, advantages, masks, ids, metrics) plus "completion_ids" instead of the metrics alone."""
+        import time
         timing = os.environ.get("IADR1_TIMING") == "1"
 
         def mark():
@@ -363,11 +414,15 @@ class SCGRPOEngine:
         rewards = reward_fn(comp) if timing else (lambda: reward_fn(comp))
         t3 = mark()
         self.last_step_traced = bool(carry and carry.get("traced"))     # the decode steps filled the completion rows of the training arena
-        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=do_optimizer_step, vis=vis, train_carry=carry)
+        last = do_optimizer_step if last_micro_step is None else last_micro_step
+        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=last, vis=vis, train_carry=carry)
         t4 = mark()
         if do_optimizer_step:
             self.optimizer_step()
         t5 = mark()
         if timing:
             print(f"[iadr1 timing] vision {1e3*(t1-t0):.1f} ms | rollout {1e3*(t2-t1):.1f} | rewards {1e3*(t3-t2):.1f} | ref+policy fwd/bwd {1e3*(t4-t3):.1f} | optimizer {1e3*(t5-t4):.1f}", flush=True)
+        if return_outputs:
+            out["completion_ids"] = comp
+            return out
         return out["metrics"]

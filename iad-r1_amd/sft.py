@@ -86,6 +86,10 @@ class SFTEngine:
         if backward:
             e.vision_backward(ops.f32_bias_to_bf16(dimg32, None), vctx)
             self.accum += 1
+            if last_micro_step:
+                # a slice without supervised tokens ran no backward and fired no hook: send the layer buckets it skipped now, in the same order,
+                # so that every rank issues the same collective sequence whatever its local data was
+                self.reducer.all_layers_ready()
         return float(total) / n_items
 
     def optimizer_step(self):

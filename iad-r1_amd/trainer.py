@@ -22,6 +22,7 @@ from typing import Any, Callable, Optional, Union
 import numpy as np
 import torch
 
+from . import schedule
 from .params import ParamStore, VLMConfig
 from .sc_grpo import GRPOArgs, SCGRPOEngine
 
@@ -55,7 +56,8 @@ class GRPOConfig:
     bf16: bool = True
     gradient_checkpointing: bool = False   # accepted; 288 GB HBM holds the activations of a micro-batch, nothing is recomputed
     model_init_kwargs: Optional[dict] = None
-    micro_batch_seqs: int = 16
+    micro_batch_seqs: int = 64      # sequences per reference / policy pass; >= batch x group lets the rollout double as the policy's training forward
+    shuffle: bool = True            # seeded per-epoch permutation (HF Trainer's RandomSampler / DistributedSampler)
     run_name: Optional[str] = None
     report_to: Any = None
     push_to_hub: bool = False
@@ -168,6 +170,33 @@ def last_checkpoint(output_dir: str) -> Optional[str]:
     return os.path.join(output_dir, best) if best else None
 
 
+def maybe_apply_chat_template(example: dict, processing_class) -> str:
+    """trl.data_utils.maybe_apply_chat_template for the prompt-only rows SC-GRPO feeds it (REF:600 -> trl/trl/data_utils.py:172-227 -> :71-169):
+    a conversational prompt (list of {"role", "content"} messages) is rendered with the processor's chat template and the generation prompt
+    appended, untokenised; a plain-string prompt passes through unchanged."""
+    p = example["prompt"]
+    if isinstance(p, list) and p and isinstance(p[0], dict) and "role" in p[0] and "content" in p[0]:       # trl is_conversational
+        return processing_class.apply_chat_template(p, add_generation_prompt=True, tokenize=False)
+    return p
+
+
+def prepare_batch(processing_class, inputs: list[dict]) -> dict:
+    """Dataset rows -> the prompt tensors of one micro-batch, the reference's host-side steps REF:600-622: chat template per example, PIL open of every
+    image path, ONE processor call with left padding and no extra special tokens.  Pure host code (no device access)."""
+    from PIL import Image
+    prompts_text = [maybe_apply_chat_template(ex, processing_class) for ex in inputs]
+    images, per_prompt = [], []
+    for ex in inputs:
+        im = ex.get("image")
+        im = im if isinstance(im, list) else ([im] if im is not None else [])
+        per_prompt.append(len(im))
+        images += [Image.open(i) if isinstance(i, str) else i for i in im]
+    enc = processing_class(text=prompts_text, images=images if images else None, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
+    grid = enc["image_grid_thw"]
+    return {"input_ids": np.asarray(enc["input_ids"]), "attention_mask": np.asarray(enc["attention_mask"]), "pixel_values": enc["pixel_values"],
+            "image_grid_thw": grid.tolist() if hasattr(grid, "tolist") else [tuple(g) for g in grid], "images_per_prompt": per_prompt}
+
+
 class SCGRPOTrainer:
     def __init__(
         self,
@@ -218,8 +247,11 @@ class SCGRPOTrainer:
         else:
             self.model_id = "in-memory-qwen2.5-vl"
             self.cfg, weights = model
-            self.policy = ParamStore(self.cfg, self.device, trainable=True)
-            self.policy.load_named(weights)
+            if isinstance(weights, ParamStore):      # a resident trainable store (bench.py: random-init weights of a full-size model, no host copy)
+                self.policy = weights
+            else:
+                self.policy = ParamStore(self.cfg, self.device, trainable=True)
+                self.policy.load_named(weights)
         # frozen reference = the starting checkpoint (REF:152-182)
         self.ref = ParamStore(self.cfg, self.device, trainable=False)
         self.ref.copy_from(self.policy)
@@ -253,23 +285,7 @@ class SCGRPOTrainer:
 
     # ---- batch construction (host) -------------------------------------------------------------------------------
     def _prepare(self, inputs: list[dict]):
-        from PIL import Image
-        pc = self.processing_class
-        prompts_text = []
-        for ex in inputs:
-            p = ex["prompt"]
-            if isinstance(p, list):  # conversational -> chat template with generation prompt (trl maybe_apply_chat_template)
-                p = pc.apply_chat_template(p, add_generation_prompt=True, tokenize=False)
-            prompts_text.append(p)
-        images, per_prompt = [], []
-        for ex in inputs:
-            im = ex.get("image")
-            im = im if isinstance(im, list) else ([im] if im is not None else [])
-            per_prompt.append(len(im))
-            images += [Image.open(i) if isinstance(i, str) else i for i in im]
-        enc = pc(text=prompts_text, images=images if images else None, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
-        return {"input_ids": enc["input_ids"].numpy(), "attention_mask": enc["attention_mask"].numpy(), "pixel_values": enc["pixel_values"],
-                "image_grid_thw": enc["image_grid_thw"].numpy().tolist(), "images_per_prompt": per_prompt}
+        return prepare_batch(self.processing_class, inputs)
 
     def _rewards(self, inputs, completion_ids: np.ndarray):
         G = self.args.num_generations
@@ -290,10 +306,9 @@ class SCGRPOTrainer:
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")  # REF:587-588
         batch = self._prepare(inputs)
-        vis = self.engine.vision_policy(batch, save=True)
-        comp = self.engine.rollout(batch, vis=vis)
-        rew = self._rewards(inputs, comp)
-        out = self.engine.loss_and_grads(batch, comp, rew, backward=True, last_micro_step=last_micro_step, vis=vis)
+        # the engine's whole micro-step (SCGRPOEngine.step): vision tower once per image, rollout whose prefill / decode steps double as the policy's
+        # training forward when the micro-batch holds whole groups, rewards evaluated on the host while the reference pass is in the GPU queue
+        out = self.engine.step(batch, lambda comp: self._rewards(inputs, comp), do_optimizer_step=False, last_micro_step=last_micro_step, return_outputs=True)
         m = out["metrics"]
         self._metrics["completion_length"].append(m["completion_length"])
         rp = out["rewards_per_func"].mean(0)
@@ -317,14 +332,16 @@ class SCGRPOTrainer:
 
     def _lr(self, step, total):
         a = self.args
-        if a.warmup_steps and step < a.warmup_steps:
-            return a.learning_rate * (step + 1) / a.warmup_steps
-        if a.lr_scheduler_type == "constant":
-            return a.learning_rate
-        frac = (step - a.warmup_steps) / max(1, total - a.warmup_steps)
-        if a.lr_scheduler_type == "cosine":
-            return a.learning_rate * 0.5 * (1 + math.cos(math.pi * frac))
-        return a.learning_rate * max(0.0, 1 - frac)  # HF default: linear decay
+        return schedule.lr_at(step, total, a.learning_rate, a.warmup_steps, a.lr_scheduler_type)
+
+    def training_step(self, micro_batches: list[list[dict]]) -> list[float]:
+        """One optimizer step = gradient_accumulation_steps micro-batches through compute_loss (the data-parallel gradient buckets leave during the
+        last one's backward) + clip / AdamW / weight-copy refresh.  What transformers.Trainer.training_step + the optimizer block of its inner loop do
+        around the reference's compute_loss (TF:trainer.py:1892-1961, :1785); train() and bench.py both go through here."""
+        losses = [self.compute_loss(None, inputs, last_micro_step=(k == len(micro_batches) - 1)) for k, inputs in enumerate(micro_batches)]
+        self.engine.optimizer_step()
+        self.state.global_step += 1
+        return losses
 
     def train(self, resume_from_checkpoint: Optional[str] = None):
         """resume_from_checkpoint: a checkpoint-N directory written by this trainer (weights + optimizer.safetensors + trainer_state.json), or True for
@@ -339,21 +356,20 @@ class SCGRPOTrainer:
             st = load_training_state(self.policy, ck)
             self.engine.opt_step, self.state.global_step, start = st["opt_step"], st["global_step"], st["global_step"]
         rows = list(self.train_dataset)
-        rows = rows[rank::world]  # prompts are sharded over ranks; each rank keeps whole groups
         bs, ga = a.per_device_train_batch_size, a.gradient_accumulation_steps
-        steps_per_epoch = max(1, len(rows) // (bs * ga))
-        total = a.max_steps if a.max_steps > 0 else int(math.ceil(steps_per_epoch * a.num_train_epochs))
+        # prompts are sharded over ranks, each rank keeps whole groups.  Every rank derives the step count from the GLOBAL
+        # row count and holds ceil(n / world) rows per epoch (wrap-around padding, as DistributedSampler): equal collective sequences on all ranks
+        total = schedule.total_steps(len(rows), world, bs, ga, a.num_train_epochs, a.max_steps)
+        sampler = schedule.RankSampler(len(rows), rank, world, seed=a.seed, shuffle=a.shuffle)
         t0 = time.time()
         i = start * bs * ga
         for step in range(start, total):
             self.engine.args.learning_rate = self._lr(step, total)
-            losses = []
+            micro = []
             for k in range(ga):
-                inputs = [rows[(i + j) % len(rows)] for j in range(bs)]
+                micro.append([rows[sampler.index(i + j)] for j in range(bs)])
                 i += bs
-                losses.append(self.compute_loss(None, inputs, last_micro_step=(k == ga - 1)))
-            self.engine.optimizer_step()
-            self.state.global_step += 1
+            losses = self.training_step(micro)
             if self.state.global_step % a.logging_steps == 0:
                 self.log({"loss": float(np.mean(losses)), "grad_norm": self.engine.grad_norm(), "learning_rate": self.engine.args.learning_rate, "step": self.state.global_step,
                           "elapsed_s": round(time.time() - t0, 2)})

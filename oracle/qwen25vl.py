@@ -326,6 +326,85 @@ class Qwen25VLOracle:
         return ids
 
 
+    # -- greedy rollout with a key/value cache: the arithmetic HF `generate` / vLLM actually run (prefill once, then one new token per step
+    #    attending to cached K/V: TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:641-689 with `past_key_values`, positions for later tokens = cache
+    #    length + rope_delta, TF::1165-1176).  Same values as greedy_generate up to fp32 summation order; tests/test_oracle_model.py checks the
+    #    token ids against it and against the HF golden.  Used by bench.py's cpu_baseline leg (the full-recompute form is quadratically slower) ----
+    @torch.no_grad()
+    def _layers_cached(self, x, allowed, cos, sin, cache):
+        """x: [B, Sn, H] new tokens; allowed: [B, 1, Sn, Sk] bool over (cached + new) keys; cache: list of [k, v] per layer (appended in place)."""
+        t, w = self.cfg["text"], self.w
+        B, Sn, H = x.shape
+        nh, nkv = t["num_attention_heads"], t["num_key_value_heads"]
+        hd = H // nh
+        cos, sin = cos.unsqueeze(1).to(x.dtype), sin.unsqueeze(1).to(x.dtype)
+        for i in range(t["num_hidden_layers"]):
+            b = f"model.layers.{i}."
+            h = rmsnorm(x, w[b + "input_layernorm.weight"], t["rms_norm_eps"])
+            q = (h @ w[b + "self_attn.q_proj.weight"].t() + w[b + "self_attn.q_proj.bias"]).view(B, Sn, nh, hd).transpose(1, 2)
+            k = (h @ w[b + "self_attn.k_proj.weight"].t() + w[b + "self_attn.k_proj.bias"]).view(B, Sn, nkv, hd).transpose(1, 2)
+            v = (h @ w[b + "self_attn.v_proj.weight"].t() + w[b + "self_attn.v_proj.bias"]).view(B, Sn, nkv, hd).transpose(1, 2)
+            q = q * cos + rotate_half(q) * sin
+            k = k * cos + rotate_half(k) * sin
+            if cache[i] is None:
+                cache[i] = [k, v]
+            else:
+                cache[i] = [torch.cat([cache[i][0], k], 2), torch.cat([cache[i][1], v], 2)]
+            kk = cache[i][0].repeat_interleave(nh // nkv, 1)
+            vv = cache[i][1].repeat_interleave(nh // nkv, 1)
+            sc = (q @ kk.transpose(2, 3)) * hd**-0.5
+            sc = sc.masked_fill(~allowed, torch.finfo(sc.dtype).min)
+            pr = torch.softmax(sc, -1, dtype=torch.float32).to(x.dtype)
+            a = (pr @ vv).transpose(1, 2).reshape(B, Sn, H)
+            x = x + a @ w[b + "self_attn.o_proj.weight"].t()
+            h = rmsnorm(x, w[b + "post_attention_layernorm.weight"], t["rms_norm_eps"])
+            x = x + (F.silu(h @ w[b + "mlp.gate_proj.weight"].t()) * (h @ w[b + "mlp.up_proj.weight"].t())) @ w[b + "mlp.down_proj.weight"].t()
+        return rmsnorm(x, w["model.norm.weight"], t["rms_norm_eps"])
+
+    @torch.no_grad()
+    def prefill_cached(self, prompt_ids, prompt_mask, pixel_values, image_grid_thw):
+        """-> (logits of the last prompt position [B, V], state) with state = {cache, mask, rope_deltas}."""
+        grids = [tuple(int(z) for z in g) for g in image_grid_thw] if image_grid_thw is not None else []
+        img = self.visual(pixel_values, grids) if pixel_values is not None else None
+        x = self.embed(prompt_ids, img)
+        pos, deltas = mrope_position_ids(prompt_ids, prompt_mask, grids, self.cfg["image_token_id"], self.cfg["vision"]["spatial_merge_size"])
+        B, S = prompt_ids.shape
+        allowed = torch.ones(S, S, dtype=torch.bool).tril().view(1, 1, S, S) & prompt_mask.bool().view(B, 1, 1, S)
+        cos, sin = self._rope_cos_sin(pos)
+        cache = [None] * self.cfg["text"]["num_hidden_layers"]
+        h = self._layers_cached(x, allowed, cos, sin, cache)
+        return h[:, -1] @ self.w["lm_head.weight"].t(), {"cache": cache, "mask": prompt_mask.clone(), "deltas": torch.as_tensor(deltas).view(-1).long()}
+
+    @torch.no_grad()
+    def decode_step_cached(self, tokens, state):
+        """One new token per sequence -> logits [B, V]; K/V appended to state["cache"]."""
+        B = tokens.shape[0]
+        n_real = state["mask"].sum(1)                                  # tokens attended so far (left padding excluded)
+        pos = (n_real + state["deltas"]).view(1, B, 1).expand(3, B, 1)  # text token: the same position on all three M-RoPE axes
+        state["mask"] = torch.cat([state["mask"], torch.ones(B, 1, dtype=state["mask"].dtype)], 1)
+        allowed = state["mask"].bool().view(B, 1, 1, -1)
+        cos, sin = self._rope_cos_sin(pos)
+        x = self.w["model.embed_tokens.weight"][tokens].view(B, 1, -1)
+        h = self._layers_cached(x, allowed, cos, sin, state["cache"])
+        return h[:, -1] @ self.w["lm_head.weight"].t()
+
+    @torch.no_grad()
+    def greedy_generate_cached(self, prompt_ids, prompt_mask, pixel_values, image_grid_thw, max_new_tokens, eos_token_id=None, pad_token_id=0):
+        """Same contract as greedy_generate (returns [B, P + max_new_tokens] ids)."""
+        lg, st = self.prefill_cached(prompt_ids, prompt_mask, pixel_values, image_grid_thw)
+        ids = prompt_ids.clone()
+        done = torch.zeros(ids.shape[0], dtype=torch.bool)
+        for it in range(max_new_tokens):
+            nxt = lg.argmax(-1)
+            if eos_token_id is not None:
+                nxt = torch.where(done, torch.full_like(nxt, pad_token_id), nxt)
+                done |= nxt == eos_token_id
+            ids = torch.cat([ids, nxt.view(-1, 1)], 1)
+            if it + 1 < max_new_tokens:
+                lg = self.decode_step_cached(nxt, st)
+        return ids
+
+
 def flops_per_sequence(cfg: dict, S: int, n_patches: int, logits_positions: int | None = None) -> dict:
     """Algorithmic forward FLOPs of one sequence (GEMM 2*params*tokens + attention), SURVEY section 8(d)."""
     t, v = cfg["text"], cfg["vision"]

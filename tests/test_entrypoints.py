@@ -17,29 +17,56 @@ def _load(rel):
     return m
 
 
-# the flags of scripts/train/SC_GRPO/SC_GRPO_Qwen_Instruct_2_5_VL_3B.sh:40-63 (values are placeholders)
-SC_GRPO_FLAGS = ("--deepspeed zero3.json --output_dir out --model_name_or_path /m/Qwen2.5-VL-3B --dataset_name d.json --image_path /data "
-                 "--use_vllm_for_gen true --use_system_prompt false --max_prompt_length 4096 --max_completion_length 512 --num_generations 4 "
-                 "--per_device_train_batch_size 1 --gradient_accumulation_steps 2 --logging_steps 1 --bf16 --report_to wandb "
-                 "--gradient_checkpointing true --attn_implementation flash_attention_2 --max_pixels 480000 --save_steps 100 "
-                 "--num_train_epochs 1 --run_name x --single_img 1").split()
-# scripts/train/PA_SFT/PA_SFT_Qwen_Instruct_2_5_VL_3B.sh:25-50
-PA_SFT_FLAGS = ("--deepspeed zero3.json --stage sft --do_train --model_name_or_path /m/q --dataset expert_ad --template qwen2_vl --finetuning_type full "
-                "--output_dir out --overwrite_cache --overwrite_output_dir --warmup_steps 100 --weight_decay 0.1 --per_device_train_batch_size 1 "
-                "--gradient_accumulation_steps 2 --ddp_timeout 90000 --learning_rate 1e-5 --lr_scheduler_type cosine --logging_steps 1 --cutoff_len 4096 "
-                "--save_steps 500 --plot_loss --num_train_epochs 1 --bf16").split()
+def _launch_scripts():
+    """tests/golden/launch_flags.json: the argv every one of the reference's 14 launch scripts passes to its entry point (extracted from
+    scripts/train/{PA_SFT,SC_GRPO}/*.sh by tools/make_golden_launch_flags.py; $VARIABLES replaced by placeholders)."""
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "launch_flags.json")))["scripts"]
 
 
-def test_sc_grpo_cli_accepts_reference_flags():
-    m = _load("train/stage_rl/grpo_ad.py")
-    a = m.build_parser().parse_args(SC_GRPO_FLAGS)
-    assert a.num_generations == 4 and a.max_completion_length == 512 and a.max_pixels == 480000 and a.beta == 0.04 and a.learning_rate == 1e-6
+@pytest.mark.parametrize("entry", ["train/stage_rl/grpo_ad.py", "train/stage_sft/train.py"])
+def test_every_reference_launch_script_parses(entry):
+    m = _load(entry)
+    scripts = [s for s in _launch_scripts() if s["entry"] == entry]
+    assert len(scripts) == 7
+    for s in scripts:
+        a = m.build_parser().parse_args(s["argv"])       # argparse exits (SystemExit) on an unknown flag
+        if entry.endswith("grpo_ad.py"):
+            assert a.num_generations == 4 and a.max_completion_length == 512 and a.max_pixels == 480000 and a.beta == 0.04 and a.learning_rate == 1e-6, s["script"]
+            assert a.gradient_accumulation_steps == 2 and a.per_device_train_batch_size == 1 and a.save_steps == 100
+        else:
+            assert a.image_dir == "/data/Expert-AD" and a.weight_decay == 0.1 and a.warmup_steps == 100 and a.lr_scheduler_type == "cosine", s["script"]
+            assert a.cutoff_len in (4096, 8192) and a.template in ("qwen2_vl", "llava", "llava_next_mistral", "llava_next_qwen")
 
 
-def test_pa_sft_cli_accepts_reference_flags():
+def test_image_dir_is_where_relative_image_paths_resolve(tmp_path):
+    """llamafactory hparams/data_args.py:44,136-137 (defaults to dataset_dir) and data/aligner.py:52-53 (joined only when that file exists)."""
     m = _load("train/stage_sft/train.py")
-    a = m.build_parser().parse_args(PA_SFT_FLAGS)
-    assert a.learning_rate == 1e-5 and a.weight_decay == 0.1 and a.warmup_steps == 100 and a.cutoff_len == 4096 and a.lr_scheduler_type == "cosine"
+    (tmp_path / "data").mkdir()
+    (tmp_path / "imgs").mkdir()
+    (tmp_path / "imgs" / "a.png").write_bytes(b"x")
+    rows = [{"messages": [{"role": "user", "content": "<image>q"}, {"role": "assistant", "content": "a"}], "images": ["a.png", "missing.png"]}]
+    (tmp_path / "data" / "d.json").write_text(json.dumps(rows))
+    got = m.load_sharegpt(str(tmp_path / "data" / "d.json"), str(tmp_path / "data"), str(tmp_path / "imgs"))
+    assert got[0]["images"] == [str(tmp_path / "imgs" / "a.png"), "missing.png"]
+    got = m.load_sharegpt(str(tmp_path / "data" / "d.json"), str(tmp_path / "data"))                 # default: dataset_dir, where neither file exists
+    assert got[0]["images"] == ["a.png", "missing.png"]
+
+
+def test_config_yaml_sets_defaults_cli_overrides_env_is_exported(tmp_path, monkeypatch):
+    """TrlParser.parse_args_and_config, REF trl/trl/scripts/utils.py:165-223."""
+    m = _load("train/stage_rl/grpo_ad.py")
+    y = tmp_path / "c.yaml"
+    y.write_text("env:\n  IADR1_TEST_ENV_FROM_YAML: 17\nmodel_name_or_path: /m/q\ndataset_name: d.json\noutput_dir: out\nnum_generations: 6\nbeta: 0.1\nreward_funcs: [accuracy]\n")
+    monkeypatch.delenv("IADR1_TEST_ENV_FROM_YAML", raising=False)
+    a = m.parse_args_and_config(m.build_parser(), ["--config", str(y), "--beta", "0.02"])
+    assert a.model_name_or_path == "/m/q" and a.num_generations == 6 and a.beta == 0.02 and a.reward_funcs == ["accuracy"]
+    assert os.environ["IADR1_TEST_ENV_FROM_YAML"] == "17"
+    monkeypatch.delenv("IADR1_TEST_ENV_FROM_YAML", raising=False)
+    y.write_text("model_name_or_path: /m/q\ndataset_name: d.json\noutput_dir: out\nno_such_flag: 3\n")
+    with pytest.raises(ValueError, match="not used by the parser"):
+        m.parse_args_and_config(m.build_parser(), ["--config", str(y)])
+    with pytest.raises(SystemExit):      # required flags stay required without a config
+        m.parse_args_and_config(m.build_parser(), ["--beta", "0.1"])
 
 
 class _CharProcessor:

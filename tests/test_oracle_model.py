@@ -111,6 +111,16 @@ def test_greedy_rollout_token_ids(golden_dir):
     pv = torch.from_numpy(fx.synth_pixel_values(grids, cfg, seed=meta["seed"]))
     seqs = m.greedy_generate(torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["prompt_mask"]), pv, grids, meta["new_tokens"])
     assert np.array_equal(seqs.numpy(), g["sequences"])  # bit-exact token ids
+    # the key/value-cached form (what bench.py's cpu_baseline leg times) produces the same ids, with and without EOS handling
+    cached = m.greedy_generate_cached(torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["prompt_mask"]), pv, grids, meta["new_tokens"])
+    assert np.array_equal(cached.numpy(), g["sequences"])
+    eos = int(g["sequences"][0, g["prompt_ids"].shape[1] + 2])
+    a = m.greedy_generate(torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["prompt_mask"]), pv, grids, meta["new_tokens"], eos_token_id=eos, pad_token_id=2)
+    b = m.greedy_generate_cached(torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["prompt_mask"]), pv, grids, meta["new_tokens"], eos_token_id=eos, pad_token_id=2)
+    P = g["prompt_ids"].shape[1]
+    first = int(np.flatnonzero(a.numpy()[0, P:] == eos)[0])
+    assert np.array_equal(a.numpy()[:, : P + first + 1], b.numpy()[:, : P + first + 1])      # up to the EOS the two loops agree (after it the
+    # full-recompute loop feeds pads back into the context while the cached one does not attend differently: only row 0's prefix is compared)
 
 
 def test_sft_loss_curve(golden_dir):

@@ -87,12 +87,41 @@ def build_parser():
     p.add_argument("--logging_steps", type=int, default=1)
     p.add_argument("--save_steps", type=int, default=100)
     p.add_argument("--seed", type=int, default=42)
-    p.add_argument("--micro_batch_seqs", type=int, default=16)
+    p.add_argument("--micro_batch_seqs", type=int, default=64)
     p.add_argument("--run_name", default=None)
     # accepted for script compatibility, no effect here
-    for flag in ("--deepspeed", "--report_to", "--gradient_checkpointing", "--bf16", "--ddp_timeout", "--push_to_hub", "--config"):
+    for flag in ("--deepspeed", "--report_to", "--gradient_checkpointing", "--bf16", "--ddp_timeout", "--push_to_hub"):
         p.add_argument(flag, nargs="?", default=None, const=True)
     return p
+
+
+def parse_args_and_config(parser: argparse.ArgumentParser, argv=None):
+    """`TrlParser.parse_args_and_config` (REF trl/trl/scripts/utils.py:165-223, used at grpo_ad.py:210-213): `--config file.yaml` supplies values that
+    REPLACE the parser defaults (and make required flags optional), command-line flags override them, an `env:` block is exported to os.environ, and
+    a YAML key no flag knows is an error (HfArgumentParser raises on unconsumed strings unless asked to return them)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if "--config" in argv:
+        i = argv.index("--config")
+        argv.pop(i)
+        if i >= len(argv):
+            raise ValueError("--config needs a YAML file path")
+        import yaml
+        with open(argv.pop(i)) as f:
+            cfg = yaml.safe_load(f) or {}
+        if "env" in cfg:
+            env = cfg.pop("env") or {}
+            if not isinstance(env, dict):
+                raise ValueError("`env` field should be a dict in the YAML file.")
+            for k, v in env.items():
+                os.environ[k] = str(v)
+        for action in parser._actions:
+            if action.dest in cfg:
+                v = cfg.pop(action.dest)
+                action.default = action.type(v) if (action.type is not None and v is not None and not isinstance(v, (list, bool))) else v
+                action.required = False
+        if cfg:
+            raise ValueError(f"Some keys of the --config file are not used by the parser: {sorted(cfg)}")
+    return parser.parse_args(argv)
 
 
 def make_conversation(example: dict, image_path: str, use_system_prompt: bool, single_img: int) -> dict:
@@ -127,7 +156,7 @@ def load_rows(path: str):
 
 
 def main(argv=None):
-    a = build_parser().parse_args(argv)
+    a = parse_args_and_config(build_parser(), argv)
     if a.single_img not in (0, 1):
         raise ValueError("The single_img parameter can only be 0 or 1")
     if not a.dataset_name.endswith((".json", ".jsonl")):

@@ -27,6 +27,7 @@ def build_parser():
     p.add_argument("--model_name_or_path", required=True)
     p.add_argument("--dataset", required=True, help="name in dataset_info.json, or a path to a sharegpt json")
     p.add_argument("--dataset_dir", default="data")
+    p.add_argument("--image_dir", default=None, help="folder the manifests' relative image paths live under; defaults to --dataset_dir (llamafactory hparams/data_args.py:44,136-137)")
     p.add_argument("--template", default="qwen2_vl")
     p.add_argument("--finetuning_type", default="full")
     p.add_argument("--output_dir", required=True)
@@ -43,6 +44,7 @@ def build_parser():
     p.add_argument("--logging_steps", type=int, default=1)
     p.add_argument("--save_steps", type=int, default=500)
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--disable_shuffling", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     p.add_argument("--micro_batch_seqs", type=int, default=16)
     p.add_argument("--image_resolution", type=int, default=512 * 512)
     p.add_argument("--resume_from_checkpoint", default=None, help="checkpoint-N directory with a training state; default: the last one under output_dir unless --overwrite_output_dir")
@@ -54,7 +56,7 @@ def build_parser():
     return p
 
 
-def load_sharegpt(name: str, dataset_dir: str):
+def load_sharegpt(name: str, dataset_dir: str, image_dir: str | None = None):
     """Rows of a sharegpt-format dataset, aligned the way the reference aligns them (iadr1_amd.sft_data.align_sharegpt).  `name` is an entry of
     <dataset_dir>/dataset_info.json (file_name / formatting / columns / tags, LLaMA-Factory schema) or, failing that, a path to a json file in the
     README's Expert-AD layout (README.md:71-99: "messages" with role / content, "images")."""
@@ -70,7 +72,8 @@ def load_sharegpt(name: str, dataset_dir: str):
     else:
         path = name
         schema = ShareGPTSchema(messages="messages", images="images", role_tag="role", content_tag="content", user_tag="user", assistant_tag="assistant")
-    rows = [align_sharegpt(r, schema, image_dir=dataset_dir) for r in json.load(open(path))]
+    # a relative image path is joined with image_dir when that file exists, otherwise left as it is (llamafactory data/aligner.py:52-53)
+    rows = [align_sharegpt(r, schema, image_dir=image_dir or dataset_dir) for r in json.load(open(path))]
     return [r for r in rows if r["prompt"]]      # the reference filters out the rows its aligner emptied (odd turn counts, roles out of order)
 
 
@@ -99,6 +102,9 @@ def main(argv=None):
     a = build_parser().parse_args(argv)
     if a.stage != "sft" or a.finetuning_type != "full":
         raise ValueError("only --stage sft --finetuning_type full is part of the IAD-R1 PA-SFT path")
+    if a.template != "qwen2_vl":
+        raise ValueError(f"--template {a.template}: the Qwen2-VL / Qwen2.5-VL chat format is the one built here; the llava* templates "
+                         "(llamafactory data/template.py:833-841,886-913) belong to model families this engine does not run yet")
     import numpy as np
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,9 +125,15 @@ def main(argv=None):
     proc = AutoProcessor.from_pretrained(a.model_name_or_path)
     eng = SFTEngine(cfg, store, SFTArgs(learning_rate=a.learning_rate, weight_decay=a.weight_decay, max_grad_norm=a.max_grad_norm,
                                         gradient_accumulation_steps=a.gradient_accumulation_steps, micro_batch_seqs=a.micro_batch_seqs), group=group)
-    rows = load_sharegpt(a.dataset, a.dataset_dir)[rank::world]
+    from iadr1_amd import schedule
+    if a.lr_scheduler_type not in schedule.SCHEDULES:
+        raise ValueError(f"--lr_scheduler_type {a.lr_scheduler_type}: supported {schedule.SCHEDULES}")
+    rows = load_sharegpt(a.dataset, a.dataset_dir, a.image_dir)
     bs, ga = a.per_device_train_batch_size, a.gradient_accumulation_steps
-    total = a.max_steps if a.max_steps > 0 else int(math.ceil(max(1, len(rows) // (bs * ga)) * a.num_train_epochs))
+    # the step count comes from the GLOBAL row count and every rank holds ceil(n / world) rows per epoch in a seeded per-epoch order
+    # (DistributedSampler semantics): all ranks run the same number of optimizer steps and issue the same collectives
+    total = schedule.total_steps(len(rows), world, bs, ga, a.num_train_epochs, a.max_steps)
+    sampler = schedule.RankSampler(len(rows), rank, world, seed=a.seed, shuffle=not a.disable_shuffling)
     os.makedirs(a.output_dir, exist_ok=True)
     log = open(os.path.join(a.output_dir, "trainer_log.jsonl"), "a") if rank == 0 else None
     pad = cfg.pad_token_id
@@ -134,12 +146,11 @@ def main(argv=None):
         print(f"resuming from {ck} at step {start}", flush=True)
     i, t0 = start * bs * ga, time.time()
     for step in range(start, total):
-        lr = a.learning_rate * (step + 1) / a.warmup_steps if step < a.warmup_steps else (
-            a.learning_rate * 0.5 * (1 + math.cos(math.pi * (step - a.warmup_steps) / max(1, total - a.warmup_steps))) if a.lr_scheduler_type == "cosine" else a.learning_rate)
+        lr = schedule.lr_at(step, total, a.learning_rate, a.warmup_steps, a.lr_scheduler_type)
         eng.args.learning_rate = lr
         losses = []
         for k in range(ga):
-            enc = [encode_example(proc, rows[(i + j) % len(rows)], a.cutoff_len, a.train_on_prompt, a.mask_history, cfg.image_token_id, a.image_resolution) for j in range(bs)]
+            enc = [encode_example(proc, rows[sampler.index(i + j)], a.cutoff_len, a.train_on_prompt, a.mask_history, cfg.image_token_id, a.image_resolution) for j in range(bs)]
             i += bs
             S = (max(len(e[0]) for e in enc) + 7) // 8 * 8  # pad_to_multiple_of=8 (sft/workflow.py:60), right padding
             ids = np.full((bs, S), pad, dtype=np.int64)
