@@ -2,14 +2,21 @@
 """bench.py -- headline metric of BASELINE.json on MI355X: GRPO samples/sec for the full SC-GRPO step
 (hipGraph group rollout + CPU rewards + frozen-ref forward + policy forward/backward + DDP all-reduce + AdamW)
 on Qwen2.5-VL-3B shapes, 8 prompts x group 8 per GPU, one 448x448 image + 512 prompt positions, 256 new tokens.
+The timed step is the drop-in API itself: `SCGRPOTrainer.training_step` -> `compute_loss` (the reference's entry, REF
+train/stage_rl/trainer/sc_grpo_trainer.py:586) -> `SCGRPOEngine.step` -> AdamW, fed by a synthetic processor.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a torchrun environment: re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU,
+      RCCL); under torchrun it checks WORLD_SIZE == N.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     : dominant kernel = gemm_nt_128 (bf16 MFMA).  achieved = sum of algorithmic 2*M*N*K over its launches
-                 in the timed region / sum of their durations, measured live with HIP events on the launch stream.
-  cpu_baseline : the CPU oracle (oracle/qwen25vl.py, kind "port") timed on this box's host cores on a bounded
-                 sample of the same workload, extrapolated by algorithmic FLOPs (see `sample`).
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline        : dominant kernel family = gemm_nt_256 / gemm_nt_128 (bf16 MFMA).  achieved = sum of algorithmic 2*M*N*K over its launches in the
+                    timed region / the length of the UNION of their HIP-event intervals on the launch streams (weight-gradient GEMMs overlap the dgrad
+                    chain on a side stream; the per-launch-sum figure is printed beside it).
+  roofline_decode : HBM roofline of the rollout's decode step (the other half of the step).
+  cpu_baseline    : the CPU oracle (oracle/qwen25vl.py, kind "port") running the components of one B=1 x G=8 step -- vision tower, prefill,
+                    KV-cached greedy decode steps, reference forward, policy forward+backward, head -- at full 3B width on this box's host
+                    cores, each timed on a bounded sample and multiplied by its count in the step (layers x 36, blocks x 32, decode steps x 255).
 """
 from __future__ import annotations
 
@@ -174,44 +181,109 @@ class GemmTimer:
         return [{"MNK_out": list(k), "calls": v[0], "ms": round(v[1] * 1e3, 2), "TF": round(v[2] / max(v[1], 1e-9) / 1e12, 1)} for k, v in rows]
 
 
-def cpu_baseline(cfg_dict_3b, seconds_budget):
-    """Oracle (CPU port) on a bounded sample: policy log-prob forward+backward of G=2 sequences (S=768) through
-    ONE decoder layer + ONE ViT block of the 3B shapes, fp32, all host cores; extrapolated by algorithmic FLOPs."""
+def cpu_baseline(cfg_dict_3b, seconds_budget, P=512, C=256, G=8):
+    """the CPU restatement (oracle, kind "port") running ONE SC-GRPO step for B = 1 prompt x G = 8 completions on the
+    host cores -- rollout = prefill once + greedy decode loop with a key/value cache, reference forward, policy forward + backward, fp32.  The
+    full-size step would take ~10 minutes of CPU, so each COMPONENT runs at full 3B width on a bounded sample and is multiplied by its count
+    in the step: decoder layer x 36, ViT block x 32 (+ patch embed / merger once per image), decode steps x (C - 1), lm_head per position."""
     from oracle import qwen25vl as oq
     cores = int(os.environ.get("IADR1_CPU_THREADS", min(os.cpu_count() or 1, 32)))  # 32 threads measured fastest on the 2x64-core host (16: same, 64: 0.6x, 128: 0.35x)
     torch.set_num_threads(cores)
-    d = json.loads(json.dumps(cfg_dict_3b))
-    d["text"]["num_hidden_layers"] = 1
-    d["text"]["vocab_size"] = 2048
-    d["vision"]["depth"] = 1
-    d["vision"]["fullatt_block_indexes"] = [0]
-    d.update(image_token_id=2040, vision_start_token_id=2041, vision_end_token_id=2042, eos_token_id=1, pad_token_id=2)
-    g = torch.Generator().manual_seed(0)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fixture_util as fx
-    w = {k: (torch.randn(s, generator=g) * 0.02) for k, s in fx.param_shapes(d).items()}
-    m = oq.Qwen25VLOracle(d, w, requires_grad=True)
-    S, P, G = 768, 512, 4
-    ids = torch.randint(3, 2000, (G, S), generator=g)
-    ids[:, 4:260] = d["image_token_id"]
+    L_full, V_full = cfg_dict_3b["text"]["num_hidden_layers"], cfg_dict_3b["vision"]["depth"]
+    gen = torch.Generator().manual_seed(0)
+
+    def model(n_layers, v_depth, vocab, grad):
+        d = json.loads(json.dumps(cfg_dict_3b))
+        d["text"]["num_hidden_layers"], d["text"]["vocab_size"] = n_layers, vocab
+        d["vision"]["depth"], d["vision"]["fullatt_block_indexes"] = v_depth, [v_depth - 1] if v_depth else []
+        d.update(image_token_id=vocab - 8, vision_start_token_id=vocab - 7, vision_end_token_id=vocab - 6, eos_token_id=1, pad_token_id=2)
+        w = {k: (torch.randn(sh, generator=gen) * 0.02) for k, sh in fx.param_shapes(d).items()}
+        return d, oq.Qwen25VLOracle(d, w, requires_grad=grad)
+
+    def timed(fn, reps=1):
+        fn()                                   # first touch (page faults, thread pool)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    S = P + C
+    grid = (1, 32, 32)
+    # ---- vision tower per image: (depth 2) - (depth 1) = one block; depth 1 - block = patch embed + merger ---------------------------
+    pv = torch.randn(1024, 1176, generator=gen)
+    vt = {}
+    for depth in (1, 2):
+        _, m = model(0, depth, 4096, True)
+        vt[depth, "f"] = timed(lambda: m.visual(pv, [grid]).detach())
+        def fb():
+            for _, t in m.parameters():
+                t.grad = None
+            m.visual(pv, [grid]).sum().backward()
+        vt[depth, "fb"] = timed(fb)
+    vit = {k: (vt[2, k] - vt[1, k]) * V_full + max(0.0, 2 * vt[1, k] - vt[2, k]) for k in ("f", "fb")}      # seconds per image, full depth
+    # ---- decoder layer on the training rows [G, S] and the prefill row [1, P]; one layer = (1 layer) - (0 layers) -------------------
+    vocab_small = 4096
+    ids = torch.randint(3, vocab_small - 16, (G, S), generator=gen)
     mask = torch.ones(G, S, dtype=torch.long)
-    pv = torch.randn(G * 1024, 1176, generator=g)
-    grids = [(1, 32, 32)] * G
-    t0 = time.time()
-    reps = 0
-    while True:
-        lp = m.per_token_logps(ids, mask, pv, grids)[:, P - 1:]
-        lp.sum().backward()
-        reps += 1
-        if time.time() - t0 > seconds_budget * 0.6 or reps >= 12:
-            break
-    dt = (time.time() - t0) / reps
-    f = oq.flops_per_sequence(d, S, 1024, logits_positions=S)
-    sample_flops = 3.0 * G * (f["llm_gemm"] + f["llm_attn"] + f["lm_head"] + f["vit"])   # fwd + bwd = 3x fwd
-    flops_per_sample_full = 26.8e12  # SURVEY.md section 8(d): rollout + 3x policy + 1x ref, P=512, C=256
-    tf = sample_flops / dt / 1e12
-    return {"value": tf * 1e12 / flops_per_sample_full, "unit": "samples/s (extrapolated)", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd of {G} sequences (S={S}, 448^2 image) through 1 decoder layer + 1 ViT block of the 3B shapes, {reps} reps, {dt:.2f} s each = {tf:.3f} TFLOP/s; scaled to 26.8 TFLOP per sample"}
+    lay = {}
+    for nl in (0, 1):
+        d, m = model(nl, 0, vocab_small, True)
+        x = m.embed(ids).detach()
+        pos = torch.arange(S).view(1, 1, S).expand(3, G, S)
+        lay[nl, "f"] = timed(lambda: m.text_model(x, mask, pos).detach())
+        def fb():
+            for _, t in m.parameters():
+                t.grad = None
+            m.text_model(x, mask, pos).sum().backward()
+        lay[nl, "fb"] = timed(fb)
+        lay[nl, "prefill"] = timed(lambda: m.text_model(x[:1, :P], mask[:1, :P], pos[:, :1, :P]).detach())
+        if nl == 1:     # KV-cached decode step of the G sequences at mid context (P + C/2 keys)
+            st = {"cache": [[torch.randn(G, d["text"]["num_key_value_heads"], P + C // 2, 128, generator=gen)] * 2], "mask": torch.ones(G, P + C // 2, dtype=torch.long),
+                  "deltas": torch.zeros(G, dtype=torch.long)}
+            tok = torch.randint(3, vocab_small - 16, (G,), generator=gen)
+            def dec():
+                st["cache"][0] = [st["cache"][0][0][:, :, : P + C // 2], st["cache"][0][1][:, :, : P + C // 2]]
+                st["mask"] = st["mask"][:, : P + C // 2]
+                m.decode_step_cached(tok, st)
+            lay["dec_layer_plus_small_head"] = timed(dec, reps=4)
+            d0, m0 = d, m
+    t_layer = {k: lay[1, k] - lay[0, k] for k in ("f", "fb", "prefill")}
+    # ---- lm_head + log-softmax + gather at the full vocabulary: the reference projects ALL S positions of every row (REF:505); timed on R rows --
+    V = cfg_dict_3b["text"]["vocab_size"]
+    H = cfg_dict_3b["text"]["hidden_size"]
+    Wh = (torch.randn(V, H, generator=gen) * 0.02).requires_grad_(True)
+    R = 1024
+    hrows = torch.randn(R, H, generator=gen)
+    tg = torch.randint(0, V, (R,), generator=gen)
+    head_f = timed(lambda: torch.log_softmax(hrows @ Wh.t(), -1).gather(-1, tg.view(-1, 1)).detach())
+    def head_fb():
+        Wh.grad = None
+        torch.log_softmax(hrows @ Wh.t(), -1).gather(-1, tg.view(-1, 1)).sum().backward()
+    head_fb_t = timed(head_fb)
+    with torch.no_grad():
+        hd = torch.randn(G, H, generator=gen)
+        head_dec = timed(lambda: (hd @ Wh.t()).argmax(-1), reps=4)           # decode: G rows against the whole matrix (weight-read bound)
+        small = (torch.randn(vocab_small, H, generator=gen) * 0.02)
+        head_dec_small = timed(lambda: (hd @ small.t()).argmax(-1), reps=4)
+    t_dec_layer = max(0.0, lay["dec_layer_plus_small_head"] - head_dec_small)
+    rows_all = G * S
+    parts = {
+        "rollout_vision_1_image_fwd": vit["f"],
+        "rollout_prefill_1_prompt": L_full * t_layer["prefill"] + head_f / R,
+        "rollout_decode_255_steps_kv_cached": (C - 1) * (L_full * t_dec_layer + head_dec),
+        "reference_forward_G_rows": G * vit["f"] + L_full * t_layer["f"] + head_f * rows_all / R,
+        "policy_forward_backward_G_rows": G * vit["fb"] + L_full * t_layer["fb"] + head_fb_t * rows_all / R,
+    }
+    step_s = sum(parts.values())
+    return {"value": G / step_s, "unit": "samples/s", "cores": cores, "kind": "port", "seconds_per_step_B1_G8": step_s,
+            "parts_seconds": {k: round(v, 3) for k, v in parts.items()},
+            "sample": (f"oracle (fp32 torch CPU restatement) components of ONE B=1 x G={G} SC-GRPO step at full Qwen2.5-VL-3B width, P={P}, C={C}: ViT block fwd / fwd+bwd "
+                       f"(1 image), decoder layer fwd / fwd+bwd on the [{G}, {S}] training rows, prefill layer on [1, {P}], KV-cached greedy decode step of {G} sequences "
+                       f"at {P + C // 2} cached keys, lm_head + log-softmax + gather on {R} rows of the {V}-token vocabulary (all S positions per row as REF:505), "
+                       f"decode head on {G} rows; each timed once after a first-touch run, multiplied by its count in the step (layers x {L_full}, ViT blocks x {V_full}, "
+                       f"decode steps x {C - 1}); ViT recomputed per sequence in the training passes as the reference does")}
 
 
 def run_pa_sft(a, cfg, dev, rank, world):
@@ -283,20 +355,61 @@ def run_pa_sft(a, cfg, dev, rank, world):
             "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30}}), flush=True)
 
 
+class SynthProcessor:
+    """Stands in for the HF AutoProcessor the trainer calls (no tokenizer / image files offline): the chat template renders a marker, the
+    processor call returns the synthetic prompt tensors of the step that the dataset rows name (already resident in HBM -- inputs are made resident
+    before the timed region), batch_decode returns the canned completion strings (so that the reward plugins do real work on real text)."""
+
+    def __init__(self, batches, texts):
+        self.batches, self.texts = batches, texts
+
+    def apply_chat_template(self, conv, add_generation_prompt=True, tokenize=False):
+        return "SYNTHETIC PROMPT"
+
+    def __call__(self, text=None, images=None, **kw):
+        step = images[0][1]
+        assert all(im[1] == step for im in images) and len(images) == len(text)
+        return self.batches[step]
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [self.texts[i % len(self.texts)] for i in range(len(ids))]
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a torchrun environment: run the same command line as N ranks of one node (one rank per GPU over RCCL)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} launched with WORLD_SIZE={world}: the two must agree (one rank per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_ranks = 1
     if world > 1 or os.environ.get("IADR1_FORCE_REDUCE"):   # IADR1_FORCE_REDUCE=1 under torchrun --nproc-per-node 1: the RCCL exchange path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        rccl_ranks = dist.get_world_size()
+        assert rccl_ranks == world
     import iadr1_amd  # noqa: F401
     from iadr1_amd import rewards
     from iadr1_amd.params import ParamStore, VLMConfig
-    from iadr1_amd.sc_grpo import GRPOArgs, SCGRPOEngine
+    from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
 
     if a.model == "3b":
         cfg = VLMConfig.qwen25vl_3b()
@@ -314,22 +427,25 @@ def main():
         a.micro_batch = 32 if a.model == "7b" else 64
     pol = ParamStore(cfg, dev, trainable=True)
     pol.init_random(seed=0)
-    ref = ParamStore(cfg, dev, trainable=False)
-    ref.copy_from(pol)
-    args = GRPOArgs(num_generations=a.group, max_prompt_length=a.prompt_len, max_completion_length=a.gen_len, micro_batch_seqs=a.micro_batch,
-                    suppress_eos=True, use_hip_graph=not a.no_graph, seed=1234 + rank)
-    eng = SCGRPOEngine(cfg, pol, ref, args)
+    N = a.prompts * a.group
+    # inputs are generated and made resident in HBM BEFORE the timed region (the processor's fp32 patches stay fp32: the bf16 cast is part of the step)
+    batches = []
+    for step_id in range(a.warmup + a.steps + 1):
+        b = synth_batch(cfg, a.prompts, a.prompt_len, seed=1234 + 7919 * rank + step_id)
+        batches.append({"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"].to(dev),
+                        "image_grid_thw": torch.tensor(b["image_grid_thw"])})
+    chat = [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "Is there any defect in the image?"}]}]
+    rows = lambda step_id: [{"prompt": chat, "image": [("synthetic", step_id, j)], "solution": SOLUTION} for j in range(a.prompts)]
+    # the reference's API: trainer object + reward plugins (train/stage_rl/grpo_ad.py:188-199); the frozen reference model is the trainer's own copy
+    tr = SCGRPOTrainer((cfg, pol), [rewards.accuracy_reward, rewards.consistency_reward],
+                       args=GRPOConfig(output_dir="/tmp/iadr1_bench", per_device_train_batch_size=a.prompts, num_generations=a.group, max_prompt_length=a.prompt_len,
+                                       max_completion_length=a.gen_len, micro_batch_seqs=a.micro_batch, seed=1234 + rank, save_steps=0),
+                       train_dataset=None, processing_class=SynthProcessor(batches, CANNED))
+    eng = tr.engine
+    eng.args.suppress_eos = True            # fixed-length completions, every sequence generates gen_len tokens
+    eng.args.use_hip_graph = not a.no_graph
     timer = GemmTimer()
     timer.install()
-    N = a.prompts * a.group
-    texts = [CANNED[i % len(CANNED)] for i in range(N)]
-    sols = [SOLUTION] * N
-
-    def reward_fn(comp_ids):
-        comps = [[{"role": "assistant", "content": t}] for t in texts]  # canned strings stand in for batch_decode (no tokenizer offline)
-        acc = rewards.accuracy_reward(comps, sols)
-        fmt = rewards.consistency_reward(comps, sols)
-        return np.stack([acc, fmt], 1).astype(np.float32)
 
     def barrier():
         if world > 1:
@@ -337,29 +453,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # inputs are generated and made resident in HBM BEFORE the timed region (the processor's fp32 patches stay fp32:
-    # the bf16 cast is part of the step)
-    batches = []
-    for step_id in range(a.warmup + a.steps):
-        b = synth_batch(cfg, a.prompts, a.prompt_len, seed=1234 + 7919 * rank + step_id)
-        b["pixel_values"] = b["pixel_values"].to(dev)
-        batches.append(b)
     step_id = 0
     for _ in range(a.warmup):
-        eng.step(batches[step_id], reward_fn)
+        tr.training_step([rows(step_id)])
         step_id += 1
     barrier()
     ms0 = torch.cuda.memory_stats()
     timer.enabled = True
-    eng._rollout.decode_events = []
+    if eng._rollout is not None:
+        eng._rollout.decode_events = []
     t0 = time.perf_counter()
-    metrics = None
     for _ in range(a.steps):
-        metrics = eng.step(batches[step_id], reward_fn)
+        tr.training_step([rows(step_id)])
         step_id += 1
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    metrics = {k: (sum(v) / len(v) if v else None) for k, v in tr._metrics.items()}
     dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
     if world > 1:
         import torch.distributed as dist
@@ -372,12 +482,10 @@ def main():
     if world == 1 and not a.no_repeated_rows_leg and eng.args.share_prefix and a.group > 1:
         try:
             eng.args.share_prefix, eng.args.micro_batch_seqs = False, min(a.micro_batch, 32)
-            b = synth_batch(cfg, a.prompts, a.prompt_len, seed=99)
-            b["pixel_values"] = b["pixel_values"].to(dev)
-            eng.step(b, reward_fn)          # buffers of this layout
+            tr.training_step([rows(step_id)])          # buffers of this layout
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            eng.step(b, reward_fn)
+            tr.training_step([rows(step_id)])
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
             repeated = {"samples_per_s": N / d1, "ms_per_step": d1 * 1e3, "micro_batch_seqs": eng.args.micro_batch_seqs, "steps": 1,
@@ -390,13 +498,19 @@ def main():
         n_launch, t_sum, fl_gemm = timer.summary()
         t_gemm = timer.busy_seconds()            # union of the launch intervals (wgrad GEMMs overlap dgrad GEMMs on a second stream)
         ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
-        # HBM-side traffic of the heaviest GEMM shape from the PMC passes recorded under profiles/ (separate rocprofv3 --pmc
-        # runs, gfx950 FETCH_SIZE correction applied there); null when the record is absent
+        # HBM-side traffic of the heaviest GEMM shape and the MFMA-pipe busy fraction from the PMC passes recorded under profiles/ (separate rocprofv3
+        # --pmc runs, gfx950 FETCH_SIZE correction applied there); null when the record is absent
         traffic = None
+        pmc_file = next((f for f in ("r02_gemm_pmc.json", "r01_gemm_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             k0 = pmc["kernels"][0]
-            traffic = {"bytes_per_launch": k0["traffic_bytes"], "algorithmic_bytes_per_launch": k0["algorithmic_bytes"], "MNK": k0["MNK"], "source": "profiles/r01_gemm_pmc.json"}
+            traffic = {"bytes_per_launch": k0["traffic_bytes"], "algorithmic_bytes_per_launch": k0["algorithmic_bytes"], "MNK": k0["MNK"], "source": "profiles/" + pmc_file}
+        except Exception:
+            pass
+        mfma_busy = None
+        try:
+            mfma_busy = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_busy.json")))
         except Exception:
             pass
         out = {
@@ -404,21 +518,26 @@ def main():
             "value": world * N * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{'Qwen2-VL-2B' if a.model == 'qwen2vl_2b' else 'Qwen2.5-VL-' + a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
-                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}",
+                       "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
+                       "grad_exchange": ({"wire": eng.reducer.wire, "bytes_per_step": getattr(eng.reducer, "last_bytes_on_wire", 0), "buckets_per_step": getattr(eng.reducer, "last_n_buckets", 0)}
+                                         if eng.reducer.active else None),
                        "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "
                                  "reference's G repeated rows, parity-tested); the rollout's prefill is the prompt part of the policy's training forward"
                                  + ("; the rollout's decode steps write the completion rows of the policy's activation arena (side outputs of the decode kernels), so the "
-                                    "policy's forward over the completions is the decode itself and is not run a second time before backward (gradient cosine 0.9999 "
-                                    "against running it, tests/test_hip_model.py::test_decode_steps_fill_the_training_arena)" if getattr(eng, "last_step_traced", False) else ""))
+                                    "policy's forward over the completions is the decode itself and is not run a second time before backward (pinned to the oracle by "
+                                    "tests/test_hip_model.py::test_api_step_with_rollout_handover_matches_the_oracle)" if getattr(eng, "last_step_traced", False) else ""))
                        if eng.args.share_prefix else "ViT once per image"},
             "repeated_rows_layout": repeated,
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+                         "mfma_busy": mfma_busy,
                          "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt,
                          "timing": "sum of algorithmic FLOPs of the launches / length of the union of their HIP-event intervals (weight-gradient GEMMs run on a side stream "
                                    "concurrently with the dgrad GEMMs; equals FLOPs / sum of launch durations when nothing overlaps: IADR1_WGRAD_STREAM=0)",
-                         "achieved_by_sum_of_launch_durations": fl_gemm / max(t_sum, 1e-9) / 1e12},
+                         "achieved_by_sum_of_launch_durations": fl_gemm / max(t_sum, 1e-9) / 1e12,
+                         "whole_step_executed_gemm_tflops": fl_gemm / dt / 1e12, "whole_step_frac_of_mfma_peak": fl_gemm / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS},
             "roofline_decode": decode_roofline(cfg, pol, dec_ev, N, a.gen_len),
             "last_step_metrics": metrics,
             "gemm_by_shape": timer.by_shape(),
@@ -433,7 +552,7 @@ def main():
                   "vision": {"depth": 32, "hidden_size": 1280, "intermediate_size": 3420, "num_heads": 16, "in_channels": 3, "patch_size": 14,
                              "spatial_merge_size": 2, "temporal_patch_size": 2, "window_size": 112, "out_hidden_size": 2048, "fullatt_block_indexes": [7, 15, 23, 31]},
                   "tie_word_embeddings": True}
-            out["cpu_baseline"] = cpu_baseline(d3, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(d3, a.cpu_seconds, P=a.prompt_len, C=a.gen_len, G=a.group)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -67,13 +67,31 @@ def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.nda
     return (np.arange(c)[None, :] <= eos_idx[:, None]).astype(np.int32)
 
 
-def right_pad(rows, pad_value: int) -> np.ndarray:
-    """trl `pad(..., padding_side='right')` for 1-D id lists (REF:682)."""
-    m = max((len(r) for r in rows), default=0)
-    out = np.full((len(rows), m), pad_value, dtype=np.int64)
-    for i, r in enumerate(rows):
-        out[i, : len(r)] = r
+def pad(rows, padding_value=0, padding_side: str = "right", pad_to_multiple_of: int | None = None) -> np.ndarray:
+    """trl `pad` (REF trl/trl/trainer/utils.py:418-478): stack arrays of possibly different shape into one, every dimension grown to the
+    largest (dimension 0 rounded up to `pad_to_multiple_of`), the data of each row at the start ("right" padding) or the end ("left") of
+    dimension 0, `padding_value` elsewhere."""
+    arrs = [np.asarray(r) for r in rows]
+    if not arrs:
+        return np.zeros((0, 0), dtype=np.int64)
+    shape = list(np.max([a.shape for a in arrs], 0))
+    if pad_to_multiple_of is not None:
+        shape[0] += (-shape[0]) % pad_to_multiple_of
+    out = np.full((len(arrs), *shape), padding_value, dtype=arrs[0].dtype)
+    for i, a in enumerate(arrs):
+        if padding_side == "left":
+            first = slice(shape[0] - a.shape[0], shape[0])
+        elif padding_side == "right":
+            first = slice(0, a.shape[0])
+        else:
+            raise ValueError("padding_side must be 'left' or 'right'")
+        out[(i, first, *[slice(0, n) for n in a.shape[1:]])] = a
     return out
+
+
+def right_pad(rows, pad_value: int) -> np.ndarray:
+    """The call at REF:682: completion id lists, right-padded with the pad token."""
+    return pad([np.asarray(r, dtype=np.int64) for r in rows], pad_value, "right").astype(np.int64).reshape(len(rows), -1)
 
 
 def group_advantages(rewards: torch.Tensor, G: int):

@@ -46,13 +46,32 @@ def grpo_loss(logps, ref_logps, advantages, completion_mask, beta):
     return loss, kl, mean_kl
 
 
-def sc_grpo_step(policy, ref, prompt_ids, prompt_mask, pixel_values, image_grid_thw, completions, rewards_per_func, G, beta, eos_token_id, pad_token_id):
-    """One micro-step for B prompts x G completions, TILE order for tensors as the reference
-    (sc_grpo_trainer.py:625-628; equal to interleaved at B=1).  `completions` = list of id lists,
-    `rewards_per_func` = [B*G, n_funcs] already evaluated on the decoded strings."""
-    rep = lambda t: t.repeat(G, *[1] * (t.dim() - 1))
-    p_ids, p_mask, pv = rep(prompt_ids), rep(prompt_mask), rep(pixel_values)
-    grids = [tuple(int(z) for z in g) for g in image_grid_thw] * G
+def sc_grpo_step(policy, ref, prompt_ids, prompt_mask, pixel_values, image_grid_thw, completions, rewards_per_func, G, beta, eos_token_id, pad_token_id,
+                 max_prompt_length=None, interleaved=False, images_per_prompt=None):
+    """One micro-step for B prompts x G completions.  Default: TILE order for tensors as the reference (sc_grpo_trainer.py:625-628; equal to
+    interleaved at B=1, the only batch size its scripts use).  interleaved=True: prompt-major order (p0 x G, p1 x G, ...) everywhere -- the
+    consistent reading of SURVEY.md Appendix B.1 the engine uses for B > 1; `completions` / `rewards_per_func` are then prompt-major too.
+    max_prompt_length: the left truncation of sc_grpo_trainer.py:630-634 (ids and mask only).
+    `completions` = list of id lists, `rewards_per_func` = [B*G, n_funcs] already evaluated on the decoded strings."""
+    grids_p = [tuple(int(z) for z in g) for g in image_grid_thw]
+    if max_prompt_length is not None:
+        prompt_ids, prompt_mask = prompt_ids[:, -max_prompt_length:], prompt_mask[:, -max_prompt_length:]
+    if interleaved:
+        B = prompt_ids.shape[0]
+        ipp = images_per_prompt or [1] * B
+        p_ids, p_mask = prompt_ids.repeat_interleave(G, 0), prompt_mask.repeat_interleave(G, 0)
+        n_patch = [g[0] * g[1] * g[2] for g in grids_p]
+        blocks, grids, k, r = [], [], 0, 0
+        for b in range(B):
+            n = sum(n_patch[k: k + ipp[b]])
+            blocks += [pixel_values[r: r + n]] * G
+            grids += grids_p[k: k + ipp[b]] * G
+            k, r = k + ipp[b], r + n
+        pv = torch.cat(blocks, 0)
+    else:
+        rep = lambda t: t.repeat(G, *[1] * (t.dim() - 1))
+        p_ids, p_mask, pv = rep(prompt_ids), rep(prompt_mask), rep(pixel_values)
+        grids = grids_p * G
     comp = right_pad(completions, pad_token_id)
     cmask = eos_completion_mask(comp, eos_token_id)
     ids = torch.cat([p_ids, comp], 1)

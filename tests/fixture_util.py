@@ -224,3 +224,58 @@ def synth_completions(n: int, max_len: int, cfg: dict, seed: int, eos_rows: dict
             ids[-1] = cfg["eos_token_id"]
         out.append(ids)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# An offline Qwen2-VL processor (no hub access, no tokenizer files): a character-level tokenizer with the Qwen2-VL special tokens, the
+# HF PIL image processor of the family, and the Qwen2-VL chat template (ChatML turns, `<|vision_start|><|image_pad|><|vision_end|>` per
+# image, default system turn).  Used by the golden generator (through the reference's own `maybe_apply_chat_template`) and by the host-side
+# test of `iadr1_amd.trainer.prepare_batch`, so that chat rendering, tokenisation with left padding and image patching really execute.
+# ------------------------------------------------------------------------------------------------------------------------------------
+QWEN2VL_CHAT_TEMPLATE = (
+    "{% set image_count = namespace(value=0) %}{% for message in messages %}{% if loop.first and message['role'] != 'system' %}<|im_start|>system\n"
+    "You are a helpful assistant.<|im_end|>\n{% endif %}<|im_start|>{{ message['role'] }}\n{% if message['content'] is string %}{{ message['content'] }}<|im_end|>\n"
+    "{% else %}{% for content in message['content'] %}{% if content['type'] == 'image' or 'image' in content or 'image_url' in content %}"
+    "{% set image_count.value = image_count.value + 1 %}{% if add_vision_id %}Picture {{ image_count.value }}: {% endif %}<|vision_start|><|image_pad|><|vision_end|>"
+    "{% elif 'text' in content %}{{ content['text'] }}{% endif %}{% endfor %}<|im_end|>\n{% endif %}{% endfor %}{% if add_generation_prompt %}<|im_start|>assistant\n{% endif %}"
+)
+QWEN2VL_SPECIAL = ["<|endoftext|>", "<|im_start|>", "<|im_end|>", "<|vision_start|>", "<|vision_end|>", "<|image_pad|>", "<|video_pad|>"]
+
+
+def local_qwen2vl_processor(max_pixels=None, min_pixels=None):
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    from transformers.models.qwen2_vl.processing_qwen2_vl import Qwen2VLProcessor
+    import transformers
+    BaseVideoProcessor = transformers.BaseVideoProcessor     # offline (no torchvision) this is the placeholder class the processor's type check looks up
+
+    words = QWEN2VL_SPECIAL + [chr(c) for c in range(32, 127)] + ["\n"]
+    tok = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<|endoftext|>"))
+    tok.pre_tokenizer = pre_tokenizers.Split("", "isolated")
+    t = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|im_end|>", pad_token="<|endoftext|>", additional_special_tokens=QWEN2VL_SPECIAL)
+
+    class _NoVideo(BaseVideoProcessor):      # the family's video processor needs torchvision (absent offline); images never touch it
+        pass
+
+    proc = Qwen2VLProcessor(image_processor=Qwen2VLImageProcessorPil(), tokenizer=t, video_processor=_NoVideo.__new__(_NoVideo), chat_template=QWEN2VL_CHAT_TEMPLATE)
+    if max_pixels is not None:               # REF train/stage_rl/trainer/sc_grpo_trainer.py:192-193
+        proc.image_processor.max_pixels = max_pixels
+        proc.image_processor.min_pixels = min_pixels
+    return proc
+
+
+def synth_pil_image(width, height, seed):
+    from PIL import Image
+    return Image.fromarray(np.random.RandomState(seed).randint(0, 256, (height, width, 3)).astype(np.uint8))
+
+
+def prepare_examples():
+    """Dataset rows as train/stage_rl/grpo_ad.py::make_conversation emits them (conversational prompt + image list), plus a plain-string prompt."""
+    img = lambda: {"type": "image"}
+    return [
+        [{"prompt": [{"role": "user", "content": [img(), {"type": "text", "text": "Is there any defect in the object?"}]}], "image": [synth_pil_image(448, 448, 1)], "solution": "s0"},
+         {"prompt": [{"role": "system", "content": "You are an inspector."}, {"role": "user", "content": [img(), img(), {"type": "text", "text": "Compare the two images."}]}],
+          "image": [synth_pil_image(300, 200, 2), synth_pil_image(448, 336, 3)], "solution": "s1"}],
+        [{"prompt": "<|im_start|>user\n<|vision_start|><|image_pad|><|vision_end|>plain string prompt<|im_end|>\n<|im_start|>assistant\n", "image": [synth_pil_image(224, 224, 4)], "solution": "s2"}],
+    ]

@@ -145,3 +145,44 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M):
                         offenders.append(os.path.join(dp, f))
     assert not offenders, offenders
+
+
+def test_pad_matches_the_reference_known_answers():
+    """§8 a18: trl `pad` (trl/trl/trainer/utils.py:418-478) restated in iadr1_amd.sc_grpo.pad, against tests/golden/pad.json -- the cases of the
+    reference's own TestPad (trl/tests/test_utils.py:47-130) run through the reference's function by tools/make_golden.py."""
+    import numpy as np
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.sc_grpo import pad, right_pad
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "pad.json")))["cases"]
+    assert len(cases) >= 8
+    for c in cases:
+        got = pad([np.asarray(r) for r in c["rows"]], c["padding_value"], c["padding_side"], c["pad_to_multiple_of"])
+        assert got.tolist() == c["out"], c
+    assert right_pad([[5, 6, 7], [8]], 2).tolist() == [[5, 6, 7], [8, 2, 2]] and right_pad([[1], []], 0).tolist() == [[1], [0]]
+
+
+def test_prepare_batch_matches_the_reference_host_path():
+    """§8 a19 + a23 executed for real: iadr1_amd.trainer.prepare_batch (chat template per example, PIL images, ONE processor call with left padding,
+    REF sc_grpo_trainer.py:600-622) on an offline Qwen2-VL processor, against tests/golden/prepare.json = the same rows through the reference's
+    `maybe_apply_chat_template` and the same processor call (tools/make_golden.py::gen_prepare).  Covers a conversational prompt with the default
+    system turn, one with an explicit system turn and TWO images (1-shot), a plain-string prompt (passes through untouched), a resized image
+    (300x200 -> multiples of 28) and the left padding of the shorter row."""
+    import numpy as np
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.trainer import maybe_apply_chat_template, prepare_batch
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "prepare.json")))
+    proc = fx.local_qwen2vl_processor(max_pixels=g["meta"]["max_pixels"], min_pixels=g["meta"]["min_pixels"])
+    for inputs, want in zip(fx.prepare_examples(), g["cases"]):
+        assert [maybe_apply_chat_template(ex, proc) for ex in inputs] == want["prompts_text"]
+        b = prepare_batch(proc, inputs)
+        assert b["input_ids"].tolist() == want["input_ids"] and b["attention_mask"].tolist() == want["attention_mask"]          # integer work: bit-exact
+        assert [list(x) for x in b["image_grid_thw"]] == want["image_grid_thw"] and b["images_per_prompt"] == [len(ex["image"]) for ex in inputs]
+        pv = np.asarray(b["pixel_values"], dtype=np.float64)
+        assert list(pv.shape) == want["pixel_shape"]
+        assert abs(pv.sum() - want["pixel_sum"]) <= 1e-6 * want["pixel_abs_sum"] and abs(np.abs(pv).sum() - want["pixel_abs_sum"]) <= 1e-6 * want["pixel_abs_sum"]
+        np.testing.assert_allclose(pv[0, :8], want["pixel_head"], rtol=1e-6)
+        np.testing.assert_allclose(pv[-1, -8:], want["pixel_tail"], rtol=1e-6)
+    first = g["cases"][0]
+    assert sorted(row[0] for row in first["attention_mask"]) == [0, 1] and all(row[-1] == 1 for row in first["attention_mask"])   # the shorter row is padded on the LEFT
+    assert first["prompts_text"][0].startswith("<|im_start|>system\nYou are a helpful assistant.") and first["prompts_text"][1].startswith("<|im_start|>system\nYou are an inspector.")

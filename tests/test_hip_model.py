@@ -68,14 +68,18 @@ def test_forward_matches_reference_golden(golden_dir):
     assert pos_ref.shape[0] == 3
 
 
-@pytest.mark.parametrize("name,mb", [("sc_grpo_g4.npz", 16), ("sc_grpo_g8.npz", 16), ("sc_grpo_g8.npz", 3)])
+@pytest.mark.parametrize("name,mb", [("sc_grpo_g4.npz", 16), ("sc_grpo_g8.npz", 16), ("sc_grpo_g8.npz", 3), ("sc_grpo_g8_far.npz", 16), ("sc_grpo_trunc.npz", 16)])
 def test_sc_grpo_step_matches_reference_golden(golden_dir, name, mb):
+    """HIP engine vs the reference's own compute_loss (tests/golden/sc_grpo_*.npz).  g4 / g8: policy close to the frozen reference (KL ~ 3e-3,
+    loss ~ 1e-4); g8_far: policy far from it (KL ~ 0.2, loss ~ 8e-3), where loss and KL tolerances are RELATIVE; trunc: the reference's left
+    truncation of the prompt (max_prompt_length = P - 2, REF:630-634)."""
     g = load(golden_dir, name)
     meta = json.loads(str(g["meta"]))
     G, C, seed = meta["G"], meta["C"], meta["seed"]
     w_ref = fx.make_weights(fx.TINY, 0)
-    pol, ref = store(fx.perturb_weights(w_ref, 1), True), store(w_ref, False)
-    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=mb))
+    pol, ref = store(fx.perturb_weights(w_ref, 1, scale=meta.get("perturb_scale", 0.02)), True), store(w_ref, False)
+    mpl = meta["max_prompt_length"] if meta.get("truncate") else 4096
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=mpl, max_completion_length=C, beta=0.04, micro_batch_seqs=mb))
     grid = tuple(meta["grid"])
     ids, mask = fx.left_pad([fx.synth_prompt(grid, meta["n_text"], fx.TINY, seed)], fx.TINY["pad_token_id"])
     batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=seed), "image_grid_thw": [grid]}
@@ -85,24 +89,32 @@ def test_sc_grpo_step_matches_reference_golden(golden_dir, name, mb):
     assert np.array_equal(out["completion_mask"], g["completion_mask"])             # integer work: bit-exact
     assert np.array_equal(out["ids"], g["prompt_completion_ids"])
     assert np.array_equal(out["mask"], g["attention_mask"])
+    if meta.get("truncate"):
+        assert out["ids"].shape[1] == ids.shape[1] - meta["truncate"] + C           # the prompt really lost its first tokens
     m = g["completion_mask"].astype(bool)
-    assert np.abs(out["logps"].cpu().numpy()[m] - g["per_token_logps"][m]).max() < 0.06
-    assert np.abs(out["ref_logps"].cpu().numpy()[m] - g["ref_per_token_logps"][m]).max() < 0.06
+    dlp = np.abs(out["logps"].cpu().numpy()[m] - g["per_token_logps"][m]).max()
+    dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - g["ref_per_token_logps"][m]).max()
+    assert dlp < 0.06 and dlr < 0.06, (dlp, dlr)
     np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=1e-5, atol=1e-6)
     mt = out["metrics"]
     assert mt["completion_length"] == float(g["metric_completion_length"])
     assert abs(mt["reward"] - float(g["metric_reward"])) < 1e-6 and abs(mt["reward_std"] - float(g["metric_reward_std"])) < 1e-5
-    # loss = beta*KL - mean(A): the advantage part is exact, the KL part carries the bf16 log-prob noise
-    assert abs(mt["loss"] - float(g["loss"])) < 1e-3, (mt["loss"], float(g["loss"]))   # north_star: loss within 1e-3
-    assert abs(mt["kl"] - float(g["metric_kl"])) < 5e-3
+    # loss = beta * KL - mean(A-term): the advantage part is exact (exp(p - p.detach()) == 1), the KL part carries the bf16 log-prob noise.  k3 KL is
+    # quadratic in (ref - policy): with |noise| ~ 0.02 on a difference of ~ 0.07 (g4 / g8) the relative error of a row's KL can reach tens of percent,
+    # on the far-policy goldens (difference ~ 0.6) a few percent.  Tolerances: relative on KL, and on the loss the same error scaled by beta.
+    gl, gk = float(g["loss"]), float(g["metric_kl"])
+    dk, dl = abs(mt["kl"] - gk), abs(mt["loss"] - gl)
+    print(f"[parity] {name} mb={mb}: loss hip={mt['loss']:.6e} ref={gl:.6e} (d={dl:.2e})  kl hip={mt['kl']:.6e} ref={gk:.6e} (d={dk:.2e}, {100 * dk / gk:.1f}%)  |dlogp|max={dlp:.4f}/{dlr:.4f}")
+    rel_kl = 0.10 if meta.get("perturb_scale", 0.02) > 0.1 else 0.25
+    assert dk <= rel_kl * gk, (mt["kl"], gk)
+    assert dl <= 0.04 * rel_kl * gk + 2e-6, (mt["loss"], gl)              # beta = 0.04; never looser than the north star's 1e-3
+    assert dl < 1e-3
     grads = pol.export_named(source="grad")
     names = [str(n) for n in g["grad_norm_names"]]
-    worst = 0.0
     for n, ref_norm in zip(names, g["grad_norms"]):
         if n == "lm_head.weight" or ref_norm < 1e-9:
             continue
         got = float(grads[n].norm())
-        worst = max(worst, abs(got - ref_norm) / ref_norm)
         assert abs(got - ref_norm) <= 0.08 * ref_norm + 1e-7, (n, got, ref_norm)
     for k in g.files:
         if k.startswith("grad::"):
@@ -252,9 +264,9 @@ def test_trainer_api_runs_two_optimizer_steps():
         assert "model.layers.0.self_attn.q_proj.weight" in sf.keys() and "visual.blocks.0.attn.qkv.weight" in sf.keys()
 
 
-def _ddp_worker(rank, world, port, q, hook):
+def _ddp_worker(rank, world, port, q, hook, wire="fp32"):
     import os as _os
-    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), IADR1_REDUCE_DTYPE=wire)
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)  # 2 ranks share the one GPU of the test box: gloo moves the CUDA buffers
@@ -274,13 +286,13 @@ def _ddp_worker(rank, world, port, q, hook):
     dist.destroy_process_group()
 
 
-def _run_ddp(hook):
+def _run_ddp(hook, wire="fp32"):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, hook)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, hook, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
@@ -307,6 +319,10 @@ def test_ddp_two_ranks_match_single_process_average():
     assert np.array_equal(h0, h1)
     # local gradients carry atomics-order noise run to run; the update is lr*sign-like for Adam's first step
     assert np.abs(h0 - w0).max() <= 4e-3
+    # the default wire type (bf16 buckets, what DeepSpeed ZeRO-3 moves for a bf16 model): replicas still bit-identical, same update up to bf16 rounding
+    (_, _, b0), (_, _, b1) = _run_ddp(hook=True, wire="bf16")
+    assert np.array_equal(b0, b1)
+    assert np.abs(b0 - w0).max() <= 4e-3
 
 
 def _rccl_one_rank_worker(port, q):
@@ -693,3 +709,97 @@ def test_decode_steps_fill_the_training_arena():
     assert bool(torch.isfinite(g1).all())
     cos = float((g0 @ g1) / (g0.norm() * g1.norm()))
     assert cos > 0.999 and float((g0 - g1).norm() / g0.norm()) < 0.03, cos
+
+
+def _oracle_cfg_dict(cfg):
+    """VLMConfig -> the nested dict form the oracle takes."""
+    return {"text": {"vocab_size": cfg.vocab_size, "hidden_size": cfg.hidden_size, "intermediate_size": cfg.intermediate_size, "num_hidden_layers": cfg.num_hidden_layers,
+                     "num_attention_heads": cfg.num_attention_heads, "num_key_value_heads": cfg.num_key_value_heads, "rms_norm_eps": cfg.rms_norm_eps,
+                     "rope_theta": cfg.rope_theta, "mrope_section": list(cfg.mrope_section)},
+            "vision": {"depth": cfg.v_depth, "hidden_size": cfg.v_hidden, "intermediate_size": cfg.v_inter, "num_heads": cfg.v_heads, "in_channels": cfg.v_in_channels,
+                       "patch_size": cfg.v_patch, "spatial_merge_size": cfg.v_merge, "temporal_patch_size": cfg.v_temporal, "window_size": cfg.v_window,
+                       "out_hidden_size": cfg.hidden_size, "fullatt_block_indexes": list(cfg.v_fullatt)},
+            "image_token_id": cfg.image_token_id, "video_token_id": cfg.image_token_id + 1, "vision_start_token_id": cfg.vision_start_token_id,
+            "vision_end_token_id": cfg.vision_end_token_id, "eos_token_id": cfg.eos_token_id, "pad_token_id": cfg.pad_token_id, "tie_word_embeddings": cfg.tie_word_embeddings}
+
+
+def test_api_step_with_rollout_handover_matches_the_oracle():
+    """The path bench.py times and SCGRPOTrainer.compute_loss runs (SCGRPOEngine.step with the rollout's prefill as the prompt part of the policy
+    forward and the decode steps filling the completion rows of the training arena) against the CPU oracle, at BASELINE widths (Qwen2.5-VL-3B
+    hidden 2048 / 16:2 heads / MLP 11008 / vocabulary 151936 / ViT 1280; 2 decoder layers, 2 ViT blocks), policy != reference, EOS ENABLED with
+    ragged completion lengths, two left-padded prompts of different length.  The tokens are whatever the device sampled; the oracle then runs
+    the reference's arithmetic (oracle.sc_grpo.sc_grpo_step, fp32) on exactly those tokens and rewards."""
+    import dataclasses
+    import sys
+    if os.environ.get("IADR1_SKINNY_PERS", "1") == "0" or os.environ.get("IADR1_DECODE_PACKED", "1") == "0":
+        pytest.skip("the side outputs live in the persistent / fused decode kernels")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import qwen25vl as oq
+    from oracle import sc_grpo as og
+    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
+    ref = ParamStore(cfg, DEV, trainable=False)
+    ref.init_random(seed=0)
+    w_ref = {k: v.float().numpy() for k, v in ref.export_named().items()}
+    w_pol = fx.perturb_weights(w_ref, 1, scale=0.25)                  # a policy well away from the reference: KL ~ 0.1, so relative tolerances bind
+    pol = ParamStore(cfg, DEV, trainable=True)
+    pol.load_named(w_pol)
+    G, C, Bp = 4, 24, 2
+    cd = _oracle_cfg_dict(cfg)
+    grids = [(1, 16, 16), (1, 16, 12)]
+    rows = [fx.synth_prompt(grids[0], 37, cd, 5), fx.synth_prompt(grids[1], 21, cd, 6)]
+    ids, mask = fx.left_pad(rows, cfg.pad_token_id)
+    px = fx.synth_pixel_values(grids, cd, seed=5)
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": px, "image_grid_thw": grids}
+    args = lambda: GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, micro_batch_seqs=Bp * G, reuse_prefill=True, reuse_decode=True, share_prefix=True,
+                            seed=11, beta=0.04)
+    reward_fn = lambda comp: np.stack([(np.asarray(comp)[:, 0] % 5).astype(np.float32), (np.asarray(comp)[:, 1] % 3).astype(np.float32) * 0.5], 1)
+    # pass 1 (EOS can practically not be sampled from 151936 tokens): find out what the sampler draws, then declare the token that ends the most rows
+    # early to be EOS -- sampling is a pure function of (seed, step, row, logits), so pass 2 draws the same tokens up to each row's first EOS
+    eng0 = SCGRPOEngine(cfg, pol, ref, args())
+    comp0 = eng0.rollout(batch, vis=None)
+    best, best_rows = None, []
+    for tok in np.unique(comp0[:, 2: C - 2]):
+        hit = [r for r in range(Bp * G) if tok in comp0[r, 2: C - 2] and tok not in comp0[r, :2]]
+        if len(hit) > len(best_rows):
+            best, best_rows = int(tok), hit
+    assert best is not None
+    cfg.eos_token_id = best                     # one config object is shared by the stores, the engines and the rollout
+    del eng0
+    eng = SCGRPOEngine(cfg, pol, ref, args())
+    out = eng.step(batch, reward_fn, do_optimizer_step=False, return_outputs=True)
+    torch.cuda.synchronize()
+    assert eng.last_step_traced                  # no policy forward ran over the completions: backward read what the decode steps wrote
+    comp = out["completion_ids"]
+    lens = out["completion_mask"].sum(1)
+    assert (lens < C).any() and (lens == C).any(), lens           # ragged: some rows stopped at EOS, some ran to the end
+    for r in range(Bp * G):
+        n = int(lens[r])
+        assert np.array_equal(comp[r, :n], comp0[r, :n]) and (n == C or (comp[r, n - 1] == best and (comp[r, n:] == cfg.pad_token_id).all()))
+    # ---- the oracle on the same tokens -------------------------------------------------------------------------------------------------
+    cd = _oracle_cfg_dict(cfg)
+    o_pol, o_ref = oq.Qwen25VLOracle(cd, w_pol, requires_grad=True), oq.Qwen25VLOracle(cd, w_ref)
+    rew = torch.from_numpy(reward_fn(comp))
+    want = og.sc_grpo_step(o_pol, o_ref, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(px), grids, [list(map(int, comp[r])) for r in range(Bp * G)], rew, G, 0.04, cfg.eos_token_id, cfg.pad_token_id, interleaved=True)
+    assert np.array_equal(want["completion_mask"].numpy(), out["completion_mask"]) and np.array_equal(want["ids"].numpy(), out["ids"])
+    m = out["completion_mask"].astype(bool)
+    dlp = np.abs(out["logps"].cpu().numpy()[m] - want["logps"].detach().numpy()[m]).max()
+    dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - want["ref_logps"].numpy()[m]).max()
+    np.testing.assert_allclose(out["advantages"].numpy(), want["advantages"].numpy(), rtol=1e-5, atol=1e-6)
+    mt = out["metrics"]
+    wl, wk = float(want["loss"]), float(want["metrics"]["kl"])
+    print(f"[parity] api step vs oracle: loss hip={mt['loss']:.6e} oracle={wl:.6e}  kl hip={mt['kl']:.6e} oracle={wk:.6e} ({100 * abs(mt['kl'] - wk) / wk:.1f}%)  "
+          f"|dlogp|max pol={dlp:.4f} ref={dlr:.4f}  lens={lens.tolist()} eos={best}")
+    assert dlp < 0.06 and dlr < 0.06, (dlp, dlr)
+    assert abs(mt["kl"] - wk) <= 0.10 * wk, (mt["kl"], wk)
+    assert abs(mt["loss"] - wl) <= 0.04 * 0.10 * wk + 2e-6, (mt["loss"], wl)
+    assert mt["completion_length"] == want["metrics"]["completion_length"] and abs(mt["reward"] - want["metrics"]["reward"]) < 1e-6
+    want["loss"].backward()
+    grads = pol.export_named(source="grad")
+    og_ = dict(o_pol.parameters())
+    for n in ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.bias", "model.layers.1.mlp.down_proj.weight", "model.layers.1.mlp.gate_proj.weight",
+              "model.layers.1.self_attn.o_proj.weight", "model.norm.weight", "visual.blocks.1.attn.qkv.weight", "visual.blocks.0.mlp.down_proj.weight", "visual.merger.mlp.2.weight",
+              "model.embed_tokens.weight"):
+        a, b = grads[n].numpy().reshape(-1).astype(np.float64), og_[n].grad.numpy().reshape(-1).astype(np.float64)
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        ratio = float(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30))
+        assert cos > 0.99 and 0.9 < ratio < 1.1, (n, cos, ratio)

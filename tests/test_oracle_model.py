@@ -59,14 +59,14 @@ def test_forward_left_padded_batch(golden_dir):
     np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("name", ["sc_grpo_g4.npz", "sc_grpo_g8.npz"])
+@pytest.mark.parametrize("name", ["sc_grpo_g4.npz", "sc_grpo_g8.npz", "sc_grpo_g8_far.npz", "sc_grpo_trunc.npz"])
 def test_sc_grpo_compute_loss(golden_dir, name):
     g = _load(golden_dir, name)
     meta = json.loads(str(g["meta"]))
     G, C, seed = meta["G"], meta["C"], meta["seed"]
     cfg = fx.TINY
     w_ref = fx.make_weights(cfg, 0)
-    pol = oq.Qwen25VLOracle(cfg, fx.perturb_weights(w_ref, 1), requires_grad=True)
+    pol = oq.Qwen25VLOracle(cfg, fx.perturb_weights(w_ref, 1, scale=meta.get("perturb_scale", 0.02)), requires_grad=True)
     ref = oq.Qwen25VLOracle(cfg, w_ref)
     grid = tuple(meta["grid"])
     rows = [fx.synth_prompt(grid, meta["n_text"], cfg, seed)]
@@ -76,7 +76,10 @@ def test_sc_grpo_compute_loss(golden_dir, name):
     comps = fx.synth_completions(G, C, cfg, seed + 100, eos_rows)
     assert np.array_equal(og.right_pad(comps, cfg["pad_token_id"]).numpy(), g["completion_ids"])
     out = og.sc_grpo_step(pol, ref, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(pv), [grid], comps,
-                          torch.from_numpy(g["rewards_per_func"]), G, 0.04, cfg["eos_token_id"], cfg["pad_token_id"])
+                          torch.from_numpy(g["rewards_per_func"]), G, 0.04, cfg["eos_token_id"], cfg["pad_token_id"],
+                          max_prompt_length=meta.get("max_prompt_length") if meta.get("truncate") else None)
+    if meta.get("truncate"):
+        assert out["ids"].shape[1] == ids.shape[1] - meta["truncate"] + C          # the left truncation really cut the prompt
     assert np.array_equal(out["completion_mask"].numpy(), g["completion_mask"])
     assert np.array_equal(out["ids"].numpy(), g["prompt_completion_ids"])
     assert np.array_equal(out["mask"].numpy(), g["attention_mask"])

@@ -400,10 +400,13 @@ GRAD_FULL = [
 ]
 
 
-def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed):
+def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed, perturb_scale=0.02, truncate=0):
+    """perturb_scale: distance policy <-> frozen reference (0.02: KL ~ 3e-3; 0.25: KL ~ 0.1, where a relative tolerance on KL and loss is a real
+    check).  truncate > 0: max_prompt_length = P - truncate, i.e. the reference's left truncation (sc_grpo_trainer.py:630-634) cuts that many
+    leading text tokens of the prompt (pixel tensors untouched, M-RoPE positions recomputed on the truncated ids)."""
     cfg = fx.TINY
     w_ref = fx.make_weights(cfg, seed=0)
-    w_pol = fx.perturb_weights(w_ref, seed=1)
+    w_pol = fx.perturb_weights(w_ref, seed=1, scale=perturb_scale)
     ref = build_hf_model(cfg, w_ref).eval()
     pol = build_hf_model(cfg, w_pol).train()
     for p in ref.parameters():
@@ -413,6 +416,12 @@ def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed):
     comps = fx.synth_completions(G, C, cfg, seed + 100, eos_rows)
     texts = [CANNED[i % len(CANNED)] for i in range(G)]
     t = make_trainer(SCGRPOTrainer, reward, cfg, ref, batch, comps, texts, G, C)
+    P_full = batch["input_ids"].shape[1]
+    if truncate:
+        t.max_prompt_length = P_full - truncate
+        # the mock processor hands `mm_token_type_ids` over at prompt+completion length; the trainer truncates ids / mask only, so cut it here the same way
+        tt = t.processing_class.batch["mm_token_type_ids"]
+        t.processing_class.batch["mm_token_type_ids"] = tt[:, truncate:]
     inputs = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "q"}]}], "image": [object()], "solution": SOLUTION}]
     # the trainer opens str images with PIL; pass non-str objects straight through (sc_grpo_trainer.py:610)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -422,7 +431,8 @@ def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed):
     inv = {hf_name(k): k for k in fx.param_shapes(cfg)}
     gnorm = {inv[k]: float(g.norm()) for k, g in grads.items() if k in inv}
     out = {
-        "meta": json.dumps({**meta(), "G": G, "C": C, "grid": grid, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows or {}, "weights": "fixture_util.make_weights(TINY,0) / perturb_weights(.,1)"}),
+        "meta": json.dumps({**meta(), "G": G, "C": C, "grid": grid, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows or {}, "perturb_scale": perturb_scale, "truncate": truncate,
+                            "max_prompt_length": int(t.max_prompt_length), "weights": f"fixture_util.make_weights(TINY,0) / perturb_weights(.,1,scale={perturb_scale})"}),
         "completion_ids": loc["completion_ids"].numpy(),
         "prompt_completion_ids": loc["prompt_completion_ids"].numpy(),
         "attention_mask": loc["attention_mask"].numpy(),
@@ -617,6 +627,30 @@ def gen_qwen2vl(SCGRPOTrainer):
     print("qwen2vl_sft.npz: losses", losses, "logps", tuple(logps.shape))
 
 
+def gen_prepare():
+    """Host-side batch construction of compute_loss, REF train/stage_rl/trainer/sc_grpo_trainer.py:600-622, run with the reference's own
+    `maybe_apply_chat_template` (trl/trl/data_utils.py:172-227) and an offline Qwen2-VL processor (tests/fixture_util.local_qwen2vl_processor):
+    rendered prompt text, left-padded token ids / mask, patch grids and pixel statistics per micro-batch -> tests/golden/prepare.json."""
+    from trl.data_utils import maybe_apply_chat_template
+    proc = fx.local_qwen2vl_processor(max_pixels=480000, min_pixels=3136)
+    cases = []
+    for inputs in fx.prepare_examples():
+        prompts_text = [maybe_apply_chat_template(example, proc)["prompt"] for example in inputs]
+        images = []
+        for x in inputs:
+            imgs = x["image"]
+            images.extend(imgs)           # PIL objects pass straight through the reference's loader (REF:606-612 opens str paths only)
+        enc = proc(text=prompts_text, images=images, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
+        pv = enc["pixel_values"].double()
+        cases.append({"prompts_text": prompts_text, "input_ids": enc["input_ids"].tolist(), "attention_mask": enc["attention_mask"].tolist(),
+                      "image_grid_thw": enc["image_grid_thw"].tolist(), "pixel_shape": list(enc["pixel_values"].shape),
+                      "pixel_sum": float(pv.sum()), "pixel_abs_sum": float(pv.abs().sum()), "pixel_head": enc["pixel_values"][0, :8].tolist(),
+                      "pixel_tail": enc["pixel_values"][-1, -8:].tolist()})
+    with open(os.path.join(OUT, "prepare.json"), "w") as f:
+        json.dump({"meta": {**meta(), "max_pixels": 480000, "min_pixels": 3136}, "cases": cases}, f)
+    print("prepare.json:", [(len(c["input_ids"]), len(c["input_ids"][0]), c["image_grid_thw"]) for c in cases])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -627,11 +661,16 @@ def main():
         gen_rewards(reward, type_reward, location_reward)
     if not only or "pad" in only:
         gen_pad(pad)
+    if not only or "prepare" in only:
+        gen_prepare()
     if not only or "index" in only:
         gen_vision_index()
     if not only or "grpo" in only:
         gen_sc_grpo(SCGRPOTrainer, reward, G=4, C=10, eos_rows={1: 6, 3: 0}, name="sc_grpo_g4.npz", seed=21)
         gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={0: 11, 2: 3, 5: 7}, name="sc_grpo_g8.npz", seed=22)
+    if not only or "grpo_far" in only:
+        gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={1: 9, 4: 2, 6: 5}, name="sc_grpo_g8_far.npz", seed=23, perturb_scale=0.25)
+        gen_sc_grpo(SCGRPOTrainer, reward, G=4, C=10, eos_rows={0: 4, 2: 8}, name="sc_grpo_trunc.npz", seed=24, perturb_scale=0.25, truncate=2)
     if not only or "logps" in only:
         gen_logps_padded(SCGRPOTrainer)
     if not only or "logps7" in only:
