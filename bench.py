@@ -470,6 +470,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     metrics = {k: (sum(v) / len(v) if v else None) for k, v in tr._metrics.items()}
+    traced = bool(getattr(eng, "last_step_traced", False))      # read now: the extra (untimed) leg below runs the other layout
     dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
     if world > 1:
         import torch.distributed as dist
@@ -526,7 +527,7 @@ def main():
                                  "reference's G repeated rows, parity-tested); the rollout's prefill is the prompt part of the policy's training forward"
                                  + ("; the rollout's decode steps write the completion rows of the policy's activation arena (side outputs of the decode kernels), so the "
                                     "policy's forward over the completions is the decode itself and is not run a second time before backward (pinned to the oracle by "
-                                    "tests/test_hip_model.py::test_api_step_with_rollout_handover_matches_the_oracle)" if getattr(eng, "last_step_traced", False) else ""))
+                                    "tests/test_hip_model.py::test_api_step_with_rollout_handover_matches_the_oracle)" if traced else ""))
                        if eng.args.share_prefix else "ViT once per image"},
             "repeated_rows_layout": repeated,
             "samples_per_sec_per_gpu": N * a.steps / dt,
