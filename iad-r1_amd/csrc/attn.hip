@@ -331,10 +331,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, long l
 // =====================================================================================================
 // backward, part 1: dQ.  Block = 64 q rows of one (segment, q head); wave = 16 q columns.
 // =====================================================================================================
-template <int D>
+template <int D, int R>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    // R = 16-row q groups per wave.  The kernel reads every staged K / V fragment from LDS once per q group it feeds: with R = 1 a block pulls
+    // 64 KB of fragments through the LDS port per 32-key tile against 24 MFMAs per wave (LDS-bound ~2.7x with two blocks per CU); R = 2 halves
+    // the LDS bytes per MFMA.
     using C = Cfg<D>;
-    constexpr int BM = 64, KB = 32;
+    constexpr int BM = 64 * R, KB = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = (bf16_t*)smem;       // [KB][LD]  (also read transposed for dQ^T += K^T . dS^T)
     bf16_t* Vs = Ks + KB * C::LD;     // [KB][LD]
@@ -346,27 +349,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     if (qt >= ntile) return;
     const int q0 = qt * BM;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
-    const int qrow = q0 + w * 16 + li;
-    const bool qok = qrow < slen;
-
-    bf16x8_t qf[C::KS], dof[C::KS];
-    {
-        const bf16_t* qs = p.q + (long long)(s0 + qrow) * p.ldq + head * D;
-        const bf16_t* ds = p.dout + (long long)(s0 + qrow) * p.lddo + head * D;
+    int qrow[R];
+    bool qok[R];
+    bf16x8_t qf[R][C::KS], dof[R][C::KS];
+    float lse2[R], dl[R];
+    const float c = p.scale * LOG2E;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        qrow[r] = q0 + (w * R + r) * 16 + li;
+        qok[r] = qrow[r] < slen;
+        const bf16_t* qs = p.q + (long long)(s0 + qrow[r]) * p.ldq + head * D;
+        const bf16_t* ds = p.dout + (long long)(s0 + qrow[r]) * p.lddo + head * D;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
             const int d0 = ks * 32 + g * 8;
-            qf[ks] = ld_frag_g(qs + d0, qok && d0 < D);
-            dof[ks] = ld_frag_g(ds + d0, qok && d0 < D);
+            qf[r][ks] = ld_frag_g(qs + d0, qok[r] && d0 < D);
+            dof[r][ks] = ld_frag_g(ds + d0, qok[r] && d0 < D);
         }
+        lse2[r] = qok[r] ? p.lse[(long long)head * p.T + s0 + qrow[r]] * LOG2E : 0.f;
+        dl[r] = qok[r] ? p.delta[(long long)head * p.T + s0 + qrow[r]] : 0.f;
     }
-    const float c = p.scale * LOG2E;
-    const float lse2 = qok ? p.lse[(long long)head * p.T + s0 + qrow] * LOG2E : 0.f;
-    const float dl = qok ? p.delta[(long long)head * p.T + s0 + qrow] : 0.f;
 
-    f32x4_t acc[C::DT];
+    f32x4_t acc[R][C::DT];
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) acc[r][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int ps0 = p.seg_prefix ? p.seg_prefix[seg * 4] : 0, plen = p.seg_prefix ? p.seg_prefix[seg * 4 + 1] : 0;
     TileRegs<D, KB> kreg, vreg;
@@ -393,28 +401,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         __syncthreads();
         if (t + 1 < nt) tile_load(t + 1);
 
-        f32x4_t st[2], dpt[2];
+        f32x4_t st[R][2], dpt[R][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) { st[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dpt[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { st[r][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dpt[r][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const int row = perm_row(kt, li);
-                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Ks + row * C::LD + ks * 32 + g * 8), qf[ks], st[kt], 0, 0, 0);
-                dpt[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Vs + row * C::LD + ks * 32 + g * 8), dof[ks], dpt[kt], 0, 0, 0);
-            }
-        f32x4_t ds[2];
+                const bf16x8_t kfr = ld_frag_s(Ks + row * C::LD + ks * 32 + g * 8), vfr = ld_frag_s(Vs + row * C::LD + ks * 32 + g * 8);
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = kv0 + g * 8 + kt * 4 + e;
-                const bool ok = qok && key < klen && !(kcausal && key > qrow);
-                const float pv = ok ? fast_exp2(__builtin_fmaf(st[kt][e], c, -lse2)) : 0.f;
-                ds[kt][e] = pv * (dpt[kt][e] - dl);
+                for (int r = 0; r < R; ++r) {
+                    st[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[r][ks], st[r][kt], 0, 0, 0);
+                    dpt[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[r][ks], dpt[r][kt], 0, 0, 0);
+                }
             }
-        const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
+        bf16x8_t dsf[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            f32x4_t ds[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kv0 + g * 8 + kt * 4 + e;
+                    const bool ok = qok[r] && key < klen && !(kcausal && key > qrow[r]);
+                    const float pv = ok ? fast_exp2(__builtin_fmaf(st[r][kt][e], c, -lse2[r])) : 0.f;
+                    ds[kt][e] = pv * (dpt[r][kt][e] - dl[r]);
+                }
+            dsf[r] = pack_frag(ds[0], ds[1]);
+        }
         {
             lds_char_t* kbase = lds_ptr(Ks) + tr_lane_off(li, g, C::LD);
             bf16x8_t kf[2];
@@ -422,16 +440,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) {
                 if (dt + 1 < C::DT) kf[(dt + 1) & 1] = tr_frag_ld(kbase + (dt + 1) * 32, kbase + (4 * C::LD + (dt + 1) * 16) * 2);
-                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[dt & 1], dsf, acc[dt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[dt & 1], dsf[r], acc[r][dt], 0, 0, 0);
             }
         }
     }
-    if (!qok) return;
-    bf16_t* dst = p.dq + (long long)(s0 + qrow) * p.lddq + head * D;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) {
-        const f32x4_t a = acc[dt] * p.scale;
-        *(u32x2_t*)(dst + dt * 16 + g * 4) = (u32x2_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+    for (int r = 0; r < R; ++r) {
+        if (!qok[r]) continue;
+        bf16_t* dst = p.dq + (long long)(s0 + qrow[r]) * p.lddq + head * D;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            const f32x4_t a = acc[r][dt] * p.scale;
+            *(u32x2_t*)(dst + dt * 16 + g * 4) = (u32x2_t){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+        }
     }
 }
 
@@ -637,6 +659,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, S
     const int b = blockIdx.x, kvh = blockIdx.y, group = p.Hq / p.Hkv;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
     const long long sb = side_base(so);
+    STAMP(0);
     const int n = p.ctx_len[b];
     const int npage = (n + PAGE - 1) / PAGE;
 
@@ -703,6 +726,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, S
             acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pf, acc[dt], 0, 0, 0);
         }
     }
+    STAMP(1);
     lsum += __shfl_xor(lsum, 16, WAVE);
     lsum += __shfl_xor(lsum, 32, WAVE);
     if (g == 0) { red_m[w * 16 + li] = m; red_l[w * 16 + li] = lsum; }
@@ -713,6 +737,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, S
             for (int e = 0; e < 4; ++e) red_o[(w * D + dt * 16 + g * 4 + e) * GS + li] = acc[dt][e];
     }
     __syncthreads();
+    STAMP(2);
     // combine the 4 partial states: thread -> (q head j, d)
     for (int idx = threadIdx.x; idx < group * D; idx += WAVES * 64) {
         const int j = idx / D, d = idx - j * D;
@@ -734,6 +759,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, S
             if (d == 0) ((float*)so.p1)[(long long)(kvh * group + j) * so.ld1 + r] = den > 0.f ? (M + log2f(den)) * LN2 : -INFINITY;
         }
     }
+    STAMP(3);
 }
 
 // Write K/V rows of `T` tokens into the paged cache (prefill: many tokens; decode: one per sequence).
@@ -833,8 +859,7 @@ extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void*
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
     p.seg_start = seg_start; p.seg_end = seg_end; p.seg_prefix = seg_prefix; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
-    static int force_r = -1;
-    if (force_r < 0) { const char* e = getenv("IADR1_ATTN_R"); force_r = e ? atoi(e) : 1; }
+    static const int force_r = iadr1_env_int("IADR1_ATTN_R", 1);
     // 64-row q tiles (R=1, ~180 VGPR, 2 blocks/CU) measured 1.4x faster than 128-row tiles (R=2, 1 block/CU): occupancy wins
     const bool small = max_seqlen <= 64 || force_r == 1;
 #define LAUNCH_FWD(DD, RR)                                                                                           \
@@ -867,13 +892,19 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
     IADR1_REQUIRE((Hq / Hkv) % hs == 0, "attn_bwd: head_splits=%d must divide the GQA group %d", hs, Hq / Hkv);
     p.dkv_ws = dkv_ws; p.hs = hs;
     const long long items = (long long)T * Hq * 16;
+    static const int dq_r = iadr1_env_int("IADR1_ATTN_BWD_R", 2);
 #define LAUNCH_BWD(DD)                                                                                                                   \
     do {                                                                                                                                 \
         hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)o, ldo,    \
                            (const bf16_t*)dout, lddo, delta, T, Hq);                                                                     \
         const int smem_dq = (2 * 32 * Cfg<DD>::LD) * 2;                                                                                  \
-        set_smem(attn_bwd_dq_kernel<DD>, smem_dq);                                                                                       \
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hq), dim3(256), smem_dq, stream, p);               \
+        if (dq_r == 2 && max_seqlen > 64) {                                                                                              \
+            set_smem(attn_bwd_dq_kernel<DD, 2>, smem_dq);                                                                                \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, 2>), dim3((max_seqlen + 127) / 128, nseg, Hq), dim3(256), smem_dq, stream, p);    \
+        } else {                                                                                                                         \
+            set_smem(attn_bwd_dq_kernel<DD, 1>, smem_dq);                                                                                \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, 1>), dim3((max_seqlen + 63) / 64, nseg, Hq), dim3(256), smem_dq, stream, p);      \
+        }                                                                                                                                \
         const int smem_kv = (2 * 32 * Cfg<DD>::LD) * 2 + 64 * 4;                                                                         \
         set_smem(attn_bwd_dkdv_kernel<DD>, smem_kv);                                                                                     \
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hkv * hs), dim3(256), smem_kv, stream, p);       \
@@ -885,17 +916,17 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
 }
 
 extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len, void* o,
-                                 int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, hipStream_t stream) {
+                                 int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, const void* side, hipStream_t stream) {
     IADR1_REQUIRE(D == 128, "attn_decode: head dim %d not built (128 is)", D);
     IADR1_REQUIRE(B > 0 && Hq % Hkv == 0 && Hq / Hkv <= 16, "attn_decode: GQA group must be <= 16");
     IADR1_REQUIRE((ldq % 8) == 0, "attn_decode: ldq must be a multiple of 8");
     DecodeArgs p{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale};
     // 16 waves per (sequence, kv head) block: a wave then walks ~1.5 pages instead of ~3 at ctx ~ 640 (the kernel is a chain of dependent
     // page loads on only B*Hkv = 128 CUs); IADR1_DECODE_ATTN_WAVES=8 keeps the 8-wave form
-    static int waves = 0;
-    if (!waves) { const char* e = getenv("IADR1_DECODE_ATTN_WAVES"); waves = (e && atoi(e) == 8) ? 8 : 16; }
+    static const int waves = iadr1_env_int("IADR1_DECODE_ATTN_WAVES", 16) == 8 ? 8 : 16;
     const int gs = (Hq / Hkv <= 8) ? 9 : 17;
-    const SideOut so = iadr1_take_side_out(stream);
+    SideOut so;
+    if (int e = iadr1_side_arg(side, &so)) return e;
     if (waves == 16) {
         const int smem = (2 * 16 * 16 + 16 * 128 * gs) * 4;
         set_smem(attn_decode_kernel<128, 16>, smem);
@@ -928,3 +959,5 @@ extern "C" int iadr1_rope_kv_store(void* qkv, long long ld, const float* cos_t, 
     hipLaunchKernelGGL(rope_kv_store_kernel<128>, dim3((int)blocks), dim3(256), 0, stream, (bf16_t*)qkv, ld, cos_t, sin_t, slot, (bf16_t*)kcache, (bf16_t*)vcache, T, Hq, Hkv);
     return iadr1_check_launch("rope_kv_store");
 }
+
+IADR1_STAMPS_EXPORT(attn)

@@ -64,6 +64,24 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return r;
 }
 
+// ---- optional in-kernel time stamps (probe builds only: -DIADR1_STAMPS; tools/kernel_stamps.py) ------------------------
+// STAMP(slot): wave 0 of every block records the 100 MHz wall clock (s_memrealtime, comparable across CUs) of that program point.
+#ifdef IADR1_STAMPS
+static __device__ unsigned long long g_stamps[8][4096];      // one table per translation unit (no relocatable device code in this build)
+#define STAMP(slot) do { if (threadIdx.x == 0) g_stamps[slot][(blockIdx.x + blockIdx.y * gridDim.x) & 4095] = wall_clock64(); } while (0)
+// probe builds only (not part of the C ABI in include/iadr1_hip.h): copies this unit's stamp table to the host and clears it
+#define IADR1_STAMPS_EXPORT(unit)                                                                                   \
+    extern "C" int iadr1_debug_stamps_##unit(unsigned long long* host_dst) {                                        \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                        \
+        if (hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -2;         \
+        static unsigned long long zeros[8][4096];                                                                   \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -3;                \
+    }
+#else
+#define STAMP(slot) do { } while (0)
+#define IADR1_STAMPS_EXPORT(unit)
+#endif
+
 // ---- host side -------------------------------------------------------------------------------
 #define IADR1_OK 0
 #define IADR1_ERR_ARG (-1)
@@ -81,19 +99,21 @@ int iadr1_check_launch(const char* what);
         }                                     \
     } while (0)
 
-// Side outputs of the decode step (rollout -> training hand-over): the kernels of a decode step can ALSO write what they compute into the row-major
-// activation arena the policy's backward pass reads, at row  base + s * seq_stride + *step  for sequence s.  Decode step t processes completion token
-// t of every sequence, which is exactly row (s, t) of the completion block of the shared-prefix training batch, so the teacher-forced policy forward
-// over the completions does not have to be run again.  iadr1_decode_side_outputs() arms the NEXT launch on a stream of one of: iadr1_rmsnorm_fwd
-// (T <= 256; p0 = residual stream rows, p1 = normalised rows, p2 = rstd fp32 [rows]), iadr1_gemm_qkv_rope_kv_bf16 (p0 = roped q|k|v rows),
-// iadr1_attn_decode (p0 = attention output rows, p1 = log-sum-exp fp32 [Hq][ld1]), iadr1_gemm_skinny_bf16 out_mode 3 (p0 = gate|up rows, p1 = SwiGLU rows).
-struct SideOut {
-    void* p0; void* p1; void* p2;
-    long long ld0, ld1, ld2;
+// Side outputs of the decode step (rollout -> training hand-over, include/iadr1_hip.h iadr1_side_out_t): the kernels of a decode step can ALSO
+// write what they compute into the row-major activation arena the policy's backward pass reads, at row  base + s * seq_stride + *step  for
+// sequence s.  Decode step t processes completion token t of every sequence, which is exactly row (s, t) of the completion block of the
+// shared-prefix training batch, so the teacher-forced policy forward over the completions does not have to be run again.
+struct SideOut {                   // same layout as iadr1_side_out_t
+    void* p0; long long ld0;
+    void* p1; long long ld1;
+    void* p2; long long ld2;
     const unsigned* step;          // device-resident decode step counter; nullptr = side outputs off
     long long base, seq_stride;
 };
-SideOut iadr1_take_side_out(hipStream_t stream);   // returns and clears what is armed for `stream` (all-zero if nothing)
+// the caller's struct (host memory, may be null) -> the by-value kernel argument; argument checks in runtime.hip
+int iadr1_side_arg(const void* side, SideOut* out);
+// IADR1_* A/B switches of the launchers: read ONCE (`static const int x = iadr1_env_int(...)`, thread-safe static initialisation), constant afterwards
+int iadr1_env_int(const char* name, int dflt);
 // read the step counter ONCE, at kernel entry (a dependent global load in an epilogue is a memory latency on the critical path of a latency-bound kernel)
 __device__ __forceinline__ long long side_base(const SideOut& so) { return so.step ? so.base + (long long)*so.step : -1; }
 

@@ -226,6 +226,30 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* ids, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// out[t] = sum over k in [ptr[t], ptr[t+1]) of src[idx[k]]  (fp32 sum, rounded once; empty list -> zeros).  The scatter of the lm_head's
+// input gradient back onto the token rows: a hidden row can feed several selected rows (the prompt's last token predicts the first token of
+// every completion of its group), most feed none.  One block per token row, 16-byte accesses; deterministic (list order).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_gather_sum_kernel(const bf16_t* src, const int* ptr, const int* idx, bf16_t* out, int T, int H) {
+    const int t = blockIdx.x;
+    const int k0 = ptr[t], k1 = ptr[t + 1];
+    for (int ch = threadIdx.x; ch < (H >> 3); ch += 256) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const u32x4_t a = *(const u32x4_t*)(src + (long long)idx[k] * H + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(a[e]); v[2 * e + 1] += hi_bf(a[e]); }
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        *(u32x4_t*)(out + (long long)t * H + ch * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // casts / strided copies
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* in, long long ldi, bf16_t* out, long long ldo, int R, int C, int Cpad) {
@@ -374,6 +398,11 @@ extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const
     IADR1_REQUIRE(T > 0 && (H % 8) == 0, "embed_bwd: H must be a multiple of 8");
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)dx, dE, dimg, T, H);
     return iadr1_check_launch("embed_bwd");
+}
+extern "C" int iadr1_rows_gather_sum(const void* src, const int* ptr, const int* idx, void* out, int T, int H, hipStream_t stream) {
+    IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0, "rows_gather_sum: H must be a multiple of 8");
+    hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(T), dim3(256), 0, stream, (const bf16_t*)src, ptr, idx, (bf16_t*)out, T, H);
+    return iadr1_check_launch("rows_gather_sum");
 }
 extern "C" int iadr1_cast_f32_to_bf16(const float* in, long long ldi, void* out, long long ldo, int R, int C, int Cpad, hipStream_t stream) {
     IADR1_REQUIRE(R > 0 && C > 0 && Cpad >= C, "cast_f32_to_bf16: bad shape");

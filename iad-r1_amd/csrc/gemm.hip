@@ -635,6 +635,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     const int nslab = p.K >> 6;  // full 64-wide slabs; a trailing 32-wide half slab (K % 64 == 32) is handled after the loops
     const int per_z = (nslab + gridDim.z - 1) / gridDim.z;
     const int s_begin = blockIdx.z * per_z, s_end = min(nslab, s_begin + per_z);
+    STAMP(0);
 
     f32x4_t acc[4][NB];
 #pragma unroll
@@ -707,6 +708,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[j], xt[i], acc[i][j], 0, 0, 0);
     }
     // lane owns rows n = j*16 + lq*4 + e of column m = i*16 + lm  (swapped-operand C layout)
+    STAMP(1);
     float* mine = red + (size_t)w * 64 * RLD;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -715,6 +717,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + j * 16 + lq * 4 + e] = acc[i][j][e];
     __syncthreads();
+    STAMP(2);
     if (NB == 1 && p.out_mode == 4) {
         // Decode-step q|k|v epilogue (replaces the separate rope + kv-store launch): this block owns one 16-column tile = 8
         // rotary pairs (d, d+64) of one head (q/k heads) or 16 plain dims (v heads).  Same rounding points as the unfused path:
@@ -748,6 +751,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
                 if (side0 >= 0) ((bf16_t*)p.so.p0)[(side0 + (long long)gm * p.so.seq_stride) * p.so.ld0 + head * D + j * 16 + n] = f2bf(vs);
             }
         }
+        STAMP(3);
         return;
     }
     for (int idx = t; idx < 64 * BNC; idx += WAVES * 64) {
@@ -901,18 +905,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     const int b = blockIdx.x, bps = gridDim.x;
     const int m_base = blockIdx.y * 64;
     const long long sb = p.out_mode == 3 ? side_base(p.so) : -1;
+    STAMP(4);
     const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks)
     // X fragments of this wave's k-steps w + j*WAVES: loaded once, resident for the whole launch
     const bool xpk = p.ldx == 0;
     const bf16_t* xbase = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + l * 8 : p.X + (long long)min(m_base + lm, p.M - 1) * p.ldx + lq * 8;
     const long long xgroup = xpk ? 512 : 16 * p.ldx, xstep = xpk ? 2048 : 32;
     const int xgroups_ok = xpk ? 4 : (p.M - m_base - lm + 15) / 16;
-    bf16x8_t xf[KSW][4];
-#pragma unroll
-    for (int j = 0; j < KSW; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            xf[j][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)(w + j * WAVES) * xstep));
     const bf16_t* wlane = p.W + (long long)w * 512 + l * 8;
     const int ngroups = p.N / (16 * TPI);
     bf16x8_t wf[KSW][TPI];
@@ -924,7 +923,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
             for (int tt = 0; tt < TPI; ++tt) wf[j][tt] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + tt * tile_stride + j * (WAVES * 512))));
     };
     int g = b;
+    // the first group's weights are requested BEFORE the X fragments: they come from HBM (the longer latency) and do not depend on anything, the
+    // X fragments are 256 KB per CU out of L2 -- measured with in-kernel stamps (profiles/r02_decode_stamps.txt): 6.4 us from entry to the first
+    // group's MFMAs with X first
+#ifndef IADR1_PERS_XFIRST
     if (g < ngroups) loadw(g);
+#endif
+    bf16x8_t xf[KSW][4];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xf[j][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)(w + j * WAVES) * xstep));
+#ifdef IADR1_PERS_XFIRST
+    if (g < ngroups) loadw(g);
+#endif
     float* mine = red + (size_t)w * 64 * RLD;
     for (; g < ngroups; g += bps) {
         f32x4_t acc[4][TPI];
@@ -938,6 +951,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][tt], xf[j][i], acc[i][tt], 0, 0, 0);
+        if (g == b) STAMP(5);
         if (g + bps < ngroups) loadw(g + bps);   // in flight during the reduction below
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -989,6 +1003,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
         }
         __syncthreads();
     }
+    STAMP(6);
 }
 
 // Split-K form of the persistent kernel for the long-K narrow-N down projection (out_mode 2, fp32 partial slabs): grid.x = nz * bps,
@@ -1014,17 +1029,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
     bf16x8_t xf[KSW][4];
     int woff[KSW];
 #pragma unroll
-    for (int j = 0; j < KSW; ++j) {
-        const int st = st_begin + w + j * WAVES;
-        const bool ok = st < st_end;
-        woff[j] = min(st, st_end - 1) * 512 + l * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x4_t v = {0, 0, 0, 0};
-            if (ok) v = *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)st * xstep);
-            xf[j][i] = __builtin_bit_cast(bf16x8_t, v);
-        }
-    }
+    for (int j = 0; j < KSW; ++j) woff[j] = min(st_begin + w + j * WAVES, st_end - 1) * 512 + l * 8;
     const int ntiles = p.N >> 4;
     bf16x8_t wf[KSW];
     auto loadw = [&](int g) {
@@ -1033,7 +1038,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
         for (int j = 0; j < KSW; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + woff[j])));
     };
     int g = b;
+#ifdef IADR1_SPLIT_WFIRST
     if (g < ntiles) loadw(g);
+#endif
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        const int st = st_begin + w + j * WAVES;
+        const bool ok = st < st_end;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (ok) v = *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)st * xstep);
+            xf[j][i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+#ifndef IADR1_SPLIT_WFIRST
+    if (g < ntiles) loadw(g);          // after the X fragments here: measured 12.2 vs 12.8 us with the weights first (the opposite of the un-split kernel)
+#endif
     float* mine = red + (size_t)w * 64 * RLD;
     for (; g < ntiles; g += bps) {
         f32x4_t acc[4];
@@ -1139,22 +1160,19 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     IADR1_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0, "gemm_nt: K, lda, ldb must be multiples of 8 (16-byte chunks); K=%d lda=%lld ldb=%lld", K, lda, ldb);
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, "gemm_nt: A/B must be 16-byte aligned");
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2, "gemm_nt: bad out_mode %d", out_mode);
-    static int band_rows = 0;
-    if (!band_rows) { const char* e = getenv("IADR1_GEMM_BAND"); band_rows = e ? atoi(e) : 4; if (band_rows < 1) band_rows = 4; }
+    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
     GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act, band_rows, nullptr, 0};
-    static int force_tile = -1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        const char* e = getenv("IADR1_GEMM_TILE");
-        force_tile = e ? atoi(e) : 0;
+    static const int force_tile = iadr1_env_int("IADR1_GEMM_TILE", 0);
+    static const bool attr_done = [] {
         (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_128<OUT_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
-        attr_done = true;
-    }
+        return true;
+    }();
+    (void)attr_done;
     // 256^2 deep-pipeline kernel when the grid fills the chip with big tiles; 128^2 kernel for small / ragged problems
     const long long tiles256 = (long long)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
     const bool big = force_tile == 256 || (force_tile != 128 && M >= 512 && N >= 512 && tiles256 >= 192);
@@ -1180,17 +1198,16 @@ extern "C" int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, vo
     IADR1_REQUIRE((M % 256) == 0 && (I % 128) == 0 && (K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldaout % 8) == 0 && (GU == nullptr || (ldgu % 8) == 0),
                   "gemm_swiglu: needs M %% 256 == 0, I %% 128 == 0 and 16-byte row strides (M=%d I=%d K=%d); use gemm_nt + swiglu_fwd otherwise", M, I, K);
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)GU) & 15) == 0 && (((uintptr_t)Aout) & 15) == 0, "gemm_swiglu: operands must be 16-byte aligned");
-    static int band_rows = 0;
-    if (!band_rows) { const char* e = getenv("IADR1_GEMM_BAND"); band_rows = e ? atoi(e) : 4; if (band_rows < 1) band_rows = 4; }
+    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
     GemmArgs p{(const bf16_t*)A, (const bf16_t*)W, GU, nullptr, zeros_ptr(), M, 2 * I, K, lda, ldw, ldgu, 0, band_rows, (bf16_t*)Aout, ldaout};
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); attr_done = true; }
+    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
+    (void)attr_done;
     hipLaunchKernelGGL(gemm_nt_256<OUT_SWIGLU>, dim3((M / 256) * (I / 128)), dim3(NT2), SMEM2_BYTES, stream, p);
     return iadr1_check_launch("gemm_swiglu_bf16");
 }
 
 extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
-                                      long long ldw, long long ldy, int out_mode, int ksplit, hipStream_t stream) {
+                                      long long ldw, long long ldy, int out_mode, int ksplit, const void* side, hipStream_t stream) {
     IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_skinny: empty problem");
     IADR1_REQUIRE((K % 32) == 0 && (N % 16) == 0 && (ldx % 8) == 0, "gemm_skinny: packed weights need K %% 32 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
     IADR1_REQUIRE(ldy != 0 || (out_mode == 3 && (N % 64) == 0), "gemm_skinny: a decode-packed output (ldy == 0) exists for the fused-SwiGLU mode only");
@@ -1202,55 +1219,41 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
     p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.out_mode = out_mode;
     const int mz = (M + 63) / 64;
-    static bool attr_done = false;
-    constexpr int SM1 = 16 * 64 * 17 * 4, SM2 = 8 * 64 * 33 * 4;
-    if (!attr_done) {
+    constexpr int SM1 = 16 * 64 * 17 * 4, SM2 = 8 * 64 * 33 * 4, SMW = 8 * 64 * 33 * 4, SMP = 8 * 64 * 33 * 4, SMS = 8 * 64 * 17 * 4;
+    // launcher configuration, fixed at first use: A/B switches, the CU count, LDS opt-ins of every kernel this entry point can launch
+    static const int wide_nb = iadr1_env_int("IADR1_SKINNY_WIDE_NB", -1);  // -1: 4 with packed X, 8 with row-major X
+    static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1);
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM2);
-        attr_done = true;
-    }
-    constexpr int SMW = 8 * 64 * 33 * 4;
-    static int wide_nb = 0;
-    if (!wide_nb) {
-        const char* e = getenv("IADR1_SKINNY_WIDE_NB");
-        wide_nb = e ? atoi(e) : -1;  // -1: 4 with packed X, 8 with row-major X
         (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
-    }
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS);
+        return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }();
     // wide kernels: NB=8 (128 columns / block) for the big-N streams (gate|up, lm_head); NB=4 with K split over
     // grid.z for the long-K narrow-N down projection; the narrow kernel for the small projections (latency-bound)
     // persistent X-resident kernel for the big un-split streams (gate|up, lm_head): K = 32 * 8 waves * KSW exactly, >= 2 tile groups per CU.
     // Not for the split-K down projection (2 groups per block: two exposed memory latencies, 18.9 vs 14.2 us measured).
     {
-        static int pers = -1, ncu = 0;
-        constexpr int SMP = 8 * 64 * 33 * 4;
-        if (pers < 0) {
-            const char* e = getenv("IADR1_SKINNY_PERS");
-            pers = e ? atoi(e) : 1;
-            int dev = 0;
-            hipDeviceProp_t prop;
-            (void)hipGetDevice(&dev);
-            ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-            (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
-            (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
-            (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
-        }
         {   // split-K slabs (down projection): <= 6 k-steps per wave in a slice, >= 4 tiles per block
             const int kst = K >> 5, per_z = (kst + ksplit - 1) / ksplit, bps = ksplit > 0 ? ncu / ksplit : 0;
-            static bool attr2 = false;
-            constexpr int SMS = 8 * 64 * 17 * 4;
-            if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS); attr2 = true; }
             if (pers && ksplit > 1 && out_mode == 2 && per_z <= 48 && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
+                IADR1_REQUIRE(side == nullptr, "gemm_skinny: no side outputs in the split-K form");
                 hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 6>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
                 return iadr1_check_launch("gemm_skinny_bf16");
             }
         }
         const int ksw = K / 256;
         const bool pers_ok = pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu;
-        if (out_mode == 3) {
-            p.so = iadr1_take_side_out(stream);
-            IADR1_REQUIRE(!p.so.step || pers_ok, "gemm_skinny: side outputs of the fused-SwiGLU projection exist in the persistent kernel only (N=%d K=%d)", N, K);
-        }
+        if (int e = iadr1_side_arg(side, &p.so)) return e;
+        IADR1_REQUIRE(!p.so.step || (out_mode == 3 && pers_ok), "gemm_skinny: side outputs exist for the fused-SwiGLU projection in the persistent kernel only (mode %d N=%d K=%d)", out_mode, N, K);
         if (pers_ok) {
             const dim3 grid(ncu, mz, 1), block(512);
             if (ksw == 8) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 8>), grid, block, SMP, stream, p);
@@ -1281,7 +1284,7 @@ extern "C" int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, in
 
 extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const void* bias_p, void* q_out, const float* rope_cos, const float* rope_sin,
                                            const long long* slot, void* kcache, void* vcache, int M, int Hq, int Hkv, int D, int K, long long ldx,
-                                           long long ldq, hipStream_t stream) {
+                                           long long ldq, const void* side, hipStream_t stream) {
     IADR1_REQUIRE(D == 128, "gemm_qkv_rope_kv: head dim %d not built (128 is)", D);
     IADR1_REQUIRE(M > 0 && Hq > 0 && Hkv > 0 && (K % 32) == 0 && (ldx % 8) == 0, "gemm_qkv_rope_kv: need K %% 32 == 0 (K=%d)", K);
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wp) & 15) == 0, "gemm_qkv_rope_kv: X/W must be 16-byte aligned");
@@ -1289,10 +1292,10 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)Wp; p.Y = q_out; p.bias = (const bf16_t*)bias_p; p.M = M; p.N = (Hq + 2 * Hkv) * D; p.K = K;
     p.ldx = ldx; p.ldw = K; p.ldy = ldq; p.out_mode = 4;
     p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.slot = slot; p.kcache = (bf16_t*)kcache; p.vcache = (bf16_t*)vcache; p.Hq = Hq; p.Hkv = Hkv;
-    p.so = iadr1_take_side_out(stream);
+    if (int e = iadr1_side_arg(side, &p.so)) return e;
     constexpr int SM1 = 16 * 64 * 17 * 4;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1); attr_done = true; }
+    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1); return true; }();
+    (void)attr_done;
     hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3(p.N / 16, (M + 63) / 64, 1), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
 }
@@ -1321,3 +1324,5 @@ extern "C" int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, in
     hipLaunchKernelGGL(pack_gateup_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, I, K);
     return iadr1_check_launch("pack_gateup_bf16");
 }
+
+IADR1_STAMPS_EXPORT(gemm)

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p, Side
     constexpr int MC = 4;  // H <= 8192
     float v[MC][8];
     float ss = 0.f;
+    STAMP(0);
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
         const int ch = c * 256 + t;
@@ -217,7 +218,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p, Side
     u32x4_t gw[MC];
 #pragma unroll
     for (int c = 0; c < MC; ++c) gw[c] = (p.y && c * 256 + t < nchunk) ? *(const u32x4_t*)(p.w + (c * 256 + t) * 8) : (u32x4_t){0, 0, 0, 0};
+    STAMP(1);
     ss = block_sum<256>(ss, scratch);
+    STAMP(2);
     const float rstd = rsqrtf(ss / (float)p.H + p.eps);
     if (p.rstd && t == 0) p.rstd[row] = rstd;
     if (sb >= 0 && so.p2 && t == 0) ((float*)so.p2)[srow] = rstd;
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p, Side
             if (sb >= 0 && so.p1) *(u32x4_t*)((bf16_t*)so.p1 + srow * so.ld1 + ch * 8) = o;
         }
     }
+    STAMP(3);
 }
 
 struct RmsBwdArgs {
@@ -340,15 +344,18 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(RmsBwdArgs p) {
 
 extern "C" int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, const void* xbias, const void* res, void* res_out,
                                  const void* w, void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy,
-                                 float eps, hipStream_t stream) {
+                                 float eps, const void* side, hipStream_t stream) {
     IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0 && H <= MAXC * 512, "rmsnorm_fwd: H=%d must be a multiple of 8 and <= %d", H, MAXC * 512);
     IADR1_REQUIRE((x != nullptr) != (x32 != nullptr), "rmsnorm_fwd: exactly one of x / x32");
     IADR1_REQUIRE((ldx % 8) == 0 && (ldr % 8) == 0 && (ldy % 8) == 0, "rmsnorm_fwd: leading dims must be multiples of 8");
     IADR1_REQUIRE(x32 == nullptr || nsplit >= 1, "rmsnorm_fwd: nsplit >= 1 with x32");
     RmsFwdArgs p{(const bf16_t*)x, x32, nsplit, (const bf16_t*)xbias, (const bf16_t*)res, (bf16_t*)res_out, (const bf16_t*)w, (bf16_t*)y, rstd, T, H, ldx, ldr, ldy, eps};
     IADR1_REQUIRE(ldy != 0 || (T <= 256 && (H % 32) == 0), "rmsnorm_fwd: decode-packed output (ldy == 0) needs T <= 256 and H %% 32 == 0");
+    SideOut so;
+    if (int e = iadr1_side_arg(side, &so)) return e;
+    IADR1_REQUIRE(!so.step || T <= 256, "rmsnorm_fwd: side outputs exist in the few-row (decode) kernel only, T=%d", T);
     if (T <= 256) {
-        hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, stream, p, iadr1_take_side_out(stream));
+        hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, stream, p, so);
         return iadr1_check_launch("rmsnorm_fwd");
     }
     const dim3 grid((T + 3) / 4), block(256);
@@ -575,3 +582,5 @@ extern "C" int iadr1_layernorm_bwd(const void* dy, const void* x, const void* w,
 #undef CALL
     return iadr1_check_launch("layernorm_bwd");
 }
+
+IADR1_STAMPS_EXPORT(norm)

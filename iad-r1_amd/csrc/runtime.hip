@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -21,24 +22,21 @@ int iadr1_check_launch(const char* what) {
     return IADR1_OK;
 }
 
-static thread_local SideOut g_side = {};
-static thread_local hipStream_t g_side_stream = nullptr;
-
-SideOut iadr1_take_side_out(hipStream_t stream) {
-    if (!g_side.step || stream != g_side_stream) return SideOut{};
-    const SideOut s = g_side;
-    g_side = SideOut{};
-    return s;
+int iadr1_side_arg(const void* side, SideOut* out) {
+    *out = SideOut{};
+    if (!side) return IADR1_OK;
+    const SideOut s = *(const SideOut*)side;
+    IADR1_REQUIRE(s.step != nullptr && s.base >= 0 && s.seq_stride >= 0, "side outputs: a device step counter and non-negative row arithmetic are required");
+    IADR1_REQUIRE((s.ld0 % 8) == 0 && (((uintptr_t)s.p0 | (uintptr_t)s.p1 | (uintptr_t)s.p2) & 15) == 0, "side outputs: 16-byte aligned rows");
+    *out = s;
+    return IADR1_OK;
 }
 
-extern "C" int iadr1_decode_side_outputs(void* p0, long long ld0, void* p1, long long ld1, void* p2, long long ld2, const unsigned* step, long long base,
-                                         long long seq_stride, hipStream_t stream) {
-    IADR1_REQUIRE(step != nullptr && base >= 0 && seq_stride >= 0, "decode_side_outputs: a device step counter and non-negative row arithmetic are required");
-    IADR1_REQUIRE((ld0 % 8) == 0 && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0, "decode_side_outputs: 16-byte aligned rows");
-    g_side = SideOut{p0, p1, p2, ld0, ld1, ld2, step, base, seq_stride};
-    g_side_stream = stream;
-    return IADR1_OK;
+int iadr1_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 extern "C" const char* iadr1_last_error(void) { return g_err; }
 extern "C" int iadr1_version(void) { return 100; }
+

@@ -11,7 +11,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "iadr1_hip.h")
-LIB_PATH = os.path.join(HERE, "lib", "libiadr1_hip.so")
+# IADR1_HIP_LIB: an alternative build of the same library (A/B probes of kernel variants: tools/build_variant.py); still no fallback of any kind
+LIB_PATH = os.environ.get("IADR1_HIP_LIB") or os.path.join(HERE, "lib", "libiadr1_hip.so")
 
 _CTYPE = {
     "int": ctypes.c_int, "unsigned": ctypes.c_uint, "float": ctypes.c_float, "long long": ctypes.c_longlong,

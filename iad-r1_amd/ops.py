@@ -3,6 +3,7 @@ torch's job, arithmetic is not) and launch on torch's current HIP stream.  2-D t
 views; a non-unit inner stride is an error, an outer stride is passed through as `ld`."""
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -50,6 +51,26 @@ def pack_gateup(w, out=None):
     return o
 
 
+class SideOut(ctypes.Structure):
+    """include/iadr1_hip.h iadr1_side_out_t: where a decode-step kernel also writes its rows of the training arena.  Built once per (kernel, layer)
+    by the rollout (the pointers are static) and handed to the four entry points that take `side`."""
+    _fields_ = [("p0", ctypes.c_void_p), ("ld0", ctypes.c_longlong), ("p1", ctypes.c_void_p), ("ld1", ctypes.c_longlong), ("p2", ctypes.c_void_p),
+                ("ld2", ctypes.c_longlong), ("step", ctypes.c_void_p), ("base", ctypes.c_longlong), ("seq_stride", ctypes.c_longlong)]
+
+    @staticmethod
+    def make(step, base, seq_stride, p0=None, p1=None, p2=None, ld1=None):
+        """p0 / p1 are [rows, width] tensors (ld = row stride) except where the header says otherwise (ld1 overrides, e.g. the [Hq][T] log-sum-exp)."""
+        ld = lambda t: 0 if t is None else (t.stride(0) if t.dim() > 1 else 1)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        so = SideOut(ptr(p0), ld(p0), ptr(p1), ld(p1) if ld1 is None else ld1, ptr(p2), ld(p2), step.data_ptr(), int(base), int(seq_stride))
+        so._keep = (step, p0, p1, p2)      # the struct holds raw device pointers: keep their owners alive with it
+        return so
+
+
+def _side(so):
+    return None if so is None else ctypes.addressof(so)
+
+
 class PackedAct:
     """bf16 activations [M, K] in the decode-packed layout (MFMA B-fragment order, rows padded to 64; C ABI: leading
     dimension 0).  Producers: pack_act, rmsnorm_fwd(out=PackedAct), attn_decode(out=PackedAct), gemm_skinny(swiglu, out=PackedAct)."""
@@ -79,7 +100,7 @@ def _xarg(x):
     return (x.buf, 0) if isinstance(x, PackedAct) else (x, _ld(x))
 
 
-def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=False):
+def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=False, side=None):
     """out[M,N] = x[M,K] @ W[N,K]^T + bias with W given decode-packed (`pack_weight`); HBM-bound weight stream.
     x may be a PackedAct.  ksplit > 1: `out` is fp32 [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=...)."""
     M, K = x.shape
@@ -91,7 +112,7 @@ def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=
         if out is None:
             out = torch.empty(M, N // 2, dtype=BF16, device=dev)
         ob, ldo = _xarg(out)
-        hip.call("gemm_skinny_bf16", xb, w, ob, None, M, N, K, ldx, K, ldo, 3, 1)
+        hip.call("gemm_skinny_bf16", xb, w, ob, None, M, N, K, ldx, K, ldo, 3, 1, _side(side))
         return out
     if out is None:
         out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=dev)
@@ -100,7 +121,7 @@ def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=
         mode, ldy = 2, N
     else:
         mode, ldy = (1 if out.dtype == F32 else 0), _ld(out)
-    hip.call("gemm_skinny_bf16", xb, w, out, bias, M, N, K, ldx, K, ldy, mode, ksplit)
+    hip.call("gemm_skinny_bf16", xb, w, out, bias, M, N, K, ldx, K, ldy, mode, ksplit, None)
     return out
 
 
@@ -113,11 +134,11 @@ def pack_qkv_rope(w, bias, Hq, Hkv, D, out=None, out_bias=None):
     return out, out_bias
 
 
-def gemm_qkv_rope_kv(x, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, Hq, Hkv, D):
+def gemm_qkv_rope_kv(x, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, Hq, Hkv, D, side=None):
     """Decode step: q_out[:, :Hq*D] = rope(x.Wq^T + bq); K / V rows of the new token appended to the paged cache."""
     M, K = x.shape
     xb, ldx = _xarg(x)
-    hip.call("gemm_qkv_rope_kv_bf16", xb, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, M, Hq, Hkv, D, K, ldx, _ld(q_out))
+    hip.call("gemm_qkv_rope_kv_bf16", xb, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, M, Hq, Hkv, D, K, ldx, _ld(q_out), _side(side))
     return q_out
 
 
@@ -134,7 +155,7 @@ def transpose(x, out=None, pad_rows_to=1):
     return out
 
 
-def rmsnorm_fwd(x, w, eps, res=None, res_out=None, x32=None, xbias=None, want_rstd=False, out=None):
+def rmsnorm_fwd(x, w, eps, res=None, res_out=None, x32=None, xbias=None, want_rstd=False, out=None, side=None):
     """x: bf16 [T,H]  or  x32: fp32 [nsplit,T,H] partial slabs (summed in the kernel)."""
     if x is not None:
         T, H = x.shape
@@ -149,7 +170,7 @@ def rmsnorm_fwd(x, w, eps, res=None, res_out=None, x32=None, xbias=None, want_rs
     rstd = torch.empty(T, dtype=F32, device=dev) if want_rstd else None
     ldr = _ld(res) if res is not None else (_ld(res_out) if res_out is not None else H)
     yb, ldy = _xarg(y)
-    hip.call("rmsnorm_fwd", x, x32, nsplit, xbias, res, res_out, w, yb, rstd, T, H, ldx, ldr, ldy, float(eps))
+    hip.call("rmsnorm_fwd", x, x32, nsplit, xbias, res, res_out, w, yb, rstd, T, H, ldx, ldr, ldy, float(eps), _side(side))
     return y, rstd
 
 
@@ -263,6 +284,15 @@ def embed_bwd(ids, img_index, dx, dE, dimg):
     hip.call("embed_bwd", ids, img_index, dx, dE, dimg, T, H)
 
 
+def rows_gather_sum(src, ptr, idx, T):
+    """out[t] = sum_{k in ptr[t]..ptr[t+1]} src[idx[k]] (include/iadr1_hip.h iadr1_rows_gather_sum)."""
+    H = src.shape[1]
+    assert src.is_contiguous() and ptr.dtype == torch.int32 and idx.dtype == torch.int32 and ptr.numel() == T + 1
+    out = torch.empty(T, H, dtype=BF16, device=src.device)
+    hip.call("rows_gather_sum", src, ptr, idx, out, T, H)
+    return out
+
+
 def cast_f32_to_bf16(x, cpad=None):
     R, C = x.shape
     cpad = cpad or C
@@ -335,18 +365,11 @@ def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq
              _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout), _ld(dq), _ld(dk), _ld(dv), 1 if causal else 0, float(scale))
 
 
-def decode_side_outputs(step, base, seq_stride, p0=None, p1=None, p2=None, ld1=None):
-    """Arms the next decode-step kernel on the current stream to also write row-major training rows (include/iadr1_hip.h iadr1_decode_side_outputs).
-    p0 / p1 are [rows, width] tensors (ld = row stride) except where the header says otherwise (ld1 overrides, e.g. the [Hq][T] log-sum-exp)."""
-    ld = lambda t: 0 if t is None else (t.stride(0) if t.dim() > 1 else 1)
-    hip.call("decode_side_outputs", p0, ld(p0), p1, ld(p1) if ld1 is None else ld1, p2, ld(p2), step, int(base), int(seq_stride))
-
-
-def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=None):
+def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=None, side=None):
     B = q.shape[0]
     o = out if out is not None else torch.empty(B, Hq * D, dtype=BF16, device=q.device)
     ob, ldo = _xarg(o)
-    hip.call("attn_decode", q, kcache, vcache, block_table, ctx_len, ob, B, Hq, Hkv, D, block_table.shape[1], _ld(q), ldo, float(scale))
+    hip.call("attn_decode", q, kcache, vcache, block_table, ctx_len, ob, B, Hq, Hkv, D, block_table.shape[1], _ld(q), ldo, float(scale), _side(side))
     return o
 
 

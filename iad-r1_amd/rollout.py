@@ -83,51 +83,51 @@ class Rollout:
         tr = self.trace      # None, or the training arena the step also fills (Rollout.generate(train_trace=...))
 
         def side(**kw):
-            if tr is not None:
-                ops.decode_side_outputs(self.step, tr["base"], tr["stride"], **kw)
+            """iadr1_side_out_t for one launch of this step: rows base + s * stride + *step of the given arena tensors (None without a trace).
+            The structs are host memory read at launch time; they are kept in self._sides so that a re-capture builds them anew."""
+            if tr is None:
+                return None
+            so = ops.SideOut.make(self.step, tr["base"], tr["stride"], **kw)
+            self._sides.append(so)
+            return so
 
+        self._sides = []
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         qw, kw = Hq * D, Hkv * D
         s = self.sampling
         ops.embed_fwd(self.cur_tok, None, P.w("embed"), None, out=self.x)
         ops.rope_table(self.pos, e.inv_freq, self.cos, self.sin)
         have_branch = False
+        T_ = lambda name, i: None if tr is None else tr[name][i]
         for i in range(c.num_hidden_layers):
             b = f"layers.{i}."
-            if not have_branch:
-                if tr is not None:
-                    side(p1=tr["h1"][i], p2=tr["rstd1"][i])          # layer 0 enters with the embedding rows (filled after the rollout)
-                ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h)
+            if not have_branch:      # layer 0 enters with the embedding rows (filled after the rollout)
+                ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h, side=side(p1=T_("h1", i), p2=T_("rstd1", i)))
             else:
-                if tr is not None:
-                    side(p0=tr["x_in"][i], p1=tr["h1"][i], p2=tr["rstd1"][i])
-                ops.rmsnorm_fwd(None, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)
-            if tr is not None:
-                side(p0=tr["qkv"][i])
+                ops.rmsnorm_fwd(None, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h,
+                                side=side(p0=T_("x_in", i), p1=T_("h1", i), p2=T_("rstd1", i)))
             if P.qkv_rope_packed:   # q|k|v projection + rotary + K/V cache append in one launch
-                ops.gemm_qkv_rope_kv(self.h, P.wpk(b + "qkv.w"), P.wpk_bias(b + "qkv.w"), self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
+                ops.gemm_qkv_rope_kv(self.h, P.wpk(b + "qkv.w"), P.wpk_bias(b + "qkv.w"), self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D,
+                                     side=side(p0=T_("qkv", i)))
             else:
+                assert tr is None
                 ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
                 ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
-            if tr is not None:
-                side(p0=tr["o"][i], p1=tr["lse"][i], ld1=tr["lse"][i].stride(0))
-            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o)
+            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o,
+                            side=side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), c.hidden_size, out=self.part_o, ksplit=self.ks_o)
-            if tr is not None:
-                side(p0=tr["x_mid"][i], p1=tr["h2"][i], p2=tr["rstd2"][i])
-            ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h)
-            if tr is not None:
-                side(p0=tr["gu"][i], p1=tr["a"][i])
+            ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h,
+                            side=side(p0=T_("x_mid", i), p1=T_("h2", i), p2=T_("rstd2", i)))
             if self.fuse_swiglu:
-                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True)
+                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True, side=side(p0=T_("gu", i), p1=T_("a", i)))
             else:
+                assert tr is None
                 ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.gu)
                 ops.swiglu_fwd(self.gu, out=self.a)
             ops.gemm_skinny(self.a, P.wpk(b + "down.w"), c.hidden_size, out=self.part_d, ksplit=self.ks_down)
             have_branch = True
-        if tr is not None:
-            side(p0=tr["x_last"], p1=tr["hf"], p2=tr["rstdf"])
-        ops.rmsnorm_fwd(None, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h)
+        ops.rmsnorm_fwd(None, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h,
+                        side=side(p0=None if tr is None else tr["x_last"], p1=None if tr is None else tr["hf"], p2=None if tr is None else tr["rstdf"]))
         ops.gemm_skinny(self.h, P.wpk(P.lm_head_name()), c.vocab_size, out=self.logits)
         self._sample_and_advance()
 

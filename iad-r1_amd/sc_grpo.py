@@ -332,12 +332,10 @@ class SCGRPOEngine:
         for si, r0 in enumerate(starts):
             r1 = min(N, r0 + mb)
             n = r1 - r0
-            dup = None
             if share:
                 b0, b1 = r0 // G, r1 // G
                 plan = self.pol.text_plan_shared(ids_p[b0:b1], mask_p[b0:b1], comp[r0:r1], cmask[r0:r1], G, gpr[b0:b1], off[b0:b1])
-                sel, fsel, fdest, fgroup = self.pol.shared_logit_rows(b1 - b0, P, n, C, G)
-                dup = tuple(torch.from_numpy(z).to(self.dev) for z in (fsel, fdest, fgroup))
+                sel = self.pol.shared_logit_rows(b1 - b0, P, n, C, G)[0]
             else:
                 rows_b = [r // G for r in range(r0, r1)]
                 plan = self.pol.text_plan(ids[r0:r1], mask[r0:r1], [gpr[b] for b in rows_b], [off[b] for b in rows_b])
@@ -357,7 +355,7 @@ class SCGRPOEngine:
                     hf, ctx = self.pol.text_forward(plan.tail, None, save=True, rows=((b1 - b0) * P, T_all, T_all), carry=train_carry)
             else:
                 hf, ctx = self.pol.text_forward(plan, img_pol, save=backward)
-            lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, dup=dup)
+            lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel)
             adv_d = advantages()["adv_d"]
             dlogp, kl, rloss, rkl = ops.grpo_loss(lp.view(n, C), rl.view(n, C), adv_d[r0:r1].contiguous(), cmask_d[r0:r1].contiguous(), a.beta, n_total_rows=N)
             logp_all[r0:r1], ref_all[r0:r1], kl_all[r0:r1] = lp.view(n, C), rl.view(n, C), kl

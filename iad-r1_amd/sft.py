@@ -76,7 +76,7 @@ class SFTEngine:
             rows_d = torch.from_numpy(sel.astype(np.int64)).to(self.dev)
             tgt_d = torch.from_numpy(tgt[r0:r1].reshape(-1)[sel]).to(self.dev)
             hf, ctx = e.text_forward(plan, img, save=backward)
-            lp, lctx = e.logprobs(hf, rows_d, tgt_d, save=backward)
+            lp, lctx = e.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel)
             total += -lp.sum()
             if backward:
                 g = torch.full((len(sel),), -1.0 / n_items, dtype=F32, device=self.dev)

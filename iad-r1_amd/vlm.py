@@ -466,10 +466,10 @@ class Engine:
             rstd1 = B["rstd1"][li, r0:r1] if save else None
             if branch is None:
                 x_in = res
-                ops.hip.call("rmsnorm_fwd", res, None, 0, None, None, None, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps))
+                ops.hip.call("rmsnorm_fwd", res, None, 0, None, None, None, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps), None)
             else:
                 x_in = buf("x_in") if save else res
-                ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps))
+                ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps), None)
             qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=buf("qkv"))
             ops.rope_(qkv, plan.cos, plan.sin, Hq + Hkv, D)
             if kv_sink is not None:
@@ -488,7 +488,7 @@ class Engine:
             x_mid = buf("x_mid") if save else x_in
             h2 = buf("h2")
             rstd2 = B["rstd2"][li, r0:r1] if save else None
-            ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, Tl, H, H, H, H, float(eps))
+            ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, Tl, H, H, H, H, float(eps), None)
             # gate|up projection with the activation in its epilogue; the gate|up matrix itself is written only when backward will read it
             gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=buf("gu"), a_out=buf("a"), keep_gu=save)
             branch = ops.gemm_nt(a, P.w(b + "down.w"))
@@ -501,7 +501,7 @@ class Engine:
                                           B["rstd2"][li, :T], full("h2"), full("gu"), full("a")))
         if part:
             hf, x_last, rstdf = carry["hf"], carry["x_last"], carry["rstdf"]
-            ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_last[r0:r1], P.w("norm"), hf[r0:r1], rstdf[r0:r1], Tl, H, H, H, H, float(eps))
+            ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_last[r0:r1], P.w("norm"), hf[r0:r1], rstdf[r0:r1], Tl, H, H, H, H, float(eps), None)
             ctx.update(x_last=x_last, rstdf=rstdf)
             return hf, ctx
         x_last = torch.empty_like(res) if save else res
@@ -513,7 +513,7 @@ class Engine:
     def text_context_from_trace(self, plan: TextPlan, rows, carry):
         """The (hf, ctx) pair text_forward(plan, None, save=True, rows=rows, carry=carry) would return for the completion rows [r0, r1), WITHOUT running
         the layers: the rollout's decode steps already wrote those rows of the activation arena (Rollout side outputs, include/iadr1_hip.h
-        iadr1_decode_side_outputs).  Only the embedding rows of the completion tokens (layer 0's residual input) are gathered here."""
+        iadr1_side_out_t).  Only the embedding rows of the completion tokens (layer 0's residual input) are gathered here."""
         c, P = self.cfg, self.p
         Hq, D, Hkv = c.num_attention_heads, c.head_dim, c.num_key_value_heads
         r0, r1, T = rows
@@ -571,7 +571,16 @@ class Engine:
     # ========================================================================================================
     # lm_head + log-softmax + gather (REF sc_grpo_trainer.py:505-513), only on the rows that are consumed
     # ========================================================================================================
-    def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool, dup=None):
+    @staticmethod
+    def scatter_plan(rows_host: np.ndarray, T: int, device):
+        """CSR (ptr [T+1], idx [R]) of `rows`: for each token row the selected rows that read it, in selection order (host integer work)."""
+        rows_host = np.asarray(rows_host, dtype=np.int64).reshape(-1)
+        order = np.argsort(rows_host, kind="stable").astype(np.int32)
+        ptr = np.zeros(T + 1, dtype=np.int32)
+        np.cumsum(np.bincount(rows_host, minlength=T), out=ptr[1:])
+        return torch.from_numpy(ptr).to(device), torch.from_numpy(order).to(device)
+
+    def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool, dup=None, rows_host=None):
         """logp[r] = log_softmax(lm_head(hf[rows[r]]))[targets[r]]  (targets < 0 -> 0).  The [R,V] logits exist
         only as fp32 chunks of `lm_chunk` rows.  `rows` may repeat a hidden row only where `dup` = (sel, dest, group) says so:
         entries rows[sel] all equal dest[group] (shared-prefix layout: the prompt's last token predicts the first token of
@@ -594,7 +603,10 @@ class Engine:
             lp, ls = ops.logprob_rows(lg, targets[r0:r1])
             logp[r0:r1] = lp
             lse[r0:r1] = ls
-        ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0], "dup": dup, "logits": lg_all} if save else None
+        ctx = None
+        if save:
+            ptr, idx = self.scatter_plan(rows_host if rows_host is not None else rows.cpu().numpy(), hf.shape[0], self.dev)
+            ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0], "scatter": (ptr, idx), "logits": lg_all}
         return logp, ctx
 
     def logprobs_backward(self, g: torch.Tensor, ctx) -> torch.Tensor:
@@ -623,16 +635,9 @@ class Engine:
                 dlT[:, n:].zero_()
             ops.transpose(dl, out=dlT)
             ops.gemm_nt(dlT, ops.transpose(hsel[r0:r1], pad_rows_to=8), out=self.p.g(name), accumulate=True)
-        # scatter rows back: dhf[t] = dhsel[inv[t]] or 0
-        inv = torch.full((ctx["T"],), -1, dtype=torch.int32, device=self.dev)
-        inv[rows] = torch.arange(R, dtype=torch.int32, device=self.dev)
-        zero_row = torch.zeros(1, H, dtype=BF16, device=self.dev)
-        dhf = ops.embed_fwd(torch.zeros(ctx["T"], dtype=torch.int64, device=self.dev), inv, zero_row, dhsel)
-        if ctx.get("dup") is not None:
-            sel, dest, group = ctx["dup"]
-            acc = torch.zeros(dest.numel(), H, dtype=F32, device=self.dev).index_add_(0, group, dhsel[sel].float())
-            dhf[dest] = acc.to(BF16)
-        return dhf
+        # scatter back onto the token rows: dhf[t] = sum of the selected rows that read hidden row t (0 for rows nothing read)
+        ptr, idx = ctx["scatter"]
+        return ops.rows_gather_sum(dhsel, ptr, idx, ctx["T"])
 
     def logits_rows(self, hf: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
         """fp32 logits of a FEW rows (rollout prefill: last prompt position of each prompt)."""

@@ -11,7 +11,8 @@
  *   - plain C: pointers + sizes, no torch types.  All pointers are DEVICE pointers unless noted.
  *   - the caller owns every buffer; nothing here allocates, frees or synchronises.
  *   - asynchronous and stream-ordered on `stream` (a hipStream_t, passed as void*); legal inside
- *     hipGraph capture; re-entrant (no mutable global state).
+ *     hipGraph capture; re-entrant: no mutable global state (the IADR1_* A/B switches
+ *     of the launchers are read once, at first use, into constants).
  *   - bf16 tensors are raw uint16 bit patterns; arithmetic is fp32; row strides (`ld*`) are in elements.
  *   - return 0 on success, negative on error; iadr1_last_error() returns the thread-local message.
  */
@@ -25,16 +26,22 @@ typedef void* iadr1_stream_t; /* hipStream_t */
 
 int iadr1_version(void);
 const char* iadr1_last_error(void);
-/* Rollout -> training hand-over.  Arms the NEXT launch on `stream` (by this thread) of one decode-step kernel to ALSO write what it computes into
- * row-major training buffers, at row  base + s * seq_stride + *step  for sequence s (`step`: device-resident decode step counter):
+/* Rollout -> training hand-over.  The four decode-step entry points that take a trailing `side` argument can ALSO write what they compute into
+ * row-major training buffers, at row  base + s * seq_stride + *step  for sequence s (`step`: device-resident decode step counter).  `side` is a
+ * HOST pointer to this struct, read during the call (NULL: no side outputs); the struct holds DEVICE pointers:
  *   iadr1_rmsnorm_fwd (T <= 256)        p0 = residual stream rows [.., ld0] (bf16), p1 = normalised rows [.., ld1], p2 = rstd (fp32, one per row)
  *   iadr1_gemm_qkv_rope_kv_bf16         p0 = roped q|k|v rows [.., ld0]
  *   iadr1_attn_decode                   p0 = attention output rows [.., ld0], p1 = log-sum-exp fp32 [Hq][ld1]
  *   iadr1_gemm_skinny_bf16 out_mode 3   p0 = gate|up rows [.., ld0], p1 = SwiGLU rows [.., ld1]   (persistent kernel shapes only)
  * Decode step t processes completion token t of every sequence = row (s, t) of the completion block of the shared-prefix training batch, so the
  * policy's teacher-forced forward over the completions (REF:505-513 on the policy model) need not be run again before backward.  Unused p*: NULL. */
-int iadr1_decode_side_outputs(void* p0, long long ld0, void* p1, long long ld1, void* p2, long long ld2, const unsigned* step, long long base,
-                              long long seq_stride, iadr1_stream_t stream);
+typedef struct iadr1_side_out {
+    void* p0; long long ld0;
+    void* p1; long long ld1;
+    void* p2; long long ld2;
+    const unsigned* step;
+    long long base, seq_stride;
+} iadr1_side_out_t;
 
 /* ---- dense contractions ----------------------------------------------------------------------------
  * C[M,N] (+)= act(A[M,K] . B[N,K]^T + bias[N]).  out_mode: 0 = bf16 store, 1 = fp32 store, 2 = fp32
@@ -59,7 +66,7 @@ int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, void* Aout, i
  * iadr1_attn_decode (ldo == 0) and out_mode 3 here (ldy == 0) emit that layout directly, so the decode step never repacks.
  * Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667). */
 int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
-                           long long ldw, long long ldy, int out_mode, int ksplit, iadr1_stream_t stream);
+                           long long ldw, long long ldy, int out_mode, int ksplit, const iadr1_side_out_t* side, iadr1_stream_t stream);
 /* W[N,K] row-major -> decode-packed MFMA-fragment order Wp[N/16][K/32][64 lanes][8] (what iadr1_gemm_skinny_bf16 reads:
  * every wave-level load of the weight stream is then 1 KiB contiguous).  N % 16 == 0, K % 32 == 0. */
 int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, iadr1_stream_t stream);
@@ -72,7 +79,7 @@ int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K,
  * head dealt into the same 16-column tile.  ldx == 0: X decode-packed.  One launch instead of two per layer of the rollout. */
 int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const void* bias_p, void* q_out, const float* rope_cos,
                                 const float* rope_sin, const long long* slot, void* kcache, void* vcache, int M, int Hq, int Hkv,
-                                int D, int K, long long ldx, long long ldq, iadr1_stream_t stream);
+                                int D, int K, long long ldx, long long ldq, const iadr1_side_out_t* side, iadr1_stream_t stream);
 int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, void* Wp, void* bias_p, int Hq, int Hkv, int D, int K,
                              iadr1_stream_t stream);
 /* X[M,K] row-major -> decode-packed activations Xp (buffer of roundup(M,64)*K elements; pad rows zeroed).  K % 32 == 0. */
@@ -86,7 +93,7 @@ int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo
  * pointer may be NULL. */
 int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, const void* xbias, const void* res, void* res_out,
                       const void* w, void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy,
-                      float eps, iadr1_stream_t stream);
+                      float eps, const iadr1_side_out_t* side, iadr1_stream_t stream);
 /* dx = dres + d rmsnorm / dx ; dw (fp32, may be NULL) += sum_t dy * x * rstd */
 int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                       float* dw, int T, int H, long long ld, iadr1_stream_t stream);
@@ -124,6 +131,11 @@ int iadr1_embed_fwd(const long long* ids, const int* img_index, const void* E, c
 int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
                     iadr1_stream_t stream);
 
+/* out[t] (bf16 [T,H]) = sum of src rows idx[ptr[t] .. ptr[t+1]) (fp32 sum, one rounding; an empty list gives zeros): the gradient of the rows the
+ * lm_head consumed (REF:...sc_grpo_trainer.py:505-513 only reads P-1 .. S-2 of each row; PA-SFT the supervised positions) scattered back onto the
+ * token rows of the decoder output, several selected rows may share one token row.  ptr: [T+1], idx: [ptr[T]] int32, src rows contiguous. */
+int iadr1_rows_gather_sum(const void* src, const int* ptr, const int* idx, void* out, int T, int H, iadr1_stream_t stream);
+
 /* ---- casts ---------------------------------------------------------------------------------------------- */
 int iadr1_cast_f32_to_bf16(const float* in, long long ldi, void* out, long long ldo, int R, int C, int Cpad,
                            iadr1_stream_t stream);
@@ -157,7 +169,7 @@ int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
  * attn_decode reads, private to these three entry points], V page [Hkv][D][32].  slot = page*32 + offset. */
 int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len,
                       void* o, int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale,
-                      iadr1_stream_t stream);
+                      const iadr1_side_out_t* side, iadr1_stream_t stream);
 int iadr1_kv_store(const void* k, long long ldk, const void* v, long long ldv, const long long* slot, void* kcache,
                    void* vcache, int T, int Hkv, int D, iadr1_stream_t stream);
 /* decode-step fusion of iadr1_rope_inplace (q,k heads) + iadr1_kv_store for one new token per sequence */

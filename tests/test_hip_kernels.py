@@ -585,8 +585,9 @@ def test_gemm_swiglu_is_bit_identical_to_gemm_then_swiglu(M, I, K, keep):
 
 @pytest.mark.gpu
 def test_decode_side_outputs_equal_the_main_outputs():
-    """iadr1_decode_side_outputs: every decode-step kernel that carries side outputs writes, at row base + s * stride + *step of row-major training
-    buffers, exactly what its main (decode-packed / paged) output holds; the armed state is consumed by one launch."""
+    """iadr1_side_out_t (`side` argument of the four decode-step entry points): every kernel that carries side outputs writes, at row
+    base + s * stride + *step of row-major training buffers, exactly what its main (decode-packed / paged) output holds; without `side` nothing else
+    is written (the struct is an explicit per-call argument, there is no armed state)."""
     step = torch.tensor([3], dtype=torch.int32, device=DEV)
     base, stride, T = 10, 7, 10 + 7 * 64 + 8
     row = lambda s: base + s * stride + 3
@@ -596,14 +597,13 @@ def test_decode_side_outputs_equal_the_main_outputs():
     H = 2048
     slabs, res, g = rnd(2, 64, H, seed=1, dtype=F32), rnd(64, H, seed=2), rnd(H, seed=3)
     sx, sy, sr = nan(T, H), nan(T, H), nan(T, dtype=F32)
-    ops.decode_side_outputs(step, base, stride, p0=sx, p1=sy, p2=sr)
     res_out, y = torch.empty_like(res), ops.PackedAct(64, H, DEV)
-    _, rstd = ops.rmsnorm_fwd(None, g, 1e-6, res=res, res_out=res_out, x32=slabs, out=y, want_rstd=True)
+    _, rstd = ops.rmsnorm_fwd(None, g, 1e-6, res=res, res_out=res_out, x32=slabs, out=y, want_rstd=True, side=ops.SideOut.make(step, base, stride, p0=sx, p1=sy, p2=sr))
     assert torch.equal(sx[rows], res_out) and torch.equal(sy[rows], y.unpack()) and torch.equal(sr[rows], rstd)
     untouched = torch.ones(T, dtype=torch.bool, device=DEV); untouched[rows] = False
     assert bool(torch.isnan(sx[untouched].float()).all())
     sy2 = nan(T, H)
-    ops.rmsnorm_fwd(None, g, 1e-6, res=res, res_out=res_out, x32=slabs, out=y)     # not armed any more
+    ops.rmsnorm_fwd(None, g, 1e-6, res=res, res_out=res_out, x32=slabs, out=y)     # no `side`: no side output
     assert bool(torch.isnan(sy2.float()).all())
     # q|k|v projection + rotary + cache append: the roped rows in [q | k | v] order
     Hq, Hkv, D, K = 16, 2, 128, 256
@@ -615,8 +615,7 @@ def test_decode_side_outputs_equal_the_main_outputs():
     kc, vc = torch.zeros(66, Hkv, 32, D, dtype=BF, device=DEV), torch.zeros(66, Hkv, D, 32, dtype=BF, device=DEV)
     wp, bp = ops.pack_qkv_rope(w, bias, Hq, Hkv, D)
     q_out, sq = torch.zeros(64, N, dtype=BF, device=DEV), nan(T, N)
-    ops.decode_side_outputs(step, base, stride, p0=sq)
-    ops.gemm_qkv_rope_kv(ops.pack_act(x), wp, bp, q_out, cos, sin, slot, kc, vc, Hq, Hkv, D)
+    ops.gemm_qkv_rope_kv(ops.pack_act(x), wp, bp, q_out, cos, sin, slot, kc, vc, Hq, Hkv, D, side=ops.SideOut.make(step, base, stride, p0=sq))
     ref = ops.gemm_skinny(x, ops.pack_weight(w), N, bias=bias)
     ops.rope_(ref, cos, sin, Hq + Hkv, D)
     assert torch.equal(sq[rows][:, : Hq * D], q_out[:, : Hq * D])
@@ -633,8 +632,8 @@ def test_decode_side_outputs_equal_the_main_outputs():
     ops.kv_store(torch.cat(ks), torch.cat(vs), slots, kc, vc, Hkv, D)
     q = rnd(64, Hq * D, seed=7)
     so, sl = nan(T, Hq * D), nan(Hq, T, dtype=F32)
-    ops.decode_side_outputs(step, base, stride, p0=so, p1=sl, ld1=T)
-    o = ops.attn_decode(q, kc, vc, table, torch.tensor(lens, dtype=torch.int32, device=DEV), Hq, Hkv, D, D ** -0.5, out=ops.PackedAct(64, Hq * D, DEV))
+    o = ops.attn_decode(q, kc, vc, table, torch.tensor(lens, dtype=torch.int32, device=DEV), Hq, Hkv, D, D ** -0.5, out=ops.PackedAct(64, Hq * D, DEV),
+                        side=ops.SideOut.make(step, base, stride, p0=so, p1=sl, ld1=T))
     assert torch.equal(so[rows], o.unpack())
     for s in (0, 17, 63):
         kf = ks[s].float().view(lens[s], Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
@@ -646,8 +645,7 @@ def test_decode_side_outputs_equal_the_main_outputs():
     I, K = 8192, 1024
     x, w = rnd(64, K, seed=8), rnd(2 * I, K, seed=9, scale=K ** -0.5 * 2)
     sg, sa = nan(T, 2 * I), nan(T, I)
-    ops.decode_side_outputs(step, base, stride, p0=sg, p1=sa)
-    a = ops.gemm_skinny(ops.pack_act(x), ops.pack_gateup(w), 2 * I, swiglu=True, out=ops.PackedAct(64, I, DEV))
+    a = ops.gemm_skinny(ops.pack_act(x), ops.pack_gateup(w), 2 * I, swiglu=True, out=ops.PackedAct(64, I, DEV), side=ops.SideOut.make(step, base, stride, p0=sg, p1=sa))
     assert torch.equal(sa[rows], a.unpack())
     gu_ref = ops.gemm_nt(x, w)
     close(sg[rows], gu_ref, 1e-2, 1e-2, "side gate|up rows")
