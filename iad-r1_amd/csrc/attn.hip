@@ -49,6 +49,7 @@ struct AttnArgs {
     // fp32 partials dkv_ws[hs][T][Hkv][2][D], summed in a fixed order by attn_dkdv_reduce_kernel (deterministic, no atomics)
     float* dkv_ws;
     int hs;
+    int seg_off;            // first segment of this launch (the launchers split the segment list into a long-segment head and a short-segment tail)
 };
 
 template <int D>
@@ -56,8 +57,28 @@ struct Cfg {
     static constexpr int DQK = (D + 31) / 32 * 32;  // contraction length of QK^T, zero padded
     static constexpr int KS = DQK / 32;             // MFMA k-steps over d
     static constexpr int DT = D / 16;               // 16-wide output tiles over d
-    static constexpr int LD = DQK + 8;              // LDS row stride (elements) of row-major [rows][d] tiles
+#ifdef IADR1_ATTN_NOSWZ
+    static constexpr int LD = DQK + 8;              // LDS row stride (elements) of row-major [rows][d] tiles (padded form: A/B probe of the swizzle)
+#else
+    static constexpr int LD = 128;                  // 256-byte tile rows = exactly one LDS bank row, 16 chunks of 16 B (swizzled, see tile_off)
+#endif
 };
+
+// LDS image of a staged [rows][d] tile.  Row r is 256 bytes; its 16-byte chunk c sits at chunk position  c ^ 2*rho(r),  rho(r) = (r & 3) | ((r >> 1) & 4).
+// Both read patterns of these kernels are then bank-conflict free (measured before, on 272-byte padded rows: SQ_LDS_BANK_CONFLICT = 39-43 % of
+// SQ_LDS_IDX_ACTIVE in all three kernels, profiles/r02_mfma_busy.json):
+//  * fragment reads (ds_read_b128; lane (li, g) reads chunk 4*ks + g of row perm_row(t, li)): the hardware serves lanes {li 0-3, 12-15 at g} with
+//    {li 4-11 at g^1} together; their rows are {0-3, 24-27} and {8-11, 16-19} (+4 for odd t, +32 per tile pair), rho enumerates each set 0..7, so
+//    the first set lands on the even chunk positions (relative to 4*ks + g) and the second, one chunk further, on the odd ones;
+//  * transpose reads (ds_read_b64_tr_b16; a 32-lane half reads 8-byte halves of chunks 2*dt, 2*dt+1 of rows (li>>2) + 8*(g&1) [+4]): the rows differ
+//    in bits {0, 1, 3}, exactly the bits of rho, so the eight rows use eight different chunk pairs = all 64 banks once.
+#ifndef IADR1_ATTN_NOSWZ
+__device__ __forceinline__ int swz_rho(int r) { return (r & 3) | ((r >> 1) & 4); }
+__device__ __forceinline__ int tile_off(int r, int c, int /*LD*/) { return r * 256 + ((c ^ (2 * swz_rho(r))) << 4); }    // byte offset of chunk c of row r
+#else
+__device__ __forceinline__ int swz_rho(int) { return 0; }
+__device__ __forceinline__ int tile_off(int r, int c, int LD) { return (r * LD + c * 8) * 2; }
+#endif
 
 __device__ __forceinline__ bf16x8_t ld_frag_g(const bf16_t* p, bool ok) {
     u32x4_t v = {0, 0, 0, 0};
@@ -65,6 +86,9 @@ __device__ __forceinline__ bf16x8_t ld_frag_g(const bf16_t* p, bool ok) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 __device__ __forceinline__ bf16x8_t ld_frag_s(const bf16_t* p) { return *(const bf16x8_t*)p; }
+// fragment (row, 16-byte chunk) of a staged tile
+template <int LD>
+__device__ __forceinline__ bf16x8_t ld_frag_t(const bf16_t* tile, int row, int chunk) { return *(const bf16x8_t*)((const char*)tile + tile_off(row, chunk, LD)); }
 
 // v_exp_f32 directly: exp2f() wraps it in a denormal-range rescale (~5 extra VALU instructions per call); softmax terms that small are zero anyway
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -86,20 +110,20 @@ __device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long 
         const int r = idx / CPR, c = idx - r * CPR;
         u32x4_t v = {0, 0, 0, 0};
         if (r < nvalid && c * 8 < D) v = *(const u32x4_t*)(src + (long long)r * ld + c * 8);
-        *(u32x4_t*)(dst + r * Cfg<D>::LD + c * 8) = v;
+        *(u32x4_t*)((char*)dst + tile_off(r, c, Cfg<D>::LD)) = v;
     }
 }
 // Split staging (issue-early / write-late): the global loads of the NEXT tile are issued into registers before the
 // MFMAs of the current tile and written to LDS after the barrier that ends it, so their latency hides under compute.
-template <int D, int ROWS>
+template <int D, int ROWS, int NT = 256>
 struct TileRegs {
     static constexpr int CPR = Cfg<D>::DQK / 8;
-    static constexpr int N = (ROWS * CPR + 255) / 256;
+    static constexpr int N = (ROWS * CPR + NT - 1) / NT;
     u32x4_t v[N];
     __device__ __forceinline__ void load(const bf16_t* src, long long ld, int nvalid) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int idx = i * 256 + threadIdx.x;
+            const int idx = i * NT + threadIdx.x;
             const int r = idx / CPR, c = idx - r * CPR;
             v[i] = (u32x4_t){0, 0, 0, 0};
             if (idx < ROWS * CPR && r < nvalid && c * 8 < D) v[i] = *(const u32x4_t*)(src + (long long)r * ld + c * 8);
@@ -108,9 +132,9 @@ struct TileRegs {
     __device__ __forceinline__ void store(bf16_t* dst) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int idx = i * 256 + threadIdx.x;
+            const int idx = i * NT + threadIdx.x;
             const int r = idx / CPR, c = idx - r * CPR;
-            if (idx < ROWS * CPR) *(u32x4_t*)(dst + r * Cfg<D>::LD + c * 8) = v[i];
+            if (idx < ROWS * CPR) *(u32x4_t*)((char*)dst + tile_off(r, c, Cfg<D>::LD)) = v[i];
         }
     }
 };
@@ -137,6 +161,14 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 // hardware transpose reads: tr_frag_ld (common.h)
 // lane-constant part of a tr-read address inside a row-major [rows][LD] tile: row (li>>2) + 8*g, column 4*(li&3)
 __device__ __forceinline__ uint32_t tr_lane_off(int li, int g, int LD) { return (uint32_t)(((g * 8 + (li >> 2)) * LD + 4 * (li & 3)) * 2); }
+// byte offset of d-tile dt (16 columns = chunks 2*dt, 2*dt+1) relative to tr_lane_off, for THIS lane's rows (swizzled image: the chunk pair moves with rho of the row)
+__device__ __forceinline__ uint32_t tr_dt_off(int dt, int li, int g) {
+#ifndef IADR1_ATTN_NOSWZ
+    return (uint32_t)((dt ^ ((li >> 2) | ((g & 1) << 2))) << 5);
+#else
+    return (uint32_t)(dt * 32);
+#endif
+}
 
 // =====================================================================================================
 // forward
@@ -149,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     bf16_t* Ks = (bf16_t*)smem;          // [BN][LD]
     bf16_t* Vs = Ks + BN * C::LD;        // [BN][LD] row-major; consumed through transpose reads
 
-    const int seg = blockIdx.y, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
+    const int seg = blockIdx.y + p.seg_off, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
     const int ntile = (slen + BM - 1) / BM;
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;  // heaviest (last) causal tiles first
@@ -216,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int ks = 0; ks < C::KS; ++ks) {
             bf16x8_t kf[4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) kf[kt] = ld_frag_s(Ks + perm_row(kt, li) * C::LD + ks * 32 + g * 8);
+            for (int kt = 0; kt < 4; ++kt) kf[kt] = ld_frag_t<C::LD>(Ks, perm_row(kt, li), ks * 4 + g);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -275,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             bf16x8_t vf[2][2];
             auto fetch = [&](bf16x8_t (&dst)[2], int dt) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) dst[j] = tr_frag_ld(vbase + ((j * 32) * C::LD + dt * 16) * 2, vbase + ((j * 32 + 4) * C::LD + dt * 16) * 2);
+                for (int j = 0; j < 2; ++j) dst[j] = tr_frag_ld(vbase + (j * 32) * C::LD * 2 + tr_dt_off(dt, li, g), vbase + (j * 32 + 4) * C::LD * 2 + tr_dt_off(dt, li, g));
             };
             fetch(vf[0], 0);
 #pragma unroll
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     bf16_t* Ks = (bf16_t*)smem;       // [KB][LD]  (also read transposed for dQ^T += K^T . dS^T)
     bf16_t* Vs = Ks + KB * C::LD;     // [KB][LD]
 
-    const int seg = blockIdx.y, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
+    const int seg = blockIdx.y + p.seg_off, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
     const int ntile = (slen + BM - 1) / BM;
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
@@ -411,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const int row = perm_row(kt, li);
-                const bf16x8_t kfr = ld_frag_s(Ks + row * C::LD + ks * 32 + g * 8), vfr = ld_frag_s(Vs + row * C::LD + ks * 32 + g * 8);
+                const bf16x8_t kfr = ld_frag_t<C::LD>(Ks, row, ks * 4 + g), vfr = ld_frag_t<C::LD>(Vs, row, ks * 4 + g);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     st[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[r][ks], st[r][kt], 0, 0, 0);
@@ -436,10 +468,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         {
             lds_char_t* kbase = lds_ptr(Ks) + tr_lane_off(li, g, C::LD);
             bf16x8_t kf[2];
-            kf[0] = tr_frag_ld(kbase, kbase + 4 * C::LD * 2);
+            kf[0] = tr_frag_ld(kbase + tr_dt_off(0, li, g), kbase + 4 * C::LD * 2 + tr_dt_off(0, li, g));
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) {
-                if (dt + 1 < C::DT) kf[(dt + 1) & 1] = tr_frag_ld(kbase + (dt + 1) * 32, kbase + (4 * C::LD + (dt + 1) * 16) * 2);
+                if (dt + 1 < C::DT) kf[(dt + 1) & 1] = tr_frag_ld(kbase + tr_dt_off(dt + 1, li, g), kbase + 4 * C::LD * 2 + tr_dt_off(dt + 1, li, g));
 #pragma unroll
                 for (int r = 0; r < R; ++r) acc[r][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[dt & 1], dsf[r], acc[r][dt], 0, 0, 0);
             }
@@ -461,18 +493,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // backward, part 2: dK, dV.  Block = 64 keys of one (segment, kv head); wave = 16 key columns; loops
 // over the q heads of the GQA group and over 32-row q blocks.
 // =====================================================================================================
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+template <int D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkdv_kernel(AttnArgs p) {
+    // WAVES x 16 key columns per block.  8 waves (128 keys): every staged q block feeds twice as many key columns, the block count halves, and two
+    // waves per SIMD overlap each other's LDS-read / MFMA chains (one 4-wave block per CU ran its phases back to back: 2.2 us per 32-row q block
+    // for 0.27 us of MFMA work).
     using C = Cfg<D>;
-    constexpr int BN = 64, QB = 32;
+    constexpr int BN = 16 * WAVES, QB = 32, NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Qs = (bf16_t*)smem;        // [QB][LD]  (also read transposed: dK^T += Q^T . dS)
     bf16_t* dOs = Qs + QB * C::LD;     // [QB][LD]  (also read transposed: dV^T += dO^T . P)
     float* lse_s = (float*)(dOs + QB * C::LD);    // [QB]
     float* del_s = lse_s + QB;                    // [QB]
 
-    const int hs = p.hs, kvh = blockIdx.z / hs, part = blockIdx.z % hs;
-    const int seg = blockIdx.y, group = p.Hq / p.Hkv, gph = group / hs;   // gph q heads per block
+    // grid = (key tile, kv head x head split, segment): the segment is the SLOWEST dimension of the dispatch order.  Shared-prefix segments (the prompts,
+    // first in the segment list) carry ~15x the iterations of a completion segment (their query loop runs over all G children); dispatched in
+    // (tile, segment, head) order the eight head slices of the prompts were spread over the whole launch and the last ones started 515 us into
+    // an 837 us kernel although every one of them fits on the chip at once (stamps: tools/attn_stamps.py).
+    const int hs = p.hs, kvh = blockIdx.y / hs, part = blockIdx.y % hs;
+    const int seg = blockIdx.z + p.seg_off, group = p.Hq / p.Hkv, gph = group / hs;   // gph q heads per block
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
     const int ntile = (slen + BN - 1) / BN;
     const int kt0 = blockIdx.x;  // causal: low kv tiles see the most q rows and are scheduled first
@@ -506,13 +545,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     int nq = nq_own;
     for (int cidx = 0; cidx < child_count; ++cidx) nq += (p.seg_end[child_first + cidx] - p.seg_start[child_first + cidx] + QB - 1) / QB;
     const int nit = gph * nq;                              // flattened (head, source, q block) iteration space
-    TileRegs<D, QB> qreg, doreg;
-    float lse_r = 0.f, del_r = 0.f;
-    // cursor of the NEXT block to prefetch, and the descriptor of the block being consumed
+    // TWO q blocks are in flight: the loads of block it+2 are issued while block it is computed (one block ahead left every iteration waiting for
+    // its loads: 2.16 us per iteration against 0.27 us of MFMA work, tools/attn_stamps.py).  Register sets A / B alternate; the loop is unrolled by two
+    // so that every access to them is static.
+    TileRegs<D, QB, NT> qregA, doregA, qregB, doregB;
+    float lse_rA = 0.f, del_rA = 0.f, lse_rB = 0.f, del_rB = 0.f;
+    // cursor of the NEXT block to prefetch
     int c_head = part * gph, c_src = nq_own > 0 ? -1 : 0, c_qb = 0;
-    int n_base = 0, n_rows = 0, n_rel = 0;                 // prefetched block: first global row, valid rows, causal index of row 0
-    int cur_rows = 0, cur_rel = 0;
-    auto prefetch = [&]() {
+    int rowsA = 0, relA = 0, rowsB = 0, relB = 0;
+    auto prefetch = [&](TileRegs<D, QB, NT>& qreg, TileRegs<D, QB, NT>& doreg, float& lse_r, float& del_r, int& o_rows, int& o_rel) {
         int base, rows, rel;
         if (c_src < 0) {
             const int q0 = q_begin + c_qb * QB;
@@ -532,63 +573,106 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
             lse_r = okr ? p.lse[(long long)head * p.T + base + threadIdx.x] * LOG2E : 0.f;
             del_r = okr ? p.delta[(long long)head * p.T + base + threadIdx.x] : 0.f;
         }
-        n_base = base; n_rows = rows; n_rel = rel;
+        o_rows = rows; o_rel = rel;
     };
-    if (nit > 0) prefetch();
-    for (int it = 0; it < nit; ++it) {
-        {
-            cur_rows = n_rows; cur_rel = n_rel;
-            __syncthreads();
-            qreg.store(Qs);
-            doreg.store(dOs);
-            if (threadIdx.x < QB) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
-            __syncthreads();
-            if (it + 1 < nit) prefetch();
-
-            // S[q, key] and dP[q, key]: A = Q / dO rows (permuted so a lane's registers are 8 consecutive q), B = K / V fragments
-            f32x4_t s[2], dp[2];
+#ifdef IADR1_STAMPS
+    long long ph[4] = {0, 0, 0, 0}, tph = 0;
+#define PH_BEGIN() tph = wall_clock64()
+#define PH_END(k) do { const long long now_ = wall_clock64(); ph[k] += now_ - tph; tph = now_; } while (0)
+#else
+#define PH_BEGIN() do { } while (0)
+#define PH_END(k) do { } while (0)
+#endif
+    auto compute = [&](const TileRegs<D, QB, NT>& qreg, const TileRegs<D, QB, NT>& doreg, float lse_r, float del_r, int cur_rows, int cur_rel) {
+        PH_BEGIN();
+        __syncthreads();
+        qreg.store(Qs);
+        doreg.store(dOs);
+        if (threadIdx.x < QB) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
+        __syncthreads();
+        PH_END(0);
+    };
+    auto mma = [&](int cur_rows, int cur_rel) {
+        // S[q, key] and dP[q, key]: A = Q / dO rows (permuted so a lane's registers are 8 consecutive q), B = K / V fragments
+        f32x4_t s[2], dp[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < 2; ++t) { s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks)
+        for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int row = perm_row(t, li);
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(Qs + row * C::LD + ks * 32 + g * 8), kf[ks], s[t], 0, 0, 0);
-                    dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_s(dOs + row * C::LD + ks * 32 + g * 8), vf[ks], dp[t], 0, 0, 0);
-                }
-            // lane (g, e) of tile t holds q = q0 + g*8 + t*4 + e for key column `key`
-            f32x4_t pv[2], ds[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int qi = g * 8 + t * 4 + e;
-                    const bool ok = kok && qi < cur_rows && !(p.causal && key > cur_rel + qi);
-                    const float pp = ok ? fast_exp2(__builtin_fmaf(s[t][e], c, -lse_s[qi])) : 0.f;
-                    pv[t][e] = pp;
-                    ds[t][e] = pp * (dp[t][e] - del_s[qi]);
-                }
-            const bf16x8_t pf = pack_frag(pv[0], pv[1]), dsf = pack_frag(ds[0], ds[1]);
-            {
-                const uint32_t off = tr_lane_off(li, g, C::LD);
-                lds_char_t* qbase = lds_ptr(Qs) + off;
-                lds_char_t* dobase = lds_ptr(dOs) + off;
-                bf16x8_t dof[2], qf2[2];
-                dof[0] = tr_frag_ld(dobase, dobase + 4 * C::LD * 2);
-                qf2[0] = tr_frag_ld(qbase, qbase + 4 * C::LD * 2);
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt) {
-                    if (dt + 1 < C::DT) {
-                        dof[(dt + 1) & 1] = tr_frag_ld(dobase + (dt + 1) * 32, dobase + (4 * C::LD + (dt + 1) * 16) * 2);
-                        qf2[(dt + 1) & 1] = tr_frag_ld(qbase + (dt + 1) * 32, qbase + (4 * C::LD + (dt + 1) * 16) * 2);
-                    }
-                    dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[dt & 1], pf, dvacc[dt], 0, 0, 0);
-                    dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf2[dt & 1], dsf, dkacc[dt], 0, 0, 0);
-                }
+            for (int t = 0; t < 2; ++t) {
+                const int row = perm_row(t, li);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<C::LD>(Qs, row, ks * 4 + g), kf[ks], s[t], 0, 0, 0);
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag_t<C::LD>(dOs, row, ks * 4 + g), vf[ks], dp[t], 0, 0, 0);
             }
+#ifdef IADR1_STAMPS
+        asm volatile("" :: "v"(s[0][0]), "v"(dp[1][3]));
+        PH_END(1);
+#endif
+        // lane (g, e) of tile t holds q = q0 + g*8 + t*4 + e for key column `key`
+        f32x4_t pv[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qi = g * 8 + t * 4 + e;
+                const bool ok = kok && qi < cur_rows && !(p.causal && key > cur_rel + qi);
+                const float pp = ok ? fast_exp2(__builtin_fmaf(s[t][e], c, -lse_s[qi])) : 0.f;
+                pv[t][e] = pp;
+                ds[t][e] = pp * (dp[t][e] - del_s[qi]);
+            }
+        const bf16x8_t pf = pack_frag(pv[0], pv[1]), dsf = pack_frag(ds[0], ds[1]);
+#ifdef IADR1_STAMPS
+        asm volatile("" :: "v"(pf), "v"(dsf));
+        PH_END(2);
+#endif
+        const uint32_t off = tr_lane_off(li, g, C::LD);
+        lds_char_t* qbase = lds_ptr(Qs) + off;
+        lds_char_t* dobase = lds_ptr(dOs) + off;
+        bf16x8_t dof[2], qf2[2];
+        dof[0] = tr_frag_ld(dobase + tr_dt_off(0, li, g), dobase + 4 * C::LD * 2 + tr_dt_off(0, li, g));
+        qf2[0] = tr_frag_ld(qbase + tr_dt_off(0, li, g), qbase + 4 * C::LD * 2 + tr_dt_off(0, li, g));
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            if (dt + 1 < C::DT) {
+                dof[(dt + 1) & 1] = tr_frag_ld(dobase + tr_dt_off(dt + 1, li, g), dobase + 4 * C::LD * 2 + tr_dt_off(dt + 1, li, g));
+                qf2[(dt + 1) & 1] = tr_frag_ld(qbase + tr_dt_off(dt + 1, li, g), qbase + 4 * C::LD * 2 + tr_dt_off(dt + 1, li, g));
+            }
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[dt & 1], pf, dvacc[dt], 0, 0, 0);
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf2[dt & 1], dsf, dkacc[dt], 0, 0, 0);
+        }
+#ifdef IADR1_STAMPS
+        asm volatile("" :: "v"(dvacc[C::DT - 1][0]), "v"(dkacc[C::DT - 1][3]));
+        PH_END(3);
+#endif
+    };
+    if (nit > 0) prefetch(qregA, doregA, lse_rA, del_rA, rowsA, relA);
+    if (nit > 1) prefetch(qregB, doregB, lse_rB, del_rB, rowsB, relB);
+#ifdef IADR1_STAMPS
+    if (threadIdx.x == 0) g_stamps[6][(blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & 4095] = (unsigned long long)nit;
+    if (threadIdx.x == 0) g_stamps[4][(blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & 4095] = wall_clock64();
+#endif
+    for (int it = 0; it < nit; it += 2) {
+        {
+            const int cr = rowsA, cl = relA;
+            compute(qregA, doregA, lse_rA, del_rA, cr, cl);          // block `it` -> LDS (its registers are free again)
+            if (it + 2 < nit) prefetch(qregA, doregA, lse_rA, del_rA, rowsA, relA);
+            mma(cr, cl);
+        }
+        if (it + 1 < nit) {
+            const int cr = rowsB, cl = relB;
+            compute(qregB, doregB, lse_rB, del_rB, cr, cl);
+            if (it + 3 < nit) prefetch(qregB, doregB, lse_rB, del_rB, rowsB, relB);
+            mma(cr, cl);
         }
     }
+#ifdef IADR1_STAMPS
+    if (threadIdx.x == 0) {
+        const int sl_ = (blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & 4095;
+        g_stamps[5][sl_] = wall_clock64();
+        g_stamps[0][sl_] = ph[0]; g_stamps[1][sl_] = ph[1]; g_stamps[2][sl_] = ph[2]; g_stamps[3][sl_] = ph[3];
+    }
+#endif
     if (!kok) return;
     if (hs > 1) {
         float* wd = p.dkv_ws + ((((long long)part * p.T + s0 + key) * p.Hkv + kvh) * 2) * D;
@@ -612,7 +696,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
 // sum of the `hs` head-split partials of dK/dV (fixed order) -> bf16; one thread per 4 consecutive d of one (token, kv head, k|v)
 template <int D>
 __global__ __launch_bounds__(256) void attn_dkdv_reduce_kernel(AttnArgs p) {
-    const int seg = blockIdx.y;
+    const int seg = blockIdx.y + p.seg_off;
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
     const int per_tok = p.Hkv * 2 * (D / 4);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)slen * per_tok; i += (long long)gridDim.x * 256) {
@@ -850,8 +934,23 @@ static int check_common(int T, int Hq, int Hkv, int D, long long ldq, long long 
     return IADR1_OK;
 }
 
+// Launch ranges of a segment list.  nseg_head > 0: the first nseg_head segments may be up to max_seqlen long, the remaining ones at most
+// max_seqlen_tail (shared-prefix batches: 8 prompts of 512 tokens in front of 64 completions of 256).  One grid sized for the longest segment
+// dispatched thousands of empty blocks for the short ones, and workgroup dispatch (~90 ns each, measured with in-kernel stamps) was the time of
+// the short-segment part of the backward kernels.
+struct SegRange { int off, n, maxlen; };
+static int seg_ranges(int nseg, int max_seqlen, int nseg_head, int max_seqlen_tail, SegRange out[2]) {
+    if (nseg_head > 0 && nseg_head < nseg && max_seqlen_tail > 0 && max_seqlen_tail <= max_seqlen) {
+        out[0] = SegRange{0, nseg_head, max_seqlen};
+        out[1] = SegRange{nseg_head, nseg - nseg_head, max_seqlen_tail};
+        return 2;
+    }
+    out[0] = SegRange{0, nseg, max_seqlen};
+    return 1;
+}
+
 extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start, const int* seg_end,
-                              const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
+                              const int* seg_prefix, int nseg, int max_seqlen, int nseg_head, int max_seqlen_tail, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
                               long long ldo, int causal, float scale, hipStream_t stream) {
     if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
     IADR1_REQUIRE(nseg > 0 && max_seqlen > 0, "attn_fwd: empty segment list");
@@ -860,23 +959,30 @@ extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void*
     p.seg_start = seg_start; p.seg_end = seg_end; p.seg_prefix = seg_prefix; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     static const int force_r = iadr1_env_int("IADR1_ATTN_R", 1);
-    // 64-row q tiles (R=1, ~180 VGPR, 2 blocks/CU) measured 1.4x faster than 128-row tiles (R=2, 1 block/CU): occupancy wins
-    const bool small = max_seqlen <= 64 || force_r == 1;
+    SegRange rg[2];
+    const int nr = seg_ranges(nseg, max_seqlen, nseg_head, max_seqlen_tail, rg);
+    for (int ri = 0; ri < nr; ++ri) {
+        p.seg_off = rg[ri].off;
+        const int ml = rg[ri].maxlen, ns = rg[ri].n;
+        // 64-row q tiles (R=1, ~180 VGPR, 2 blocks/CU) measured 1.4x faster than 128-row tiles (R=2, 1 block/CU): occupancy wins
+        const bool small = ml <= 64 || force_r == 1;
 #define LAUNCH_FWD(DD, RR)                                                                                           \
     do {                                                                                                             \
         const int smem = (2 * 64 * Cfg<DD>::LD) * 2;                                                                 \
         set_smem(attn_fwd_kernel<DD, RR>, smem);                                                                     \
         const int bm = 64 * RR;                                                                                      \
-        hipLaunchKernelGGL((attn_fwd_kernel<DD, RR>), dim3((max_seqlen + bm - 1) / bm, nseg, Hq), dim3(256), smem, stream, p); \
+        hipLaunchKernelGGL((attn_fwd_kernel<DD, RR>), dim3((ml + bm - 1) / bm, ns, Hq), dim3(256), smem, stream, p); \
     } while (0)
-    if (D == 128) { if (small) LAUNCH_FWD(128, 1); else LAUNCH_FWD(128, 2); }
-    else { if (small) LAUNCH_FWD(80, 1); else LAUNCH_FWD(80, 2); }
+        if (D == 128) { if (small) LAUNCH_FWD(128, 1); else LAUNCH_FWD(128, 2); }
+        else { if (small) LAUNCH_FWD(80, 1); else LAUNCH_FWD(80, 2); }
 #undef LAUNCH_FWD
+    }
     return iadr1_check_launch("attn_fwd");
 }
 
 extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta,
-                              void* dq, void* dk, void* dv, float* dkv_ws, int head_splits, const int* seg_start, const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T,
+                              void* dq, void* dk, void* dv, float* dkv_ws, int head_splits, const int* seg_start, const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen,
+                              int nseg_head, int max_seqlen_tail, int T,
                               int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv, long long ldo, long long lddo,
                               long long lddq, long long lddk, long long lddv, int causal, float scale, hipStream_t stream) {
     if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
@@ -888,27 +994,42 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
     p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
-    const int hs = (dkv_ws && head_splits > 1) ? head_splits : 1;
-    IADR1_REQUIRE((Hq / Hkv) % hs == 0, "attn_bwd: head_splits=%d must divide the GQA group %d", hs, Hq / Hkv);
-    p.dkv_ws = dkv_ws; p.hs = hs;
+    const int hs_all = (dkv_ws && head_splits > 1) ? head_splits : 1;
+    IADR1_REQUIRE((Hq / Hkv) % hs_all == 0, "attn_bwd: head_splits=%d must divide the GQA group %d", hs_all, Hq / Hkv);
+    p.dkv_ws = dkv_ws;
     const long long items = (long long)T * Hq * 16;
     static const int dq_r = iadr1_env_int("IADR1_ATTN_BWD_R", 2);
+    static const int kv_waves = iadr1_env_int("IADR1_ATTN_DKDV_WAVES", 8);
+    SegRange rg[2];
+    const int nr = seg_ranges(nseg, max_seqlen, nseg_head, max_seqlen_tail, rg);
 #define LAUNCH_BWD(DD)                                                                                                                   \
     do {                                                                                                                                 \
         hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)o, ldo,    \
                            (const bf16_t*)dout, lddo, delta, T, Hq);                                                                     \
-        const int smem_dq = (2 * 32 * Cfg<DD>::LD) * 2;                                                                                  \
-        if (dq_r == 2 && max_seqlen > 64) {                                                                                              \
-            set_smem(attn_bwd_dq_kernel<DD, 2>, smem_dq);                                                                                \
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, 2>), dim3((max_seqlen + 127) / 128, nseg, Hq), dim3(256), smem_dq, stream, p);    \
-        } else {                                                                                                                         \
-            set_smem(attn_bwd_dq_kernel<DD, 1>, smem_dq);                                                                                \
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, 1>), dim3((max_seqlen + 63) / 64, nseg, Hq), dim3(256), smem_dq, stream, p);      \
+        for (int ri = 0; ri < nr; ++ri) {                                                                                                \
+            p.seg_off = rg[ri].off;                                                                                                      \
+            const int ml = rg[ri].maxlen, ns = rg[ri].n;                                                                                 \
+            /* the head split of dK/dV balances the long query loops of shared-prefix segments: only the head range needs it (a short  */ \
+            /* segment split 4 ways is 4x the blocks for 9 iterations each)                                                            */ \
+            p.hs = (nr == 2 && ri == 1) ? 1 : hs_all;                                                                                    \
+            const int smem_dq = (2 * 32 * Cfg<DD>::LD) * 2;                                                                              \
+            if (dq_r == 2 && ml > 64) {                                                                                                  \
+                set_smem(attn_bwd_dq_kernel<DD, 2>, smem_dq);                                                                            \
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, 2>), dim3((ml + 127) / 128, ns, Hq), dim3(256), smem_dq, stream, p);          \
+            } else {                                                                                                                     \
+                set_smem(attn_bwd_dq_kernel<DD, 1>, smem_dq);                                                                            \
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, 1>), dim3((ml + 63) / 64, ns, Hq), dim3(256), smem_dq, stream, p);            \
+            }                                                                                                                            \
+            const int smem_kv = (2 * 32 * Cfg<DD>::LD) * 2 + 64 * 4;                                                                     \
+            if (kv_waves == 8 && ml > 64) {                                                                                              \
+                set_smem(attn_bwd_dkdv_kernel<DD, 8>, smem_kv);                                                                          \
+                hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, 8>), dim3((ml + 127) / 128, Hkv * p.hs, ns), dim3(512), smem_kv, stream, p); \
+            } else {                                                                                                                     \
+                set_smem(attn_bwd_dkdv_kernel<DD, 4>, smem_kv);                                                                          \
+                hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, 4>), dim3((ml + 63) / 64, Hkv * p.hs, ns), dim3(256), smem_kv, stream, p);  \
+            }                                                                                                                            \
+            if (p.hs > 1) hipLaunchKernelGGL(attn_dkdv_reduce_kernel<DD>, dim3((ml * Hkv * 2 * (DD / 4) + 255) / 256, ns), dim3(256), 0, stream, p); \
         }                                                                                                                                \
-        const int smem_kv = (2 * 32 * Cfg<DD>::LD) * 2 + 64 * 4;                                                                         \
-        set_smem(attn_bwd_dkdv_kernel<DD>, smem_kv);                                                                                     \
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DD>, dim3((max_seqlen + 63) / 64, nseg, Hkv * hs), dim3(256), smem_kv, stream, p);       \
-        if (hs > 1) hipLaunchKernelGGL(attn_dkdv_reduce_kernel<DD>, dim3((max_seqlen * Hkv * 2 * (DD / 4) + 255) / 256, nseg), dim3(256), 0, stream, p); \
     } while (0)
     if (D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(80);
 #undef LAUNCH_BWD
@@ -961,3 +1082,16 @@ extern "C" int iadr1_rope_kv_store(void* qkv, long long ld, const float* cos_t, 
 }
 
 IADR1_STAMPS_EXPORT(attn)
+#ifdef IADR1_STAMPS
+// probe builds only: blocks per CU the runtime admits for the attention kernels at their launch configuration
+extern "C" int iadr1_debug_attn_occupancy(int* out6) {
+    const int smem_kv = (2 * 32 * Cfg<128>::LD) * 2 + 64 * 4, smem_dq = (2 * 32 * Cfg<128>::LD) * 2, smem_f = (2 * 64 * Cfg<128>::LD) * 2;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out6[0], attn_bwd_dkdv_kernel<128, 4>, 256, smem_kv);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out6[1], attn_bwd_dkdv_kernel<128, 8>, 512, smem_kv);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out6[2], attn_bwd_dq_kernel<128, 1>, 256, smem_dq);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out6[3], attn_bwd_dq_kernel<128, 2>, 256, smem_dq);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out6[4], attn_fwd_kernel<128, 1>, 256, smem_f);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&out6[5], attn_fwd_kernel<128, 2>, 256, smem_f);
+    return 0;
+}
+#endif

@@ -322,9 +322,15 @@ class Segments:
         self.start = torch.tensor(starts, dtype=torch.int32, device=device)
         self.end = torch.tensor(ends, dtype=torch.int32, device=device)
         self.prefix = None
+        # launch hint (include/iadr1_hip.h nseg_head / max_seqlen_tail): a leading run of long segments followed by shorter ones
+        self.n_head, self.max_tail = 0, 0
         if prefix is not None:
             assert len(prefix) == self.n and all(e > s for s, e in zip(starts, ends)), "shared-prefix segments must be non-empty"
             self.prefix = torch.tensor(prefix, dtype=torch.int32, device=device).contiguous()
+            parents = [i for i, pr in enumerate(prefix) if pr[3] > 0]
+            nh = (max(parents) + 1) if parents else 0
+            if 0 < nh < self.n and parents == list(range(nh)):
+                self.n_head, self.max_tail = nh, max(e - s for s, e in zip(starts[nh:], ends[nh:]))
 
     def covers(self, r0, r1):
         """True when every row of [r0, r1) lies in a segment (no left / post-EOS padding rows)."""
@@ -339,7 +345,7 @@ def attn_fwd(q, k, v, seg: Segments, Hq, Hkv, D, causal, scale, out=None, want_l
     T = q.shape[0]
     o = out if out is not None else torch.zeros(T, Hq * D, dtype=BF16, device=q.device)
     lse = torch.empty(Hq, T, dtype=F32, device=q.device) if want_lse else None
-    hip.call("attn_fwd", q, k, v, o, lse, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, T, Hq, Hkv, D, _ld(q), _ld(k), _ld(v), _ld(o), 1 if causal else 0, float(scale))
+    hip.call("attn_fwd", q, k, v, o, lse, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, seg.n_head, seg.max_tail, T, Hq, Hkv, D, _ld(q), _ld(k), _ld(v), _ld(o), 1 if causal else 0, float(scale))
     return o, lse
 
 
@@ -361,7 +367,7 @@ def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq
     if seg.prefix is not None:   # shared-prefix segments: split the long query loops of the prefix blocks over the q heads of the group
         hs = 4 if group % 4 == 0 else (group if 1 < group <= 8 else 1)
     ws = _dkv_workspace(hs * T * Hkv * 2 * D, q.device) if hs > 1 else None
-    hip.call("attn_bwd", q, k, v, o, dout, lse, delta, dq, dk, dv, ws, hs, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, T, Hq, Hkv, D,
+    hip.call("attn_bwd", q, k, v, o, dout, lse, delta, dq, dk, dv, ws, hs, seg.start, seg.end, seg.prefix, seg.n, seg.max_len, seg.n_head, seg.max_tail, T, Hq, Hkv, D,
              _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout), _ld(dq), _ld(dk), _ld(dv), 1 if causal else 0, float(scale))
 
 

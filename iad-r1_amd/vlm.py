@@ -483,7 +483,7 @@ class Engine:
             # attention addresses rows absolutely: the keys of a completion segment live in the prompt rows written by the other phase
             qkv_all, o_all = full("qkv"), full("o")
             ops.hip.call("attn_fwd", qkv_all[:, :qw], qkv_all[:, qw: qw + kw], qkv_all[:, qw + kw:], o_all, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
-                         T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, float(D**-0.5))
+                         plan.seg.n_head, plan.seg.max_tail, T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, float(D**-0.5))
             ab = ops.gemm_nt(o, P.w(b + "o.w"))
             x_mid = buf("x_mid") if save else x_in
             h2 = buf("h2")

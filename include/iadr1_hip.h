@@ -155,13 +155,16 @@ int iadr1_f32_bias_to_bf16(float* in_zeroed_after, const void* bias, void* out, 
  * (their queries contribute to segment i's dK/dV); segments must be non-empty; max_seqlen covers own lengths only.
  * dkv_ws / head_splits (backward): NULL / 1, or an fp32 scratch of head_splits*T*Hkv*2*D floats: the q heads of each GQA group
  * are then split over head_splits dK/dV blocks (the query loop of a shared prefix block is G+1 segments long) and the partials
- * are summed in a fixed order -- deterministic, no atomics. */
+ * are summed in a fixed order -- deterministic, no atomics.
+ * nseg_head / max_seqlen_tail: 0 / 0, or a hint about the segment lengths: the first nseg_head segments are at most max_seqlen long, the
+ * others at most max_seqlen_tail (<= max_seqlen).  The two ranges are then launched with their own grids (no empty blocks for the short
+ * segments; with shared prefixes the head split applies to the head range, which must hold every segment that has children). */
 int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start,
-                   const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq,
+                   const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int nseg_head, int max_seqlen_tail, int T, int Hq, int Hkv, int D, long long ldq,
                    long long ldk, long long ldv, long long ldo, int causal, float scale, iadr1_stream_t stream);
 int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    float* delta, void* dq, void* dk, void* dv, float* dkv_ws, int head_splits, const int* seg_start,
-                   const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
+                   const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int nseg_head, int max_seqlen_tail, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
                    long long ldo, long long lddo, long long lddq, long long lddk, long long lddv, int causal,
                    float scale, iadr1_stream_t stream);
 /* Paged-KV decode attention + cache writes for the group rollout (vLLM's role at REF:...sc_grpo_trainer.py:

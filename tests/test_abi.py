@@ -26,5 +26,5 @@ def test_argument_errors_are_reported_without_a_gpu():
     L = hip.lib()
     rc = L.iadr1_gemm_nt_bf16(None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, None)
     assert rc < 0 and b"gemm_nt" in L.iadr1_last_error()
-    rc = L.iadr1_attn_fwd(None, None, None, None, None, None, None, None, 1, 1, 4, 2, 1, 64, 8, 8, 8, 8, 1, 1.0, None)
+    rc = L.iadr1_attn_fwd(None, None, None, None, None, None, None, None, 1, 1, 0, 0, 4, 2, 1, 64, 8, 8, 8, 8, 1, 1.0, None)
     assert rc < 0 and b"head dim" in L.iadr1_last_error()
