@@ -611,16 +611,34 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #endif
         // lane (g, e) of tile t holds q = q0 + g*8 + t*4 + e for key column `key`
         f32x4_t pv[2], ds[2];
+        // the q block is fully visible to every key of this block (all rows valid, no causal cut): the common case -- every block of a child
+        // segment and every own block below the diagonal -- needs no per-element predicate.  Block-uniform, so no divergence.
+        const bool all_visible = cur_rows >= QB && (!p.causal || cur_rel >= kv0 + BN - 1);
+        f32x4_t l4[2], d4[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) { l4[t] = *(const f32x4_t*)(lse_s + g * 8 + t * 4); d4[t] = *(const f32x4_t*)(del_s + g * 8 + t * 4); }
+        if (all_visible) {
+            const float km = kok ? 1.f : 0.f;     // key columns past the segment end contribute nothing
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int qi = g * 8 + t * 4 + e;
-                const bool ok = kok && qi < cur_rows && !(p.causal && key > cur_rel + qi);
-                const float pp = ok ? fast_exp2(__builtin_fmaf(s[t][e], c, -lse_s[qi])) : 0.f;
-                pv[t][e] = pp;
-                ds[t][e] = pp * (dp[t][e] - del_s[qi]);
-            }
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pp = km * fast_exp2(__builtin_fmaf(s[t][e], c, -l4[t][e]));
+                    pv[t][e] = pp;
+                    ds[t][e] = pp * (dp[t][e] - d4[t][e]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qi = g * 8 + t * 4 + e;
+                    const bool ok = kok && qi < cur_rows && !(p.causal && key > cur_rel + qi);
+                    const float pp = ok ? fast_exp2(__builtin_fmaf(s[t][e], c, -l4[t][e])) : 0.f;
+                    pv[t][e] = pp;
+                    ds[t][e] = pp * (dp[t][e] - d4[t][e]);
+                }
+        }
         const bf16x8_t pf = pack_frag(pv[0], pv[1]), dsf = pack_frag(ds[0], ds[1]);
 #ifdef IADR1_STAMPS
         asm volatile("" :: "v"(pf), "v"(dsf));

@@ -47,11 +47,13 @@ def grpo_loss(logps, ref_logps, advantages, completion_mask, beta):
 
 
 def sc_grpo_step(policy, ref, prompt_ids, prompt_mask, pixel_values, image_grid_thw, completions, rewards_per_func, G, beta, eos_token_id, pad_token_id,
-                 max_prompt_length=None, interleaved=False, images_per_prompt=None):
+                 max_prompt_length=None, interleaved=False, images_per_prompt=None, rotate_right_padded_rows=False):
     """One micro-step for B prompts x G completions.  Default: TILE order for tensors as the reference (sc_grpo_trainer.py:625-628; equal to
     interleaved at B=1, the only batch size its scripts use).  interleaved=True: prompt-major order (p0 x G, p1 x G, ...) everywhere -- the
     consistent reading of SURVEY.md Appendix B.1 the engine uses for B > 1; `completions` / `rewards_per_func` are then prompt-major too.
     max_prompt_length: the left truncation of sc_grpo_trainer.py:630-634 (ids and mask only).
+    rotate_right_padded_rows: the llava branches of `_get_per_token_logps` (sc_grpo_trainer.py:502-504 -> :516-567): rows that end in padding and carry
+    no left padding are rotated before the model runs, while the log-probs are still sliced and masked at the un-rotated columns.
     `completions` = list of id lists, `rewards_per_func` = [B*G, n_funcs] already evaluated on the decoded strings."""
     grids_p = [tuple(int(z) for z in g) for g in image_grid_thw]
     if max_prompt_length is not None:
@@ -77,9 +79,13 @@ def sc_grpo_step(policy, ref, prompt_ids, prompt_mask, pixel_values, image_grid_
     ids = torch.cat([p_ids, comp], 1)
     mask = torch.cat([p_mask, cmask], 1)
     P = p_ids.shape[1]
-    logps = policy.per_token_logps(ids, mask, pv, grids)[:, P - 1:]
+    m_ids, m_mask = ids, mask
+    if rotate_right_padded_rows:
+        from .llava_ov import ensure_left_padding
+        m_ids, m_mask = ensure_left_padding(ids, mask, pad_token_id)
+    logps = policy.per_token_logps(m_ids, m_mask, pv, grids)[:, P - 1:]
     with torch.no_grad():
-        ref_logps = ref.per_token_logps(ids, mask, pv, grids)[:, P - 1:]
+        ref_logps = ref.per_token_logps(m_ids, m_mask, pv, grids)[:, P - 1:]
     rewards = rewards_per_func.sum(1)
     adv, std = group_advantages(rewards, G)
     loss, kl, mean_kl = grpo_loss(logps, ref_logps, adv, cmask, beta)

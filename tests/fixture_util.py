@@ -279,3 +279,83 @@ def prepare_examples():
           "image": [synth_pil_image(300, 200, 2), synth_pil_image(448, 336, 3)], "solution": "s1"}],
         [{"prompt": "<|im_start|>user\n<|vision_start|><|image_pad|><|vision_end|>plain string prompt<|im_end|>\n<|im_start|>assistant\n", "image": [synth_pil_image(224, 224, 4)], "solution": "s2"}],
     ]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# LLaVA-OneVision structure (BASELINE.json config 5: LLaVA-OV-SI-7B; the reference's model switch sc_grpo_trainer.py:124-132): SigLIP tower with
+# the real head size 72 (2 heads -> width 144), LayerNorm + GELU(tanh) MLP, learned positions, 4 x 4 tokens per 56-pixel crop; Linear-GELU-Linear
+# projector; any-resolution crop grid; Qwen2 decoder (untied head, 1-D rotary).  Checkpoint names as transformers 4.51.3 (the reference's pin) writes them.
+# ------------------------------------------------------------------------------------------------------------------------------------
+TINY_OV = {
+    "text": dict(TINY["text"]),
+    "vision": {"arch": "siglip", "depth": 2, "hidden_size": 144, "intermediate_size": 256, "num_heads": 2, "in_channels": 3, "patch_size": 14, "image_size": 56,
+               "layer_norm_eps": 1e-6},
+    "image_grid_pinpoints": [[56, 56], [56, 112], [112, 56], [112, 112], [168, 112], [112, 168], [168, 168], [224, 224], [280, 280]],
+    "anyres_max": 9,
+    "image_token_id": 630, "video_token_id": 631, "vision_start_token_id": 628, "vision_end_token_id": 629,
+    "eos_token_id": 1, "pad_token_id": 2, "tie_word_embeddings": False,
+}
+
+
+def param_shapes_ov(cfg: dict) -> dict[str, tuple[int, ...]]:
+    t, v = cfg["text"], cfg["vision"]
+    h, inter = t["hidden_size"], t["intermediate_size"]
+    hd = h // t["num_attention_heads"]
+    kvd = hd * t["num_key_value_heads"]
+    vh, vi, p = v["hidden_size"], v["intermediate_size"], v["patch_size"]
+    npos = (v["image_size"] // p) ** 2
+    s: dict[str, tuple[int, ...]] = {}
+    pre = "vision_tower.vision_model."
+    s[pre + "embeddings.patch_embedding.weight"] = (vh, v["in_channels"], p, p)
+    s[pre + "embeddings.patch_embedding.bias"] = (vh,)
+    s[pre + "embeddings.position_embedding.weight"] = (npos, vh)
+    for i in range(v["depth"]):
+        b = f"{pre}encoder.layers.{i}."
+        for ln in ("layer_norm1", "layer_norm2"):
+            s[b + ln + ".weight"] = (vh,)
+            s[b + ln + ".bias"] = (vh,)
+        for z in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[b + f"self_attn.{z}.weight"] = (vh, vh)
+            s[b + f"self_attn.{z}.bias"] = (vh,)
+        s[b + "mlp.fc1.weight"], s[b + "mlp.fc1.bias"] = (vi, vh), (vi,)
+        s[b + "mlp.fc2.weight"], s[b + "mlp.fc2.bias"] = (vh, vi), (vh,)
+    s["multi_modal_projector.linear_1.weight"], s["multi_modal_projector.linear_1.bias"] = (h, vh), (h,)
+    s["multi_modal_projector.linear_2.weight"], s["multi_modal_projector.linear_2.bias"] = (h, h), (h,)
+    s["image_newline"] = (h,)
+    s["language_model.model.embed_tokens.weight"] = (t["vocab_size"], h)
+    for i in range(t["num_hidden_layers"]):
+        b = f"language_model.model.layers.{i}."
+        s[b + "input_layernorm.weight"] = (h,)
+        s[b + "self_attn.q_proj.weight"], s[b + "self_attn.q_proj.bias"] = (h, h), (h,)
+        s[b + "self_attn.k_proj.weight"], s[b + "self_attn.k_proj.bias"] = (kvd, h), (kvd,)
+        s[b + "self_attn.v_proj.weight"], s[b + "self_attn.v_proj.bias"] = (kvd, h), (kvd,)
+        s[b + "self_attn.o_proj.weight"] = (h, h)
+        s[b + "post_attention_layernorm.weight"] = (h,)
+        s[b + "mlp.gate_proj.weight"], s[b + "mlp.up_proj.weight"], s[b + "mlp.down_proj.weight"] = (inter, h), (inter, h), (h, inter)
+    s["language_model.model.norm.weight"] = (h,)
+    if not cfg.get("tie_word_embeddings", False):
+        s["language_model.lm_head.weight"] = (t["vocab_size"], h)
+    return s
+
+
+def make_weights_ov(cfg: dict, seed: int = 0, std: float = 0.05) -> dict[str, np.ndarray]:
+    out = {}
+    for name, shape in param_shapes_ov(cfg).items():
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        x = rs.standard_normal(shape).astype(np.float32)
+        if "layer_norm" in name and name.endswith(".weight") or name.endswith("layernorm.weight") or name.endswith("norm.weight"):
+            x = 1.0 + 0.1 * x
+        elif name.endswith(".bias"):
+            x = 0.02 * x
+        elif name == "image_newline":
+            x = 0.06 * x
+        else:
+            x = std * x
+        out[name] = _bf16_round(x)
+    return out
+
+
+def synth_crops(n_crops: int, cfg: dict, seed: int) -> np.ndarray:
+    """Processor-shaped crops [n, 3, S, S] fp32, bf16-representable, ~N(0,1) (normalised pixels)."""
+    s = cfg["vision"]["image_size"]
+    return _bf16_round(np.random.RandomState(seed).standard_normal((n_crops, cfg["vision"]["in_channels"], s, s)).astype(np.float32))

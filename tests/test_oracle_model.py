@@ -187,3 +187,77 @@ def test_qwen2vl_variant(golden_dir):
         opt.step()
         losses.append(loss.item())
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
+
+
+def test_llava_onevision_forward(golden_dir):
+    """oracle/llava_ov.py (SigLIP tower, projector, any-resolution packing incl. the bilinear shrink, Qwen2 decoder) vs a tiny HF
+    LlavaOnevisionForConditionalGeneration (tests/golden/llava_ov.npz), and the product's host-side packing plan (iadr1_amd.llava_ov) vs both."""
+    from oracle import llava_ov as oo
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import llava_ov as lo
+    g = _load(golden_dir, "llava_ov.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = fx.TINY_OV
+    m = oo.LlavaOVOracle(cfg, fx.make_weights_ov(cfg, 0))
+    sizes = [tuple(s) for s in meta["sizes"]]
+    pv = torch.from_numpy(fx.synth_crops(meta["crops"], cfg, meta["seed"]))
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    with torch.no_grad():
+        feats = m.visual(pv, sizes)
+        np.testing.assert_allclose(feats.numpy(), g["image_features"], rtol=1e-3, atol=2e-4)
+        lg = m.logits(ids, mask, pv, sizes)
+        np.testing.assert_allclose(lg[:, -1].numpy(), g["logits_last"], rtol=1e-3, atol=1e-3)
+        lp = m.per_token_logps(ids, mask, pv, sizes)
+    valid = (mask[:, 1:] * mask[:, :-1]).bool().numpy()
+    np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=3e-4)
+    # host plan of the product: token counts per image, crop counts, and the sparse map itself applied to the oracle's projector rows
+    v = cfg["vision"]
+    side = v["image_size"] // v["patch_size"]
+    plan = lo.pack_plan(sizes, cfg["image_grid_pinpoints"], v["image_size"], side, cfg["anyres_max"])
+    assert plan["lens"] == g["feature_lens"].tolist() and sum(plan["crops"]) == meta["crops"]
+    assert [int((ids[b] == cfg["image_token_id"]).sum()) for b in range(2)] == plan["lens"]
+    with torch.no_grad():
+        src = torch.cat([m.project(m.tower(pv)).reshape(-1, cfg["text"]["hidden_size"]), m.w["image_newline"][None]], 0)
+    T = len(plan["ptr"]) - 1
+    rows = np.repeat(np.arange(T), np.diff(plan["ptr"]))
+    packed = torch.zeros(T, src.shape[1]).index_add_(0, torch.from_numpy(rows), src[torch.from_numpy(plan["idx"]).long()] * torch.from_numpy(plan["w"])[:, None])
+    np.testing.assert_allclose(packed.numpy(), g["image_features"], rtol=1e-3, atol=2e-4)
+    tp = lo.transpose_plan(plan)                                  # the backward map is the exact transpose
+    dense = np.zeros((T, plan["n_src"])); dense[rows, plan["idx"]] += plan["w"]
+    rows_t = np.repeat(np.arange(plan["n_src"]), np.diff(tp["ptr"]))
+    dense_t = np.zeros((plan["n_src"], T)); dense_t[rows_t, tp["idx"]] += tp["w"]
+    assert np.array_equal(dense.T, dense_t)
+
+
+def test_llava_onevision_sc_grpo_compute_loss(golden_dir):
+    """The reference's compute_loss on its llava branch (model id containing "llava_ov": `_ensure_left_padding_data` rotates the rows whose completion
+    ended early, REF:502-504,516-567) vs oracle.sc_grpo.sc_grpo_step(rotate_right_padded_rows=True)."""
+    from oracle import llava_ov as oo
+    g = _load(golden_dir, "sc_grpo_llava_ov.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = fx.TINY_OV
+    G, C, seed = meta["G"], meta["C"], meta["seed"]
+    w_ref = fx.make_weights_ov(cfg, 0)
+    pol = oo.LlavaOVOracle(cfg, fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"]), requires_grad=True)
+    ref = oo.LlavaOVOracle(cfg, w_ref)
+    sizes = [tuple(s) for s in meta["sizes"]]
+    P = g["prompt_completion_ids"].shape[1] - C
+    ids, mask = g["prompt_completion_ids"][:1, :P], g["attention_mask"][:1, :P]
+    pv = torch.from_numpy(fx.synth_crops(meta["crops"], cfg, seed))
+    comps = fx.synth_completions(G, C, cfg, seed + 100, {int(k): v for k, v in meta["eos_rows"].items()})
+    out = og.sc_grpo_step(pol, ref, torch.from_numpy(ids), torch.from_numpy(mask), pv, sizes, comps, torch.from_numpy(g["rewards_per_func"]), G, 0.04,
+                          cfg["eos_token_id"], cfg["pad_token_id"], rotate_right_padded_rows=True)
+    assert np.array_equal(out["ids"].numpy(), g["prompt_completion_ids"]) and np.array_equal(out["completion_mask"].numpy(), g["completion_mask"])
+    np.testing.assert_allclose(out["logps"].detach().numpy(), g["per_token_logps"], rtol=1e-4, atol=3e-4)
+    np.testing.assert_allclose(out["ref_logps"].numpy(), g["ref_per_token_logps"], rtol=1e-4, atol=3e-4)
+    np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=1e-5, atol=1e-6)
+    assert abs(out["loss"].item() - float(g["loss"])) < 5e-6 and abs(out["metrics"]["kl"] - float(g["metric_kl"])) < 5e-5
+    # without the rotation the rows that ended early differ: the quirk is really exercised by this fixture
+    plain = og.sc_grpo_step(oo.LlavaOVOracle(cfg, fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"])), ref, torch.from_numpy(ids), torch.from_numpy(mask), pv, sizes, comps,
+                            torch.from_numpy(g["rewards_per_func"]), G, 0.04, cfg["eos_token_id"], cfg["pad_token_id"])
+    assert abs(plain["loss"].item() - float(g["loss"])) > 1e-4
+    out["loss"].backward()
+    grads = dict(pol.parameters())
+    for n, ref_norm in zip([str(n) for n in g["grad_norm_names"]], g["grad_norms"]):
+        if ref_norm > 1e-9:
+            assert abs(float(grads[n].grad.norm()) - ref_norm) <= 3e-3 * ref_norm + 1e-7, n

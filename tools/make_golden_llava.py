@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Golden vectors of the LLaVA-OneVision branch (BASELINE.json config 5), captured in the build container from
+  * a tiny random-init transformers `LlavaOnevisionForConditionalGeneration` (the arithmetic of the reference's pinned dependency), and
+  * the reference's own `SCGRPOTrainer.compute_loss` driven with that model under a model id containing "llava_ov", so that the llava-only
+    code path `_ensure_left_padding_data` (REF train/stage_rl/trainer/sc_grpo_trainer.py:502-504,516-567) is part of what is pinned.
+Writes tests/golden/llava_ov.npz and tests/golden/sc_grpo_llava_ov.npz.  Run here only (imports /root/reference)."""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+import make_golden as mg  # noqa: E402  (reference import helpers, mock trainer)
+
+fx = mg.fx
+OUT = mg.OUT
+
+
+def hf_name(k):
+    if k.startswith("vision_tower.vision_model."):
+        return "model.vision_tower." + k[len("vision_tower.vision_model."):]
+    if k.startswith("multi_modal_projector."):
+        return "model." + k
+    if k == "image_newline":
+        return "model.image_newline"
+    if k.startswith("language_model.model."):
+        return "model.language_model." + k[len("language_model.model."):]
+    if k == "language_model.lm_head.weight":
+        return "lm_head.weight"
+    raise KeyError(k)
+
+
+def build_hf(cfg, weights):
+    from transformers import LlavaOnevisionConfig, LlavaOnevisionForConditionalGeneration
+    from transformers.models.qwen2.configuration_qwen2 import Qwen2Config
+    from transformers.models.siglip.configuration_siglip import SiglipVisionConfig
+    t, v = cfg["text"], cfg["vision"]
+    vc = SiglipVisionConfig(hidden_size=v["hidden_size"], intermediate_size=v["intermediate_size"], num_hidden_layers=v["depth"], num_attention_heads=v["num_heads"],
+                            image_size=v["image_size"], patch_size=v["patch_size"], layer_norm_eps=v["layer_norm_eps"])
+    tc = Qwen2Config(vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"], num_hidden_layers=t["num_hidden_layers"],
+                     num_attention_heads=t["num_attention_heads"], num_key_value_heads=t["num_key_value_heads"], rms_norm_eps=t["rms_norm_eps"], rope_theta=t["rope_theta"],
+                     tie_word_embeddings=cfg["tie_word_embeddings"], max_position_embeddings=4096)
+    c = LlavaOnevisionConfig(vision_config=vc, text_config=tc, image_token_index=cfg["image_token_id"], image_grid_pinpoints=cfg["image_grid_pinpoints"],
+                             vision_feature_layer=-1, vision_feature_select_strategy="full", vision_aspect_ratio=f"anyres_max_{cfg['anyres_max']}", tie_word_embeddings=cfg["tie_word_embeddings"])
+    m = LlavaOnevisionForConditionalGeneration(c)
+    m.config._attn_implementation = "eager"
+    sd = m.state_dict()
+    new = {hf_name(k): torch.from_numpy(np.asarray(a)).float() for k, a in weights.items()}
+    missing = [k for k in sd if k not in new and "post_layernorm" not in k and ".head." not in k]
+    assert not missing, missing[:5]
+    m.load_state_dict(new, strict=False)
+    return m.float()
+
+
+def tiny_ov_batch(cfg, sizes, n_texts, seed):
+    import iadr1_amd  # noqa: F401  (the product's host plan gives the token counts the processor would reserve)
+    from iadr1_amd import llava_ov as lo
+    v = cfg["vision"]
+    side = v["image_size"] // v["patch_size"]
+    rs = np.random.RandomState(seed)
+    rows, crops = [], 0
+    for sz, nt in zip(sizes, n_texts):
+        n_img = lo.num_image_tokens(sz, cfg["image_grid_pinpoints"], v["image_size"], side, cfg["anyres_max"])
+        rows.append(rs.randint(3, 600, 3).tolist() + [cfg["image_token_id"]] * n_img + rs.randint(3, 600, nt).tolist())
+        crops += lo.num_crops(sz, cfg["image_grid_pinpoints"], v["image_size"])
+    ids, mask = fx.left_pad(rows, cfg["pad_token_id"])
+    return ids, mask, fx.synth_crops(crops, cfg, seed), crops
+
+
+def gen_forward():
+    cfg = fx.TINY_OV
+    w = fx.make_weights_ov(cfg, 0)
+    m = build_hf(cfg, w).eval()
+    sizes = [(80, 100), (400, 380)]            # 2 x 2 crop grid; 5 x 5 grid (26 crops: shrunk by bilinear interpolation above anyres_max_9)
+    ids, mask, pv, ncrops = tiny_ov_batch(cfg, sizes, [6, 11], seed=31)
+    with torch.no_grad():
+        feats = m.model.get_image_features(torch.from_numpy(pv), torch.tensor(sizes), vision_feature_layer=-1, vision_feature_select_strategy="full").pooler_output
+        out = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), pixel_values=torch.from_numpy(pv), image_sizes=torch.tensor(sizes))
+        lp = torch.log_softmax(out.logits[:, :-1].float(), -1).gather(-1, torch.from_numpy(ids)[:, 1:].unsqueeze(-1)).squeeze(-1)
+    np.savez_compressed(os.path.join(OUT, "llava_ov.npz"), meta=json.dumps({**mg.meta(), "sizes": sizes, "n_text": [6, 11], "seed": 31, "crops": ncrops}),
+                        input_ids=ids, attention_mask=mask, image_features=torch.cat(list(feats), 0).numpy(), feature_lens=np.array([f.shape[0] for f in feats]),
+                        logits_last=out.logits[:, -1].numpy(), per_token_logps=lp.numpy())
+    print("llava_ov.npz: feature lens", [f.shape[0] for f in feats], "ids", ids.shape)
+
+
+class OVProcessor(mg.FakeProcessor):
+    """Mock processor for the llava branch: hands over pixel_values / image_sizes; `tokenizer.pad_token_id` is what _ensure_left_padding_data reads."""
+
+    def __init__(self, cfg, batch, texts):
+        self.cfg, self.batch = cfg, dict(batch)
+        self.pad_token_id, self.eos_token_id = cfg["pad_token_id"], cfg["eos_token_id"]
+        self.tokenizer = self
+        self._texts = texts
+        self.chat_template = "x"
+
+
+def gen_sc_grpo(SCGRPOTrainer, reward):
+    cfg = fx.TINY_OV
+    w_ref = fx.make_weights_ov(cfg, 0)
+    w_pol = fx.perturb_weights(w_ref, seed=1, scale=0.25)
+    ref, pol = build_hf(cfg, w_ref).eval(), build_hf(cfg, w_pol).train()
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    G, C, seed = 4, 10, 41
+    sizes = [(120, 100)]
+    ids, mask, pv, ncrops = tiny_ov_batch(cfg, sizes, [9], seed)
+    batch = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "pixel_values": torch.from_numpy(pv)[None], "image_sizes": torch.tensor(sizes)}
+    eos_rows = {1: 6, 3: 2}                    # rows 1 and 3 end early -> they are the rows the reference rotates
+    comps = fx.synth_completions(G, C, cfg, seed + 100, eos_rows)
+    texts = [mg.CANNED[i % len(mg.CANNED)] for i in range(G)]
+    t = mg.make_trainer(SCGRPOTrainer, reward, cfg, ref, {**batch, "mm_token_type_ids": torch.zeros(1, ids.shape[1], dtype=torch.int32)}, comps, texts, G, C)
+    t.processing_class = OVProcessor(cfg, batch, texts)
+    t.model_id = "tiny-llava_ov-si"
+    inputs = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "q"}]}], "image": [object()], "solution": mg.SOLUTION}]
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss, loc = mg.capture_locals(lambda: t.compute_loss(pol, inputs), "compute_loss")
+    loss.backward()
+    inv = {hf_name(k): k for k in fx.param_shapes_ov(cfg)}
+    grads = {inv[k]: p.grad for k, p in pol.named_parameters() if p.grad is not None and k in inv}
+    keep = ["language_model.model.norm.weight", "language_model.model.layers.1.self_attn.k_proj.bias", "multi_modal_projector.linear_2.bias", "image_newline",
+            "vision_tower.vision_model.encoder.layers.1.layer_norm2.weight", "vision_tower.vision_model.embeddings.patch_embedding.bias"]
+    out = {"meta": json.dumps({**mg.meta(), "G": G, "C": C, "sizes": sizes, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows, "perturb_scale": 0.25, "crops": ncrops,
+                               "model_id": t.model_id}),
+           "prompt_completion_ids": loc["prompt_completion_ids"].numpy(), "attention_mask": loc["attention_mask"].numpy(), "completion_mask": loc["completion_mask"].numpy(),
+           "per_token_logps": loc["per_token_logps"].detach().numpy(), "ref_per_token_logps": loc["ref_per_token_logps"].numpy(), "rewards_per_func": loc["rewards_per_func"].numpy(),
+           "advantages": loc["advantages"].numpy(), "loss": np.float64(loss.item()), "metric_kl": np.float64(t._metrics["kl"][0]),
+           "metric_completion_length": np.float64(t._metrics["completion_length"][0]), "metric_reward": np.float64(t._metrics["reward"][0]),
+           "grad_norm_names": np.array(sorted(grads)), "grad_norms": np.array([float(grads[k].norm()) for k in sorted(grads)], dtype=np.float64)}
+    for k in keep:
+        out["grad::" + k] = grads[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "sc_grpo_llava_ov.npz"), **out)
+    print(f"sc_grpo_llava_ov.npz: loss={loss.item():.8f} kl={t._metrics['kl'][0]:.6f} len={t._metrics['completion_length'][0]}")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen_forward()
+    reward, _, _, SCGRPOTrainer, _ = mg.import_reference()
+    gen_sc_grpo(SCGRPOTrainer, reward)
