@@ -225,12 +225,41 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* ids, co
     }
 }
 
+// GELU, tanh approximation (SigLIP MLP: ACT2FN["gelu_pytorch_tanh"], transformers/models/siglip/modeling_siglip.py:310-322):
+// 0.5 x (1 + tanh(c (x + 0.044715 x^3))), c = sqrt(2/pi); fp32 math on bf16 values
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_tanh_df(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x), th = tanhf(u);
+    return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
+}
+__global__ __launch_bounds__(256) void gelu_tanh_fwd_kernel(const bf16_t* z, bf16_t* a, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4_t v = *(const u32x4_t*)(z + i * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(gelu_tanh_f(lo_bf(v[e])), gelu_tanh_f(hi_bf(v[e])));
+        *(u32x4_t*)(a + i * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void gelu_tanh_bwd_kernel(const bf16_t* da, const bf16_t* z, bf16_t* dz, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4_t v = *(const u32x4_t*)(z + i * 8), d = *(const u32x4_t*)(da + i * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(d[e]) * gelu_tanh_df(lo_bf(v[e])), hi_bf(d[e]) * gelu_tanh_df(hi_bf(v[e])));
+        *(u32x4_t*)(dz + i * 8) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // out[t] = sum over k in [ptr[t], ptr[t+1]) of src[idx[k]]  (fp32 sum, rounded once; empty list -> zeros).  The scatter of the lm_head's
 // input gradient back onto the token rows: a hidden row can feed several selected rows (the prompt's last token predicts the first token of
 // every completion of its group), most feed none.  One block per token row, 16-byte accesses; deterministic (list order).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rows_gather_sum_kernel(const bf16_t* src, const int* ptr, const int* idx, bf16_t* out, int T, int H) {
+__global__ __launch_bounds__(256) void rows_gather_sum_kernel(const bf16_t* src, const int* ptr, const int* idx, const float* wts, bf16_t* out, int T, int H) {
     const int t = blockIdx.x;
     const int k0 = ptr[t], k1 = ptr[t + 1];
     for (int ch = threadIdx.x; ch < (H >> 3); ch += 256) {
@@ -239,8 +268,9 @@ __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const bf16_t* src,
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
         for (int k = k0; k < k1; ++k) {
             const u32x4_t a = *(const u32x4_t*)(src + (long long)idx[k] * H + ch * 8);
+            const float wk = wts ? wts[k] : 1.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(a[e]); v[2 * e + 1] += hi_bf(a[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += wk * lo_bf(a[e]); v[2 * e + 1] += wk * hi_bf(a[e]); }
         }
         u32x4_t o;
 #pragma unroll
@@ -399,9 +429,19 @@ extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)dx, dE, dimg, T, H);
     return iadr1_check_launch("embed_bwd");
 }
-extern "C" int iadr1_rows_gather_sum(const void* src, const int* ptr, const int* idx, void* out, int T, int H, hipStream_t stream) {
+extern "C" int iadr1_gelu_tanh_fwd(const void* z, void* a, long long n, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0 && (n % 8) == 0, "gelu_tanh_fwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_tanh_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)z, (bf16_t*)a, n / 8);
+    return iadr1_check_launch("gelu_tanh_fwd");
+}
+extern "C" int iadr1_gelu_tanh_bwd(const void* da, const void* z, void* dz, long long n, hipStream_t stream) {
+    IADR1_REQUIRE(n > 0 && (n % 8) == 0, "gelu_tanh_bwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_tanh_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)da, (const bf16_t*)z, (bf16_t*)dz, n / 8);
+    return iadr1_check_launch("gelu_tanh_bwd");
+}
+extern "C" int iadr1_rows_gather_sum(const void* src, const int* ptr, const int* idx, const float* weights, void* out, int T, int H, hipStream_t stream) {
     IADR1_REQUIRE(T > 0 && H > 0 && (H % 8) == 0, "rows_gather_sum: H must be a multiple of 8");
-    hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(T), dim3(256), 0, stream, (const bf16_t*)src, ptr, idx, (bf16_t*)out, T, H);
+    hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(T), dim3(256), 0, stream, (const bf16_t*)src, ptr, idx, weights, (bf16_t*)out, T, H);
     return iadr1_check_launch("rows_gather_sum");
 }
 extern "C" int iadr1_cast_f32_to_bf16(const float* in, long long ldi, void* out, long long ldo, int R, int C, int Cpad, hipStream_t stream) {

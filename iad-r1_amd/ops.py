@@ -284,13 +284,26 @@ def embed_bwd(ids, img_index, dx, dE, dimg):
     hip.call("embed_bwd", ids, img_index, dx, dE, dimg, T, H)
 
 
-def rows_gather_sum(src, ptr, idx, T):
-    """out[t] = sum_{k in ptr[t]..ptr[t+1]} src[idx[k]] (include/iadr1_hip.h iadr1_rows_gather_sum)."""
+def rows_gather_sum(src, ptr, idx, T, weights=None):
+    """out[t] = sum_{k in ptr[t]..ptr[t+1]} weights[k] * src[idx[k]] (include/iadr1_hip.h iadr1_rows_gather_sum)."""
     H = src.shape[1]
     assert src.is_contiguous() and ptr.dtype == torch.int32 and idx.dtype == torch.int32 and ptr.numel() == T + 1
+    assert weights is None or (weights.dtype == F32 and weights.numel() == idx.numel())
     out = torch.empty(T, H, dtype=BF16, device=src.device)
-    hip.call("rows_gather_sum", src, ptr, idx, out, T, H)
+    hip.call("rows_gather_sum", src, ptr, idx, weights, out, T, H)
     return out
+
+
+def gelu_tanh_fwd(z):
+    a = torch.empty_like(z)
+    hip.call("gelu_tanh_fwd", z, a, z.numel())
+    return a
+
+
+def gelu_tanh_bwd(da, z):
+    dz = torch.empty_like(z)
+    hip.call("gelu_tanh_bwd", da, z, dz, z.numel())
+    return dz
 
 
 def cast_f32_to_bf16(x, cpad=None):

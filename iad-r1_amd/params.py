@@ -60,6 +60,40 @@ class VLMConfig:
     # "qwen2_5_vl": RMSNorm + gated SwiGLU MLP + window attention;  "qwen2_vl": LayerNorm(+bias) + fc1/QuickGELU/fc2, full
     # attention only (TF:models/qwen2_vl/modeling_qwen2_vl.py:418-447) -- the decoder is identical
     v_arch: str = "qwen2_5_vl"
+    # "siglip" (LLaVA-OneVision branch of the reference's model switch, sc_grpo_trainer.py:124-132): SigLIP tower -- learned positions, LayerNorm(+bias),
+    # biased q/k/v/out attention over the v_tokens of one crop (no rotary), fc1 / GELU(tanh) / fc2 -- Linear-GELU-Linear projector, any-resolution
+    # crop grid with `image_newline`, Qwen2 decoder with ordinary 1-D rotary positions
+    v_image_size: int = 0            # crop side in pixels (384)
+    v_ln_eps: float = 1e-6
+    image_grid_pinpoints: tuple = ()
+    anyres_max: int = 9
+
+    @property
+    def is_llava(self):
+        return self.v_arch == "siglip"
+
+    @property
+    def v_head_pad(self):
+        """Head width the attention kernels run at: SigLIP's 72 is zero-padded to 80 (a built head size) inside the fused q|k|v / out-projection
+        weights -- the padded dims are zero in q, k, v and meet zero out-projection columns, so values and gradients are exactly those of width 72."""
+        d = self.v_hidden // self.v_heads
+        if d in (80, 128):
+            return d
+        if d == 72:
+            return 80
+        raise ValueError(f"vision head dim {d}: the attention kernels are built for 128 and 80 (72 runs zero-padded to 80)")
+
+    @property
+    def v_side(self):
+        return self.v_image_size // self.v_patch
+
+    @property
+    def v_tokens(self):
+        return self.v_side**2
+
+    @property
+    def patch_dim_pad(self):
+        return _rup(self.patch_dim, 8)
 
     @property
     def head_dim(self):
@@ -85,6 +119,17 @@ class VLMConfig:
     def from_dict(d: dict) -> "VLMConfig":
         """Accepts the nested {text, vision, ...} form of tests/fixture_util.TINY."""
         t, v = d["text"], d["vision"]
+        if v.get("arch") == "siglip":
+            hd = t["hidden_size"] // t["num_attention_heads"]
+            return VLMConfig(
+                vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"], num_hidden_layers=t["num_hidden_layers"],
+                num_attention_heads=t["num_attention_heads"], num_key_value_heads=t["num_key_value_heads"], rms_norm_eps=t["rms_norm_eps"], rope_theta=t["rope_theta"],
+                mrope_section=(hd // 2, 0, 0), v_depth=v["depth"], v_hidden=v["hidden_size"], v_inter=v["intermediate_size"], v_heads=v["num_heads"],
+                v_in_channels=v["in_channels"], v_patch=v["patch_size"], v_merge=1, v_temporal=1, v_window=0, v_fullatt=tuple(range(v["depth"])),
+                image_token_id=d["image_token_id"], vision_start_token_id=d.get("vision_start_token_id", -1), vision_end_token_id=d.get("vision_end_token_id", -1),
+                eos_token_id=d["eos_token_id"], pad_token_id=d["pad_token_id"], tie_word_embeddings=d.get("tie_word_embeddings", False), v_arch="siglip",
+                v_image_size=v["image_size"], v_ln_eps=v.get("layer_norm_eps", 1e-6), image_grid_pinpoints=tuple(tuple(p) for p in d["image_grid_pinpoints"]),
+                anyres_max=d.get("anyres_max", 9))
         return VLMConfig(
             vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
             num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
@@ -99,9 +144,24 @@ class VLMConfig:
 
     @staticmethod
     def from_hf_config(c: dict) -> "VLMConfig":
-        """config.json of a Qwen2.5-VL checkpoint (flat 4.51-style or nested text_config 5.x-style)."""
+        """config.json of a Qwen2.5-VL / Qwen2-VL checkpoint (flat 4.51-style or nested text_config 5.x-style) or of a LLaVA-OneVision one."""
         t = c.get("text_config", c)
         v = c["vision_config"]
+        if c.get("model_type") == "llava_onevision" or "image_grid_pinpoints" in c:
+            asp = str(c.get("vision_aspect_ratio", "anyres_max_9"))
+            eos = t.get("eos_token_id", c.get("eos_token_id", 151645))
+            d = {"text": {"vocab_size": t.get("vocab_size", 152000), "hidden_size": t["hidden_size"], "intermediate_size": t["intermediate_size"], "num_hidden_layers": t["num_hidden_layers"],
+                          "num_attention_heads": t["num_attention_heads"], "num_key_value_heads": t.get("num_key_value_heads", t["num_attention_heads"]),
+                          "rms_norm_eps": t.get("rms_norm_eps", 1e-6), "rope_theta": float((t.get("rope_parameters") or {}).get("rope_theta", t.get("rope_theta", 1e6)))},
+                 "vision": {"arch": "siglip", "depth": v.get("num_hidden_layers", 26), "hidden_size": v.get("hidden_size", 1152), "intermediate_size": v.get("intermediate_size", 4304),
+                            "num_heads": v.get("num_attention_heads", 16), "in_channels": v.get("num_channels", 3), "patch_size": v.get("patch_size", 14),
+                            "image_size": v.get("image_size", 384), "layer_norm_eps": v.get("layer_norm_eps", 1e-6)},
+                 "image_grid_pinpoints": c["image_grid_pinpoints"], "anyres_max": int(asp.rsplit("_", 1)[-1]) if asp.startswith("anyres_max_") else 9,
+                 "image_token_id": c.get("image_token_index", c.get("image_token_id", 151646)), "eos_token_id": eos[0] if isinstance(eos, (list, tuple)) else eos,
+                 "pad_token_id": t.get("pad_token_id") or c.get("pad_token_id") or 151643, "tie_word_embeddings": bool(c.get("tie_word_embeddings", t.get("tie_word_embeddings", False)))}
+            if c.get("vision_feature_layer", -1) != -1 or c.get("vision_feature_select_strategy", "full") != "full":
+                raise ValueError("llava_onevision: vision_feature_layer = -1 with the 'full' select strategy is the configuration built here")
+            return VLMConfig.from_dict(d)
         rope = t.get("rope_parameters") or t.get("rope_scaling") or c.get("rope_scaling") or {}
         eos = t.get("eos_token_id", c.get("eos_token_id", 151645))
         if "embed_dim" in v:  # Qwen2-VL: ViT width is `embed_dim`, vision `hidden_size` is the merger output
@@ -177,9 +237,35 @@ class ParamStore:
             specs.append((name, tuple(shape), decay, gemm))
 
         q2 = c.v_arch == "qwen2_vl"
-        assert c.v_arch in ("qwen2_5_vl", "qwen2_vl"), c.v_arch
-        add("visual.patch_embed", (vh, c.patch_dim), True, True)
-        for i in range(c.v_depth):
+        assert c.v_arch in ("qwen2_5_vl", "qwen2_vl", "siglip"), c.v_arch
+        self.extra = {}      # checkpoint tensors this engine does not use (SigLIP post_layernorm / pooling head): kept as loaded, written back on save
+        if c.is_llava:
+            dp, nh = c.v_head_pad, c.v_heads
+            add("visual.patch_embed", (vh, c.patch_dim_pad), True, True)
+            add("visual.patch_embed.b", (vh,), False, False)
+            add("visual.pos", (c.v_tokens, vh), True, False)
+            for i in range(c.v_depth):
+                b = f"visual.blocks.{i}."
+                add(b + "norm1", (vh,), False, False)
+                add(b + "norm1.b", (vh,), False, False)
+                add(b + "qkv.w", (3 * nh * dp, vh), True, True)
+                add(b + "qkv.b", (3 * nh * dp,), False, False)
+                add(b + "proj.w", (vh, nh * dp), True, True)
+                add(b + "proj.b", (vh,), False, False)
+                add(b + "norm2", (vh,), False, False)
+                add(b + "norm2.b", (vh,), False, False)
+                add(b + "fc1.w", (c.v_inter, vh), True, True)
+                add(b + "fc1.b", (c.v_inter,), False, False)
+                add(b + "fc2.w", (vh, c.v_inter), True, True)
+                add(b + "fc2.b", (vh,), False, False)
+            add("visual.merger.fc1.w", (H, vh), True, True)
+            add("visual.merger.fc1.b", (H,), False, False)
+            add("visual.merger.fc2.w", (H, H), True, True)
+            add("visual.merger.fc2.b", (H,), False, False)
+            add("visual.newline", (H,), True, False)
+        else:
+            add("visual.patch_embed", (vh, c.patch_dim), True, True)
+        for i in range(0 if c.is_llava else c.v_depth):
             b = f"visual.blocks.{i}."
             add(b + "norm1", (vh,), False, False)
             add(b + "qkv.w", (3 * vh, vh), True, True)
@@ -200,13 +286,14 @@ class ParamStore:
             add(b + "down.w", (vh, vip), True, True)
             add(b + "down.b", (vh,), False, False)
         mu = c.v_merge**2
-        add("visual.merger.ln_q", (vh,), False, False)
-        if q2:
-            add("visual.merger.ln_q.b", (vh,), False, False)
-        add("visual.merger.fc1.w", (vh * mu, vh * mu), True, True)
-        add("visual.merger.fc1.b", (vh * mu,), False, False)
-        add("visual.merger.fc2.w", (H, vh * mu), True, True)
-        add("visual.merger.fc2.b", (H,), False, False)
+        if not c.is_llava:
+            add("visual.merger.ln_q", (vh,), False, False)
+            if q2:
+                add("visual.merger.ln_q.b", (vh,), False, False)
+            add("visual.merger.fc1.w", (vh * mu, vh * mu), True, True)
+            add("visual.merger.fc1.b", (vh * mu,), False, False)
+            add("visual.merger.fc2.w", (H, vh * mu), True, True)
+            add("visual.merger.fc2.b", (H,), False, False)
         add("embed", (c.vocab_size, H), True, True)
         for i in range(c.num_hidden_layers):
             b = f"layers.{i}."
@@ -328,9 +415,124 @@ class ParamStore:
         assert tuple(src.shape) == tuple(dst.shape), (name, tuple(src.shape), tuple(dst.shape))
         dst.copy_(src.to(BF16))
 
+    # names of the LLaVA-OneVision checkpoints as transformers 4.51.3 (the reference's pin) writes them; 5.x prefixes are accepted on load
+    @staticmethod
+    def _llava_canonical(name: str) -> str:
+        if name.startswith("model.vision_tower."):
+            return "vision_tower.vision_model." + name[len("model.vision_tower."):]
+        if name.startswith("model.multi_modal_projector."):
+            return name[len("model."):]
+        if name == "model.image_newline":
+            return "image_newline"
+        if name.startswith("model.language_model."):
+            return "language_model.model." + name[len("model.language_model."):]
+        if name == "lm_head.weight":
+            return "language_model.lm_head.weight"
+        return name
+
+    def _load_named_llava(self, sd: dict):
+        c = self.cfg
+        sd = {self._llava_canonical(k): v for k, v in sd.items()}
+        t = lambda k: torch.as_tensor(sd.pop(k)).float()
+        vh, nh, d, dp = c.v_hidden, c.v_heads, c.v_hidden // c.v_heads, c.v_head_pad
+        pre = "vision_tower.vision_model."
+        pe = torch.zeros(vh, c.patch_dim_pad)
+        pe[:, : c.patch_dim] = t(pre + "embeddings.patch_embedding.weight").reshape(vh, -1)
+        self._assign("visual.patch_embed", pe)
+        self._assign("visual.patch_embed.b", t(pre + "embeddings.patch_embedding.bias"))
+        self._assign("visual.pos", t(pre + "embeddings.position_embedding.weight"))
+
+        def pad_rows(w):          # [nh*d, K] -> [nh*dp, K], zero rows for the padded dims of every head
+            out = torch.zeros(nh, dp, *w.shape[1:])
+            out[:, :d] = w.reshape(nh, d, *w.shape[1:])
+            return out.reshape(nh * dp, *w.shape[1:])
+
+        for i in range(c.v_depth):
+            s_, b = f"{pre}encoder.layers.{i}.", f"visual.blocks.{i}."
+            self._assign(b + "norm1", t(s_ + "layer_norm1.weight"))
+            self._assign(b + "norm1.b", t(s_ + "layer_norm1.bias"))
+            self._assign(b + "norm2", t(s_ + "layer_norm2.weight"))
+            self._assign(b + "norm2.b", t(s_ + "layer_norm2.bias"))
+            self._assign(b + "qkv.w", torch.cat([pad_rows(t(s_ + f"self_attn.{z}_proj.weight")) for z in "qkv"], 0))
+            self._assign(b + "qkv.b", torch.cat([pad_rows(t(s_ + f"self_attn.{z}_proj.bias")) for z in "qkv"], 0))
+            self._assign(b + "proj.w", pad_rows(t(s_ + "self_attn.out_proj.weight").t().contiguous()).t().contiguous())
+            self._assign(b + "proj.b", t(s_ + "self_attn.out_proj.bias"))
+            self._assign(b + "fc1.w", t(s_ + "mlp.fc1.weight"))
+            self._assign(b + "fc1.b", t(s_ + "mlp.fc1.bias"))
+            self._assign(b + "fc2.w", t(s_ + "mlp.fc2.weight"))
+            self._assign(b + "fc2.b", t(s_ + "mlp.fc2.bias"))
+        self._assign("visual.merger.fc1.w", t("multi_modal_projector.linear_1.weight"))
+        self._assign("visual.merger.fc1.b", t("multi_modal_projector.linear_1.bias"))
+        self._assign("visual.merger.fc2.w", t("multi_modal_projector.linear_2.weight"))
+        self._assign("visual.merger.fc2.b", t("multi_modal_projector.linear_2.bias"))
+        self._assign("visual.newline", t("image_newline"))
+        lm = "language_model.model."
+        self._assign("embed", t(lm + "embed_tokens.weight"))
+        for i in range(c.num_hidden_layers):
+            s_, b = f"{lm}layers.{i}.", f"layers.{i}."
+            self._assign(b + "ln1", t(s_ + "input_layernorm.weight"))
+            self._assign(b + "ln2", t(s_ + "post_attention_layernorm.weight"))
+            self._assign(b + "qkv.w", torch.cat([t(s_ + "self_attn.q_proj.weight"), t(s_ + "self_attn.k_proj.weight"), t(s_ + "self_attn.v_proj.weight")], 0))
+            self._assign(b + "qkv.b", torch.cat([t(s_ + "self_attn.q_proj.bias"), t(s_ + "self_attn.k_proj.bias"), t(s_ + "self_attn.v_proj.bias")], 0))
+            self._assign(b + "o.w", t(s_ + "self_attn.o_proj.weight"))
+            self._assign(b + "gu.w", torch.cat([t(s_ + "mlp.gate_proj.weight"), t(s_ + "mlp.up_proj.weight")], 0))
+            self._assign(b + "down.w", t(s_ + "mlp.down_proj.weight"))
+        self._assign("norm", t(lm + "norm.weight"))
+        if not c.tie_word_embeddings:
+            self._assign("lm_head", t("language_model.lm_head.weight"))
+        else:
+            sd.pop("language_model.lm_head.weight", None)
+        self.extra = {k: torch.as_tensor(v).clone() for k, v in sd.items()}      # post_layernorm, pooling head, ...: not on this path
+        self.finalize()
+
+    def _export_named_llava(self, source: str = "param") -> dict:
+        c = self.cfg
+        get = (lambda n: self.w(n).float().cpu()) if source == "param" else (lambda n: self.g(n).float().cpu())
+        vh, nh, d, dp = c.v_hidden, c.v_heads, c.v_hidden // c.v_heads, c.v_head_pad
+        unpad = lambda w: w.reshape(nh, dp, *w.shape[1:])[:, :d].reshape(nh * d, *w.shape[1:]).clone()
+        pre, out = "vision_tower.vision_model.", {}
+        out[pre + "embeddings.patch_embedding.weight"] = get("visual.patch_embed")[:, : c.patch_dim].reshape(vh, c.v_in_channels, c.v_patch, c.v_patch).clone()
+        out[pre + "embeddings.patch_embedding.bias"] = get("visual.patch_embed.b")
+        out[pre + "embeddings.position_embedding.weight"] = get("visual.pos")
+        for i in range(c.v_depth):
+            s_, b = f"{pre}encoder.layers.{i}.", f"visual.blocks.{i}."
+            out[s_ + "layer_norm1.weight"], out[s_ + "layer_norm1.bias"] = get(b + "norm1"), get(b + "norm1.b")
+            out[s_ + "layer_norm2.weight"], out[s_ + "layer_norm2.bias"] = get(b + "norm2"), get(b + "norm2.b")
+            qw, qb = get(b + "qkv.w"), get(b + "qkv.b")
+            for j, z in enumerate("qkv"):
+                out[s_ + f"self_attn.{z}_proj.weight"] = unpad(qw[j * nh * dp: (j + 1) * nh * dp])
+                out[s_ + f"self_attn.{z}_proj.bias"] = unpad(qb[j * nh * dp: (j + 1) * nh * dp])
+            out[s_ + "self_attn.out_proj.weight"] = unpad(get(b + "proj.w").t().contiguous()).t().contiguous()
+            out[s_ + "self_attn.out_proj.bias"] = get(b + "proj.b")
+            out[s_ + "mlp.fc1.weight"], out[s_ + "mlp.fc1.bias"] = get(b + "fc1.w"), get(b + "fc1.b")
+            out[s_ + "mlp.fc2.weight"], out[s_ + "mlp.fc2.bias"] = get(b + "fc2.w"), get(b + "fc2.b")
+        out["multi_modal_projector.linear_1.weight"], out["multi_modal_projector.linear_1.bias"] = get("visual.merger.fc1.w"), get("visual.merger.fc1.b")
+        out["multi_modal_projector.linear_2.weight"], out["multi_modal_projector.linear_2.bias"] = get("visual.merger.fc2.w"), get("visual.merger.fc2.b")
+        out["image_newline"] = get("visual.newline")
+        lm = "language_model.model."
+        out[lm + "embed_tokens.weight"] = get("embed")
+        hq, hk = c.num_attention_heads * c.head_dim, c.num_key_value_heads * c.head_dim
+        for i in range(c.num_hidden_layers):
+            s_, b = f"{lm}layers.{i}.", f"layers.{i}."
+            out[s_ + "input_layernorm.weight"], out[s_ + "post_attention_layernorm.weight"] = get(b + "ln1"), get(b + "ln2")
+            qw, qb = get(b + "qkv.w"), get(b + "qkv.b")
+            out[s_ + "self_attn.q_proj.weight"], out[s_ + "self_attn.k_proj.weight"], out[s_ + "self_attn.v_proj.weight"] = qw[:hq].clone(), qw[hq: hq + hk].clone(), qw[hq + hk:].clone()
+            out[s_ + "self_attn.q_proj.bias"], out[s_ + "self_attn.k_proj.bias"], out[s_ + "self_attn.v_proj.bias"] = qb[:hq].clone(), qb[hq: hq + hk].clone(), qb[hq + hk:].clone()
+            out[s_ + "self_attn.o_proj.weight"] = get(b + "o.w")
+            gu = get(b + "gu.w")
+            out[s_ + "mlp.gate_proj.weight"], out[s_ + "mlp.up_proj.weight"] = gu[: c.intermediate_size].clone(), gu[c.intermediate_size:].clone()
+            out[s_ + "mlp.down_proj.weight"] = get(b + "down.w")
+        out[lm + "norm.weight"] = get("norm")
+        out["language_model.lm_head.weight"] = get(self.lm_head_name())
+        if source == "param":
+            out.update({k: v.float().cpu() for k, v in self.extra.items()})
+        return out
+
     def load_named(self, sd: dict):
         """`sd`: checkpoint-name -> array/tensor (HF Qwen2.5-VL names)."""
         c = self.cfg
+        if c.is_llava:
+            return self._load_named_llava(sd)
         t = lambda k: torch.as_tensor(sd[k]).float()
         vi, vip = c.v_inter, c.v_inter_pad
         self._assign("visual.patch_embed", t("visual.patch_embed.proj.weight").reshape(c.v_hidden, -1))
@@ -412,6 +614,8 @@ class ParamStore:
     def export_named(self, source: str = "param") -> dict:
         """Inverse of load_named (bf16 params, or fp32 `grad` views for tests): checkpoint-name -> CPU tensor."""
         c = self.cfg
+        if c.is_llava:
+            return self._export_named_llava(source)
         get = (lambda n: self.w(n).float().cpu()) if source == "param" else (lambda n: self.g(n).float().cpu())
         vi, vip = c.v_inter, c.v_inter_pad
         out = {}
@@ -472,6 +676,14 @@ class ParamStore:
                 self.w(b + "gu.w")[vi:vip].zero_()
                 self.w(b + "gu.w")[vip + vi:].zero_()
                 self.w(b + "down.w")[:, vi:].zero_()
+        if c.is_llava:       # zero padding: the 592 - 588 extra patch columns and the 80 - 72 padded dims of every vision head
+            d, dp, nh = c.v_hidden // c.v_heads, c.v_head_pad, c.v_heads
+            self.w("visual.patch_embed")[:, c.patch_dim:].zero_()
+            for i in range(c.v_depth):
+                b = f"visual.blocks.{i}."
+                self.w(b + "qkv.w").view(3 * nh, dp, -1)[:, d:].zero_()
+                self.w(b + "qkv.b").view(3 * nh, dp)[:, d:].zero_()
+                self.w(b + "proj.w").view(-1, nh, dp)[:, :, d:].zero_()
         self.finalize()
 
     def copy_from(self, other: "ParamStore"):

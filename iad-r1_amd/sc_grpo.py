@@ -57,6 +57,11 @@ class GRPOArgs:
     # the rollout's decode steps also write the completion rows of the policy's activation arena, so the policy forward over the completions is not
     # run before backward (needs reuse_prefill's conditions and the fused decode kernels)
     reuse_decode: bool = os.environ.get("IADR1_REUSE_DECODE", "1") != "0"
+    # LLaVA branches only: reproduce the reference's `_ensure_left_padding_data` (REF:502-504,516-567) -- a row whose completion ended early (right
+    # padding, no left padding) is rotated before the model runs while the log-probs are still sliced / masked at the un-rotated columns, so its
+    # loss terms are the log-probs of the tokens `C - len` positions EARLIER (the end of the prompt, then the start of the completion).  False
+    # scores the completion tokens themselves, as the Qwen branches do.
+    llava_rotate_right_padded_rows: bool = True
 
 
 def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.ndarray:
@@ -222,14 +227,7 @@ class SCGRPOEngine:
 
     # ---- vision: once per unique image ---------------------------------------------------------------------
     def _vision(self, batch, want_policy_ctx: bool):
-        grids = [tuple(int(z) for z in g) for g in np.asarray(batch["image_grid_thw"])]
-        plan_v = self.pol.vision_plan(grids)
-        px = batch["pixel_values"]
-        px = torch.as_tensor(px).to(self.dev)
-        px = px if px.dtype == BF16 else ops.cast_f32_to_bf16(px.to(F32).contiguous())
-        m2 = self.cfg.v_merge**2
-        rows = np.cumsum([0] + [g[0] * g[1] * g[2] // m2 for g in grids])
-        return grids, plan_v, px, rows
+        return self.pol.vision_inputs(batch)
 
     def _per_row_images(self, batch, grids, rows):
         ipp = batch.get("images_per_prompt") or [1] * len(batch["input_ids"])
@@ -340,8 +338,25 @@ class SCGRPOEngine:
                 rows_b = [r // G for r in range(r0, r1)]
                 plan = self.pol.text_plan(ids[r0:r1], mask[r0:r1], [gpr[b] for b in rows_b], [off[b] for b in rows_b])
                 sel = (np.arange(n)[:, None] * S + (P - 1) + col[None, :]).reshape(-1)        # logits rows P-1 .. S-2
+            tgt = ids[r0:r1, P:].astype(np.int64).copy()
+            if c.is_llava and a.llava_rotate_right_padded_rows:
+                sel = sel.reshape(n, C).copy()
+                for r in range(r0, r1):
+                    ln = int(cmask[r].sum())
+                    if ln == C or (ids[r, : P + ln] == c.pad_token_id).any():
+                        continue                       # no right padding / left padding present: the reference leaves the row alone
+                    pl = C - ln                        # the row is shifted right by pl columns: window column t holds original token P - pl + t
+                    for t_ in range(ln):
+                        qi = P - pl + t_               # predicted token (original column), read from the hidden state of column qi - 1
+                        hi = qi - 1
+                        if share:
+                            sel[r - r0, t_] = (r // G - b0) * P + hi if hi < P else (b1 - b0) * P + (r - r0) * C + (hi - P)
+                        else:
+                            sel[r - r0, t_] = (r - r0) * S + hi
+                        tgt[r - r0, t_] = ids[r, qi]
+                sel = sel.reshape(-1)
             rows_d = torch.from_numpy(sel.astype(np.int64)).to(self.dev)
-            tgt_d = torch.from_numpy(ids[r0:r1, P:].reshape(-1).astype(np.int64)).to(self.dev)
+            tgt_d = torch.from_numpy(tgt.reshape(-1)).to(self.dev)
             hf, _ = self.ref.text_forward(plan, img_ref, save=False)
             rl, _ = self.ref.logprobs(hf, rows_d, tgt_d, save=False)
             del hf

@@ -46,13 +46,8 @@ class SFTEngine:
         c, e = self.cfg, self.eng
         ids, mask, labels = (np.asarray(batch[k]) for k in ("input_ids", "attention_mask", "labels"))
         B, S = ids.shape
-        grids = [tuple(int(z) for z in g) for g in np.asarray(batch["image_grid_thw"])]
-        plan_v = e.vision_plan(grids)
-        px = torch.as_tensor(batch["pixel_values"]).to(self.dev)
-        px = px if px.dtype == BF16 else ops.cast_f32_to_bf16(px.to(F32).contiguous())
+        grids, plan_v, px, rows = e.vision_inputs(batch)
         img, vctx = e.vision_forward(px, plan_v, save=backward)
-        m2 = c.v_merge**2
-        rows = np.cumsum([0] + [g[0] * g[1] * g[2] // m2 for g in grids])
         ipr = batch.get("images_per_row") or [1] * B
         gpr, off, k = [], [], 0
         for n in ipr:

@@ -80,11 +80,12 @@ def load_checkpoint(path: str, device, trainable: bool, with_decode_pack=None):
         with safe_open(os.path.join(path, fn), framework="pt") as sf:
             for k in sf.keys():
                 name = k
-                # transformers>=5 layout -> classic checkpoint names
-                if name.startswith("model.visual."):
-                    name = name[len("model."):]
-                elif name.startswith("model.language_model."):
-                    name = "model." + name[len("model.language_model."):]
+                # transformers>=5 layout -> classic checkpoint names (the LLaVA-OneVision store normalises its own names: ParamStore._llava_canonical)
+                if not cfg.is_llava:
+                    if name.startswith("model.visual."):
+                        name = name[len("model."):]
+                    elif name.startswith("model.language_model."):
+                        name = "model." + name[len("model.language_model."):]
                 sd[name] = sf.get_tensor(k)
     store.load_named(sd)
     return cfg, store
@@ -192,9 +193,13 @@ def prepare_batch(processing_class, inputs: list[dict]) -> dict:
         per_prompt.append(len(im))
         images += [Image.open(i) if isinstance(i, str) else i for i in im]
     enc = processing_class(text=prompts_text, images=images if images else None, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
-    grid = enc["image_grid_thw"]
-    return {"input_ids": np.asarray(enc["input_ids"]), "attention_mask": np.asarray(enc["attention_mask"]), "pixel_values": enc["pixel_values"],
-            "image_grid_thw": grid.tolist() if hasattr(grid, "tolist") else [tuple(g) for g in grid], "images_per_prompt": per_prompt}
+    out = {"input_ids": np.asarray(enc["input_ids"]), "attention_mask": np.asarray(enc["attention_mask"]), "pixel_values": enc["pixel_values"], "images_per_prompt": per_prompt}
+    if "image_sizes" in enc:            # LLaVA-OneVision processor: crops [images, max crops, 3, S, S] + original (height, width) per image
+        out["image_sizes"] = np.asarray(enc["image_sizes"]).reshape(-1, 2).tolist()
+    else:
+        grid = enc["image_grid_thw"]
+        out["image_grid_thw"] = grid.tolist() if hasattr(grid, "tolist") else [tuple(g) for g in grid]
+    return out
 
 
 class SCGRPOTrainer:
@@ -229,9 +234,9 @@ class SCGRPOTrainer:
                     raise ValueError("Invalid `torch_dtype` passed to `GRPOConfig`. Expected either 'auto' or a string representing "
                                      f"a `torch.dtype` (e.g., 'float32'), but got {td}.")  # REF:108-111
             mid = model.lower()
-            if not any(t in mid for t in ("qwen2.5-vl", "qwen2.5_vl", "qwen2.5vl", "qwen2-vl", "qwen2_vl", "qwen2vl")):
-                raise ValueError(f"{model}: this engine implements the Qwen2-VL and Qwen2.5-VL branches of the reference's model switch "
-                                 "(REF:116-137; which of the two is read from the checkpoint's config.json, not from the path); the LLaVA variants are not built yet")
+            if not any(t in mid for t in ("qwen2.5-vl", "qwen2.5_vl", "qwen2.5vl", "qwen2-vl", "qwen2_vl", "qwen2vl", "llava-ov", "llava_ov", "llava_si")):
+                raise ValueError(f"{model}: this engine implements the Qwen2-VL, Qwen2.5-VL and LLaVA-OneVision branches of the reference's model switch "
+                                 "(REF:116-137; which one is read from the checkpoint's config.json, not from the path); LLaVA-1.5 / LLaVA-NeXT are not built")
         elif mik:
             raise ValueError("You passed `model_init_kwargs` to the `GRPOConfig`, but your model is already instantiated. "
                              "This argument can only be used when the `model` argument is a string.")  # REF:141-145
@@ -263,6 +268,8 @@ class SCGRPOTrainer:
             if hasattr(processing_class, "image_processor"):
                 processing_class.image_processor.max_pixels = max_pixels  # REF:192-193
                 processing_class.image_processor.min_pixels = min_pixels
+        if self.cfg.is_llava and hasattr(processing_class, "tokenizer"):
+            processing_class.tokenizer.padding_side = "left"              # REF:218-219
         self.processing_class = processing_class
         self.reward_funcs = list(reward_funcs) if isinstance(reward_funcs, (list, tuple)) else [reward_funcs]
         for f in self.reward_funcs:

@@ -16,7 +16,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
-from . import indexing, ops
+from . import indexing, llava_ov, ops
 from .params import ParamStore, VLMConfig
 
 # IADR1_POISON=1: outputs that skip their zero fill (every row is written by the kernel) start as NaN instead of stale memory, so a row the kernel
@@ -38,6 +38,21 @@ class VisionPlan:
     seg_full: ops.Segments
     cos: torch.Tensor            # [N, d/2] fp32, already in window order
     sin: torch.Tensor
+
+
+@dataclass
+class SiglipPlan:
+    """LLaVA-OneVision vision plan for a list of image sizes (height, width): crops are the attention segments of the SigLIP tower, `pack` is the
+    sparse map projector rows -> packed image tokens (iadr1_amd.llava_ov.pack_plan) and `pack_t` its transpose for the backward pass."""
+    n_crops: int
+    n_patches: int               # n_crops * tokens per crop
+    seg: ops.Segments
+    pos_ids: torch.Tensor        # [n_patches] int64: position-embedding row of every patch row
+    pack: tuple                  # (ptr, idx, w) device tensors; T_img packed tokens
+    pack_t: tuple
+    n_tokens: int
+    lens: list
+    crops: list
 
 
 @dataclass
@@ -96,8 +111,57 @@ class Engine:
             cache[key] = plan
         return plan
 
+    def vision_inputs(self, batch):
+        """Batch dict -> (grids, vision plan, pixel tensor on the device, first image-embed row of every image).
+        Qwen-VL: `image_grid_thw` [(t, h, w)] + `pixel_values` [patches, patch_dim] (fp32 from the processor, cast to bf16 here).
+        LLaVA-OneVision: `image_sizes` [(height, width)] + `pixel_values` as the HF processor emits them -- [images, max crops, 3, S, S] padded to the
+        largest crop count (each image's first num_crops are real: transformers llava_onevision get_image_features), a list of per-image crop stacks,
+        or the crops already concatenated [total crops, 3, S, S]."""
+        c = self.cfg
+        if c.is_llava:
+            sizes = [(int(h), int(w)) for h, w in np.asarray(batch["image_sizes"]).reshape(-1, 2)]
+            plan_v = self.vision_plan(sizes)
+            px = batch["pixel_values"]
+            if isinstance(px, (list, tuple)):
+                px = torch.cat([torch.as_tensor(z) for z in px], 0)
+            px = torch.as_tensor(px)
+            if px.dim() == 5:
+                px = torch.cat([px[i, :n] for i, n in enumerate(plan_v.crops)], 0)
+            assert px.dim() == 4 and px.shape[0] == plan_v.n_crops, (tuple(px.shape), plan_v.n_crops)
+            return sizes, plan_v, px.to(self.dev), np.cumsum([0] + list(plan_v.lens))
+        grids = [tuple(int(z) for z in g) for g in np.asarray(batch["image_grid_thw"])]
+        plan_v = self.vision_plan(grids)
+        px = torch.as_tensor(batch["pixel_values"]).to(self.dev)
+        px = px if px.dtype == BF16 else ops.cast_f32_to_bf16(px.to(F32).contiguous())
+        m2 = c.v_merge**2
+        return grids, plan_v, px, np.cumsum([0] + [g[0] * g[1] * g[2] // m2 for g in grids])
+
+    def n_image_tokens(self, g) -> int:
+        """Placeholder tokens one image occupies in the prompt: merged patches of a Qwen grid (t, h, w), packed any-resolution features of a
+        LLaVA-OneVision image size (height, width)."""
+        c = self.cfg
+        if c.is_llava:
+            cache = self.__dict__.setdefault("_ov_tokens", {})
+            key = (int(g[0]), int(g[1]))
+            if key not in cache:
+                cache[key] = llava_ov.num_image_tokens(key, c.image_grid_pinpoints, c.v_image_size, c.v_side, c.anyres_max)
+            return cache[key]
+        return int(g[0]) * int(g[1]) * int(g[2]) // c.v_merge**2
+
+    def _siglip_plan_build(self, sizes) -> SiglipPlan:
+        c = self.cfg
+        plan = llava_ov.pack_plan(sizes, c.image_grid_pinpoints, c.v_image_size, c.v_side, c.anyres_max)
+        tp = llava_ov.transpose_plan(plan)
+        nc, per = sum(plan["crops"]), c.v_tokens
+        dev = self.dev
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return SiglipPlan(nc, nc * per, ops.Segments.from_cu(np.arange(nc + 1) * per, dev), up(np.tile(np.arange(per, dtype=np.int64), nc)),
+                          (up(plan["ptr"]), up(plan["idx"]), up(plan["w"])), (up(tp["ptr"]), up(tp["idx"]), up(tp["w"])), len(plan["ptr"]) - 1, plan["lens"], plan["crops"])
+
     def _vision_plan_build(self, grids) -> VisionPlan:
         c = self.cfg
+        if c.is_llava:
+            return self._siglip_plan_build([(int(g[0]), int(g[1])) for g in grids])
         grids = [tuple(int(z) for z in g) for g in grids]
         m2 = c.v_merge**2
         if c.v_arch == "qwen2_vl":   # no window reorder, every block attends over the whole image (TF:qwen2_vl ::690-720)
@@ -117,6 +181,17 @@ class Engine:
         rev = torch.from_numpy(np.argsort(win)).to(self.dev)
         return VisionPlan(n, win_t, rev, ops.Segments.from_cu(cu_win, self.dev), ops.Segments.from_cu(cu_full, self.dev), rot_t.cos().contiguous(), rot_t.sin().contiguous())
 
+    def _positions(self, input_ids, attention_mask, flat_grids):
+        """Rotary positions [3, B, S] + per-row delta (position of the next token - number of real tokens).  Qwen-VL: the image-aware M-RoPE index
+        (TF:944-1062).  LLaVA-OneVision / Qwen2: ordinary 1-D positions, the same on all three axes; counted over the real tokens, so left padding
+        does not shift them (HF numbers the padded columns too -- rotary attention depends on position differences only)."""
+        c = self.cfg
+        if c.is_llava:
+            m = (np.asarray(attention_mask) != 0).astype(np.int64)
+            p1 = np.maximum(np.cumsum(m, 1) - 1, 0)
+            return np.broadcast_to(p1[None], (3, *p1.shape)).copy(), np.zeros(m.shape[0], dtype=np.int64)
+        return indexing.mrope_position_ids(input_ids, attention_mask, flat_grids, c.image_token_id, c.v_merge)
+
     def text_plan(self, input_ids: np.ndarray, attention_mask: np.ndarray, grids_per_row, img_row_offset) -> TextPlan:
         """input_ids / attention_mask: [B,S] numpy.  grids_per_row[b]: list of (t,h,w) of the images in row b.
         img_row_offset[b]: list, per image of row b, of the first row of that image in the image-embed matrix
@@ -124,14 +199,13 @@ class Engine:
         c = self.cfg
         B, S = input_ids.shape
         flat_grids = [g for row in grids_per_row for g in row]
-        pos, deltas = indexing.mrope_position_ids(input_ids, attention_mask, flat_grids, c.image_token_id, c.v_merge)
+        pos, deltas = self._positions(input_ids, attention_mask, flat_grids)
         img_index = np.full((B, S), -1, dtype=np.int32)
-        m2 = c.v_merge**2
         for b in range(B):
             cols = np.flatnonzero((input_ids[b] == c.image_token_id) & (attention_mask[b] != 0))
             k = 0
             for g, off in zip(grids_per_row[b], img_row_offset[b]):
-                n = g[0] * g[1] * g[2] // m2
+                n = self.n_image_tokens(g)
                 img_index[b, cols[k: k + n]] = off + np.arange(n)
                 k += n
             if k != len(cols):
@@ -168,7 +242,7 @@ class Engine:
         # and every later text token `max prompt position + 1 + j` on all three axes (TF:1042-1176) -- so it is evaluated on the ng
         # unique prompts only and the completion part is arithmetic (same values; 0.8 instead of 6 ms of host time per step)
         flat_grids = [g for b in range(ng) for g in grids_per_prompt[b]]
-        pos_p, deltas_p = indexing.mrope_position_ids(ids_p, mask_p, flat_grids, c.image_token_id, c.v_merge)   # [3, ng, P], [ng]
+        pos_p, deltas_p = self._positions(ids_p, mask_p, flat_grids)   # [3, ng, P], [ng]
         first = (mask_p.sum(1).astype(np.int64) + np.asarray(deltas_p).reshape(-1).astype(np.int64))              # position of completion token 0
         pos_c = np.repeat(first, G)[:, None] + np.arange(C, dtype=np.int64)[None, :]                               # [n, C]
         pos_flat = np.concatenate([pos_p.reshape(3, ng * P), np.broadcast_to(pos_c.reshape(1, n * C), (3, n * C))], 1)
@@ -176,13 +250,12 @@ class Engine:
         mask_full = np.concatenate([np.repeat(mask_p, G, 0), cmask.astype(mask_p.dtype)], 1)
         T = ng * P + n * C
         img_index = np.full(T, -1, dtype=np.int32)
-        m2 = c.v_merge**2
         starts, ends, prefix = [], [], []
         for b in range(ng):
             cols = np.flatnonzero((ids_p[b] == c.image_token_id) & (mask_p[b] != 0))
             k = 0
             for g, off in zip(grids_per_prompt[b], img_off_per_prompt[b]):
-                cnt = g[0] * g[1] * g[2] // m2
+                cnt = self.n_image_tokens(g)
                 img_index[b * P + cols[k: k + cnt]] = off + np.arange(cnt)
                 k += cnt
             if k != len(cols):
@@ -230,6 +303,8 @@ class Engine:
     def vision_forward(self, pixel_values: torch.Tensor, plan: VisionPlan, save: bool):
         """pixel_values: [N, C*T*P*P] fp32 or bf16 on device -> merged image embeds [N/m2, H] bf16 (raster order)."""
         c, P = self.cfg, self.p
+        if c.is_llava:
+            return self._vision_forward_siglip(pixel_values, plan, save)
         vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
         N = plan.n_patches
         px = pixel_values if pixel_values.dtype == BF16 else ops.cast_f32_to_bf16(pixel_values)
@@ -269,6 +344,104 @@ class Engine:
         if save:
             ctx.update(x_last=x_last, rstdq=rstdq, hq4=hq4, z=z, ga=ga, plan=plan)
         return out, ctx
+
+    # ========================================================================================================
+    # LLaVA-OneVision vision path: SigLIP tower -> projector -> any-resolution packing
+    # (transformers/models/siglip/modeling_siglip.py:116-181,310-356; models/llava_onevision/modeling_llava_onevision.py:131-150,280-348,399-418)
+    # ========================================================================================================
+    def _siglip_patches(self, crops: torch.Tensor) -> torch.Tensor:
+        """Crops [n, 3, S, S] (fp32 or bf16, the processor's layout) -> patch rows [n * tokens, patch_dim_pad] bf16 in the order (c, dy, dx) the
+        conv weight is flattened in: the stride == kernel Conv2d of SG:124-130 is then a GEMM.  Pure data movement."""
+        c = self.cfg
+        n, ch, S, _ = crops.shape
+        p, side = c.v_patch, c.v_side
+        rows = crops.reshape(n, ch, side, p, side, p).permute(0, 2, 4, 1, 3, 5).reshape(n * side * side, ch * p * p)
+        if rows.dtype == BF16 and c.patch_dim_pad == c.patch_dim:
+            return rows.contiguous()
+        return ops.cast_f32_to_bf16(rows.to(F32).contiguous(), cpad=c.patch_dim_pad)
+
+    def _vision_forward_siglip(self, crops, plan: SiglipPlan, save: bool):
+        """crops: [n_crops, 3, S, S] on device (all images of the batch, base image first per image) -> packed image tokens [n_tokens, H] bf16."""
+        c, P = self.cfg, self.p
+        vh, nh, dp, H = c.v_hidden, c.v_heads, c.v_head_pad, c.hidden_size
+        N, seg, eps = plan.n_patches, plan.seg, c.v_ln_eps
+        scale = (vh // nh) ** -0.5          # the TRUE head width (72), not the padded one
+        px = self._siglip_patches(crops)
+        assert px.shape[0] == N, (px.shape, N)
+        res = ops.gemm_nt(px, P.w("visual.patch_embed"), bias=P.w("visual.patch_embed.b"))
+        branch = ops.embed_fwd(plan.pos_ids, None, P.w("visual.pos"), None)                    # learned positions, one row per patch
+        ctx = {"px": px, "layers": []} if save else None
+        w3 = nh * dp
+        for i in range(c.v_depth):
+            b = f"visual.blocks.{i}."
+            x_in = torch.empty_like(res) if save else res
+            h1, mu1, rs1 = ops.layernorm_fwd(branch, P.w(b + "norm1"), P.w(b + "norm1.b"), eps, res=res, res_out=x_in, want_stats=save)
+            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"))
+            o, lse = ops.attn_fwd(qkv[:, :w3], qkv[:, w3: 2 * w3], qkv[:, 2 * w3:], seg, nh, nh, dp, False, scale, want_lse=save)
+            ab = ops.gemm_nt(o, P.w(b + "proj.w"), bias=P.w(b + "proj.b"))
+            x_mid = torch.empty_like(x_in) if save else x_in
+            h2, mu2, rs2 = ops.layernorm_fwd(ab, P.w(b + "norm2"), P.w(b + "norm2.b"), eps, res=x_in, res_out=x_mid, want_stats=save)
+            z = ops.gemm_nt(h2, P.w(b + "fc1.w"), bias=P.w(b + "fc1.b"))
+            a = ops.gelu_tanh_fwd(z)
+            branch = ops.gemm_nt(a, P.w(b + "fc2.w"), bias=P.w(b + "fc2.b"))
+            res = x_mid
+            if save:
+                ctx["layers"].append((x_in, mu1, rs1, h1, qkv, o, lse, x_mid, mu2, rs2, h2, z, a))
+        # hidden state of the last encoder layer (vision_feature_layer = -1: before post_layernorm): residual + MLP branch
+        feat = torch.empty_like(res)
+        ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, feat, P.w("visual.blocks.0.norm1"), None, None, N, vh, vh, vh, vh, 1e-6, None)
+        z = ops.gemm_nt(feat, P.w("visual.merger.fc1.w"), bias=P.w("visual.merger.fc1.b"))
+        ga = ops.gelu_fwd(z)                                                                  # exact GELU (projector_hidden_act "gelu")
+        src = torch.empty(N + 1, H, dtype=BF16, device=self.dev)
+        ops.gemm_nt(ga, P.w("visual.merger.fc2.w"), bias=P.w("visual.merger.fc2.b"), out=src[:N])
+        src[N].copy_(P.w("visual.newline"))
+        out = ops.rows_gather_sum(src, plan.pack[0], plan.pack[1], plan.n_tokens, weights=plan.pack[2])
+        if save:
+            ctx.update(feat=feat, z=z, ga=ga, plan=plan)
+        return out, ctx
+
+    def _vision_backward_siglip(self, d_out, ctx):
+        c, P = self.cfg, self.p
+        vh, nh, dp, H = c.v_hidden, c.v_heads, c.v_head_pad, c.hidden_size
+        plan: SiglipPlan = ctx["plan"]
+        N, seg = plan.n_patches, plan.seg
+        scale = (vh // nh) ** -0.5
+        w3 = nh * dp
+        dsrc = ops.rows_gather_sum(d_out.contiguous(), plan.pack_t[0], plan.pack_t[1], N + 1, weights=plan.pack_t[2])
+        ops.colsum_acc(dsrc[N: N + 1], P.g("visual.newline"))
+        dmo = dsrc[:N]
+        ops.colsum_acc(dmo, P.g("visual.merger.fc2.b"))
+        dga = ops.gemm_nt(dmo, P.wT("visual.merger.fc2.w"))
+        self._wgrad("visual.merger.fc2.w", dmo, ctx["ga"])
+        dz = ops.gelu_bwd(dga, ctx["z"])
+        ops.colsum_acc(dz, P.g("visual.merger.fc1.b"))
+        dres = ops.gemm_nt(dz, P.wT("visual.merger.fc1.w"))        # gradient of the last hidden state = of the residual stream AND of the last MLP branch
+        self._wgrad("visual.merger.fc1.w", dz, ctx["feat"])
+        for i in reversed(range(c.v_depth)):
+            b = f"visual.blocks.{i}."
+            x_in, mu1, rs1, h1, qkv, o, lse, x_mid, mu2, rs2, h2, z, a = ctx["layers"][i]
+            ops.colsum_acc(dres, P.g(b + "fc2.b"))
+            da = ops.gemm_nt(dres, P.wT(b + "fc2.w"))
+            self._wgrad(b + "fc2.w", dres, a)
+            dz = ops.gelu_tanh_bwd(da, z)
+            ops.colsum_acc(dz, P.g(b + "fc1.b"))
+            dh2 = ops.gemm_nt(dz, P.wT(b + "fc1.w"))
+            self._wgrad(b + "fc1.w", dz, h2)
+            dx_mid = ops.layernorm_bwd(dh2, x_mid, P.w(b + "norm2"), mu2, rs2, dres=dres, dw=P.g(b + "norm2"), db=P.g(b + "norm2.b"))
+            ops.colsum_acc(dx_mid, P.g(b + "proj.b"))
+            do = ops.gemm_nt(dx_mid, P.wT(b + "proj.w"))
+            self._wgrad(b + "proj.w", dx_mid, o)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :w3], qkv[:, w3: 2 * w3], qkv[:, 2 * w3:], o, do, lse, seg, nh, nh, dp, False, scale, dqkv[:, :w3], dqkv[:, w3: 2 * w3], dqkv[:, 2 * w3:])
+            ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
+            dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"))
+            self._wgrad(b + "qkv.w", dqkv, h1)
+            dres = ops.layernorm_bwd(dh1, x_in, P.w(b + "norm1"), mu1, rs1, dres=dx_mid, dw=P.g(b + "norm1"), db=P.g(b + "norm1.b"))
+        # dres = gradient of (patch embedding + position embedding)
+        ops.embed_bwd(plan.pos_ids, None, dres, P.g("visual.pos"), None)
+        ops.colsum_acc(dres, P.g("visual.patch_embed.b"))
+        self._wgrad("visual.patch_embed", dres, ctx["px"])
+        self.join_wgrads()
 
     def _vision_forward_q2(self, px, plan: VisionPlan, save: bool):
         """Qwen2-VL tower (TF:models/qwen2_vl/modeling_qwen2_vl.py:418-447 block, ::293-301 MLP, ::270-290 merger)."""
@@ -367,6 +540,8 @@ class Engine:
     def vision_backward(self, d_out: torch.Tensor, ctx):
         """d_out: [N/m2, H] bf16 gradient of the merged image embeds (raster order)."""
         c, P = self.cfg, self.p
+        if c.is_llava:
+            return self._vision_backward_siglip(d_out, ctx)
         vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
         plan: VisionPlan = ctx["plan"]
         N = plan.n_patches

@@ -118,6 +118,9 @@ int iadr1_swiglu_bwd(const void* da, long long lda, const void* gu, long long ld
                      iadr1_stream_t stream);
 int iadr1_gelu_fwd(const void* z, void* a, long long n, iadr1_stream_t stream);
 int iadr1_gelu_bwd(const void* da, const void* z, void* dz, long long n, iadr1_stream_t stream);
+/* GELU, tanh approximation: SigLIP vision MLP of the LLaVA-OneVision branch (transformers/models/siglip/modeling_siglip.py:310-322) */
+int iadr1_gelu_tanh_fwd(const void* z, void* a, long long n, iadr1_stream_t stream);
+int iadr1_gelu_tanh_bwd(const void* da, const void* z, void* dz, long long n, iadr1_stream_t stream);
 /* QuickGELU x*sigmoid(1.702x): Qwen2-VL vision MLP (TF:models/qwen2_vl/modeling_qwen2_vl.py:293-301) */
 int iadr1_quick_gelu_fwd(const void* z, void* a, long long n, iadr1_stream_t stream);
 int iadr1_quick_gelu_bwd(const void* da, const void* z, void* dz, long long n, iadr1_stream_t stream);
@@ -131,10 +134,12 @@ int iadr1_embed_fwd(const long long* ids, const int* img_index, const void* E, c
 int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
                     iadr1_stream_t stream);
 
-/* out[t] (bf16 [T,H]) = sum of src rows idx[ptr[t] .. ptr[t+1]) (fp32 sum, one rounding; an empty list gives zeros): the gradient of the rows the
- * lm_head consumed (REF:...sc_grpo_trainer.py:505-513 only reads P-1 .. S-2 of each row; PA-SFT the supervised positions) scattered back onto the
- * token rows of the decoder output, several selected rows may share one token row.  ptr: [T+1], idx: [ptr[T]] int32, src rows contiguous. */
-int iadr1_rows_gather_sum(const void* src, const int* ptr, const int* idx, void* out, int T, int H, iadr1_stream_t stream);
+/* out[t] (bf16 [T,H]) = sum_k weights[k] * src[idx[k]], k in [ptr[t], ptr[t+1]) (fp32 sum, one rounding; an empty list gives zeros; weights NULL = 1).
+ * Two uses: (1) the gradient of the rows the lm_head consumed (REF:...sc_grpo_trainer.py:505-513 only reads P-1 .. S-2 of each row; PA-SFT the
+ * supervised positions) scattered back onto the token rows of the decoder output, several selected rows may share one token row; (2) the
+ * LLaVA-OneVision feature packing (transformers/models/llava_onevision/modeling_llava_onevision.py:280-348: crop grid, unpad, bilinear shrink,
+ * image_newline per row) and its transpose, as a sparse linear map built on the host.  ptr: [T+1], idx / weights: [ptr[T]], src rows contiguous. */
+int iadr1_rows_gather_sum(const void* src, const int* ptr, const int* idx, const float* weights, void* out, int T, int H, iadr1_stream_t stream);
 
 /* ---- casts ---------------------------------------------------------------------------------------------- */
 int iadr1_cast_f32_to_bf16(const float* in, long long ldi, void* out, long long ldo, int R, int C, int Cpad,

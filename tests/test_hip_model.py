@@ -803,3 +803,136 @@ def test_api_step_with_rollout_handover_matches_the_oracle():
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
         ratio = float(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30))
         assert cos > 0.99 and 0.9 < ratio < 1.1, (n, cos, ratio)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# LLaVA-OneVision branch (BASELINE.json config 5)
+# ------------------------------------------------------------------------------------------------------------------------------------
+CFG_OV = VLMConfig.from_dict(fx.TINY_OV)
+
+
+def _ov_store(weights, trainable):
+    s_ = ParamStore(CFG_OV, DEV, trainable=trainable)
+    s_.load_named(weights)
+    return s_
+
+
+def test_llava_onevision_forward_matches_hf_golden(golden_dir):
+    """SigLIP tower (head width 72 run zero-padded to 80), projector, any-resolution packing (one image shrunk by the bilinear interpolation) and the
+    Qwen2 decoder with 1-D rotary positions on the HIP kernels vs a tiny HF LlavaOnevisionForConditionalGeneration (tests/golden/llava_ov.npz)."""
+    g = load(golden_dir, "llava_ov.npz")
+    meta = json.loads(str(g["meta"]))
+    w = fx.make_weights_ov(fx.TINY_OV, 0)
+    st = _ov_store(w, False)
+    back = st.export_named()
+    for k, v in w.items():
+        assert np.array_equal(back[k].numpy(), v.reshape(back[k].shape)), k           # checkpoint names <-> padded fused layout round trip
+    e = Engine(st)
+    sizes = [tuple(x) for x in meta["sizes"]]
+    batch = {"input_ids": g["input_ids"], "attention_mask": g["attention_mask"], "pixel_values": fx.synth_crops(meta["crops"], fx.TINY_OV, meta["seed"]), "image_sizes": sizes}
+    grids, plan_v, px, rows = e.vision_inputs(batch)
+    assert plan_v.lens == g["feature_lens"].tolist()
+    img, _ = e.vision_forward(px, plan_v, save=False)
+    assert relerr(img.float().cpu().numpy(), g["image_features"]) < 3e-2          # bf16 tower vs fp32 reference
+    ids, mask = g["input_ids"], g["attention_mask"]
+    plan = e.text_plan(ids, mask, [[s_] for s_ in sizes], [[int(r)] for r in rows[:-1]])
+    hf, _ = e.text_forward(plan, img, save=False)
+    B, S = ids.shape
+    valid = (mask[:, 1:] * mask[:, :-1]).astype(bool)
+    rr = (np.arange(B)[:, None] * S + np.arange(S - 1)[None, :])[valid]
+    lp, _ = e.logprobs(hf, torch.from_numpy(rr).to(DEV), torch.from_numpy(ids[:, 1:][valid].astype(np.int64)).to(DEV), save=False)
+    err = np.abs(lp.cpu().numpy() - g["per_token_logps"][valid]).max()
+    assert err < 0.08, err
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_llava_onevision_sc_grpo_matches_reference_golden(golden_dir, share):
+    """The reference's compute_loss on its llava branch (tests/golden/sc_grpo_llava_ov.npz, model id containing "llava_ov"): two of the four rows end
+    early, so `_ensure_left_padding_data` (REF:516-567) rotates them and their loss terms are the log-probs of EARLIER tokens; the engine reproduces
+    that by index arithmetic on the host (GRPOArgs.llava_rotate_right_padded_rows), in the shared-prefix and in the repeated-rows layout."""
+    g = load(golden_dir, "sc_grpo_llava_ov.npz")
+    meta = json.loads(str(g["meta"]))
+    G, C, seed = meta["G"], meta["C"], meta["seed"]
+    w_ref = fx.make_weights_ov(fx.TINY_OV, 0)
+    pol, ref = _ov_store(fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"]), True), _ov_store(w_ref, False)
+    eng = SCGRPOEngine(CFG_OV, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=16, share_prefix=share))
+    P = g["prompt_completion_ids"].shape[1] - C
+    batch = {"input_ids": g["prompt_completion_ids"][:1, :P], "attention_mask": g["attention_mask"][:1, :P], "pixel_values": fx.synth_crops(meta["crops"], fx.TINY_OV, seed),
+             "image_sizes": [tuple(x) for x in meta["sizes"]]}
+    comps = fx.synth_completions(G, C, fx.TINY_OV, seed + 100, {int(k): v for k, v in meta["eos_rows"].items()})
+    out = eng.loss_and_grads(batch, comps, g["rewards_per_func"])
+    assert np.array_equal(out["ids"], g["prompt_completion_ids"]) and np.array_equal(out["completion_mask"], g["completion_mask"])
+    m = g["completion_mask"].astype(bool)
+    dlp = np.abs(out["logps"].cpu().numpy()[m] - g["per_token_logps"][m]).max()
+    dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - g["ref_per_token_logps"][m]).max()
+    gl, gk = float(g["loss"]), float(g["metric_kl"])
+    mt = out["metrics"]
+    print(f"[parity] llava-ov share={share}: loss hip={mt['loss']:.6e} ref={gl:.6e}  kl hip={mt['kl']:.6e} ref={gk:.6e} ({100 * abs(mt['kl'] - gk) / gk:.1f}%)  |dlogp|max={dlp:.4f}/{dlr:.4f}")
+    assert dlp < 0.08 and dlr < 0.08, (dlp, dlr)
+    np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=1e-5, atol=1e-6)
+    assert abs(mt["kl"] - gk) <= 0.10 * gk and abs(mt["loss"] - gl) <= 0.04 * 0.10 * gk + 2e-6
+    grads = pol.export_named(source="grad")
+    for n, ref_norm in zip([str(n) for n in g["grad_norm_names"]], g["grad_norms"]):
+        if n == "language_model.lm_head.weight" or ref_norm < 1e-9:
+            continue
+        got = float(grads[n].norm())
+        assert abs(got - ref_norm) <= 0.10 * ref_norm + 1e-7, (n, got, ref_norm)
+    for k in g.files:
+        if k.startswith("grad::"):
+            a, b = grads[k[6:]].numpy().reshape(-1).astype(np.float64), g[k].reshape(-1).astype(np.float64)
+            cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+            assert cos > 0.99, (k, cos)
+    # without the rotation the two early-ended rows are scored on their own completion tokens: a different loss (the quirk is exercised)
+    pol2 = _ov_store(fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"]), True)
+    eng2 = SCGRPOEngine(CFG_OV, pol2, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=16, share_prefix=share,
+                                                    llava_rotate_right_padded_rows=False))
+    out2 = eng2.loss_and_grads(batch, comps, g["rewards_per_func"], backward=False)
+    assert abs(out2["metrics"]["loss"] - gl) > 1e-4
+
+
+def test_llava_onevision_rollout_and_step():
+    """Group rollout on the LLaVA-OneVision structure: hipGraph and eager rollouts agree, the greedy tokens are the arg-max of the training kernels'
+    logits (decode path vs training path on the same weights), and one full SC-GRPO step (trainer-level engine.step) moves the parameters of both
+    towers with finite loss; policy == reference gives KL exactly 0."""
+    w = fx.make_weights_ov(fx.TINY_OV, 0)
+    pol, ref = _ov_store(w, True), _ov_store(w, False)
+    sizes = [(80, 100), (120, 100)]
+    v = fx.TINY_OV["vision"]
+    from iadr1_amd import llava_ov as lo
+    rs = np.random.RandomState(7)
+    rows, ncrops = [], 0
+    for sz, nt in zip(sizes, (5, 12)):
+        n_img = lo.num_image_tokens(sz, fx.TINY_OV["image_grid_pinpoints"], v["image_size"], v["image_size"] // v["patch_size"], 9)
+        rows.append(rs.randint(3, 600, 3).tolist() + [CFG_OV.image_token_id] * n_img + rs.randint(3, 600, nt).tolist())
+        ncrops += lo.num_crops(sz, fx.TINY_OV["image_grid_pinpoints"], v["image_size"])
+    ids, mask = fx.left_pad(rows, CFG_OV.pad_token_id)
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_crops(ncrops, fx.TINY_OV, 9), "image_sizes": sizes}
+    G, C = 4, 8
+    eng = SCGRPOEngine(CFG_OV, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, suppress_eos=True))
+    toks = eng.rollout(batch, greedy=True)
+    eager = SCGRPOEngine(CFG_OV, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, suppress_eos=True, use_hip_graph=False))
+    assert np.array_equal(toks, eager.rollout(batch, greedy=True)) and toks.shape == (2 * G, C)
+    e = eng.pol
+    full = np.concatenate([np.repeat(ids, G, 0), toks], 1)
+    fmask = np.concatenate([np.repeat(mask, G, 0), np.ones_like(toks)], 1)
+    grids, plan_v, px, off = e.vision_inputs(batch)
+    img, _ = e.vision_forward(px, plan_v, save=False)
+    plan = e.text_plan(full, fmask, [[sizes[r // G]] for r in range(2 * G)], [[int(off[r // G])] for r in range(2 * G)])
+    hf, _ = e.text_forward(plan, img, save=False)
+    S, P = full.shape[1], ids.shape[1]
+    rr = (np.arange(2 * G)[:, None] * S + np.arange(P - 1, S - 1)[None, :]).reshape(-1)
+    logits = hf[torch.from_numpy(rr).to(DEV)].float() @ pol.w("lm_head").float().t()
+    top2 = logits.topk(2, -1)
+    sure = (top2.values[:, 0] - top2.values[:, 1]) > 0.05
+    assert sure.float().mean() > 0.5 and torch.equal(top2.indices[:, 0][sure].cpu(), torch.from_numpy(toks.reshape(-1))[sure.cpu()])
+    before = pol.flat.clone()
+    eng2 = SCGRPOEngine(CFG_OV, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, learning_rate=1e-3, seed=3))
+    mt = eng2.step(batch, lambda comp: np.stack([(np.asarray(comp)[:, 0] % 5).astype(np.float32), (np.asarray(comp)[:, 1] % 3).astype(np.float32)], 1))
+    assert np.isfinite(mt["loss"]) and mt["kl"] == 0.0 and np.isfinite(eng2.grad_norm()) and eng2.grad_norm() > 0
+    moved = (pol.flat != before)
+    sl = pol.slots["visual.blocks.0.fc1.w"]
+    assert bool(moved[sl.offset: sl.offset + 100].any()) and bool(moved[pol.slots["layers.0.qkv.w"].offset: pol.slots["layers.0.qkv.w"].offset + 100].any())
+    # the zero padding of the vision heads (72 -> 80) and of the patch columns (588 -> 592) is still exactly zero after an optimizer step
+    d, dp, nh = CFG_OV.v_hidden // CFG_OV.v_heads, CFG_OV.v_head_pad, CFG_OV.v_heads
+    assert float(pol.w("visual.blocks.0.qkv.w").view(3 * nh, dp, -1)[:, d:].abs().max()) == 0.0 and float(pol.w("visual.patch_embed")[:, CFG_OV.patch_dim:].abs().max()) == 0.0
+    assert float(pol.w("visual.blocks.1.proj.w").view(-1, nh, dp)[:, :, d:].abs().max()) == 0.0
