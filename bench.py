@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="3b", choices=["3b", "7b", "qwen2vl_2b", "tiny"])
+    ap.add_argument("--model", default="3b", choices=["3b", "7b", "qwen2vl_2b", "llava_ov_7b", "tiny"])
     ap.add_argument("--prompts", type=int, default=8)
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=512)
@@ -93,6 +93,19 @@ CANNED = [
     "<think>z</think><location>top</location><type>scrach</type><answer>yes</answer> extra",
 ]
 SOLUTION = "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"
+
+
+def synth_batch_llava(cfg, n_prompts, n_text, seed, image_hw=(448, 448)):
+    """BASELINE config 5 input: one 448 x 448 image per prompt through the any-resolution path (fitted to 768 x 768: 2 x 2 crops + the base image =
+    5 crops of 384 x 384 -> 729 + 54 x 55 = 3699 packed image tokens) + 3 prefix ids + n_text text ids."""
+    from iadr1_amd import llava_ov as lo
+    rs = np.random.RandomState(seed)
+    n_img = lo.num_image_tokens(image_hw, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
+    nc = lo.num_crops(image_hw, cfg.image_grid_pinpoints, cfg.v_image_size)
+    rows = [rs.randint(1000, 150000, 3).tolist() + [cfg.image_token_id] * n_img + rs.randint(1000, 150000, n_text).tolist() for _ in range(n_prompts)]
+    ids = np.array(rows, dtype=np.int64)
+    px = rs.standard_normal((n_prompts * nc, 3, cfg.v_image_size, cfg.v_image_size)).astype(np.float32)
+    return {"input_ids": ids, "attention_mask": np.ones_like(ids), "pixel_values": torch.from_numpy(px), "image_sizes": [image_hw] * n_prompts}
 
 
 def synth_batch(cfg, n_prompts, prompt_len, seed):
@@ -417,20 +430,29 @@ def main():
         cfg = VLMConfig.qwen25vl_7b()
     elif a.model == "qwen2vl_2b":
         cfg = VLMConfig.qwen2vl_2b()      # BASELINE config 1 (Qwen2-VL-2B PA-SFT): LayerNorm / QuickGELU ViT, no window attention
+    elif a.model == "llava_ov_7b":
+        cfg = VLMConfig.llava_ov_7b()     # BASELINE config 5 (LLaVA-OneVision-SI-7B SC-GRPO): SigLIP tower + any-resolution packing + Qwen2-7B decoder
     else:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import fixture_util as fx
         cfg = VLMConfig.from_dict(fx.TINY)
     if a.workload == "pa_sft":
         return run_pa_sft(a, cfg, dev, rank, world)
+    llava = a.model == "llava_ov_7b"
     if a.micro_batch <= 0:
-        a.micro_batch = 32 if a.model == "7b" else 64
+        # llava_ov_7b: 3699 image tokens per prompt -> one group (prompt + its 8 completions) per pass keeps the saved activations at ~26 GB
+        a.micro_batch = 32 if a.model == "7b" else (a.group if llava else 64)
     pol = ParamStore(cfg, dev, trainable=True)
     pol.init_random(seed=0)
     N = a.prompts * a.group
     # inputs are generated and made resident in HBM BEFORE the timed region (the processor's fp32 patches stay fp32: the bf16 cast is part of the step)
     batches = []
     for step_id in range(a.warmup + a.steps + 1):
+        if llava:
+            b = synth_batch_llava(cfg, a.prompts, 253, seed=1234 + 7919 * rank + step_id)
+            batches.append({"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"].to(dev),
+                            "image_sizes": torch.tensor(b["image_sizes"])})
+            continue
         b = synth_batch(cfg, a.prompts, a.prompt_len, seed=1234 + 7919 * rank + step_id)
         batches.append({"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"].to(dev),
                         "image_grid_thw": torch.tensor(b["image_grid_thw"])})
@@ -438,8 +460,9 @@ def main():
     rows = lambda step_id: [{"prompt": chat, "image": [("synthetic", step_id, j)], "solution": SOLUTION} for j in range(a.prompts)]
     # the reference's API: trainer object + reward plugins (train/stage_rl/grpo_ad.py:188-199); the frozen reference model is the trainer's own copy
     tr = SCGRPOTrainer((cfg, pol), [rewards.accuracy_reward, rewards.consistency_reward],
-                       args=GRPOConfig(output_dir="/tmp/iadr1_bench", per_device_train_batch_size=a.prompts, num_generations=a.group, max_prompt_length=a.prompt_len,
-                                       max_completion_length=a.gen_len, micro_batch_seqs=a.micro_batch, seed=1234 + rank, save_steps=0),
+                       args=GRPOConfig(output_dir="/tmp/iadr1_bench", per_device_train_batch_size=a.prompts, num_generations=a.group,
+                                       max_completion_length=a.gen_len, micro_batch_seqs=a.micro_batch, seed=1234 + rank, save_steps=0,
+                                       max_prompt_length=None if llava else a.prompt_len),
                        train_dataset=None, processing_class=SynthProcessor(batches, CANNED))
     eng = tr.engine
     eng.args.suppress_eos = True            # fixed-length completions, every sequence generates gen_len tokens
@@ -519,9 +542,11 @@ def main():
             pass
         out = {
             "metric": "GRPO samples/sec (img448+512tok, group=8) Qwen2.5-VL-3B" if a.model == "3b" else f"GRPO samples/sec {a.model}",
+            "model_note": ("LLaVA-OneVision-SI-7B shapes (BASELINE config 5): 448x448 image -> 5 crops of 384x384 through the SigLIP tower -> 3699 packed image tokens + 256 text positions per prompt"
+                           if llava else None),
             "value": world * N * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{'Qwen2-VL-2B' if a.model == 'qwen2vl_2b' else 'Qwen2.5-VL-' + a.model.upper()} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, 448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
+            "config": {"workload": f"{'LLaVA-OneVision-SI-7B' if llava else ('Qwen2-VL-2B' if a.model == 'qwen2vl_2b' else 'Qwen2.5-VL-' + a.model.upper())} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {'448x448 image (any-resolution: 5 crops of 384x384 -> 3699 packed image tokens) + 256 text positions' if llava else f'448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions'}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
                        "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "grad_exchange": ({"wire": eng.reducer.wire, "bytes_per_step": getattr(eng.reducer, "last_bytes_on_wire", 0), "buckets_per_step": getattr(eng.reducer, "last_n_buckets", 0)}

@@ -27,6 +27,11 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+def _first_set(*values):
+    """First value that is not None (a token id of 0 is a value, not 'unset')."""
+    return next(v for v in values if v is not None)
+
+
 @dataclass
 class VLMConfig:
     # text decoder
@@ -158,7 +163,7 @@ class VLMConfig:
                             "image_size": v.get("image_size", 384), "layer_norm_eps": v.get("layer_norm_eps", 1e-6)},
                  "image_grid_pinpoints": c["image_grid_pinpoints"], "anyres_max": int(asp.rsplit("_", 1)[-1]) if asp.startswith("anyres_max_") else 9,
                  "image_token_id": c.get("image_token_index", c.get("image_token_id", 151646)), "eos_token_id": eos[0] if isinstance(eos, (list, tuple)) else eos,
-                 "pad_token_id": t.get("pad_token_id") or c.get("pad_token_id") or 151643, "tie_word_embeddings": bool(c.get("tie_word_embeddings", t.get("tie_word_embeddings", False)))}
+                 "pad_token_id": _first_set(t.get("pad_token_id"), c.get("pad_token_id"), 151643), "tie_word_embeddings": bool(c.get("tie_word_embeddings", t.get("tie_word_embeddings", False)))}
             if c.get("vision_feature_layer", -1) != -1 or c.get("vision_feature_select_strategy", "full") != "full":
                 raise ValueError("llava_onevision: vision_feature_layer = -1 with the 'full' select strategy is the configuration built here")
             return VLMConfig.from_dict(d)
@@ -177,7 +182,7 @@ class VLMConfig:
             v_temporal=v["temporal_patch_size"], v_window=v["window_size"], v_fullatt=tuple(v["fullatt_block_indexes"]),
             image_token_id=c.get("image_token_id", 151655), vision_start_token_id=c.get("vision_start_token_id", 151652),
             vision_end_token_id=c.get("vision_end_token_id", 151653), eos_token_id=eos[0] if isinstance(eos, (list, tuple)) else eos,
-            pad_token_id=t.get("pad_token_id") or c.get("pad_token_id") or 151643, tie_word_embeddings=c.get("tie_word_embeddings", False),
+            pad_token_id=_first_set(t.get("pad_token_id"), c.get("pad_token_id"), 151643), tie_word_embeddings=c.get("tie_word_embeddings", False),
             v_arch=v.get("arch", "qwen2_5_vl"),
         )
 
@@ -209,6 +214,22 @@ class VLMConfig:
         c.vocab_size, c.hidden_size, c.intermediate_size, c.num_hidden_layers = 152064, 3584, 18944, 28
         c.num_attention_heads, c.num_key_value_heads, c.tie_word_embeddings = 28, 4, False
         return c
+
+
+def _llava_ov_7b() -> VLMConfig:
+    """LLaVA-OneVision-Qwen2-7B-SI shapes (public config.json; BASELINE.json config 5): SigLIP-so400m/14-384 tower as LLaVA-OV ships it (26 layers,
+    width 1152, 16 heads of 72, MLP 4304), Qwen2-7B decoder (width 3584, 28 layers, 28/4 heads, MLP 18944, untied head), any-resolution pinpoints
+    384 x {1..6} by 384 x {1..6}, anyres_max_9."""
+    pins = tuple((384 * i, 384 * j) for i in range(1, 7) for j in range(1, 7))
+    return VLMConfig.from_dict({
+        "text": {"vocab_size": 152064, "hidden_size": 3584, "intermediate_size": 18944, "num_hidden_layers": 28, "num_attention_heads": 28, "num_key_value_heads": 4,
+                 "rms_norm_eps": 1e-6, "rope_theta": 1e6},
+        "vision": {"arch": "siglip", "depth": 26, "hidden_size": 1152, "intermediate_size": 4304, "num_heads": 16, "in_channels": 3, "patch_size": 14, "image_size": 384,
+                   "layer_norm_eps": 1e-6},
+        "image_grid_pinpoints": pins, "anyres_max": 9, "image_token_id": 151646, "eos_token_id": 151645, "pad_token_id": 151643, "tie_word_embeddings": False})
+
+
+VLMConfig.llava_ov_7b = staticmethod(_llava_ov_7b)
 
 
 @dataclass

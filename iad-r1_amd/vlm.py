@@ -355,6 +355,8 @@ class Engine:
         c = self.cfg
         n, ch, S, _ = crops.shape
         p, side = c.v_patch, c.v_side
+        if S != side * p:      # valid-padding conv: the last S - side * p pixel rows / columns are never read (384 = 27 * 14 + 6 in the SigLIP-so400m tower)
+            crops = crops[:, :, :side * p, :side * p]
         rows = crops.reshape(n, ch, side, p, side, p).permute(0, 2, 4, 1, 3, 5).reshape(n * side * side, ch * p * p)
         if rows.dtype == BF16 and c.patch_dim_pad == c.patch_dim:
             return rows.contiguous()

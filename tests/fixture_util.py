@@ -359,3 +359,35 @@ def synth_crops(n_crops: int, cfg: dict, seed: int) -> np.ndarray:
     """Processor-shaped crops [n, 3, S, S] fp32, bf16-representable, ~N(0,1) (normalised pixels)."""
     s = cfg["vision"]["image_size"]
     return _bf16_round(np.random.RandomState(seed).standard_normal((n_crops, cfg["vision"]["in_channels"], s, s)).astype(np.float32))
+
+
+LLAVA_OV_SPECIAL = ["<|endoftext|>", "<|im_start|>", "<|im_end|>", "<image>", "<video>"]
+LLAVA_OV_CHAT_TEMPLATE = (     # the llava-onevision-qwen2 chat template's structure: ChatML turns, every image placeholder of a turn before its text
+    "{% for message in messages %}<|im_start|>{{ message['role'] }}\n{% if message['content'] is string %}{{ message['content'] }}{% else %}"
+    "{% for content in message['content'] %}{% if content['type'] == 'image' %}<image>{% endif %}{% endfor %}"
+    "{% for content in message['content'] %}{% if content['type'] == 'text' %}\n{{ content['text'] }}{% endif %}{% endfor %}{% endif %}<|im_end|>\n{% endfor %}"
+    "{% if add_generation_prompt %}<|im_start|>assistant\n{% endif %}"
+)
+
+
+def local_llava_ov_processor(cfg: dict = None):
+    """Offline transformers LlavaOnevisionProcessor (character-level tokenizer, the family's PIL image processor with the tiny structure's crop size and
+    pinpoints): any-resolution cropping and the expansion of every `<image>` to the packed feature count really execute."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    import transformers
+    from transformers import LlavaOnevisionImageProcessorPil, PreTrainedTokenizerFast
+    from transformers.models.llava_onevision.processing_llava_onevision import LlavaOnevisionProcessor
+
+    cfg = cfg or TINY_OV
+    v = cfg["vision"]
+    words = LLAVA_OV_SPECIAL + [chr(c) for c in range(32, 127)] + ["\n"]
+    tok = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<|endoftext|>"))
+    tok.pre_tokenizer = pre_tokenizers.Split("", "isolated")
+    t = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|im_end|>", pad_token="<|endoftext|>", additional_special_tokens=LLAVA_OV_SPECIAL)
+
+    class _NoVideo(transformers.BaseVideoProcessor):
+        pass
+
+    ip = LlavaOnevisionImageProcessorPil(size={"height": v["image_size"], "width": v["image_size"]}, image_grid_pinpoints=[list(p) for p in cfg["image_grid_pinpoints"]])
+    return LlavaOnevisionProcessor(image_processor=ip, tokenizer=t, video_processor=_NoVideo.__new__(_NoVideo), num_image_tokens=(v["image_size"] // v["patch_size"]) ** 2,
+                                   vision_feature_select_strategy="full", chat_template=LLAVA_OV_CHAT_TEMPLATE, vision_aspect_ratio=f"anyres_max_{cfg.get('anyres_max', 9)}")

@@ -186,3 +186,35 @@ def test_prepare_batch_matches_the_reference_host_path():
     first = g["cases"][0]
     assert sorted(row[0] for row in first["attention_mask"]) == [0, 1] and all(row[-1] == 1 for row in first["attention_mask"])   # the shorter row is padded on the LEFT
     assert first["prompts_text"][0].startswith("<|im_start|>system\nYou are a helpful assistant.") and first["prompts_text"][1].startswith("<|im_start|>system\nYou are an inspector.")
+
+
+def test_prepare_batch_on_a_llava_onevision_processor():
+    """The LLaVA-OneVision side of prepare_batch (BASELINE config 5): the transformers LlavaOnevisionProcessor (offline: character tokenizer + the
+    family's PIL image processor) crops by the any-resolution rule and expands every `<image>` to the packed feature count ITSELF; the host-side
+    restatement of pack_image_features (iadr1_amd.llava_ov) must reserve exactly the same number of placeholders and crops for every image --
+    a no-shrink case, an un-padded case and one shrunk by the bilinear interpolation (26 crops > anyres_max_9)."""
+    import numpy as np
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import llava_ov as lo
+    from iadr1_amd.trainer import prepare_batch
+    proc = fx.local_llava_ov_processor()
+    v, pins = fx.TINY_OV["vision"], fx.TINY_OV["image_grid_pinpoints"]
+    side = v["image_size"] // v["patch_size"]
+    sizes = [(80, 100), (120, 100), (150, 400)]                                   # (height, width)
+    q = lambda n: [{"type": "image"}, {"type": "text", "text": "Is there any defect?" + " more" * n}]
+    rows = [{"prompt": [{"role": "user", "content": q(i)}], "image": [fx.synth_pil_image(w, h, 10 + i)], "solution": "s"} for i, (h, w) in enumerate(sizes)]
+    b = prepare_batch(proc, rows)
+    assert b["image_sizes"] == [list(s) for s in sizes] and b["images_per_prompt"] == [1, 1, 1] and "image_grid_thw" not in b
+    image_id = proc.tokenizer.convert_tokens_to_ids("<image>")
+    want_tokens = [lo.num_image_tokens(s, pins, v["image_size"], side, 9) for s in sizes]
+    want_crops = [lo.num_crops(s, pins, v["image_size"]) for s in sizes]
+    assert (b["input_ids"] == image_id).sum(1).tolist() == want_tokens == [70, 106, 184]
+    px = np.asarray(b["pixel_values"])
+    assert px.shape == (3, max(want_crops), 3, v["image_size"], v["image_size"]) and want_crops == [5, 7, 26]
+    for i, n in enumerate(want_crops):                                           # crops past an image's own count are the processor's zero padding
+        assert np.abs(px[i, n:]).max(initial=0.0) == 0.0 and np.abs(px[i, n - 1]).max() > 0.0
+    m = b["attention_mask"]
+    assert m[:, -1].all() and (m[:, 0] == 0).sum() == 2 and (np.diff(m, axis=1) >= 0).all()                # left padding
+    plan = lo.pack_plan(sizes, pins, v["image_size"], side, 9)
+    assert plan["lens"] == want_tokens and plan["crops"] == want_crops and plan["n_src"] == sum(want_crops) * side * side + 1

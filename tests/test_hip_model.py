@@ -936,3 +936,65 @@ def test_llava_onevision_rollout_and_step():
     d, dp, nh = CFG_OV.v_hidden // CFG_OV.v_heads, CFG_OV.v_head_pad, CFG_OV.v_heads
     assert float(pol.w("visual.blocks.0.qkv.w").view(3 * nh, dp, -1)[:, d:].abs().max()) == 0.0 and float(pol.w("visual.patch_embed")[:, CFG_OV.patch_dim:].abs().max()) == 0.0
     assert float(pol.w("visual.blocks.1.proj.w").view(-1, nh, dp)[:, :, d:].abs().max()) == 0.0
+
+
+def _ov_hf_config(d):
+    """config.json of a LLaVA-OneVision checkpoint (transformers 4.51.3 layout, the reference's pin) for the tiny structure."""
+    t, v = d["text"], d["vision"]
+    return {"model_type": "llava_onevision", "architectures": ["LlavaOnevisionForConditionalGeneration"], "image_token_index": d["image_token_id"],
+            "image_grid_pinpoints": [list(p) for p in d["image_grid_pinpoints"]], "vision_aspect_ratio": f"anyres_max_{d['anyres_max']}", "vision_feature_layer": -1,
+            "vision_feature_select_strategy": "full", "tie_word_embeddings": d["tie_word_embeddings"],
+            "text_config": {"model_type": "qwen2", "vocab_size": t["vocab_size"], "hidden_size": t["hidden_size"], "intermediate_size": t["intermediate_size"],
+                            "num_hidden_layers": t["num_hidden_layers"], "num_attention_heads": t["num_attention_heads"], "num_key_value_heads": t["num_key_value_heads"],
+                            "rms_norm_eps": t["rms_norm_eps"], "rope_theta": t["rope_theta"], "eos_token_id": d["eos_token_id"], "pad_token_id": d["pad_token_id"]},
+            "vision_config": {"model_type": "siglip_vision_model", "num_hidden_layers": v["depth"], "hidden_size": v["hidden_size"], "intermediate_size": v["intermediate_size"],
+                              "num_attention_heads": v["num_heads"], "num_channels": v["in_channels"], "patch_size": v["patch_size"], "image_size": v["image_size"],
+                              "layer_norm_eps": v["layer_norm_eps"]}}
+
+
+def test_llava_onevision_through_the_trainer_api_and_checkpoint_roundtrip(tmp_path):
+    """BASELINE config 5 end to end at the reference's API: a LLaVA-OneVision checkpoint DIRECTORY (config.json + safetensors in the 4.51.3 names) is
+    what `SCGRPOTrainer(model=<path>)` loads (REF:124-132), the prompt tensors come from a real transformers LlavaOnevisionProcessor (any-resolution
+    crops + `<image>` expansion, tests/fixture_util.py::local_llava_ov_processor) through prepare_batch, two images of different crop counts (one shrunk
+    by the interpolation) in one batch, one optimizer step, save_model, and the saved directory loads back bit-identical (bf16)."""
+    from iadr1_amd import rewards
+    from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer, load_checkpoint, save_checkpoint
+    proc = fx.local_llava_ov_processor()
+    d = dict(fx.TINY_OV, image_token_id=proc.tokenizer.convert_tokens_to_ids("<image>"), eos_token_id=proc.tokenizer.eos_token_id, pad_token_id=proc.tokenizer.pad_token_id)
+    cfg = VLMConfig.from_dict(d)
+    src = str(tmp_path / "llava-ov-tiny")
+    s0 = ParamStore(cfg, DEV, trainable=False)
+    w0 = fx.make_weights_ov(d, 0)
+    s0.load_named(w0)
+    save_checkpoint(s0, src, _ov_hf_config(d))
+    import dataclasses
+    cfg = dataclasses.replace(cfg, vision_start_token_id=-1, vision_end_token_id=-1)       # Qwen-VL special tokens: not part of a LLaVA-OneVision config.json
+    cfg_l, s1 = load_checkpoint(src, DEV, trainable=False)
+    assert cfg_l == cfg
+    back = s1.export_named()
+    assert set(back) == set(w0)
+    for k, v_ in w0.items():
+        assert np.array_equal(back[k].float().numpy().reshape(-1), v_.reshape(-1)), k
+    q = lambda n: [{"type": "image"}, {"type": "text", "text": "Is there any defect?" + " more" * n}]
+    sizes = [(80, 100), (150, 400)]
+    rows = [{"prompt": [{"role": "user", "content": q(3 * i)}], "image": [fx.synth_pil_image(w_, h_, 20 + i)],
+             "solution": "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"} for i, (h_, w_) in enumerate(sizes)]
+    out_dir = str(tmp_path / "run")
+    def text_checksum_reward(prompts, completions, **kw):       # a reward plugin that separates the random completions (the shipped ones score 0 on noise)
+        return [float(sum(map(ord, c[0]["content"])) % 7) for c in completions]
+
+    tr = SCGRPOTrainer(src, [rewards.accuracy_reward, rewards.consistency_reward, text_checksum_reward],
+                       args=GRPOConfig(output_dir=out_dir, num_generations=4, max_completion_length=8, max_prompt_length=None, learning_rate=1e-3, per_device_train_batch_size=2,
+                                       max_steps=1, save_steps=0, shuffle=False),
+                       train_dataset=rows, processing_class=proc)
+    assert tr.cfg.is_llava and proc.tokenizer.padding_side == "left"
+    before = tr.policy.flat.clone()
+    hist = tr.train()
+    assert len(hist) == 1 and np.isfinite(hist[0]["loss"]) and np.isfinite(hist[0]["grad_norm"]) and hist[0]["grad_norm"] > 0 and hist[0]["kl"] == 0.0
+    assert not torch.equal(before, tr.policy.flat) and torch.equal(tr.ref.flat, before)
+    tr.save_model(out_dir + "/final")
+    cfg2, s2 = load_checkpoint(out_dir + "/final", DEV, trainable=False)
+    assert cfg2 == cfg
+    a, b = tr.policy.export_named(), s2.export_named()
+    assert set(a) == set(b) and all(torch.equal(a[k].to(torch.bfloat16), b[k].to(torch.bfloat16)) for k in a)
+    assert "vision_tower.vision_model.encoder.layers.0.self_attn.q_proj.weight" in b and "language_model.model.layers.0.self_attn.q_proj.weight" in b and "image_newline" in b
