@@ -256,7 +256,7 @@ def local_qwen2vl_processor(max_pixels=None, min_pixels=None):
     t = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|im_end|>", pad_token="<|endoftext|>", additional_special_tokens=QWEN2VL_SPECIAL)
 
     class _NoVideo(BaseVideoProcessor):      # the family's video processor needs torchvision (absent offline); images never touch it
-        pass
+        _auto_class = None                   # (save_pretrained of the processor skips it)
 
     proc = Qwen2VLProcessor(image_processor=Qwen2VLImageProcessorPil(), tokenizer=t, video_processor=_NoVideo.__new__(_NoVideo), chat_template=QWEN2VL_CHAT_TEMPLATE)
     if max_pixels is not None:               # REF train/stage_rl/trainer/sc_grpo_trainer.py:192-193
@@ -386,7 +386,7 @@ def local_llava_ov_processor(cfg: dict = None):
     t = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|im_end|>", pad_token="<|endoftext|>", additional_special_tokens=LLAVA_OV_SPECIAL)
 
     class _NoVideo(transformers.BaseVideoProcessor):
-        pass
+        _auto_class = None
 
     ip = LlavaOnevisionImageProcessorPil(size={"height": v["image_size"], "width": v["image_size"]}, image_grid_pinpoints=[list(p) for p in cfg["image_grid_pinpoints"]])
     return LlavaOnevisionProcessor(image_processor=ip, tokenizer=t, video_processor=_NoVideo.__new__(_NoVideo), num_image_tokens=(v["image_size"] // v["patch_size"]) ** 2,
