@@ -621,6 +621,7 @@ struct SkinnyArgs {
     bf16_t* vcache;
     int Hq, Hkv;
     SideOut so;                // out_mode 4: p0 = roped q|k|v rows; out_mode 3 (persistent kernel): p0 = gate|up rows, p1 = SwiGLU rows; 5: p0 = residual rows (common.h)
+    int xcd_order;             // persistent kernel with side outputs: XCD-aware order of the tile groups (IADR1_PERS_XCD_ORDER=0: plain)
     NormFold nf;               // norm folding (include/iadr1_hip.h iadr1_norm_fold_t): ssq_in -> every output row is scaled by 1/rms(x row); out_mode 5 -> producer
 };
 
@@ -1066,7 +1067,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
 #pragma unroll
             for (int tt = 0; tt < TPI; ++tt) wf[j][tt] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + tt * tile_stride + j * (WAVES * 512))));
     };
-    int g = b;
+    // Order of the tile groups.  Plain: block b takes b, b + bps, ...  With side outputs (rows of the row-major training arena: 32 bytes of a row per
+    // group and array) the four groups that share a 128-byte line of a row go, in the SAME iteration, to four blocks of ONE XCD (blockIdx.x % 8 is
+    // the XCD a block lands on), so that the partial-line stores merge in that XCD's L2 instead of leaving four L2s as four masked writes:
+    // XCD x owns the groups g with (g / 4) % 8 == x; its bps / 8 blocks take them round-robin.
+    const bool xcd_order = sb >= 0 && (bps & 7) == 0 && p.xcd_order;
+    const int gq0 = xcd_order ? (b >> 3) : b, gstep = xcd_order ? (bps >> 3) : bps;
+    auto group_of = [&](int q) { return xcd_order ? (((q >> 2) * 8 + (b & 7)) * 4 + (q & 3)) : q; };
+    int gq = gq0;
+    int g = group_of(gq);
     // the first group's weights are requested BEFORE the X fragments: they come from HBM (the longer latency) and do not depend on anything, the
     // X fragments are 256 KB per CU out of L2 -- measured with in-kernel stamps (profiles/r02_decode_stamps.txt): 6.4 us from entry to the first
     // group's MFMAs with X first
@@ -1092,7 +1101,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
         __syncthreads();
     }
     float* mine = red + (size_t)w * 64 * RLD;
-    for (; g < ngroups; g += bps) {
+    for (; g < ngroups; gq += gstep, g = group_of(gq)) {
+        const int g_next = group_of(gq + gstep);
         f32x4_t acc[4][TPI];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1104,8 +1114,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][tt], xf[j][i], acc[i][tt], 0, 0, 0);
-        if (g == b) STAMP(5);
-        if (g + bps < ngroups) loadw(g + bps);   // in flight during the reduction below
+        if (gq == gq0) STAMP(5);
+        if (g_next < ngroups) loadw(g_next);     // in flight during the reduction below
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1412,6 +1422,8 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
     p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.out_mode = out_mode;
     if (int e = skinny_fold_arg(fold, out_mode, ksplit, &p.nf)) return e;
+    static const int xcd_order = iadr1_env_int("IADR1_PERS_XCD_ORDER", 1);
+    p.xcd_order = xcd_order;
     const int mz = (M + 63) / 64;
     // dynamic LDS: the cross-wave reduction buffer [WAVES][64][RLD] + (norm folding) [WAVES][64] partial row sums and one flag word
     constexpr int SM1 = 16 * 64 * 17 * 4 + 16 * 64 * 4 + 64, SM2 = 8 * 64 * 33 * 4 + 8 * 64 * 4 + 64, SMW = 8 * 64 * 33 * 4 + 8 * 64 * 4 + 64, SMP = SMW + 256, SMS = 8 * 64 * 17 * 4 + 64;

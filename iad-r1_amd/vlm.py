@@ -82,6 +82,8 @@ class Engine:
         vd = c.v_head_dim
         self.v_inv_freq = 1.0 / (10000.0 ** (np.arange(0, vd // 2, 2, dtype=np.float32) / (vd // 2)))
         self.lm_chunk = 4096
+        # side stream of the weight-gradient GEMMs (_wgrad).  Same priority as the main stream: measured with the dgrad chain on a high-priority stream
+        # (torch priority -1; the range here is (0, -1)): 1294-1306 ms/step against 1272 -- the starved wgrad queue lengthens the join at the end
         self.wgrad_stream = torch.cuda.Stream() if (self.dev.type == "cuda" and os.environ.get("IADR1_WGRAD_STREAM", "1") != "0") else None
         self.keep_logits_bytes = 24 << 30
         self._ws = {}
