@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="3b", choices=["3b", "7b", "qwen2vl_2b", "llava_ov_7b", "tiny"])
+    ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the rollout streams gate|up / down / lm_head as e4m3 + per-row scales (opt-in, BASELINE config 5; NOT the headline precision)")
     ap.add_argument("--prompts", type=int, default=8)
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=512)
@@ -419,6 +421,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         rccl_ranks = dist.get_world_size()
         assert rccl_ranks == world
+    if a.decode_weights == "fp8":
+        os.environ["IADR1_DECODE_WEIGHTS"] = "fp8"       # read by every ParamStore of this process
     import iadr1_amd  # noqa: F401
     from iadr1_amd import rewards
     from iadr1_amd.params import ParamStore, VLMConfig
@@ -548,7 +552,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{'LLaVA-OneVision-SI-7B' if llava else ('Qwen2-VL-2B' if a.model == 'qwen2vl_2b' else 'Qwen2.5-VL-' + a.model.upper())} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {'448x448 image (any-resolution: 5 crops of 384x384 -> 3699 packed image tokens) + 256 text positions' if llava else f'448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions'}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
-                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "grad_exchange": ({"wire": eng.reducer.wire, "bytes_per_step": getattr(eng.reducer, "last_bytes_on_wire", 0), "buckets_per_step": getattr(eng.reducer, "last_n_buckets", 0)}
                                          if eng.reducer.active else None),
                        "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "

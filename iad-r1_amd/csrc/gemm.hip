@@ -621,6 +621,7 @@ struct SkinnyArgs {
     bf16_t* vcache;
     int Hq, Hkv;
     SideOut so;                // out_mode 4: p0 = roped q|k|v rows; out_mode 3 (persistent kernel): p0 = gate|up rows, p1 = SwiGLU rows; 5: p0 = residual rows (common.h)
+    const float* wscale;       // non-null: W is FP8 (OCP e4m3) decode-packed (iadr1_pack_weight_fp8), wscale[n] = dequantisation scale of output row n
     int xcd_order;             // persistent kernel with side outputs: XCD-aware order of the tile groups (IADR1_PERS_XCD_ORDER=0: plain)
     NormFold nf;               // norm folding (include/iadr1_hip.h iadr1_norm_fold_t): ssq_in -> every output row is scaled by 1/rms(x row); out_mode 5 -> producer
 };
@@ -913,7 +914,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 // to 1.5-2x: the X re-read through L2, not HBM, limited the narrow kernel), and the 32-deep half-slabs are
 // software pipelined: the loads of step j+1 are in flight while the MFMAs of step j run.  K may also be split
 // over grid.z (narrow-N, long-K down projection) -> fp32 partial slabs for the fused residual+RMSNorm.
-template <int NB, int WAVES>
+// eight FP8 (OCP e4m3) weights -> a bf16 MFMA fragment: v_cvt_scalef32_pk_bf16_fp8, one instruction per pair (exact: every e4m3 value is a bf16 value)
+__device__ __forceinline__ bf16x8_t fp8x8_to_bf16(uint32_t lo, uint32_t hi) {
+    const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    return (bf16x8_t){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+// FP8 = true: the weights are FP8 decode-packed -- Wp8[n/16][k/64][lane][16 B], bytes 0-7 = the lane's 8 weights of k-step 2s, bytes 8-15 = of k-step 2s+1
+// (iadr1_pack_weight_fp8) -- so ONE 16-byte load feeds two 32-deep MFMA steps and the weight stream is half as long; the fragments are widened to bf16
+// in registers and the output columns are multiplied by the per-row dequantisation scale in the epilogue.  A "step" of the loops is then 64 deep.
+template <int NB, int WAVES, bool FP8 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs p) {
     constexpr int RC = 32, RLD = RC + 1;  // columns per reduction round
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -926,7 +937,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
     const bool scaled = p.nf.ssq_in != nullptr;
     FoldRegs<WAVES, 16> fr;
     if (scaled) fr.load(p, m_base);
-    const int nstep = p.K >> 5;
+    const int nstep = FP8 ? p.K >> 6 : p.K >> 5;
     const int per_z = (nstep + gridDim.z - 1) / gridDim.z;
     const int st_begin = blockIdx.z * per_z, st_end = min(nstep, st_begin + per_z);
 
@@ -938,8 +949,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
     // addressing kept in a few registers: tile j of this block starts j*tile_stride after tile 0 (wide kernel requires
     // N % (16*NB) == 0), X row group i is i*16 rows further down
     const int ksteps = p.K >> 5;
-    const long long tile_stride = (long long)ksteps * 512;
+    const long long tile_stride = (long long)ksteps * 512;      // elements of one 16-row weight tile (= bytes in the FP8 form)
     const bf16_t* wbase = p.W + (long long)blockIdx.x * NB * tile_stride + l * 8;
+    const char* wbase8 = (const char*)p.W + (long long)blockIdx.x * NB * tile_stride + l * 16;
     // X row-major: lane (lm, lq) reads 16 B of row m_base + 16 i + lm (16 cache lines per wave-load).  X decode-packed
     // (ldx == 0, common.h xpk_off): fragment (k-step, row group) is 1 KiB contiguous in lane order, rows padded to 64.
     const bool xpk = p.ldx == 0;
@@ -958,6 +970,32 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
     constexpr int DEPTH = 2;
     auto trip = [&](int s0, auto depth_tag) {
         constexpr int DD = decltype(depth_tag)::value;
+        if constexpr (FP8) {
+            u32x4_t wq[DD][NB];
+            bf16x8_t xq[DD][2][4];
+#pragma unroll
+            for (int d = 0; d < DD; ++d) {
+                const long long st = s0 + d * WAVES;
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj) wq[d][jj] = __builtin_nontemporal_load((const u32x4_t*)(wbase8 + jj * tile_stride + st * 1024));
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        xq[d][h][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (2 * st + h) * xstep));
+            }
+#pragma unroll
+            for (int d = 0; d < DD; ++d)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int jj = 0; jj < NB; ++jj) {
+                        const bf16x8_t wfr = fp8x8_to_bf16(wq[d][jj][2 * h], wq[d][jj][2 * h + 1]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xq[d][h][i], acc[i][jj], 0, 0, 0);
+                    }
+            return;
+        }
         bf16x8_t wf[DD][NB], xf[DD][4];
 #pragma unroll
         for (int d = 0; d < DD; ++d) {
@@ -1004,6 +1042,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
                     g += red[((size_t)ww * 64 + m) * RLD + n];
                     u += red[((size_t)ww * 64 + m) * RLD + 16 + n];
                 }
+                if constexpr (FP8) { g *= p.wscale[gn]; u *= p.wscale[(p.N >> 1) + gn]; }
                 if (scaled) { const float ri = fold_rinv<WAVES>(p, part, m); g *= ri; u *= ri; }
                 g = bf2f(f2bf(g));
                 u = bf2f(f2bf(u));
@@ -1019,6 +1058,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
             float v = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+            if constexpr (FP8) v *= p.wscale[gn];
             if (scaled) v *= fold_rinv<WAVES>(p, part, m);
             if (p.out_mode == 0) {
                 if (p.bias) v += bf2f(p.bias[gn]);
@@ -1315,6 +1355,48 @@ __global__ __launch_bounds__(256) void pack_qkv_rope_kernel(const bf16_t* W, lon
     }
 }
 
+// FP8 decode pack, pass 1: dequantisation scale of every output row, scale[n] = max_k |w[n][k] * g[k]| / 448 (448 = largest finite OCP e4m3 value)
+__global__ __launch_bounds__(256) void fp8_row_scale_kernel(const bf16_t* W, long long ldw, const bf16_t* colscale, float* scale, int K) {
+    __shared__ float scratch[16];
+    const long long n = blockIdx.x;
+    float amax = 0.f;
+    for (int c = threadIdx.x; c < (K >> 3); c += 256) {
+        const u32x4_t v = scale8(*(const u32x4_t*)(W + n * ldw + c * 8), colscale, c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo_bf(v[e])), fabsf(hi_bf(v[e]))));
+    }
+    amax = block_max<256>(amax, scratch);
+    if (threadIdx.x == 0) scale[n] = fmaxf(amax, 1e-30f) / 448.f;
+}
+// pass 2: Wp8[n/16][k/64][lane][16 bytes] (see gemm_skinny_wide_kernel<.., FP8>); I > 0: gate|up matrix, 16-row tiles of gate and up interleaved like
+// pack_gateup_kernel.  Round-to-nearest-even through v_cvt_pk_fp8_f32; |w / scale| <= 448 by construction.
+__global__ __launch_bounds__(256) void pack_fp8_kernel(const bf16_t* W, long long ldw, const bf16_t* colscale, const float* scale, uint32_t* Wp8, int N, int K, int I) {
+    const int dsteps = K >> 6;
+    const long long total = (long long)(N >> 4) * dsteps * 64;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long long ts = i >> 6;
+        const int sd = (int)(ts % dsteps);
+        const long long tile = ts / dsteps;
+        const long long n = I > 0 ? ((tile & 1 ? I : 0) + (tile >> 1) * 16 + (lane & 15)) : tile * 16 + (lane & 15);
+        const float sc = scale[n];     // true divisions below (not a reciprocal multiply): the quantised values are then the round-to-nearest e4m3 of w / scale exactly
+        u32x4_t o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = sd * 64 + h * 32 + (lane >> 4) * 8;
+            const u32x4_t v = scale8(*(const u32x4_t*)(W + n * ldw + k), colscale, k);
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[0]) / sc, hi_bf(v[0]) / sc, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[1]) / sc, hi_bf(v[1]) / sc, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[2]) / sc, hi_bf(v[2]) / sc, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[3]) / sc, hi_bf(v[3]) / sc, hi, true);
+            o[2 * h] = (uint32_t)lo;
+            o[2 * h + 1] = (uint32_t)hi;
+        }
+        *(u32x4_t*)(Wp8 + i * 4) = o;
+    }
+}
+
 // X[M,K] row-major -> decode-packed (common.h xpk_off); pad rows (M..roundup64) are zero-filled
 __global__ __launch_bounds__(256) void pack_act_kernel(const bf16_t* X, long long ldx, bf16_t* Xp, int M, int K) {
     const int Mp = (M + 63) & ~63;
@@ -1538,6 +1620,37 @@ extern "C" int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, in
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_gateup_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, I, K, (const bf16_t*)colscale);
     return iadr1_check_launch("pack_gateup_bf16");
+}
+
+// Decode-time skinny GEMM on FP8 weights (include/iadr1_hip.h): the wide kernel, 64 output columns per block, K slices over grid.z.
+extern "C" int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const float* wscale, void* Y, const void* bias, int M, int N, int K, long long ldx, long long ldy,
+                                      int out_mode, int ksplit, const void* fold, hipStream_t stream) {
+    IADR1_REQUIRE(M > 0 && N > 0 && K > 0 && wscale != nullptr, "gemm_skinny_fp8w: empty problem / no scales");
+    IADR1_REQUIRE((K % 64) == 0 && (N % 64) == 0 && (ldx % 8) == 0, "gemm_skinny_fp8w: FP8-packed weights need K %% 64 == 0 and N %% 64 == 0 (K=%d N=%d)", K, N);
+    IADR1_REQUIRE(ldy != 0 || (out_mode == 3 && (N % 64) == 0), "gemm_skinny_fp8w: a decode-packed output (ldy == 0) exists for the fused-SwiGLU mode only");
+    IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wp8) & 15) == 0, "gemm_skinny_fp8w: X/W must be 16-byte aligned");
+    IADR1_REQUIRE(out_mode >= 0 && out_mode <= 3 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny_fp8w: out_mode 0-3; ksplit > 1 needs out_mode 2 (partial slabs)");
+    IADR1_REQUIRE(out_mode != 3 || (N % 128) == 0, "gemm_skinny_fp8w: fused SwiGLU needs N (= 2*I) to be a multiple of 128, got %d", N);
+    SkinnyArgs p{};
+    p.X = (const bf16_t*)X; p.W = (const bf16_t*)Wp8; p.wscale = wscale; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
+    p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.out_mode = out_mode;
+    if (int e = skinny_fold_arg(fold, out_mode, ksplit, &p.nf)) return e;
+    constexpr int SMW = 8 * 64 * 33 * 4 + 8 * 64 * 4 + 64;
+    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW); return true; }();
+    (void)attr_done;
+    hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8, true>), dim3(N / 64, (M + 63) / 64, ksplit), dim3(512), SMW, stream, p);
+    return iadr1_check_launch("gemm_skinny_fp8w");
+}
+
+extern "C" int iadr1_pack_weight_fp8(const void* W, long long ldw, void* Wp8, float* scale, int N, int K, int gateup_I, const void* colscale, hipStream_t stream) {
+    IADR1_REQUIRE(N > 0 && K > 0 && (N % 16) == 0 && (K % 64) == 0 && (ldw % 8) == 0, "pack_weight_fp8: need N %% 16 == 0, K %% 64 == 0 (N=%d K=%d)", N, K);
+    IADR1_REQUIRE(gateup_I == 0 || (2 * gateup_I == N && (gateup_I % 64) == 0), "pack_weight_fp8: gateup_I must be N / 2 and a multiple of 64");
+    IADR1_REQUIRE(scale != nullptr && (((uintptr_t)Wp8) & 15) == 0, "pack_weight_fp8: scale buffer / 16-byte aligned destination required");
+    hipLaunchKernelGGL(fp8_row_scale_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)W, ldw, (const bf16_t*)colscale, scale, K);
+    long long blocks = ((long long)N * K / 16 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_fp8_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (const bf16_t*)colscale, scale, (uint32_t*)Wp8, N, K, gateup_I);
+    return iadr1_check_launch("pack_weight_fp8");
 }
 
 IADR1_STAMPS_EXPORT(gemm)

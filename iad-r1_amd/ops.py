@@ -54,6 +54,18 @@ def pack_gateup(w, out=None, colscale=None):
     return o
 
 
+def pack_weight_fp8(w, out=None, out_scale=None, colscale=None, gateup=False):
+    """[N,K] bf16 -> (FP8 e4m3 decode pack: flat uint8 [N*K], fp32 scale per output row [N]) for gemm_skinny (include/iadr1_hip.h iadr1_pack_weight_fp8).
+    gateup: w is a gate|up matrix, tiles interleaved for the fused-SwiGLU mode."""
+    N, K = w.shape
+    out = out if out is not None else torch.empty(N * K, dtype=torch.uint8, device=w.device)
+    out_scale = out_scale if out_scale is not None else torch.empty(N, dtype=F32, device=w.device)
+    assert out.dtype == torch.uint8 and out.numel() == N * K and out_scale.dtype == F32 and out_scale.numel() == N
+    assert colscale is None or (colscale.dtype == BF16 and colscale.numel() == K and colscale.is_contiguous())
+    hip.call("pack_weight_fp8", w, _ld(w), out, out_scale, N, K, N // 2 if gateup else 0, colscale)
+    return out, out_scale
+
+
 class NormFold(ctypes.Structure):
     """include/iadr1_hip.h iadr1_norm_fold_t: the decode step's RMSNorms folded into the GEMMs around them.  `consumer(ssq, eps)`: the GEMM reads the
     un-normalised residual stream (weights packed with colscale = the norm gain) and scales every output row by 1/rms from the tile partials `ssq`
@@ -144,10 +156,27 @@ def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=
     fold = NormFold.consumer(...): rows scaled by 1/rms of the x rows.  resid (tensor or PackedAct [M, N]) with fold = NormFold.producer(...):
     resid = bf16(resid + bf16(x @ W^T)) in place, + the tile partials of its rows' sums of squares (C ABI out_mode 5)."""
     M, K = x.shape
-    w = wp
-    assert wp.numel() == N * K
     xb, ldx = _xarg(x)
     dev = xb.device
+    if isinstance(wp, tuple):       # (FP8 pack, per-row scales): ops.pack_weight_fp8 -- the opt-in FP8 weight stream of the rollout
+        w8, wscale = wp
+        assert w8.dtype == torch.uint8 and w8.numel() == N * K and wscale.numel() == N and resid is None and side is None
+        if swiglu:
+            out = out if out is not None else torch.empty(M, N // 2, dtype=BF16, device=dev)
+            ob, ldo = _xarg(out)
+            hip.call("gemm_skinny_fp8w", xb, w8, wscale, ob, None, M, N, K, ldx, ldo, 3, 1, _side(fold))
+            return out
+        if out is None:
+            out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=dev)
+        if out.dim() == 3:
+            assert out.dtype == F32 and out.shape[0] == ksplit and out.is_contiguous() and bias is None
+            mode, ldy = 2, N
+        else:
+            mode, ldy = (1 if out.dtype == F32 else 0), _ld(out)
+        hip.call("gemm_skinny_fp8w", xb, w8, wscale, out, bias, M, N, K, ldx, ldy, mode, ksplit, _side(fold))
+        return out
+    w = wp
+    assert wp.numel() == N * K
     if resid is not None:
         assert fold is not None and bias is None and out is None and not swiglu and tuple(resid.shape) == (M, N)
         rb, ldr = _xarg(resid)

@@ -247,7 +247,7 @@ class _Slot:
 class ParamStore:
     """Flat parameter buffers + named views in the engine's fused layout."""
 
-    def __init__(self, cfg: VLMConfig, device, trainable: bool, with_transposes: bool | None = None, with_decode_pack: bool | None = None):
+    def __init__(self, cfg: VLMConfig, device, trainable: bool, with_transposes: bool | None = None, with_decode_pack: bool | None = None, decode_weights: str | None = None):
         self.cfg, self.device, self.trainable = cfg, torch.device(device), trainable
         self.with_transposes = trainable if with_transposes is None else with_transposes
         self.with_decode_pack = trainable if with_decode_pack is None else with_decode_pack
@@ -355,8 +355,24 @@ class ParamStore:
         self._views, self._tviews, self._gviews = {}, {}, {}
         # decode-packed (MFMA fragment order) shadows of the weights the rollout streams every step
         self._pk = {}
+        # opt-in FP8 weight stream of the rollout (BASELINE config 5; IADR1_DECODE_WEIGHTS=fp8 or ParamStore(..., decode_weights="fp8")): the three big
+        # streams of a decode step -- gate|up, down, lm_head -- are kept as OCP e4m3 + one fp32 scale per output row instead of bf16 packs; q|k|v and o
+        # (latency-bound, 10 MB) stay bf16.  Training passes never read these copies.
+        self.decode_fp8 = (decode_weights or os.environ.get("IADR1_DECODE_WEIGHTS", "bf16")) == "fp8"
+        assert not self.decode_fp8 or (c.hidden_size % 64 == 0 and c.intermediate_size % 64 == 0 and c.vocab_size % 64 == 0), "fp8 decode weights need widths that are multiples of 64"
+        self._pk8 = {}
         if self.with_decode_pack:
             names = [f"layers.{i}.{k}" for i in range(c.num_hidden_layers) for k in ("qkv.w", "o.w", "gu.w", "down.w")] + [self.lm_head_name()]
+            if self.decode_fp8:
+                names8 = [n for n in names if n.endswith(("gu.w", "down.w")) or n == self.lm_head_name()]
+                names = [n for n in names if n not in names8]
+                tot8 = sum(_rup(int(np.prod(self.slots[n].shape)), 64) for n in names8)
+                self.flat_pk8 = torch.zeros(tot8, dtype=torch.uint8, device=self.device)
+                o8 = 0
+                for n in names8:
+                    k = int(np.prod(self.slots[n].shape))
+                    self._pk8[n] = (self.flat_pk8[o8: o8 + k], torch.zeros(self.slots[n].shape[0], dtype=F32, device=self.device))
+                    o8 += _rup(k, 64)
             tot = sum(_rup(int(np.prod(self.slots[n].shape)), 64) for n in names)
             self.flat_pk = torch.zeros(tot, dtype=BF16, device=self.device)
             o = 0
@@ -397,8 +413,8 @@ class ParamStore:
         return "embed" if self.cfg.tie_word_embeddings else "lm_head"
 
     def wpk(self, name: str) -> torch.Tensor:
-        """Decode-packed shadow (flat) of GEMM weight `name`."""
-        return self._pk[name]
+        """Decode-packed shadow (flat) of GEMM weight `name`; an (FP8 pack, row scales) pair for the streams kept in FP8 (ops.gemm_skinny takes either)."""
+        return self._pk8[name] if name in self._pk8 else self._pk[name]
 
     def wpk_bias(self, name: str) -> torch.Tensor:
         """Bias permuted like the rope-ordered decode pack of q|k|v weight `name`."""
@@ -424,6 +440,10 @@ class ParamStore:
         fuse = self.cfg.intermediate_size % 64 == 0
         c = self.cfg
         fold1, fold2 = self.fold_norm
+        for name, (dst8, sc8) in self._pk8.items():
+            gain = ("ln2" if name.endswith(".gu.w") else None) if fold2 else None
+            colscale = self.w(name[:-len("gu.w")] + gain) if gain else (self.w("norm") if (fold1 and name == self.lm_head_name()) else None)
+            ops.pack_weight_fp8(self.w(name), out=dst8, out_scale=sc8, colscale=colscale, gateup=name.endswith(".gu.w") and self.cfg.intermediate_size % 64 == 0)
         for name, dst in self._pk.items():
             if self.qkv_rope_packed and name.endswith(".qkv.w"):
                 # rotary partners share a tile: the decode q|k|v GEMM applies rope and appends K/V in its epilogue

@@ -262,7 +262,8 @@ class SCGRPOEngine:
         c, st = self.cfg, self.pol.p
         # decode steps that also fill the training arena (no policy forward over the completions afterwards): needs the fused decode kernels that carry
         # the side outputs (q|k|v + rotary + cache append, persistent fused-SwiGLU gate|up GEMM)
-        trace = (train_carry is not None and a.reuse_decode and st.qkv_rope_packed and self._rollout_fuses_swiglu(N))
+        # (not with the opt-in FP8 weight stream: the policy's training activations must come from its bf16 weights, so its forward runs after the rollout)
+        trace = (train_carry is not None and a.reuse_decode and st.qkv_rope_packed and not st.decode_fp8 and self._rollout_fuses_swiglu(N))
         toks = self._rollout.generate(plan, img_pol, a.num_generations, a.max_completion_length, temperature=0.0 if greedy else a.temperature,
                                       top_k=a.top_k, top_p=a.top_p, seed=a.seed + 1000003 * self.opt_step + 7919 * self.accum, suppress_eos=a.suppress_eos,
                                       train_carry=train_carry, train_trace=trace)

@@ -109,6 +109,17 @@ int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, voi
 /* First kernel of a folded decode step: x[m] = E[ids[m]] (row-major, or decode-packed when ldx == 0; pad rows untouched) and ssq_out[0][m] = sum x[m]^2
  * (ONE tile: the consumer is called with ssq_in_tiles = 1). */
 int iadr1_embed_decode(const long long* ids, const void* E, void* x, long long ldx, float* ssq_out, int M, int H, iadr1_stream_t stream);
+/* FP8 weights for the decode stream (BASELINE config 5: "fp8 weights"; opt-in, the rollout only -- the training passes and the log-probs of the loss stay
+ * bf16).  iadr1_pack_weight_fp8: W[N,K] bf16 -> OCP e4m3 with ONE fp32 scale per output row (scale[n] = max_k |w[n][k]| / 448, round to nearest even),
+ * decode-packed so that a lane's 16-byte load holds its 8 weights of TWO consecutive 32-deep k-steps: Wp8[N/16][K/64][64 lanes][16 B].  gateup_I > 0:
+ * W is a gate|up matrix [2I, K], tiles interleaved as by iadr1_pack_gateup_bf16.  colscale as for the bf16 packs.  K % 64 == 0.
+ * iadr1_gemm_skinny_fp8w: Y = (X . dequant(Wp8)^T) with the out_modes 0-3 of iadr1_gemm_skinny_bf16 (the fragments are widened to bf16 in registers --
+ * exact, every e4m3 value is a bf16 value -- and fed to the bf16 MFMA; columns are multiplied by wscale in the epilogue).  N % 64 == 0.
+ * Stated tolerance of the format: |w - dequant(quant(w))| <= 2^-4 |w| + scale * 2^-10 per weight (3 mantissa bits); the kernel adds nothing to it
+ * (tests/test_hip_kernels.py::test_fp8_weight_gemm compares against the dequantised weights at the bf16 GEMM's own tolerance). */
+int iadr1_pack_weight_fp8(const void* W, long long ldw, void* Wp8, float* scale, int N, int K, int gateup_I, const void* colscale, iadr1_stream_t stream);
+int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const float* wscale, void* Y, const void* bias, int M, int N, int K, long long ldx,
+                           long long ldy, int out_mode, int ksplit, const iadr1_norm_fold_t* fold, iadr1_stream_t stream);
 /* X[M,K] row-major -> decode-packed activations Xp (buffer of roundup(M,64)*K elements; pad rows zeroed).  K % 32 == 0. */
 int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);

@@ -752,3 +752,61 @@ def test_embed_decode_rows_and_sums_of_squares():
         got = x.unpack() if packed else x
         assert torch.equal(got, E[ids])
         close(ssq[0, :5], (E[ids].float() ** 2).sum(-1), 1e-6, 1e-6, "embed ssq")
+
+
+# ------------------------------------------------------------------------------------------------ FP8 weight stream of the rollout (opt-in)
+def _fp8_reference(w, colscale=None, scale=None):
+    """torch restatement of iadr1_pack_weight_fp8: per-row scale amax / 448, round-to-nearest-even to OCP e4m3; returns (fp8 values [N,K], scales, dequantised fp32).
+    `scale`: quantise with these scales (the device's: its amax / 448 may differ from torch's in the last bit, which moves exact ties like 84 -> 80 | 88)."""
+    wf = w.float() * (colscale.float()[None, :] if colscale is not None else 1.0)
+    if colscale is not None:
+        wf = wf.to(BF).float()                                  # the gain is folded in with one bf16 rounding, as in the bf16 packs
+    own = wf.abs().amax(1).clamp_min(1e-30) / 448.0
+    scale = own if scale is None else scale
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    return q, own, q.float() * scale[:, None]
+
+
+def _unpack_fp8(buf, N, K, gateup=False):
+    t = buf.view(N // 16, K // 64, 4, 16, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(N, K)      # [tile][dstep][g][n%16][h][8] -> [n][k]
+    if gateup:                                                                                 # tiles 2q / 2q+1 = gate / up rows of the same 16 columns
+        I = N // 2
+        t = t.view(N // 32, 2, 16, K)
+        t = torch.cat([t[:, 0].reshape(I, K), t[:, 1].reshape(I, K)], 0)
+    return t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,packed", [(64, 2048, 11008, True), (64, 151936, 2048, True), (8, 256, 512, False), (33, 3584, 18944, True), (100, 640, 256, False)])
+def test_fp8_weight_gemm(M, N, K, packed):
+    """FP8 (e4m3, per-row scale) decode weights: the pack holds exactly torch's round-to-nearest e4m3 of w / scale, and the GEMM on it equals the GEMM on the
+    dequantised weights at the bf16 kernels' own tolerance -- the kernel adds no error to the format's.  fp32 / bf16+bias / split-K slab outputs."""
+    x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
+    w8, sc = ops.pack_weight_fp8(w)
+    q, scale, deq = _fp8_reference(w, scale=sc)
+    assert torch.equal(_unpack_fp8(w8, N, K), q.view(torch.uint8)) and torch.allclose(sc, scale, rtol=1e-6, atol=0)
+    ref = x.float() @ deq.t()
+    xin = ops.pack_act(x) if packed else x
+    close(ops.gemm_skinny(xin, (w8, sc), N, out_dtype=F32), ref, 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"fp8w f32 {M}x{N}x{K}")
+    close(ops.gemm_skinny(xin, (w8, sc), N, bias=bias), ref + bias.float(), 1e-2, 1e-2 * math.sqrt(K) * 0.3, f"fp8w bf16+bias {M}x{N}x{K}")
+    for ks in (2, 8):
+        part = ops.gemm_skinny(xin, (w8, sc), N, out=torch.full((ks, M, N), 7.0, dtype=F32, device=DEV), ksplit=ks)
+        close(part.sum(0), ref, 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"fp8w split-K {ks}")
+    # against the ORIGINAL weights: the format's error, 3 mantissa bits per weight -> a few percent of the output's scale
+    full = x.float() @ w.float().t()
+    rel = ((ref - full).norm() / full.norm()).item()
+    assert rel < 0.04, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 128), (64, 18944, 3584)])
+def test_fp8_weight_gemm_fused_swiglu(M, I, K):
+    x, w, g = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.3), (1 + 0.2 * rnd(K, seed=4).float()).to(BF)
+    for colscale in (None, g):
+        w8, sc = ops.pack_weight_fp8(w, gateup=True, colscale=colscale)
+        q, scale, deq = _fp8_reference(w, colscale, scale=sc)
+        assert torch.equal(_unpack_fp8(w8, 2 * I, K, gateup=True), q.view(torch.uint8))
+        gu = (x.float() @ deq.t()).to(BF)
+        ref = torch.nn.functional.silu(gu[:, :I].float()).to(BF).float() * gu[:, I:].float()
+        a = ops.gemm_skinny(ops.pack_act(x), (w8, sc), 2 * I, swiglu=True, out=ops.PackedAct(M, I, DEV)).unpack()
+        close(a, ref, 2e-2, 2e-2 * math.sqrt(K) * 0.3, f"fp8w swiglu {M}x{I}x{K}")

@@ -88,6 +88,8 @@ def build_parser():
     p.add_argument("--save_steps", type=int, default=100)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--micro_batch_seqs", type=int, default=64)
+    p.add_argument("--decode_weights", default="bf16", choices=["bf16", "fp8"],
+                   help="fp8: the rollout streams the gate|up / down / lm_head weights as e4m3 + per-row scales (BASELINE config 5); the loss and its gradients stay bf16")
     p.add_argument("--run_name", default=None)
     # accepted for script compatibility, no effect here
     for flag in ("--deepspeed", "--report_to", "--gradient_checkpointing", "--bf16", "--ddp_timeout", "--push_to_hub"):
@@ -168,6 +170,8 @@ def main(argv=None):
         dist.init_process_group("nccl")
     import iadr1_amd  # noqa: F401
     from iadr1_amd.rewards import REWARD_FUNCS
+    if a.decode_weights == "fp8":
+        os.environ["IADR1_DECODE_WEIGHTS"] = "fp8"       # read by the parameter stores the trainer builds
     from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
 
     rows = [make_conversation(r, a.image_path, str2bool(a.use_system_prompt), a.single_img) for r in load_rows(a.dataset_name)]
