@@ -1,0 +1,152 @@
+"""The two reference entry points run END TO END on the GPU from what a user has on disk: an HF checkpoint directory (config.json in the layout the
+published checkpoints use + safetensors in the published names), a dataset manifest, image files.  Only the processor is a stand-in (the published
+tokenizer / video processor files cannot be fetched offline): `AutoProcessor.from_pretrained` is pointed at the offline Qwen2-VL processor of
+tests/fixture_util.py, which really renders the chat template, tokenises and patches the images."""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fixture_util as fx  # noqa: E402
+import iadr1_amd  # noqa: E402,F401
+from iadr1_amd.params import ParamStore, VLMConfig  # noqa: E402
+from iadr1_amd.trainer import load_checkpoint, save_checkpoint  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def _load(rel):
+    spec = importlib.util.spec_from_file_location(os.path.basename(rel)[:-3] + "_e2e", os.path.join(ROOT, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _tiny_with_processor_ids(proc):
+    tid = proc.tokenizer.convert_tokens_to_ids
+    return dict(fx.TINY, image_token_id=tid("<|image_pad|>"), video_token_id=tid("<|video_pad|>"), vision_start_token_id=tid("<|vision_start|>"),
+                vision_end_token_id=tid("<|vision_end|>"), eos_token_id=tid("<|im_end|>"), pad_token_id=tid("<|endoftext|>"))
+
+
+def _qwen25vl_config_json(d, nested):
+    """config.json as Qwen2.5-VL checkpoints carry it: flat (transformers 4.51.3, the reference's pin) or with `text_config` (5.x)."""
+    t, v = d["text"], d["vision"]
+    text = {"vocab_size": t["vocab_size"], "hidden_size": t["hidden_size"], "intermediate_size": t["intermediate_size"], "num_hidden_layers": t["num_hidden_layers"],
+            "num_attention_heads": t["num_attention_heads"], "num_key_value_heads": t["num_key_value_heads"], "rms_norm_eps": t["rms_norm_eps"], "rope_theta": t["rope_theta"],
+            "rope_scaling": {"type": "mrope", "mrope_section": t["mrope_section"]}, "hidden_act": "silu", "max_position_embeddings": 128000}
+    vis = {"depth": v["depth"], "hidden_size": v["hidden_size"], "intermediate_size": v["intermediate_size"], "num_heads": v["num_heads"], "in_chans": v["in_channels"],
+           "out_hidden_size": v["out_hidden_size"], "patch_size": v["patch_size"], "spatial_merge_size": v["spatial_merge_size"], "temporal_patch_size": v["temporal_patch_size"],
+           "window_size": v["window_size"], "fullatt_block_indexes": v["fullatt_block_indexes"], "hidden_act": "silu", "tokens_per_second": 2}
+    top = {"architectures": ["Qwen2_5_VLForConditionalGeneration"], "model_type": "qwen2_5_vl", "image_token_id": d["image_token_id"], "video_token_id": d["video_token_id"],
+           "vision_start_token_id": d["vision_start_token_id"], "vision_end_token_id": d["vision_end_token_id"], "eos_token_id": d["eos_token_id"],
+           "pad_token_id": d["pad_token_id"], "tie_word_embeddings": d["tie_word_embeddings"], "vision_config": vis, "torch_dtype": "bfloat16"}
+    if nested:
+        top["text_config"] = dict(text, model_type="qwen2_5_vl_text", eos_token_id=d["eos_token_id"], pad_token_id=d["pad_token_id"])
+    else:
+        top.update(text)
+    return top
+
+
+def _write_checkpoint(path, d, nested=False, seed=0):
+    cfg = VLMConfig.from_dict(d)
+    s = ParamStore(cfg, DEV, trainable=False)
+    s.load_named(fx.make_weights(d, seed))
+    save_checkpoint(s, path, _qwen25vl_config_json(d, nested))
+    return cfg, s
+
+
+@pytest.fixture
+def offline_processor(monkeypatch):
+    proc = fx.local_qwen2vl_processor()
+    proc.save_pretrained = lambda *a, **k: None
+    import transformers
+    monkeypatch.setattr(transformers.AutoProcessor, "from_pretrained", classmethod(lambda cls, *a, **k: proc))
+    return proc
+
+
+@pytest.mark.parametrize("nested", [False, True])
+def test_checkpoint_directory_of_the_published_layout_loads(tmp_path, offline_processor, nested):
+    """config.json in both published layouts -> the same VLMConfig; every tensor of the safetensors file comes back bit-identical."""
+    d = _tiny_with_processor_ids(offline_processor)
+    cfg, s = _write_checkpoint(str(tmp_path / "Qwen2.5-VL-tiny"), d, nested)
+    cfg2, s2 = load_checkpoint(str(tmp_path / "Qwen2.5-VL-tiny"), DEV, trainable=False)
+    assert cfg2 == cfg
+    a, b = s.export_named(), s2.export_named()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_sc_grpo_entry_point_end_to_end(tmp_path, offline_processor, monkeypatch, capsys):
+    """`train/stage_rl/grpo_ad.py` with the flags of scripts/train/SC_GRPO/SC_GRPO_Qwen_Instruct_2_5_VL_3B.sh (paths swapped): manifest rows -> 1-image
+    prompts (REF grpo_ad.py:135-181) -> chat template + PIL images + processor -> group rollout, reward plugins on the decoded text, SC-GRPO steps, HF-layout
+    save.  Two optimizer steps over a 4-row manifest with gradient accumulation 2; the saved directory loads back and differs from the start."""
+    d = _tiny_with_processor_ids(offline_processor)
+    src = str(tmp_path / "Qwen2.5-VL-tiny-Instruct")
+    _, s0 = _write_checkpoint(src, d)
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    rows = []
+    for i in range(4):
+        fx.synth_pil_image(112 + 28 * (i % 2), 84, 40 + i).save(str(img_dir / f"part_{i}.png"))
+        rows.append({"image": f"part_{i}.png", "problem": "Are there any defects in the query image?",
+                     "solution": "<think>x</think><location>top left</location><type>scratch</type><answer>Yes</answer>" if i % 2 else "<answer>No</answer>"})
+    manifest = tmp_path / "expert_ad_tiny.json"
+    manifest.write_text(json.dumps(rows))
+    out = str(tmp_path / "out")
+    m = _load("train/stage_rl/grpo_ad.py")
+
+    def text_checksum_reward(prompts, completions, **kw):      # the shipped rewards score 0 on the noise a random-weight model writes: no advantage, no update
+        assert set(kw) >= {"solution", "image", "problem"} and len(prompts) == len(completions) == 4
+        return [float(sum(map(ord, c[0]["content"])) % 7) for c in completions]
+
+    from iadr1_amd import rewards
+    monkeypatch.setitem(rewards.REWARD_FUNCS, "format", text_checksum_reward)
+    m.main(["--model_name_or_path", src, "--dataset_name", str(manifest), "--image_path", str(img_dir), "--output_dir", out, "--max_prompt_length", "1024",
+            "--max_completion_length", "8", "--num_generations", "4", "--per_device_train_batch_size", "1", "--gradient_accumulation_steps", "2", "--learning_rate", "1e-3",
+            "--num_train_epochs", "1", "--logging_steps", "1", "--save_steps", "100", "--bf16", "--attn_implementation", "flash_attention_2", "--max_pixels", "401408",
+            "--reward_funcs", "accuracy", "format", "--use_vllm_for_gen", "true", "--use_system_prompt", "false", "--single_img", "1", "--report_to", "none",
+            "--deepspeed", "local_scripts/zero3.json", "--run_name", "e2e"])
+    logs = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert [r["step"] for r in logs] == [1, 2] and all(np.isfinite(r["loss"]) and r["grad_norm"] > 0 and r["completion_length"] == 8.0 for r in logs)
+    assert {"rewards/accuracy_reward", "rewards/text_checksum_reward", "reward", "reward_std", "kl", "learning_rate"} <= set(logs[0])
+    assert os.path.exists(os.path.join(out, "model.safetensors")) and os.path.exists(os.path.join(out, "config.json"))
+    cfg2, s2 = load_checkpoint(out, DEV, trainable=False)
+    assert cfg2 == VLMConfig.from_dict(d)
+    assert not torch.equal(s2.flat, s0.flat) and bool(torch.isfinite(s2.flat.float()).all())
+
+
+def test_pa_sft_entry_point_end_to_end(tmp_path, offline_processor):
+    """`train/stage_sft/train.py` with the flags of scripts/train/PA_SFT/PA_SFT_Qwen_Instruct_2_5_VL_3B.sh: dataset_info.json + sharegpt manifest + --image_dir,
+    qwen2_vl template, 2 optimizer steps; the loss log is written and finite, the saved checkpoint loads back and differs from the start."""
+    d = _tiny_with_processor_ids(offline_processor)
+    src = str(tmp_path / "Qwen2.5-VL-tiny-Instruct")
+    _, s0 = _write_checkpoint(src, d)
+    data_dir, img_dir = tmp_path / "data", tmp_path / "imgs"
+    data_dir.mkdir()
+    img_dir.mkdir()
+    rows = []
+    for i in range(4):
+        fx.synth_pil_image(112, 84 + 28 * (i % 2), 60 + i).save(str(img_dir / f"s_{i}.png"))
+        rows.append({"messages": [{"role": "user", "content": "<image>Are there any defects in the query image?"},
+                                  {"role": "assistant", "content": "<think>the surface is clean</think><answer>No</answer>" if i % 2 else "<think>a scratch</think><answer>Yes</answer>"}],
+                     "images": [f"s_{i}.png"]})
+    (data_dir / "expert_ad.json").write_text(json.dumps(rows))
+    (data_dir / "dataset_info.json").write_text(json.dumps({"expert_ad": {"file_name": "expert_ad.json", "formatting": "sharegpt", "columns": {"messages": "messages", "images": "images"},
+                                                                          "tags": {"role_tag": "role", "content_tag": "content", "user_tag": "user", "assistant_tag": "assistant"}}}))
+    out = str(tmp_path / "sft_out")
+    m = _load("train/stage_sft/train.py")
+    m.main(["--stage", "sft", "--do_train", "--model_name_or_path", src, "--dataset", "expert_ad", "--dataset_dir", str(data_dir), "--image_dir", str(img_dir), "--template", "qwen2_vl",
+            "--finetuning_type", "full", "--output_dir", out, "--overwrite_output_dir", "--per_device_train_batch_size", "1", "--gradient_accumulation_steps", "2",
+            "--learning_rate", "1e-3", "--lr_scheduler_type", "cosine", "--warmup_steps", "1", "--num_train_epochs", "1", "--cutoff_len", "2048", "--logging_steps", "1",
+            "--save_steps", "500", "--bf16", "--deepspeed", "ds_z3.json", "--plot_loss", "--ddp_timeout", "9000"])
+    log = [json.loads(l) for l in open(os.path.join(out, "trainer_log.jsonl"))]
+    assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
+    cfg2, s2 = load_checkpoint(out, DEV, trainable=False)
+    assert cfg2 == VLMConfig.from_dict(d) and not torch.equal(s2.flat, s0.flat) and bool(torch.isfinite(s2.flat.float()).all())

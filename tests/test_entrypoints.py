@@ -218,3 +218,47 @@ def test_prepare_batch_on_a_llava_onevision_processor():
     assert m[:, -1].all() and (m[:, 0] == 0).sum() == 2 and (np.diff(m, axis=1) >= 0).all()                # left padding
     plan = lo.pack_plan(sizes, pins, v["image_size"], side, 9)
     assert plan["lens"] == want_tokens and plan["crops"] == want_crops and plan["n_src"] == sum(want_crops) * side * side + 1
+
+
+def test_from_hf_config_parses_the_published_config_layouts():
+    """`VLMConfig.from_hf_config` on config.json files in the layouts the published checkpoints use (field names and nesting as on the model cards:
+    Qwen2.5-VL flat 4.x layout with `rope_scaling.mrope_section` and `in_chans`; Qwen2-VL with `embed_dim` / `mlp_ratio`; LLaVA-OneVision with
+    `text_config` / `vision_config` / `image_grid_pinpoints` / `vision_aspect_ratio`) gives the shapes the static constructors (bench.py) use."""
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.params import VLMConfig
+    q25_3b = {"architectures": ["Qwen2_5_VLForConditionalGeneration"], "model_type": "qwen2_5_vl", "bos_token_id": 151643, "eos_token_id": 151645, "vision_start_token_id": 151652,
+              "vision_end_token_id": 151653, "vision_token_id": 151654, "image_token_id": 151655, "video_token_id": 151656, "hidden_act": "silu", "hidden_size": 2048,
+              "intermediate_size": 11008, "max_position_embeddings": 128000, "num_attention_heads": 16, "num_hidden_layers": 36, "num_key_value_heads": 2, "rms_norm_eps": 1e-06,
+              "rope_theta": 1000000.0, "tie_word_embeddings": True, "torch_dtype": "bfloat16", "vocab_size": 151936, "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]},
+              "vision_config": {"depth": 32, "hidden_act": "silu", "hidden_size": 1280, "intermediate_size": 3420, "num_heads": 16, "in_chans": 3, "out_hidden_size": 2048,
+                                "patch_size": 14, "spatial_merge_size": 2, "spatial_patch_size": 14, "window_size": 112, "fullatt_block_indexes": [7, 15, 23, 31],
+                                "tokens_per_second": 2, "temporal_patch_size": 2}}
+    assert VLMConfig.from_hf_config(q25_3b) == VLMConfig.qwen25vl_3b()
+    q25_7b = dict(q25_3b, hidden_size=3584, intermediate_size=18944, num_attention_heads=28, num_hidden_layers=28, num_key_value_heads=4, tie_word_embeddings=False, vocab_size=152064,
+                  vision_config=dict(q25_3b["vision_config"], out_hidden_size=3584))
+    assert VLMConfig.from_hf_config(q25_7b) == VLMConfig.qwen25vl_7b()
+    nested = {k: v for k, v in q25_3b.items() if k not in ("hidden_size", "intermediate_size", "num_attention_heads", "num_hidden_layers", "num_key_value_heads", "rms_norm_eps",
+                                                             "rope_theta", "vocab_size", "rope_scaling")}
+    nested["text_config"] = {k: q25_3b[k] for k in ("hidden_size", "intermediate_size", "num_attention_heads", "num_hidden_layers", "num_key_value_heads", "rms_norm_eps", "vocab_size")}
+    nested["text_config"]["rope_parameters"] = {"rope_type": "default", "mrope_section": [16, 24, 24], "rope_theta": 1000000.0}
+    assert VLMConfig.from_hf_config(nested) == VLMConfig.qwen25vl_3b()                      # transformers 5.x layout of the same checkpoint
+    q2_2b = {"architectures": ["Qwen2VLForConditionalGeneration"], "model_type": "qwen2_vl", "eos_token_id": 151645, "vision_start_token_id": 151652, "vision_end_token_id": 151653,
+             "image_token_id": 151655, "video_token_id": 151656, "hidden_size": 1536, "intermediate_size": 8960, "num_attention_heads": 12, "num_hidden_layers": 28,
+             "num_key_value_heads": 2, "rms_norm_eps": 1e-06, "rope_theta": 1000000.0, "tie_word_embeddings": True, "vocab_size": 151936,
+             "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]},
+             "vision_config": {"depth": 32, "embed_dim": 1280, "mlp_ratio": 4, "num_heads": 16, "in_chans": 3, "hidden_size": 1536, "patch_size": 14, "spatial_merge_size": 2,
+                               "spatial_patch_size": 14, "temporal_patch_size": 2}}
+    assert VLMConfig.from_hf_config(q2_2b) == VLMConfig.qwen2vl_2b()
+    pins = [[384 * i, 384 * j] for i in range(1, 7) for j in range(1, 7)]
+    ov_7b = {"architectures": ["LlavaOnevisionForConditionalGeneration"], "model_type": "llava_onevision", "image_token_index": 151646, "video_token_index": 151647,
+             "image_grid_pinpoints": pins, "vision_aspect_ratio": "anyres_max_9", "vision_feature_layer": -1, "vision_feature_select_strategy": "full", "tie_word_embeddings": False,
+             "projector_hidden_act": "gelu",
+             "text_config": {"model_type": "qwen2", "vocab_size": 152064, "hidden_size": 3584, "intermediate_size": 18944, "num_hidden_layers": 28, "num_attention_heads": 28,
+                             "num_key_value_heads": 4, "rms_norm_eps": 1e-06, "rope_theta": 1000000.0, "eos_token_id": 151645},
+             "vision_config": {"model_type": "siglip_vision_model", "hidden_size": 1152, "image_size": 384, "intermediate_size": 4304, "num_attention_heads": 16, "num_hidden_layers": 26,
+                               "patch_size": 14, "vision_use_head": False}}
+    import dataclasses
+    want = dataclasses.replace(VLMConfig.llava_ov_7b(), vision_start_token_id=-1, vision_end_token_id=-1)
+    assert VLMConfig.from_hf_config(ov_7b) == want
+    with pytest.raises(ValueError, match="vision_feature_layer"):
+        VLMConfig.from_hf_config(dict(ov_7b, vision_feature_layer=-2))
