@@ -169,6 +169,34 @@ def regularize_image(image, max_pixels: int = 512 * 512):
     return image if image.mode == "RGB" else image.convert("RGB")
 
 
+def regularize_image_base(image, max_pixels: int = 512 * 512):
+    """The BASE plugin's image pre-processing (llamafactory mm_plugin.py:108-123), which the llava* templates use: area capped at `max_pixels` (both sides scaled
+    by the same factor, truncated; nearest-neighbour), RGB -- without the minimum-side / aspect-ratio steps the Qwen2-VL plugin adds (`regularize_image`)."""
+    from PIL import Image
+    if image.width * image.height > max_pixels:
+        f = math.sqrt(max_pixels / (image.width * image.height))
+        image = image.resize((int(image.width * f), int(image.height * f)), resample=Image.Resampling.NEAREST)
+    return image if image.mode == "RGB" else image.convert("RGB")
+
+
+def expand_image_placeholders_llava(messages, image_sizes, tokens_of, image_token: str = "<image>"):
+    """LlavaNextPlugin.process_messages (mm_plugin.py:327-366) for the LLaVA-OneVision processor: every "<image>" in the message contents, in order, becomes
+    tokens_of((height, width)) copies of the image token (the packed any-resolution feature count, `iadr1_amd.llava_ov.num_image_tokens`; the
+    `vision_feature_select_strategy` is "full": no class-token correction).  Counts must match exactly."""
+    out, used = [], 0
+    for m in messages:
+        content = m["content"]
+        while IMAGE_PLACEHOLDER in content:
+            if used >= len(image_sizes):
+                raise ValueError("`len(images)` is less than the number of %s tokens." % IMAGE_PLACEHOLDER)
+            content = content.replace(IMAGE_PLACEHOLDER, "{{image}}" * int(tokens_of(tuple(int(v) for v in image_sizes[used]))), 1)
+            used += 1
+        out.append({**m, "content": content.replace("{{image}}", image_token)})
+    if used != len(image_sizes):
+        raise ValueError("The number of images does not match the number of %s tokens." % IMAGE_PLACEHOLDER)
+    return out
+
+
 def expand_image_placeholders(messages, grids, merge_size: int = 2, image_token: str = "<|image_pad|>"):
     """Every "<image>" in the message contents, in order, becomes <|vision_start|> + t*h*w / merge_size^2 image tokens + <|vision_end|> for the
     corresponding entry of `grids` ([t, h, w] patch grids).  Counts must match exactly."""
@@ -207,6 +235,10 @@ def qwen2_vl_turn_texts(messages, system: Optional[str] = None):
             raise NotImplementedError("Unexpected role: %s (tool calls are not part of the IAD-R1 data)" % m["role"])
         rendered.append(pieces)
     return [(rendered[i], rendered[i + 1]) for i in range(0, len(rendered), 2)]
+
+
+# "llava_next_qwen" (llamafactory template.py:899-913, "copied from chatml template"): the same ChatML turns and the same default system prompt as "qwen2_vl"
+llava_next_qwen_turn_texts = qwen2_vl_turn_texts
 
 
 def encode_turns(tokenizer, turn_texts):

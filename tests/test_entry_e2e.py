@@ -150,3 +150,51 @@ def test_pa_sft_entry_point_end_to_end(tmp_path, offline_processor):
     assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
     cfg2, s2 = load_checkpoint(out, DEV, trainable=False)
     assert cfg2 == VLMConfig.from_dict(d) and not torch.equal(s2.flat, s0.flat) and bool(torch.isfinite(s2.flat.float()).all())
+
+
+def test_pa_sft_entry_point_end_to_end_llava_onevision(tmp_path, monkeypatch):
+    """`train/stage_sft/train.py` with the flags of scripts/train/PA_SFT/PA_SFT_LLaVA_OneVision_SI_7B.sh (--template llava_next_qwen) on a LLaVA-OneVision checkpoint
+    directory: any-resolution crops from the transformers LlavaOnevisionProcessor, `<image>` expanded to the packed feature count, SigLIP tower + projector + packing
+    + Qwen2 decoder trained for 2 optimizer steps; a mismatching template is refused."""
+    proc = fx.local_llava_ov_processor()
+    proc.save_pretrained = lambda *a, **k: None
+    import transformers
+    monkeypatch.setattr(transformers.AutoProcessor, "from_pretrained", classmethod(lambda cls, *a, **k: proc))
+    d = dict(fx.TINY_OV, image_token_id=proc.tokenizer.convert_tokens_to_ids("<image>"), eos_token_id=proc.tokenizer.eos_token_id, pad_token_id=proc.tokenizer.pad_token_id)
+    t, v = d["text"], d["vision"]
+    hf = {"model_type": "llava_onevision", "architectures": ["LlavaOnevisionForConditionalGeneration"], "image_token_index": d["image_token_id"],
+          "image_grid_pinpoints": [list(p) for p in d["image_grid_pinpoints"]], "vision_aspect_ratio": "anyres_max_9", "vision_feature_layer": -1,
+          "vision_feature_select_strategy": "full", "tie_word_embeddings": False,
+          "text_config": {"model_type": "qwen2", "vocab_size": t["vocab_size"], "hidden_size": t["hidden_size"], "intermediate_size": t["intermediate_size"],
+                          "num_hidden_layers": t["num_hidden_layers"], "num_attention_heads": t["num_attention_heads"], "num_key_value_heads": t["num_key_value_heads"],
+                          "rms_norm_eps": t["rms_norm_eps"], "rope_theta": t["rope_theta"], "eos_token_id": d["eos_token_id"], "pad_token_id": d["pad_token_id"]},
+          "vision_config": {"model_type": "siglip_vision_model", "num_hidden_layers": v["depth"], "hidden_size": v["hidden_size"], "intermediate_size": v["intermediate_size"],
+                            "num_attention_heads": v["num_heads"], "num_channels": v["in_channels"], "patch_size": v["patch_size"], "image_size": v["image_size"], "layer_norm_eps": 1e-6}}
+    src = str(tmp_path / "llava-onevision-tiny-si")
+    s0 = ParamStore(VLMConfig.from_dict(d), DEV, trainable=False)
+    s0.load_named(fx.make_weights_ov(d, 0))
+    save_checkpoint(s0, src, hf)
+    data_dir, img_dir = tmp_path / "data", tmp_path / "imgs"
+    data_dir.mkdir()
+    img_dir.mkdir()
+    rows = []
+    for i, (w, h) in enumerate(((100, 80), (100, 120), (400, 150), (90, 90))):
+        fx.synth_pil_image(w, h, 70 + i).save(str(img_dir / f"s_{i}.png"))
+        rows.append({"messages": [{"role": "user", "content": "<image>Are there any defects in the query image?"},
+                                  {"role": "assistant", "content": "<think>a scratch</think><answer>Yes</answer>" if i % 2 else "<answer>No</answer>"}], "images": [f"s_{i}.png"]})
+    (data_dir / "expert_ad.json").write_text(json.dumps(rows))
+    (data_dir / "dataset_info.json").write_text(json.dumps({"Expert_AD_Stage_1": {"file_name": "expert_ad.json", "formatting": "sharegpt", "columns": {"messages": "messages", "images": "images"},
+                                                                                  "tags": {"role_tag": "role", "content_tag": "content", "user_tag": "user", "assistant_tag": "assistant"}}}))
+    out = str(tmp_path / "sft_out")
+    m = _load("train/stage_sft/train.py")
+    flags = ["--deepspeed", "scripts/train/zero3.json", "--stage", "sft", "--do_train", "--model_name_or_path", src, "--dataset", "Expert_AD_Stage_1", "--dataset_dir", str(data_dir),
+             "--image_dir", str(img_dir), "--finetuning_type", "full", "--output_dir", out, "--overwrite_cache", "--overwrite_output_dir", "--warmup_steps", "1",
+             "--weight_decay", "0.1", "--per_device_train_batch_size", "1", "--gradient_accumulation_steps", "2", "--ddp_timeout", "90000", "--learning_rate", "1e-3",
+             "--lr_scheduler_type", "cosine", "--logging_steps", "1", "--cutoff_len", "8192", "--save_steps", "500", "--plot_loss", "--num_train_epochs", "1", "--bf16"]
+    with pytest.raises(ValueError, match="does not belong to the model family"):
+        m.main(flags + ["--template", "qwen2_vl"])
+    m.main(flags + ["--template", "llava_next_qwen"])
+    log = [json.loads(l) for l in open(os.path.join(out, "trainer_log.jsonl"))]
+    assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
+    cfg2, s2 = load_checkpoint(out, DEV, trainable=False)
+    assert cfg2.is_llava and not torch.equal(s2.flat, s0.flat) and bool(torch.isfinite(s2.flat.float()).all())

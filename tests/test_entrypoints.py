@@ -262,3 +262,50 @@ def test_from_hf_config_parses_the_published_config_layouts():
     assert VLMConfig.from_hf_config(ov_7b) == want
     with pytest.raises(ValueError, match="vision_feature_layer"):
         VLMConfig.from_hf_config(dict(ov_7b, vision_feature_layer=-2))
+
+
+def test_pa_sft_llava_next_qwen_template_matches_the_reference():
+    """The text path of scripts/train/PA_SFT/PA_SFT_LLaVA_OneVision_SI_*.sh (--template llava_next_qwen) against tests/golden/sft_llava.json = the reference's own
+    template + LlavaNextPlugin on the same offline LlavaOnevisionProcessor (tools/make_golden_sft_llava.py): area-cap regularisation, the processor's crops and
+    image sizes, `<image>` expansion to the packed feature count, ChatML turn pairs with the default / an explicit system prompt, a text-only row; and through
+    train.py::encode_example: ids / labels with the image tokens intact and the per-image crop stacks the engine consumes."""
+    import re
+    import numpy as np
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import llava_ov as lo
+    from iadr1_amd import sft_data as sd
+    from iadr1_amd.params import VLMConfig
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "sft_llava.json")))
+    assert g["meta"]["default_system"] == sd.QWEN2_VL_DEFAULT_SYSTEM and g["meta"]["image_token"] == "<image>"
+    proc = fx.local_llava_ov_processor()
+    cfg = VLMConfig.from_dict(fx.TINY_OV)
+    tokens_of = lambda size: lo.num_image_tokens(size, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
+    collapse = lambda s: re.sub(r"(?:<image>)+", lambda m: "<image*%d>" % (len(m.group(0)) // 7), s)
+    char_tok = type("T", (), {"encode": staticmethod(lambda text, add_special_tokens=False: [ord(c) for c in text])})
+    for c in g["cases"]:
+        pil = [sd.regularize_image_base(fx.synth_pil_image(w, h, seed), c["image_resolution"]) for w, h, seed in c["images"]]
+        assert [[im.width, im.height] for im in pil] == c["regularized_sizes"]
+        sizes = []
+        if pil:
+            feats = proc.image_processor(images=pil, return_tensors="pt")
+            sizes = [list(map(int, s)) for s in feats["image_sizes"].tolist()]
+            assert sizes == c["image_sizes"] and list(feats["pixel_values"].shape) == c["pixel_shape"]
+            assert abs(float(feats["pixel_values"].double().abs().sum()) - c["pixel_abs_sum"]) <= 1e-6 * c["pixel_abs_sum"]
+        msgs = sd.expand_image_placeholders_llava(c["messages"], sizes, tokens_of)
+        assert [{**m, "content": collapse(m["content"])} for m in msgs] == c["expanded"]
+        pairs = sd.encode_turns(char_tok, sd.llava_next_qwen_turn_texts([{**m, "content": collapse(m["content"])} for m in msgs], c["system"]))
+        assert [[list(s), list(t)] for s, t in pairs] == c["pairs_collapsed"]
+    with pytest.raises(ValueError, match="does not match"):
+        sd.expand_image_placeholders_llava([{"role": "user", "content": "no placeholder"}], [(80, 100)], tokens_of)
+    # the entry point's encoder on the real tokenizer of the processor
+    m = _load("train/stage_sft/train.py")
+    image_id = proc.tokenizer.convert_tokens_to_ids("<image>")
+    row = {"prompt": [{"role": "user", "content": "<image>Any defect?"}], "response": [{"role": "assistant", "content": "<answer>No</answer>"}], "system": "",
+           "images": [fx.synth_pil_image(100, 80, 1)]}
+    ids, labels, pixels, grids = m.encode_example(proc, row, 4096, image_token_id=image_id, template="llava_next_qwen", cfg=cfg)
+    assert grids == [(80, 100)] and ids.count(image_id) == 70 and len(pixels) == 1 and tuple(pixels[0].shape) == (5, 3, 56, 56)
+    sup = [t for t in labels if t != -100]
+    assert sup == proc.tokenizer.encode("<answer>No</answer><|im_end|>\n", add_special_tokens=False) and len(ids) == len(labels)
+    with pytest.raises(ValueError, match="truncates image placeholder"):
+        m.encode_example(proc, row, 60, image_token_id=image_id, template="llava_next_qwen", cfg=cfg)

@@ -77,34 +77,50 @@ def load_sharegpt(name: str, dataset_dir: str, image_dir: str | None = None):
     return [r for r in rows if r["prompt"]]      # the reference filters out the rows its aligner emptied (odd turn counts, roles out of order)
 
 
-def encode_example(proc, row, cutoff_len, train_on_prompt=False, mask_history=False, image_token_id=151655, image_resolution=512 * 512):
-    """Aligned row -> (input_ids, labels, pixel_values, grids), the reference's supervised preprocessing end to end (iadr1_amd.sft_data): images
-    regularised (mm_plugin.py:108-123,810-824), "<image>" expanded to the vision tokens of its patch grid (mm_plugin.py:850-896), "qwen2_vl" ChatML
-    turns tokenised piecewise (template.py:85-160,1120-1133), per-turn budget and label mask (processors/supervised.py:33-87)."""
-    from iadr1_amd.sft_data import encode_turns, expand_image_placeholders, qwen2_vl_turn_texts, regularize_image, supervised_labels
+TEMPLATES = ("qwen2_vl", "llava_next_qwen")
+
+
+def encode_example(proc, row, cutoff_len, train_on_prompt=False, mask_history=False, image_token_id=151655, image_resolution=512 * 512, template="qwen2_vl", cfg=None):
+    """Aligned row -> (input_ids, labels, pixel_values, grids), the reference's supervised preprocessing end to end (iadr1_amd.sft_data).
+    "qwen2_vl": images regularised (mm_plugin.py:108-123,810-824), "<image>" expanded to the vision tokens of its patch grid (mm_plugin.py:850-896), ChatML
+    turns tokenised piecewise (template.py:85-160,1120-1133), per-turn budget and label mask (processors/supervised.py:33-87); grids = [t, h, w] per image.
+    "llava_next_qwen" (the LLaVA-OneVision scripts): the base plugin's area cap only, the LLaVA-OneVision image processor's any-resolution crops, "<image>" ->
+    packed feature count copies of the image token (mm_plugin.py:327-366); pixel_values = list of per-image crop stacks, grids = (height, width) per image."""
+    from iadr1_amd.sft_data import (encode_turns, expand_image_placeholders, expand_image_placeholders_llava, llava_next_qwen_turn_texts, qwen2_vl_turn_texts, regularize_image,
+                                    regularize_image_base, supervised_labels)
+    llava = template == "llava_next_qwen"
     images = []
     for im in row["images"] or []:
         if isinstance(im, str):
             from PIL import Image
             im = Image.open(im)
-        images.append(regularize_image(im, image_resolution))
+        images.append(regularize_image_base(im, image_resolution) if llava else regularize_image(im, image_resolution))
     feats = proc.image_processor(images=images, return_tensors="pt") if images else None
-    grids = feats["image_grid_thw"].tolist() if images else []
-    msgs = expand_image_placeholders(row["prompt"] + row["response"], grids, merge_size=getattr(proc.image_processor, "merge_size", 2))
-    turns = encode_turns(proc.tokenizer, qwen2_vl_turn_texts(msgs, row["system"]))
+    if llava:
+        from iadr1_amd import llava_ov
+        grids = [tuple(int(v) for v in s) for s in feats["image_sizes"].tolist()] if images else []
+        tokens_of = lambda size: llava_ov.num_image_tokens(size, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
+        msgs = expand_image_placeholders_llava(row["prompt"] + row["response"], grids, tokens_of)
+        turns = encode_turns(proc.tokenizer, llava_next_qwen_turn_texts(msgs, row["system"]))
+        pixels = [feats["pixel_values"][i, : llava_ov.num_crops(g, cfg.image_grid_pinpoints, cfg.v_image_size)] for i, g in enumerate(grids)] if images else None
+    else:
+        grids = feats["image_grid_thw"].tolist() if images else []
+        msgs = expand_image_placeholders(row["prompt"] + row["response"], grids, merge_size=getattr(proc.image_processor, "merge_size", 2))
+        turns = encode_turns(proc.tokenizer, qwen2_vl_turn_texts(msgs, row["system"]))
+        pixels = feats["pixel_values"] if images else None
     ids, labels = supervised_labels(turns, cutoff_len, train_on_prompt=train_on_prompt, mask_history=mask_history)
     if images and ids.count(image_token_id) != sum(part.count(image_token_id) for tn in turns for part in tn):
         raise ValueError("cutoff_len=%d truncates image placeholder tokens; raise --cutoff_len" % cutoff_len)
-    return ids, labels, (feats["pixel_values"] if images else None), grids
+    return ids, labels, pixels, grids
 
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
     if a.stage != "sft" or a.finetuning_type != "full":
         raise ValueError("only --stage sft --finetuning_type full is part of the IAD-R1 PA-SFT path")
-    if a.template != "qwen2_vl":
-        raise ValueError(f"--template {a.template}: the Qwen2-VL / Qwen2.5-VL chat format is the one built here; the llava* templates "
-                         "(llamafactory data/template.py:833-841,886-913) belong to model families this engine does not run yet")
+    if a.template not in TEMPLATES:
+        raise ValueError(f"--template {a.template}: built here are {TEMPLATES} (Qwen2-VL / Qwen2.5-VL and LLaVA-OneVision); the `llava` / `llava_next_mistral` templates "
+                         "(llamafactory data/template.py:833-841,886-897) belong to model families this engine does not run yet")
     import numpy as np
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +138,8 @@ def main(argv=None):
     from iadr1_amd.trainer import last_checkpoint, load_checkpoint, load_training_state, save_checkpoint, save_training_state
 
     cfg, store = load_checkpoint(a.model_name_or_path, dev, trainable=True)
+    if cfg.is_llava != (a.template == "llava_next_qwen"):
+        raise ValueError(f"--template {a.template} does not belong to the model family of {a.model_name_or_path}")
     proc = AutoProcessor.from_pretrained(a.model_name_or_path)
     eng = SFTEngine(cfg, store, SFTArgs(learning_rate=a.learning_rate, weight_decay=a.weight_decay, max_grad_norm=a.max_grad_norm,
                                         gradient_accumulation_steps=a.gradient_accumulation_steps, micro_batch_seqs=a.micro_batch_seqs), group=group)
@@ -150,7 +168,8 @@ def main(argv=None):
         eng.args.learning_rate = lr
         losses = []
         for k in range(ga):
-            enc = [encode_example(proc, rows[sampler.index(i + j)], a.cutoff_len, a.train_on_prompt, a.mask_history, cfg.image_token_id, a.image_resolution) for j in range(bs)]
+            enc = [encode_example(proc, rows[sampler.index(i + j)], a.cutoff_len, a.train_on_prompt, a.mask_history, cfg.image_token_id, a.image_resolution, a.template, cfg)
+                   for j in range(bs)]
             i += bs
             S = (max(len(e[0]) for e in enc) + 7) // 8 * 8  # pad_to_multiple_of=8 (sft/workflow.py:60), right padding
             ids = np.full((bs, S), pad, dtype=np.int64)
@@ -158,10 +177,13 @@ def main(argv=None):
             labels = np.full((bs, S), -100, dtype=np.int64)
             for r, (x, y, _, _) in enumerate(enc):
                 ids[r, : len(x)], mask[r, : len(x)], labels[r, : len(y)] = x, 1, y
-            pv = torch.cat([e[2] for e in enc if e[2] is not None], 0)
             grids = [tuple(g) for e in enc for g in e[3]]
-            batch = {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": pv, "image_grid_thw": grids,
-                     "images_per_row": [len(e[3]) for e in enc]}
+            if cfg.is_llava:     # per-image crop stacks + original (height, width) of every image
+                batch = {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": [c for e in enc if e[2] is not None for c in e[2]], "image_sizes": grids,
+                         "images_per_row": [len(e[3]) for e in enc]}
+            else:
+                pv = torch.cat([e[2] for e in enc if e[2] is not None], 0)
+                batch = {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": pv, "image_grid_thw": grids, "images_per_row": [len(e[3]) for e in enc]}
             losses.append(eng.loss_and_grads(batch, last_micro_step=(k == ga - 1)))
         eng.optimizer_step()
         if log and (step + 1) % a.logging_steps == 0:
