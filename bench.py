@@ -579,7 +579,7 @@ def main():
                     "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
                     "device_frees_in_timed_region": torch.cuda.memory_stats().get("num_device_free", 0) - ms0.get("num_device_free", 0)},
         }
-        if not a.no_cpu_baseline and a.model == "3b":
+        if not a.no_cpu_baseline and a.model == "3b" and world == 1:     # rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in the closing barrier
             d3 = {"text": {"vocab_size": 151936, "hidden_size": 2048, "intermediate_size": 11008, "num_hidden_layers": 36, "num_attention_heads": 16,
                            "num_key_value_heads": 2, "rms_norm_eps": 1e-6, "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
                   "vision": {"depth": 32, "hidden_size": 1280, "intermediate_size": 3420, "num_heads": 16, "in_channels": 3, "patch_size": 14,

@@ -103,8 +103,26 @@ class VLMConfig:
         return _rup(self.patch_dim, 8)
 
     @property
-    def head_dim(self):
+    def head_dim_real(self):
         return self.hidden_size // self.num_attention_heads
+
+    @property
+    def head_dim(self):
+        """Head width the decoder KERNELS run at: 128.  A narrower head (64: the Qwen2-0.5B decoder of LLaVA-OneVision-0.5B) is stored zero-padded to 128 in
+        q|k|v rows / o columns with its two rotary halves at [0, r/2) and [64, 64 + r/2) (`head_slots`), so that the kernels' rotary partners (d, d + 64)
+        are the model's (d, d + r/2); the zero dims add nothing to q.k, give zero outputs, and keep zero gradients.  `attn_scale` uses the real width."""
+        r = self.head_dim_real
+        return r if r >= 128 else 128
+
+    @property
+    def attn_scale(self):
+        return float(self.head_dim_real) ** -0.5
+
+    @property
+    def head_slots(self):
+        """Index of real head dim d inside the padded head (identity when nothing is padded)."""
+        r, D = self.head_dim_real, self.head_dim
+        return np.arange(r) if r == D else np.concatenate([np.arange(r // 2), D // 2 + np.arange(r // 2)])
 
     @property
     def v_head_dim(self):
@@ -127,7 +145,7 @@ class VLMConfig:
         """Accepts the nested {text, vision, ...} form of tests/fixture_util.TINY."""
         t, v = d["text"], d["vision"]
         if v.get("arch") == "siglip":
-            hd = t["hidden_size"] // t["num_attention_heads"]
+            hd = max(128, t["hidden_size"] // t["num_attention_heads"])      # the width the kernels run at (VLMConfig.head_dim): 1-D positions drive every rotary pair
             return VLMConfig(
                 vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"], num_hidden_layers=t["num_hidden_layers"],
                 num_attention_heads=t["num_attention_heads"], num_key_value_heads=t["num_key_value_heads"], rms_norm_eps=t["rms_norm_eps"], rope_theta=t["rope_theta"],
@@ -532,13 +550,23 @@ class ParamStore:
         self._assign("visual.newline", t("image_newline"))
         lm = "language_model.model."
         self._assign("embed", t(lm + "embed_tokens.weight"))
+        slots_t, Dr, Dk = torch.from_numpy(c.head_slots), c.head_dim_real, c.head_dim
+
+        def pad_heads(w):         # [heads * Dr, ...] -> [heads * Dk, ...]: every head's dims scattered to their slots of the padded head (VLMConfig.head_dim)
+            if Dr == Dk:
+                return w
+            nh_ = w.shape[0] // Dr
+            out = torch.zeros(nh_, Dk, *w.shape[1:])
+            out[:, slots_t] = w.reshape(nh_, Dr, *w.shape[1:])
+            return out.reshape(nh_ * Dk, *w.shape[1:])
+
         for i in range(c.num_hidden_layers):
             s_, b = f"{lm}layers.{i}.", f"layers.{i}."
             self._assign(b + "ln1", t(s_ + "input_layernorm.weight"))
             self._assign(b + "ln2", t(s_ + "post_attention_layernorm.weight"))
-            self._assign(b + "qkv.w", torch.cat([t(s_ + "self_attn.q_proj.weight"), t(s_ + "self_attn.k_proj.weight"), t(s_ + "self_attn.v_proj.weight")], 0))
-            self._assign(b + "qkv.b", torch.cat([t(s_ + "self_attn.q_proj.bias"), t(s_ + "self_attn.k_proj.bias"), t(s_ + "self_attn.v_proj.bias")], 0))
-            self._assign(b + "o.w", t(s_ + "self_attn.o_proj.weight"))
+            self._assign(b + "qkv.w", torch.cat([pad_heads(t(s_ + f"self_attn.{z}_proj.weight")) for z in "qkv"], 0))
+            self._assign(b + "qkv.b", torch.cat([pad_heads(t(s_ + f"self_attn.{z}_proj.bias")) for z in "qkv"], 0))
+            self._assign(b + "o.w", pad_heads(t(s_ + "self_attn.o_proj.weight").t().contiguous()).t().contiguous())
             self._assign(b + "gu.w", torch.cat([t(s_ + "mlp.gate_proj.weight"), t(s_ + "mlp.up_proj.weight")], 0))
             self._assign(b + "down.w", t(s_ + "mlp.down_proj.weight"))
         self._assign("norm", t(lm + "norm.weight"))
@@ -576,13 +604,15 @@ class ParamStore:
         lm = "language_model.model."
         out[lm + "embed_tokens.weight"] = get("embed")
         hq, hk = c.num_attention_heads * c.head_dim, c.num_key_value_heads * c.head_dim
+        slots_t, Dr, Dk = torch.from_numpy(c.head_slots), c.head_dim_real, c.head_dim
+        unpad_heads = lambda w: w.clone() if Dr == Dk else w.reshape(w.shape[0] // Dk, Dk, *w.shape[1:])[:, slots_t].reshape(w.shape[0] // Dk * Dr, *w.shape[1:]).clone()
         for i in range(c.num_hidden_layers):
             s_, b = f"{lm}layers.{i}.", f"layers.{i}."
             out[s_ + "input_layernorm.weight"], out[s_ + "post_attention_layernorm.weight"] = get(b + "ln1"), get(b + "ln2")
             qw, qb = get(b + "qkv.w"), get(b + "qkv.b")
-            out[s_ + "self_attn.q_proj.weight"], out[s_ + "self_attn.k_proj.weight"], out[s_ + "self_attn.v_proj.weight"] = qw[:hq].clone(), qw[hq: hq + hk].clone(), qw[hq + hk:].clone()
-            out[s_ + "self_attn.q_proj.bias"], out[s_ + "self_attn.k_proj.bias"], out[s_ + "self_attn.v_proj.bias"] = qb[:hq].clone(), qb[hq: hq + hk].clone(), qb[hq + hk:].clone()
-            out[s_ + "self_attn.o_proj.weight"] = get(b + "o.w")
+            out[s_ + "self_attn.q_proj.weight"], out[s_ + "self_attn.k_proj.weight"], out[s_ + "self_attn.v_proj.weight"] = unpad_heads(qw[:hq]), unpad_heads(qw[hq: hq + hk]), unpad_heads(qw[hq + hk:])
+            out[s_ + "self_attn.q_proj.bias"], out[s_ + "self_attn.k_proj.bias"], out[s_ + "self_attn.v_proj.bias"] = unpad_heads(qb[:hq]), unpad_heads(qb[hq: hq + hk]), unpad_heads(qb[hq + hk:])
+            out[s_ + "self_attn.o_proj.weight"] = unpad_heads(get(b + "o.w").t().contiguous()).t().contiguous()
             gu = get(b + "gu.w")
             out[s_ + "mlp.gate_proj.weight"], out[s_ + "mlp.up_proj.weight"] = gu[: c.intermediate_size].clone(), gu[c.intermediate_size:].clone()
             out[s_ + "mlp.down_proj.weight"] = get(b + "down.w")
@@ -597,6 +627,7 @@ class ParamStore:
         c = self.cfg
         if c.is_llava:
             return self._load_named_llava(sd)
+        assert c.head_dim == c.head_dim_real, "Qwen-VL checkpoints have 128-wide decoder heads"
         t = lambda k: torch.as_tensor(sd[k]).float()
         vi, vip = c.v_inter, c.v_inter_pad
         self._assign("visual.patch_embed", t("visual.patch_embed.proj.weight").reshape(c.v_hidden, -1))
@@ -748,6 +779,15 @@ class ParamStore:
                 self.w(b + "qkv.w").view(3 * nh, dp, -1)[:, d:].zero_()
                 self.w(b + "qkv.b").view(3 * nh, dp)[:, d:].zero_()
                 self.w(b + "proj.w").view(-1, nh, dp)[:, :, d:].zero_()
+        if c.head_dim != c.head_dim_real:       # padded decoder heads (VLMConfig.head_dim): everything outside the real dims' slots is zero
+            keep = torch.zeros(c.head_dim, dtype=torch.bool, device=self.device)
+            keep[torch.from_numpy(c.head_slots).to(self.device)] = True
+            nh_all = c.num_attention_heads + 2 * c.num_key_value_heads
+            for i in range(c.num_hidden_layers):
+                b = f"layers.{i}."
+                self.w(b + "qkv.w").view(nh_all, c.head_dim, -1)[:, ~keep].zero_()
+                self.w(b + "qkv.b").view(nh_all, c.head_dim)[:, ~keep].zero_()
+                self.w(b + "o.w").view(-1, c.num_attention_heads, c.head_dim)[:, :, ~keep].zero_()
         self.finalize()
 
     def copy_from(self, other: "ParamStore"):

@@ -130,7 +130,7 @@ class Rollout:
                 assert tr is None
                 ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
                 ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
-            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o,
+            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o,
                             side=side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), c.hidden_size, out=self.part_o, ksplit=self.ks_o)
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h,
@@ -202,7 +202,7 @@ class Rollout:
                 assert tr is None
                 ops.gemm_skinny(xin, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv, fold=nf1)
                 ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
-            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, D**-0.5, out=self.o,
+            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o,
                             side=side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), H, resid=self.x, ksplit=self.ks_o, side=side(p0=T_("x_mid", i)),
                             fold=producer(self.ssq_b, self.part_o, self.ks_o, None if f1 else self.xp))

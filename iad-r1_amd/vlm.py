@@ -76,8 +76,10 @@ class Engine:
         self.cfg: VLMConfig = params.cfg
         self.dev = params.device
         c = self.cfg
-        hd = c.head_dim
-        self.inv_freq = torch.tensor(1.0 / (c.rope_theta ** (np.arange(0, hd, 2, dtype=np.float32) / hd)), dtype=F32, device=self.dev)
+        hd, hr = c.head_dim, c.head_dim_real
+        inv = np.zeros(hd // 2, dtype=np.float32)      # padded heads (VLMConfig.head_dim): the rotary pairs past the real width rotate zeros, frequency 0
+        inv[: hr // 2] = 1.0 / (c.rope_theta ** (np.arange(0, hr, 2, dtype=np.float32) / hr))
+        self.inv_freq = torch.tensor(inv, dtype=F32, device=self.dev)
         self.mrope_comp = torch.tensor(indexing.mrope_component_of_channel(c.mrope_section, hd // 2), dtype=torch.long, device=self.dev)
         vd = c.v_head_dim
         self.v_inv_freq = 1.0 / (10000.0 ** (np.arange(0, vd // 2, 2, dtype=np.float32) / (vd // 2)))
@@ -662,7 +664,7 @@ class Engine:
             # attention addresses rows absolutely: the keys of a completion segment live in the prompt rows written by the other phase
             qkv_all, o_all = full("qkv"), full("o")
             ops.hip.call("attn_fwd", qkv_all[:, :qw], qkv_all[:, qw: qw + kw], qkv_all[:, qw + kw:], o_all, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
-                         plan.seg.n_head, plan.seg.max_tail, T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, float(D**-0.5))
+                         plan.seg.n_head, plan.seg.max_tail, T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, c.attn_scale)
             ab = ops.gemm_nt(o, P.w(b + "o.w"))
             x_mid = buf("x_mid") if save else x_in
             h2 = buf("h2")
@@ -744,7 +746,7 @@ class Engine:
             dqkv = torch.empty_like(qkv) if plan.seg.covers(0, qkv.shape[0]) else torch.zeros_like(qkv)
             if _POISON and plan.seg.covers(0, qkv.shape[0]):
                 dqkv.fill_(float("nan"))
-            ops.attn_bwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, do, lse, plan.seg, Hq, Hkv, D, True, D**-0.5,
+            ops.attn_bwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, do, lse, plan.seg, Hq, Hkv, D, True, c.attn_scale,
                          dqkv[:, :qw], dqkv[:, qw: qw + kw], dqkv[:, qw + kw:])
             ops.rope_(dqkv, plan.cos, plan.sin, Hq + Hkv, D, backward=True)
             ops.colsum_acc(dqkv, P.g(b + "qkv.b"))

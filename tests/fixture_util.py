@@ -297,6 +297,10 @@ TINY_OV = {
 }
 
 
+# the same structure with 64-wide decoder heads (the Qwen2-0.5B decoder of LLaVA-OneVision-0.5B: 14 heads of 64): 4 query heads, 2 kv heads on width 256
+TINY_OV64 = dict(TINY_OV, text=dict(TINY_OV["text"], num_attention_heads=4, num_key_value_heads=2))
+
+
 def param_shapes_ov(cfg: dict) -> dict[str, tuple[int, ...]]:
     t, v = cfg["text"], cfg["vision"]
     h, inter = t["hidden_size"], t["intermediate_size"]

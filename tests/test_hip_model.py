@@ -817,19 +817,24 @@ def _ov_store(weights, trainable):
     return s_
 
 
-def test_llava_onevision_forward_matches_hf_golden(golden_dir):
-    """SigLIP tower (head width 72 run zero-padded to 80), projector, any-resolution packing (one image shrunk by the bilinear interpolation) and the
+@pytest.mark.parametrize("cfg_name,golden", [("TINY_OV", "llava_ov.npz"), ("TINY_OV64", "llava_ov_hd64.npz")])
+def test_llava_onevision_forward_matches_hf_golden(golden_dir, cfg_name, golden):
+    """(second case: 64-wide decoder heads -- LLaVA-OneVision-0.5B's Qwen2-0.5B structure -- stored zero-padded to the 128 the decoder kernels run at, rotary
+    halves at [0, 32) and [64, 96): VLMConfig.head_dim)  SigLIP tower (head width 72 run zero-padded to 80), projector, any-resolution packing (one image shrunk by the bilinear interpolation) and the
     Qwen2 decoder with 1-D rotary positions on the HIP kernels vs a tiny HF LlavaOnevisionForConditionalGeneration (tests/golden/llava_ov.npz)."""
-    g = load(golden_dir, "llava_ov.npz")
+    g = load(golden_dir, golden)
     meta = json.loads(str(g["meta"]))
-    w = fx.make_weights_ov(fx.TINY_OV, 0)
-    st = _ov_store(w, False)
+    cfg_d = getattr(fx, cfg_name)
+    w = fx.make_weights_ov(cfg_d, 0)
+    st = ParamStore(VLMConfig.from_dict(cfg_d), DEV, trainable=False)
+    st.load_named(w)
+    assert st.cfg.head_dim == 128 and st.cfg.head_dim_real == (64 if cfg_name == "TINY_OV64" else 128)
     back = st.export_named()
     for k, v in w.items():
         assert np.array_equal(back[k].numpy(), v.reshape(back[k].shape)), k           # checkpoint names <-> padded fused layout round trip
     e = Engine(st)
     sizes = [tuple(x) for x in meta["sizes"]]
-    batch = {"input_ids": g["input_ids"], "attention_mask": g["attention_mask"], "pixel_values": fx.synth_crops(meta["crops"], fx.TINY_OV, meta["seed"]), "image_sizes": sizes}
+    batch = {"input_ids": g["input_ids"], "attention_mask": g["attention_mask"], "pixel_values": fx.synth_crops(meta["crops"], cfg_d, meta["seed"]), "image_sizes": sizes}
     grids, plan_v, px, rows = e.vision_inputs(batch)
     assert plan_v.lens == g["feature_lens"].tolist()
     img, _ = e.vision_forward(px, plan_v, save=False)
@@ -1030,3 +1035,50 @@ def test_fp8_decode_weights_rollout_and_step():
     mt = eng8.step(batch, lambda comp: np.stack([(np.asarray(comp)[:, 0] % 5).astype(np.float32), (np.asarray(comp)[:, 1] % 3).astype(np.float32)], 1))
     assert np.isfinite(mt["loss"]) and mt["kl"] == 0.0 and not eng8.last_step_traced and not torch.equal(before, pol.flat)
     assert eng8.grad_norm() > 0
+
+
+def test_llava_onevision_64_wide_heads_train_and_roll_out():
+    """LLaVA-OneVision-0.5B's decoder structure (64-wide heads, stored padded to 128): one SC-GRPO step moves the parameters with finite loss and KL exactly 0 for
+    policy == reference; the padding of every head (q|k|v rows, o columns outside the real dims' slots) is still exactly zero after the optimizer step; the greedy
+    rollout's tokens are the arg-max of the training kernels' logits; the checkpoint written afterwards has the model's own shapes."""
+    cfg = VLMConfig.from_dict(fx.TINY_OV64)
+    w = fx.make_weights_ov(fx.TINY_OV64, 0)
+    pol, ref = ParamStore(cfg, DEV, trainable=True), ParamStore(cfg, DEV, trainable=False)
+    pol.load_named(w)
+    ref.load_named(w)
+    from iadr1_amd import llava_ov as lo
+    v = fx.TINY_OV64["vision"]
+    sizes, rs, rows, ncrops = [(80, 100), (120, 100)], np.random.RandomState(11), [], 0
+    for sz, nt in zip(sizes, (5, 12)):
+        n_img = lo.num_image_tokens(sz, fx.TINY_OV64["image_grid_pinpoints"], v["image_size"], v["image_size"] // v["patch_size"], 9)
+        rows.append(rs.randint(3, 600, 3).tolist() + [cfg.image_token_id] * n_img + rs.randint(3, 600, nt).tolist())
+        ncrops += lo.num_crops(sz, fx.TINY_OV64["image_grid_pinpoints"], v["image_size"])
+    ids, mask = fx.left_pad(rows, cfg.pad_token_id)
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_crops(ncrops, fx.TINY_OV64, 9), "image_sizes": sizes}
+    G, C = 4, 8
+    eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, suppress_eos=True, learning_rate=1e-3, seed=3))
+    toks = eng.rollout(batch, greedy=True)
+    e = eng.pol
+    full, fmask = np.concatenate([np.repeat(ids, G, 0), toks], 1), np.concatenate([np.repeat(mask, G, 0), np.ones_like(toks)], 1)
+    grids, plan_v, px, off = e.vision_inputs(batch)
+    img, _ = e.vision_forward(px, plan_v, save=False)
+    plan = e.text_plan(full, fmask, [[sizes[r // G]] for r in range(2 * G)], [[int(off[r // G])] for r in range(2 * G)])
+    hf, _ = e.text_forward(plan, img, save=False)
+    S, P = full.shape[1], ids.shape[1]
+    rr = (np.arange(2 * G)[:, None] * S + np.arange(P - 1, S - 1)[None, :]).reshape(-1)
+    logits = hf[torch.from_numpy(rr).to(DEV)].float() @ pol.w("lm_head").float().t()
+    top2 = logits.topk(2, -1)
+    sure = (top2.values[:, 0] - top2.values[:, 1]) > 0.05
+    assert sure.float().mean() > 0.5 and torch.equal(top2.indices[:, 0][sure].cpu(), torch.from_numpy(toks.reshape(-1))[sure.cpu()])
+    before = pol.flat.clone()
+    mt = eng.step(batch, lambda comp: np.stack([(np.asarray(comp)[:, 0] % 5).astype(np.float32), (np.asarray(comp)[:, 1] % 3).astype(np.float32)], 1))
+    assert np.isfinite(mt["loss"]) and mt["kl"] == 0.0 and eng.grad_norm() > 0 and not torch.equal(before, pol.flat)
+    keep = torch.zeros(128, dtype=torch.bool, device=DEV)
+    keep[torch.from_numpy(cfg.head_slots).to(DEV)] = True
+    for i in range(cfg.num_hidden_layers):
+        assert float(pol.w(f"layers.{i}.qkv.w").view(-1, 128, cfg.hidden_size)[:, ~keep].abs().max()) == 0.0
+        assert float(pol.w(f"layers.{i}.qkv.b").view(-1, 128)[:, ~keep].abs().max()) == 0.0
+        assert float(pol.w(f"layers.{i}.o.w").view(cfg.hidden_size, -1, 128)[:, :, ~keep].abs().max()) == 0.0
+    out = pol.export_named()
+    assert tuple(out["language_model.model.layers.0.self_attn.q_proj.weight"].shape) == (256, 256) and tuple(out["language_model.model.layers.0.self_attn.k_proj.bias"].shape) == (128,)
+    assert tuple(out["language_model.model.layers.1.self_attn.o_proj.weight"].shape) == (256, 256)

@@ -189,15 +189,16 @@ def test_qwen2vl_variant(golden_dir):
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
 
 
-def test_llava_onevision_forward(golden_dir):
-    """oracle/llava_ov.py (SigLIP tower, projector, any-resolution packing incl. the bilinear shrink, Qwen2 decoder) vs a tiny HF
+@pytest.mark.parametrize("cfg_name,golden", [("TINY_OV", "llava_ov.npz"), ("TINY_OV64", "llava_ov_hd64.npz")])
+def test_llava_onevision_forward(golden_dir, cfg_name, golden):
+    """(second case: 64-wide decoder heads, the Qwen2-0.5B structure of LLaVA-OneVision-0.5B)  oracle/llava_ov.py (SigLIP tower, projector, any-resolution packing incl. the bilinear shrink, Qwen2 decoder) vs a tiny HF
     LlavaOnevisionForConditionalGeneration (tests/golden/llava_ov.npz), and the product's host-side packing plan (iadr1_amd.llava_ov) vs both."""
     from oracle import llava_ov as oo
     import iadr1_amd  # noqa: F401
     from iadr1_amd import llava_ov as lo
-    g = _load(golden_dir, "llava_ov.npz")
+    g = _load(golden_dir, golden)
     meta = json.loads(str(g["meta"]))
-    cfg = fx.TINY_OV
+    cfg = getattr(fx, cfg_name)
     m = oo.LlavaOVOracle(cfg, fx.make_weights_ov(cfg, 0))
     sizes = [tuple(s) for s in meta["sizes"]]
     pv = torch.from_numpy(fx.synth_crops(meta["crops"], cfg, meta["seed"]))

@@ -73,8 +73,8 @@ def tiny_ov_batch(cfg, sizes, n_texts, seed):
     return ids, mask, fx.synth_crops(crops, cfg, seed), crops
 
 
-def gen_forward():
-    cfg = fx.TINY_OV
+def gen_forward(cfg=None, name="llava_ov.npz"):
+    cfg = cfg or fx.TINY_OV
     w = fx.make_weights_ov(cfg, 0)
     m = build_hf(cfg, w).eval()
     sizes = [(80, 100), (400, 380)]            # 2 x 2 crop grid; 5 x 5 grid (26 crops: shrunk by bilinear interpolation above anyres_max_9)
@@ -83,10 +83,10 @@ def gen_forward():
         feats = m.model.get_image_features(torch.from_numpy(pv), torch.tensor(sizes), vision_feature_layer=-1, vision_feature_select_strategy="full").pooler_output
         out = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), pixel_values=torch.from_numpy(pv), image_sizes=torch.tensor(sizes))
         lp = torch.log_softmax(out.logits[:, :-1].float(), -1).gather(-1, torch.from_numpy(ids)[:, 1:].unsqueeze(-1)).squeeze(-1)
-    np.savez_compressed(os.path.join(OUT, "llava_ov.npz"), meta=json.dumps({**mg.meta(), "sizes": sizes, "n_text": [6, 11], "seed": 31, "crops": ncrops}),
+    np.savez_compressed(os.path.join(OUT, name), meta=json.dumps({**mg.meta(), "sizes": sizes, "n_text": [6, 11], "seed": 31, "crops": ncrops}),
                         input_ids=ids, attention_mask=mask, image_features=torch.cat(list(feats), 0).numpy(), feature_lens=np.array([f.shape[0] for f in feats]),
                         logits_last=out.logits[:, -1].numpy(), per_token_logps=lp.numpy())
-    print("llava_ov.npz: feature lens", [f.shape[0] for f in feats], "ids", ids.shape)
+    print(name + ": feature lens", [f.shape[0] for f in feats], "ids", ids.shape)
 
 
 class OVProcessor(mg.FakeProcessor):
@@ -142,5 +142,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     gen_forward()
+    gen_forward(fx.TINY_OV64, "llava_ov_hd64.npz")        # 64-wide decoder heads (LLaVA-OneVision-0.5B's Qwen2-0.5B structure)
     reward, _, _, SCGRPOTrainer, _ = mg.import_reference()
     gen_sc_grpo(SCGRPOTrainer, reward)
