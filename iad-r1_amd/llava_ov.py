@@ -71,7 +71,9 @@ def _bilinear_taps(n_in, n_out):
 def pack_plan(image_sizes, pinpoints, crop, side, max_patches=9):
     """CSR of pack_image_features for a list of images.
 
-    image_sizes: [(height, width)] per image; `crop` = vision image_size (384), `side` = feature-map side of one crop (27).
+    image_sizes: [(height, width)] per image; `crop` = vision image_size (384), `side` = feature-map side of one crop (27); max_patches: the N of
+    `vision_aspect_ratio = anyres_max_N` (LLaVA-OneVision), None for LLaVA-NeXT (transformers/models/llava_next/modeling_llava_next.py:265-330: the same
+    assembly without the bilinear shrink).
     The source rows are numbered crop-major: image i owns rows [first_i, first_i + num_crops_i * side^2) in processor order (base image first);
     the row after the last image's rows is the `image_newline` vector.
     Returns dict(ptr [T+1] int32, idx [nnz] int32, w [nnz] float32, lens [n_images], n_src (incl. the newline row)) -- T = total packed tokens."""
@@ -98,7 +100,7 @@ def pack_plan(image_sizes, pinpoints, crop, side, max_patches=9):
         src_of = lambda y, x: f0 + per * (1 + (y // side) * gw + (x // side)) + (y % side) * side + (x % side)
         y0, y1, x0, x1 = _unpad_window(H, W, int(size[0]), int(size[1]))
         ch, cw = y1 - y0, x1 - x0
-        ratio = math.sqrt(ch * cw / (max_patches * side**2))
+        ratio = math.sqrt(ch * cw / (max_patches * side**2)) if max_patches else 0.0      # max_patches None: LLaVA-NeXT's packing (LN:265-330) has no shrink step
         if ratio > 1.1:                                        # TF:318-323: bilinear shrink to (ch // ratio, cw // ratio)
             oh, ow = int(ch // ratio), int(cw // ratio)
             ya, yb, wya, wyb = _bilinear_taps(ch, oh)

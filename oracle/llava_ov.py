@@ -159,3 +159,82 @@ def ensure_left_padding(input_ids, attention_mask, pad_token_id):
                 ids[i] = torch.cat([torch.full((n,), pad_token_id, dtype=ids.dtype), input_ids[i, :first]])
                 mask[i] = torch.cat([torch.zeros(n, dtype=mask.dtype), torch.ones(first, dtype=mask.dtype)])
     return ids, mask
+
+
+class LlavaOracle(LlavaOVOracle):
+    """LLaVA-1.5 (`LlavaForConditionalGeneration`, REF sc_grpo_trainer.py:133-135) and LLaVA-NeXT / 1.6 (`LlavaNextForConditionalGeneration`, REF:130-132):
+    cfg["family"] in ("llava", "llava_next").  CL: = transformers models/clip/modeling_clip.py, LV: = models/llava/modeling_llava.py, LN: =
+    models/llava_next/modeling_llava_next.py (installed 5.15.0).
+
+      vision tower  CLIP ViT (CL:141-200 embeddings: bias-free patch conv, class token first, learned positions; CL pre_layrnorm; pre-LN blocks with
+                    biased q/k/v/out attention over the 1 + side^2 tokens of one crop and fc1 -> QuickGELU -> fc2), hidden state of encoder layer
+                    `vision_feature_layer` = -2 (the last block is not run), strategy "default": the class token is dropped (LV:161-172)
+      projector     linear_1 -> exact GELU -> linear_2 (LV:96-128)
+      llava         one 336-pixel crop per image, its side^2 features replace the image tokens (LV:174-189)
+      llava_next    LN:265-330: base features ++ crop grid un-padded to the aspect ratio, `image_newline` after every feature row; no shrink step
+      decoder       LLaMA / Mistral = the Qwen2 decoder without q/k/v biases (zeros here, not parameters)
+
+    Pinned by tests/golden/llava15.npz / llava_next.npz (tiny HF models, tools/make_golden_llava.py)."""
+
+    def __init__(self, cfg, weights, requires_grad=False, dtype=torch.float32):
+        import numpy as np
+        t = cfg["text"]
+        hd = t["hidden_size"] // t["num_attention_heads"]
+        w = dict(weights)
+        self._no_bias = set()
+        for i in range(t["num_hidden_layers"]):
+            for z, n in (("q", t["num_attention_heads"]), ("k", t["num_key_value_heads"]), ("v", t["num_key_value_heads"])):
+                k = f"language_model.model.layers.{i}.self_attn.{z}_proj.bias"
+                if k not in w:
+                    w[k] = np.zeros(n * hd, dtype=np.float32)
+                    self._no_bias.add(k)
+        super().__init__(cfg, w, requires_grad=requires_grad, dtype=dtype)
+        for k in self._no_bias:                      # constants, not parameters
+            kk = "model." + k[len("language_model.model."):]
+            self.w[kk] = self.w[kk].detach().requires_grad_(False)
+
+    def parameters(self):
+        for k, t_ in super().parameters():
+            if k not in self._no_bias:
+                yield k, t_
+
+    def tower(self, crops):
+        v, w = self.cfg["vision"], self.w
+        p, vh, nh = v["patch_size"], v["hidden_size"], v["num_heads"]
+        pre = "vision_tower.vision_model."
+        x = F.conv2d(crops.to(w[pre + "embeddings.patch_embedding.weight"].dtype), w[pre + "embeddings.patch_embedding.weight"], None, stride=p).flatten(2).transpose(1, 2)
+        n = x.shape[0]
+        x = torch.cat([w[pre + "embeddings.class_embedding"].expand(n, 1, -1), x], 1) + w[pre + "embeddings.position_embedding.weight"][None]      # CL:188-200
+        x = F.layer_norm(x, (vh,), w[pre + "pre_layrnorm.weight"], w[pre + "pre_layrnorm.bias"], v["layer_norm_eps"])
+        L, hd = x.shape[1], vh // nh
+        run = v["depth"] + 1 + self.cfg.get("vision_feature_layer", -2)          # hidden_states[-2] of depth + 1 entries = the output of block depth - 2
+        for i in range(run):
+            b = f"{pre}encoder.layers.{i}."
+            h = F.layer_norm(x, (vh,), w[b + "layer_norm1.weight"], w[b + "layer_norm1.bias"], v["layer_norm_eps"])
+            q, k, vv = (F.linear(h, w[b + f"self_attn.{z}_proj.weight"], w[b + f"self_attn.{z}_proj.bias"]).view(n, L, nh, hd).transpose(1, 2) for z in "qkv")
+            pr = torch.softmax((q @ k.transpose(2, 3)) * hd**-0.5, -1, dtype=torch.float32).to(x.dtype)
+            x = x + F.linear((pr @ vv).transpose(1, 2).reshape(n, L, vh), w[b + "self_attn.out_proj.weight"], w[b + "self_attn.out_proj.bias"])
+            h = F.layer_norm(x, (vh,), w[b + "layer_norm2.weight"], w[b + "layer_norm2.bias"], v["layer_norm_eps"])
+            h = F.linear(h, w[b + "mlp.fc1.weight"], w[b + "mlp.fc1.bias"])
+            x = x + F.linear(h * torch.sigmoid(1.702 * h), w[b + "mlp.fc2.weight"], w[b + "mlp.fc2.bias"])
+        return x[:, 1:]                                                         # "default": without the class token
+
+    def visual(self, pixel_values, image_sizes=None, return_last_hidden=False):
+        v = self.cfg["vision"]
+        crop, side = v["image_size"], v["image_size"] // v["patch_size"]
+        feats = self.project(self.tower(pixel_values))                          # [crops, side^2, H]
+        if self.cfg["family"] == "llava":
+            return feats.reshape(-1, feats.shape[-1])
+        pins = [tuple(p) for p in self.cfg["image_grid_pinpoints"]]
+        newline = self.w["image_newline"]
+        out, c0 = [], 0
+        for size in image_sizes:
+            bh, bw = _select_best_resolution(size, pins)
+            gh, gw = bh // crop, bw // crop
+            f = feats[c0: c0 + gh * gw + 1]
+            c0 += gh * gw + 1
+            rest = f[1:].view(gh, gw, side, side, -1).permute(4, 0, 2, 1, 3).contiguous().flatten(1, 2).flatten(2, 3)
+            rest = _unpad(rest, size)
+            rest = torch.cat([rest, newline[:, None, None].expand(*rest.shape[:-1], 1).to(rest.dtype)], -1)
+            out.append(torch.cat([f[0], rest.flatten(1, 2).transpose(0, 1)], 0))
+        return torch.cat(out, 0)

@@ -395,3 +395,76 @@ def local_llava_ov_processor(cfg: dict = None):
     ip = LlavaOnevisionImageProcessorPil(size={"height": v["image_size"], "width": v["image_size"]}, image_grid_pinpoints=[list(p) for p in cfg["image_grid_pinpoints"]])
     return LlavaOnevisionProcessor(image_processor=ip, tokenizer=t, video_processor=_NoVideo.__new__(_NoVideo), num_image_tokens=(v["image_size"] // v["patch_size"]) ** 2,
                                    vision_feature_select_strategy="full", chat_template=LLAVA_OV_CHAT_TEMPLATE, vision_aspect_ratio=f"anyres_max_{cfg.get('anyres_max', 9)}")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# LLaVA-1.5 / LLaVA-NeXT structures (the remaining branches of the reference's model switch, sc_grpo_trainer.py:130-135): CLIP tower (class token, pre-LayerNorm,
+# QuickGELU MLP, 64-wide heads, bias-free patch conv, feature layer -2 without the class token), Linear-GELU-Linear projector, LLaMA (MHA) / Mistral (GQA)
+# decoder without q/k/v biases; NeXT adds the any-resolution crop grid + image_newline.  Checkpoint names as transformers 4.51.3 writes them.
+# ------------------------------------------------------------------------------------------------------------------------------------
+TINY_LLAVA15 = {
+    "family": "llava",
+    "text": {"vocab_size": 640, "hidden_size": 256, "intermediate_size": 512, "num_hidden_layers": 2, "num_attention_heads": 2, "num_key_value_heads": 2,
+             "rms_norm_eps": 1e-5, "rope_theta": 10000.0, "attention_bias": False},
+    "vision": {"arch": "clip", "depth": 3, "hidden_size": 128, "intermediate_size": 256, "num_heads": 2, "in_channels": 3, "patch_size": 14, "image_size": 56,
+               "layer_norm_eps": 1e-5},
+    "vision_feature_layer": -2, "vision_feature_select_strategy": "default",
+    "image_token_id": 630, "video_token_id": 631, "vision_start_token_id": 628, "vision_end_token_id": 629, "eos_token_id": 1, "pad_token_id": 2, "tie_word_embeddings": False,
+}
+TINY_LLAVA_NEXT = dict(TINY_LLAVA15, family="llava_next", text=dict(TINY_LLAVA15["text"], num_key_value_heads=1, rope_theta=1000000.0),
+                       image_grid_pinpoints=[[56, 112], [112, 56], [112, 112], [168, 56], [56, 168]])
+
+
+def param_shapes_llava(cfg: dict) -> dict[str, tuple[int, ...]]:
+    t, v = cfg["text"], cfg["vision"]
+    h, inter = t["hidden_size"], t["intermediate_size"]
+    hd = h // t["num_attention_heads"]
+    kvd = hd * t["num_key_value_heads"]
+    vh, vi, p = v["hidden_size"], v["intermediate_size"], v["patch_size"]
+    npos = (v["image_size"] // p) ** 2 + 1
+    s: dict[str, tuple[int, ...]] = {}
+    pre = "vision_tower.vision_model."
+    s[pre + "embeddings.class_embedding"] = (vh,)
+    s[pre + "embeddings.patch_embedding.weight"] = (vh, v["in_channels"], p, p)
+    s[pre + "embeddings.position_embedding.weight"] = (npos, vh)
+    s[pre + "pre_layrnorm.weight"], s[pre + "pre_layrnorm.bias"] = (vh,), (vh,)
+    for i in range(v["depth"]):
+        b = f"{pre}encoder.layers.{i}."
+        for ln in ("layer_norm1", "layer_norm2"):
+            s[b + ln + ".weight"], s[b + ln + ".bias"] = (vh,), (vh,)
+        for z in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[b + f"self_attn.{z}.weight"], s[b + f"self_attn.{z}.bias"] = (vh, vh), (vh,)
+        s[b + "mlp.fc1.weight"], s[b + "mlp.fc1.bias"] = (vi, vh), (vi,)
+        s[b + "mlp.fc2.weight"], s[b + "mlp.fc2.bias"] = (vh, vi), (vh,)
+    s[pre + "post_layernorm.weight"], s[pre + "post_layernorm.bias"] = (vh,), (vh,)
+    s["multi_modal_projector.linear_1.weight"], s["multi_modal_projector.linear_1.bias"] = (h, vh), (h,)
+    s["multi_modal_projector.linear_2.weight"], s["multi_modal_projector.linear_2.bias"] = (h, h), (h,)
+    if cfg["family"] == "llava_next":
+        s["image_newline"] = (h,)
+    s["language_model.model.embed_tokens.weight"] = (t["vocab_size"], h)
+    for i in range(t["num_hidden_layers"]):
+        b = f"language_model.model.layers.{i}."
+        s[b + "input_layernorm.weight"] = (h,)
+        s[b + "self_attn.q_proj.weight"], s[b + "self_attn.k_proj.weight"], s[b + "self_attn.v_proj.weight"], s[b + "self_attn.o_proj.weight"] = (h, h), (kvd, h), (kvd, h), (h, h)
+        s[b + "post_attention_layernorm.weight"] = (h,)
+        s[b + "mlp.gate_proj.weight"], s[b + "mlp.up_proj.weight"], s[b + "mlp.down_proj.weight"] = (inter, h), (inter, h), (h, inter)
+    s["language_model.model.norm.weight"] = (h,)
+    s["language_model.lm_head.weight"] = (t["vocab_size"], h)
+    return s
+
+
+def make_weights_llava(cfg: dict, seed: int = 0, std: float = 0.05) -> dict[str, np.ndarray]:
+    out = {}
+    for name, shape in param_shapes_llava(cfg).items():
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        x = rs.standard_normal(shape).astype(np.float32)
+        if ("layer_norm" in name or "layrnorm" in name or "layernorm" in name or name.endswith("norm.weight")) and name.endswith(".weight"):
+            x = 1.0 + 0.1 * x
+        elif name.endswith(".bias"):
+            x = 0.02 * x
+        elif name in ("image_newline",) or name.endswith("class_embedding"):
+            x = 0.06 * x
+        else:
+            x = std * x
+        out[name] = _bf16_round(x)
+    return out

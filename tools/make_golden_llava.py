@@ -89,6 +89,82 @@ def gen_forward(cfg=None, name="llava_ov.npz"):
     print(name + ": feature lens", [f.shape[0] for f in feats], "ids", ids.shape)
 
 
+hf_name_llava = hf_name      # (the installed transformers 5.x names the CLIP tower of Llava / LlavaNext like the SigLIP tower of LlavaOnevision)
+
+
+def build_hf_llava(cfg, weights):
+    """Tiny `LlavaForConditionalGeneration` (family "llava") / `LlavaNextForConditionalGeneration` ("llava_next") with the fixture's weights."""
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration, LlavaNextConfig, LlavaNextForConditionalGeneration, MistralConfig
+    t, v = cfg["text"], cfg["vision"]
+    vc = CLIPVisionConfig(hidden_size=v["hidden_size"], intermediate_size=v["intermediate_size"], num_hidden_layers=v["depth"], num_attention_heads=v["num_heads"],
+                          image_size=v["image_size"], patch_size=v["patch_size"], layer_norm_eps=v["layer_norm_eps"], hidden_act="quick_gelu", projection_dim=64)
+    kw = dict(vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"], num_hidden_layers=t["num_hidden_layers"],
+              num_attention_heads=t["num_attention_heads"], num_key_value_heads=t["num_key_value_heads"], rms_norm_eps=t["rms_norm_eps"], rope_theta=t["rope_theta"],
+              tie_word_embeddings=False, max_position_embeddings=4096)
+    if cfg["family"] == "llava":
+        c = LlavaConfig(vision_config=vc, text_config=LlamaConfig(attention_bias=False, **kw), image_token_index=cfg["image_token_id"], vision_feature_layer=-2,
+                        vision_feature_select_strategy="default", projector_hidden_act="gelu", tie_word_embeddings=False)
+        m = LlavaForConditionalGeneration(c)
+    else:
+        c = LlavaNextConfig(vision_config=vc, text_config=MistralConfig(sliding_window=None, **kw), image_token_index=cfg["image_token_id"], vision_feature_layer=-2,
+                            vision_feature_select_strategy="default", projector_hidden_act="gelu", image_grid_pinpoints=cfg["image_grid_pinpoints"], tie_word_embeddings=False)
+        m = LlavaNextForConditionalGeneration(c)
+    m.config._attn_implementation = "eager"
+    sd = m.state_dict()
+    new = {hf_name_llava(k): torch.from_numpy(np.asarray(a)).float() for k, a in weights.items()}
+    unknown = [k for k in new if k not in sd]
+    missing = [k for k in sd if k not in new and "position_ids" not in k]
+    assert not unknown and not missing, (unknown[:5], missing[:5])
+    m.load_state_dict(new, strict=False)
+    return m.float()
+
+
+def tiny_llava_batch(cfg, sizes, n_texts, seed):
+    """Left-padded prompts with the image tokens the family's processor reserves: side^2 for LLaVA-1.5 (one crop), the packed any-resolution count for NeXT."""
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import llava_ov as lo
+    v = cfg["vision"]
+    side = v["image_size"] // v["patch_size"]
+    rs = np.random.RandomState(seed)
+    rows, crops = [], 0
+    for sz, nt in zip(sizes, n_texts):
+        if cfg["family"] == "llava":
+            n_img, nc = side * side, 1
+        else:
+            n_img, nc = lo.num_image_tokens(sz, cfg["image_grid_pinpoints"], v["image_size"], side, None), lo.num_crops(sz, cfg["image_grid_pinpoints"], v["image_size"])
+        rows.append(rs.randint(3, 600, 3).tolist() + [cfg["image_token_id"]] * n_img + rs.randint(3, 600, nt).tolist())
+        crops += nc
+    ids, mask = fx.left_pad(rows, cfg["pad_token_id"])
+    return ids, mask, fx.synth_crops(crops, cfg, seed), crops
+
+
+def gen_forward_llava(cfg, name, sizes):
+    w = fx.make_weights_llava(cfg, 0)
+    m = build_hf_llava(cfg, w).eval()
+    ids, mask, pv, ncrops = tiny_llava_batch(cfg, sizes, [6, 11], seed=33)
+    kw = {}
+    px = torch.from_numpy(pv)
+    if cfg["family"] == "llava_next":          # processor layout: [images, max crops, 3, S, S], zero-padded; + the original sizes
+        import iadr1_amd  # noqa: F401
+        from iadr1_amd import llava_ov as lo
+        ncs = [lo.num_crops(s_, cfg["image_grid_pinpoints"], cfg["vision"]["image_size"]) for s_ in sizes]
+        px5 = torch.zeros(len(sizes), max(ncs), *px.shape[1:])
+        o = 0
+        for i, n in enumerate(ncs):
+            px5[i, :n] = px[o: o + n]
+            o += n
+        px, kw = px5, {"image_sizes": torch.tensor(sizes)}
+    with torch.no_grad():
+        out = m(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), pixel_values=px, **kw)
+        feats = m.model.get_image_features(px, vision_feature_layer=-2, vision_feature_select_strategy="default", **kw).pooler_output
+        lp = torch.log_softmax(out.logits[:, :-1].float(), -1).gather(-1, torch.from_numpy(ids)[:, 1:].unsqueeze(-1)).squeeze(-1)
+    feats = list(feats)
+    np.savez_compressed(os.path.join(OUT, name), meta=json.dumps({**mg.meta(), "family": cfg["family"], "sizes": sizes, "n_text": [6, 11], "seed": 33, "crops": ncrops}),
+                        input_ids=ids, attention_mask=mask, image_features=torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], 0).numpy(),
+                        feature_lens=np.array([f.reshape(-1, f.shape[-1]).shape[0] for f in feats]), logits_last=out.logits[:, -1].numpy(), per_token_logps=lp.numpy())
+    print(name + ": feature lens", [f.reshape(-1, f.shape[-1]).shape[0] for f in feats], "ids", ids.shape)
+
+
 class OVProcessor(mg.FakeProcessor):
     """Mock processor for the llava branch: hands over pixel_values / image_sizes; `tokenizer.pad_token_id` is what _ensure_left_padding_data reads."""
 
@@ -100,31 +176,48 @@ class OVProcessor(mg.FakeProcessor):
         self.chat_template = "x"
 
 
-def gen_sc_grpo(SCGRPOTrainer, reward):
-    cfg = fx.TINY_OV
-    w_ref = fx.make_weights_ov(cfg, 0)
+def gen_sc_grpo(SCGRPOTrainer, reward, family="llava_ov"):
+    """family "llava_ov": LLaVA-OneVision; "llava" / "llava_next": LLaVA-1.5 / NeXT under the model ids the reference's switch routes to them."""
+    if family == "llava_ov":
+        cfg = fx.TINY_OV
+        w_ref = fx.make_weights_ov(cfg, 0)
+    else:
+        cfg = fx.TINY_LLAVA15 if family == "llava" else fx.TINY_LLAVA_NEXT
+        w_ref = fx.make_weights_llava(cfg, 0)
     w_pol = fx.perturb_weights(w_ref, seed=1, scale=0.25)
-    ref, pol = build_hf(cfg, w_ref).eval(), build_hf(cfg, w_pol).train()
+    bh = build_hf if family == "llava_ov" else build_hf_llava
+    ref, pol = bh(cfg, w_ref).eval(), bh(cfg, w_pol).train()
     for p in ref.parameters():
         p.requires_grad_(False)
     G, C, seed = 4, 10, 41
     sizes = [(120, 100)]
-    ids, mask, pv, ncrops = tiny_ov_batch(cfg, sizes, [9], seed)
+    if family == "llava_ov":
+        ids, mask, pv, ncrops = tiny_ov_batch(cfg, sizes, [9], seed)
+    else:
+        ids, mask, pv, ncrops = tiny_llava_batch(cfg, sizes, [9], seed)
     batch = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "pixel_values": torch.from_numpy(pv)[None], "image_sizes": torch.tensor(sizes)}
+    if family == "llava":
+        batch = {"input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"], "pixel_values": torch.from_numpy(pv)}
     eos_rows = {1: 6, 3: 2}                    # rows 1 and 3 end early -> they are the rows the reference rotates
     comps = fx.synth_completions(G, C, cfg, seed + 100, eos_rows)
     texts = [mg.CANNED[i % len(mg.CANNED)] for i in range(G)]
     t = mg.make_trainer(SCGRPOTrainer, reward, cfg, ref, {**batch, "mm_token_type_ids": torch.zeros(1, ids.shape[1], dtype=torch.int32)}, comps, texts, G, C)
     t.processing_class = OVProcessor(cfg, batch, texts)
-    t.model_id = "tiny-llava_ov-si"
+    t.model_id = {"llava_ov": "tiny-llava_ov-si", "llava": "tiny-llava_1_5-7b", "llava_next": "tiny-llava_next-mistral"}[family]
     inputs = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "q"}]}], "image": [object()], "solution": mg.SOLUTION}]
     with contextlib.redirect_stdout(io.StringIO()):
         loss, loc = mg.capture_locals(lambda: t.compute_loss(pol, inputs), "compute_loss")
     loss.backward()
-    inv = {hf_name(k): k for k in fx.param_shapes_ov(cfg)}
+    if family == "llava_ov":
+        inv = {hf_name(k): k for k in fx.param_shapes_ov(cfg)}
+        keep = ["language_model.model.norm.weight", "language_model.model.layers.1.self_attn.k_proj.bias", "multi_modal_projector.linear_2.bias", "image_newline",
+                "vision_tower.vision_model.encoder.layers.1.layer_norm2.weight", "vision_tower.vision_model.embeddings.patch_embedding.bias"]
+    else:
+        inv = {hf_name_llava(k): k for k in fx.param_shapes_llava(cfg)}
+        keep = ["language_model.model.norm.weight", "language_model.model.layers.1.self_attn.k_proj.weight", "multi_modal_projector.linear_2.bias",
+                "vision_tower.vision_model.encoder.layers.1.layer_norm2.weight", "vision_tower.vision_model.embeddings.class_embedding",
+                "vision_tower.vision_model.pre_layrnorm.bias"] + (["image_newline"] if family == "llava_next" else [])
     grads = {inv[k]: p.grad for k, p in pol.named_parameters() if p.grad is not None and k in inv}
-    keep = ["language_model.model.norm.weight", "language_model.model.layers.1.self_attn.k_proj.bias", "multi_modal_projector.linear_2.bias", "image_newline",
-            "vision_tower.vision_model.encoder.layers.1.layer_norm2.weight", "vision_tower.vision_model.embeddings.patch_embedding.bias"]
     out = {"meta": json.dumps({**mg.meta(), "G": G, "C": C, "sizes": sizes, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows, "perturb_scale": 0.25, "crops": ncrops,
                                "model_id": t.model_id}),
            "prompt_completion_ids": loc["prompt_completion_ids"].numpy(), "attention_mask": loc["attention_mask"].numpy(), "completion_mask": loc["completion_mask"].numpy(),
@@ -134,8 +227,9 @@ def gen_sc_grpo(SCGRPOTrainer, reward):
            "grad_norm_names": np.array(sorted(grads)), "grad_norms": np.array([float(grads[k].norm()) for k in sorted(grads)], dtype=np.float64)}
     for k in keep:
         out["grad::" + k] = grads[k].numpy()
-    np.savez_compressed(os.path.join(OUT, "sc_grpo_llava_ov.npz"), **out)
-    print(f"sc_grpo_llava_ov.npz: loss={loss.item():.8f} kl={t._metrics['kl'][0]:.6f} len={t._metrics['completion_length'][0]}")
+    fname = {"llava_ov": "sc_grpo_llava_ov.npz", "llava": "sc_grpo_llava15.npz", "llava_next": "sc_grpo_llava_next.npz"}[family]
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(f"{fname}: loss={loss.item():.8f} kl={t._metrics['kl'][0]:.6f} len={t._metrics['completion_length'][0]}")
 
 
 if __name__ == "__main__":
@@ -143,5 +237,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_forward()
     gen_forward(fx.TINY_OV64, "llava_ov_hd64.npz")        # 64-wide decoder heads (LLaVA-OneVision-0.5B's Qwen2-0.5B structure)
+    gen_forward_llava(fx.TINY_LLAVA15, "llava15.npz", [(56, 56), (56, 56)])
+    gen_forward_llava(fx.TINY_LLAVA_NEXT, "llava_next.npz", [(80, 100), (150, 60)])
     reward, _, _, SCGRPOTrainer, _ = mg.import_reference()
     gen_sc_grpo(SCGRPOTrainer, reward)
+    gen_sc_grpo(SCGRPOTrainer, reward, "llava")
+    gen_sc_grpo(SCGRPOTrainer, reward, "llava_next")
