@@ -73,11 +73,32 @@ class VLMConfig:
     v_image_size: int = 0            # crop side in pixels (384)
     v_ln_eps: float = 1e-6
     image_grid_pinpoints: tuple = ()
-    anyres_max: int = 9
+    anyres_max: int | None = 9       # N of vision_aspect_ratio "anyres_max_N" (LLaVA-OneVision); None: no shrink step (LLaVA-NeXT)
+    # "clip" (LLaVA-1.5 / LLaVA-NeXT branches, sc_grpo_trainer.py:130-135): CLIP tower -- bias-free patch conv, class token, learned positions, pre-LayerNorm,
+    # LayerNorm(+bias) blocks with QuickGELU MLPs, features of encoder layer `v_feature_layer` (-2: the last block is not run) without the class token.
+    # llava_family: "onevision" (any-resolution packing with shrink), "next" (without), "llava" (one crop per image, no packing, no image_newline)
+    llava_family: str = ""
+    v_feature_layer: int = -1
+    qkv_bias: bool = True            # q/k/v projections of the decoder carry biases (Qwen2); False: LLaMA / Mistral -- the fused q|k|v bias stays zero and is no parameter
 
     @property
     def is_llava(self):
-        return self.v_arch == "siglip"
+        return self.v_arch in ("siglip", "clip")
+
+    @property
+    def v_cls(self):
+        """Class tokens in front of a crop's patch tokens (CLIP: 1)."""
+        return 1 if self.v_arch == "clip" else 0
+
+    @property
+    def v_seq(self):
+        """Tokens of one crop inside the tower."""
+        return self.v_tokens + self.v_cls
+
+    @property
+    def v_run_depth(self):
+        """Encoder blocks that are run: hidden_states[v_feature_layer] of the depth + 1 recorded states."""
+        return self.v_depth + 1 + self.v_feature_layer
 
     @property
     def v_head_pad(self):
@@ -86,9 +107,9 @@ class VLMConfig:
         d = self.v_hidden // self.v_heads
         if d in (80, 128):
             return d
-        if d == 72:
+        if d in (72, 64):        # SigLIP-so400m: 72, CLIP ViT-L: 64
             return 80
-        raise ValueError(f"vision head dim {d}: the attention kernels are built for 128 and 80 (72 runs zero-padded to 80)")
+        raise ValueError(f"vision head dim {d}: the attention kernels are built for 128 and 80 (72 and 64 run zero-padded to 80)")
 
     @property
     def v_side(self):
@@ -144,7 +165,8 @@ class VLMConfig:
     def from_dict(d: dict) -> "VLMConfig":
         """Accepts the nested {text, vision, ...} form of tests/fixture_util.TINY."""
         t, v = d["text"], d["vision"]
-        if v.get("arch") == "siglip":
+        if v.get("arch") in ("siglip", "clip"):
+            clip = v["arch"] == "clip"
             hd = max(128, t["hidden_size"] // t["num_attention_heads"])      # the width the kernels run at (VLMConfig.head_dim): 1-D positions drive every rotary pair
             return VLMConfig(
                 vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"], num_hidden_layers=t["num_hidden_layers"],
@@ -152,9 +174,12 @@ class VLMConfig:
                 mrope_section=(hd // 2, 0, 0), v_depth=v["depth"], v_hidden=v["hidden_size"], v_inter=v["intermediate_size"], v_heads=v["num_heads"],
                 v_in_channels=v["in_channels"], v_patch=v["patch_size"], v_merge=1, v_temporal=1, v_window=0, v_fullatt=tuple(range(v["depth"])),
                 image_token_id=d["image_token_id"], vision_start_token_id=d.get("vision_start_token_id", -1), vision_end_token_id=d.get("vision_end_token_id", -1),
-                eos_token_id=d["eos_token_id"], pad_token_id=d["pad_token_id"], tie_word_embeddings=d.get("tie_word_embeddings", False), v_arch="siglip",
-                v_image_size=v["image_size"], v_ln_eps=v.get("layer_norm_eps", 1e-6), image_grid_pinpoints=tuple(tuple(p) for p in d["image_grid_pinpoints"]),
-                anyres_max=d.get("anyres_max", 9))
+                eos_token_id=d["eos_token_id"], pad_token_id=d["pad_token_id"], tie_word_embeddings=d.get("tie_word_embeddings", False), v_arch=v["arch"],
+                v_image_size=v["image_size"], v_ln_eps=v.get("layer_norm_eps", 1e-5 if clip else 1e-6),
+                image_grid_pinpoints=tuple(tuple(p) for p in d.get("image_grid_pinpoints", ())),
+                anyres_max=d.get("anyres_max", 9) if not clip else None,
+                llava_family={"llava": "llava", "llava_next": "next"}[d["family"]] if clip else "onevision",
+                v_feature_layer=d.get("vision_feature_layer", -2 if clip else -1), qkv_bias=bool(t.get("attention_bias", not clip)))
         return VLMConfig(
             vocab_size=t["vocab_size"], hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
             num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
@@ -172,6 +197,33 @@ class VLMConfig:
         """config.json of a Qwen2.5-VL / Qwen2-VL checkpoint (flat 4.51-style or nested text_config 5.x-style) or of a LLaVA-OneVision one."""
         t = c.get("text_config", c)
         v = c["vision_config"]
+        if c.get("model_type") in ("llava", "llava_next"):
+            # LLaVA-1.5 / LLaVA-NeXT: the published config.json files list only what differs from the defaults of the text model's config class
+            dflt = {"llama": dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32, rms_norm_eps=1e-6, rope_theta=10000.0),
+                    "mistral": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-6, rope_theta=10000.0)}
+            mt = t.get("model_type", "llama")
+            if mt not in dflt:
+                raise ValueError(f"{c['model_type']}: text model type {mt!r} not built (llama and mistral are)")
+            tt = {**dflt[mt], **{k: v_ for k, v_ in t.items() if v_ is not None}}
+            if tt.get("attention_bias") or tt.get("mlp_bias"):
+                raise ValueError("llava: decoders with attention / MLP biases are not the published LLaVA-1.5 / NeXT configurations")
+            if c.get("vision_feature_select_strategy", "default") != "default" or not isinstance(c.get("vision_feature_layer", -2), int) or c.get("projector_hidden_act", "gelu") != "gelu":
+                raise ValueError("llava: built for vision_feature_select_strategy 'default', a single vision_feature_layer and the 'gelu' projector")
+            if v.get("hidden_act", "quick_gelu") != "quick_gelu":
+                raise ValueError("llava: the CLIP tower's MLP activation built here is quick_gelu")
+            eos = tt.get("eos_token_id", 2)
+            d = {"family": c["model_type"],
+                 "text": {"vocab_size": tt.get("vocab_size", c.get("vocab_size", 32064)), "hidden_size": tt["hidden_size"], "intermediate_size": tt["intermediate_size"],
+                          "num_hidden_layers": tt["num_hidden_layers"], "num_attention_heads": tt["num_attention_heads"],
+                          "num_key_value_heads": tt.get("num_key_value_heads", tt["num_attention_heads"]), "rms_norm_eps": tt["rms_norm_eps"],
+                          "rope_theta": float((tt.get("rope_parameters") or {}).get("rope_theta", tt["rope_theta"])), "attention_bias": False},
+                 "vision": {"arch": "clip", "depth": v.get("num_hidden_layers", 12), "hidden_size": v.get("hidden_size", 768), "intermediate_size": v.get("intermediate_size", 3072),
+                            "num_heads": v.get("num_attention_heads", 12), "in_channels": v.get("num_channels", 3), "patch_size": v.get("patch_size", 32),
+                            "image_size": v.get("image_size", 224), "layer_norm_eps": v.get("layer_norm_eps", 1e-5)},
+                 "vision_feature_layer": c.get("vision_feature_layer", -2), "image_grid_pinpoints": c.get("image_grid_pinpoints", ()) if c["model_type"] == "llava_next" else (),
+                 "image_token_id": c.get("image_token_index", c.get("image_token_id", 32000)), "eos_token_id": eos[0] if isinstance(eos, (list, tuple)) else eos,
+                 "pad_token_id": _first_set(c.get("pad_token_id"), tt.get("pad_token_id"), 0), "tie_word_embeddings": False}
+            return VLMConfig.from_dict(d)
         if c.get("model_type") == "llava_onevision" or "image_grid_pinpoints" in c:
             asp = str(c.get("vision_aspect_ratio", "anyres_max_9"))
             eos = t.get("eos_token_id", c.get("eos_token_id", 151645))
@@ -278,14 +330,19 @@ class ParamStore:
             specs.append((name, tuple(shape), decay, gemm))
 
         q2 = c.v_arch == "qwen2_vl"
-        assert c.v_arch in ("qwen2_5_vl", "qwen2_vl", "siglip"), c.v_arch
-        self.extra = {}      # checkpoint tensors this engine does not use (SigLIP post_layernorm / pooling head): kept as loaded, written back on save
+        assert c.v_arch in ("qwen2_5_vl", "qwen2_vl", "siglip", "clip"), c.v_arch
+        self.extra = {}      # checkpoint tensors this engine does not use (post_layernorm, SigLIP pooling head, CLIP blocks past the feature layer): kept as loaded, written back on save
         if c.is_llava:
             dp, nh = c.v_head_pad, c.v_heads
             add("visual.patch_embed", (vh, c.patch_dim_pad), True, True)
-            add("visual.patch_embed.b", (vh,), False, False)
-            add("visual.pos", (c.v_tokens, vh), True, False)
-            for i in range(c.v_depth):
+            if c.v_arch == "clip":          # bias-free patch conv, class token, pre-LayerNorm (transformers models/clip/modeling_clip.py:141-200)
+                add("visual.cls", (vh,), True, False)
+                add("visual.pre_ln", (vh,), False, False)
+                add("visual.pre_ln.b", (vh,), False, False)
+            else:
+                add("visual.patch_embed.b", (vh,), False, False)
+            add("visual.pos", (c.v_seq, vh), True, False)
+            for i in range(c.v_run_depth):
                 b = f"visual.blocks.{i}."
                 add(b + "norm1", (vh,), False, False)
                 add(b + "norm1.b", (vh,), False, False)
@@ -303,7 +360,8 @@ class ParamStore:
             add("visual.merger.fc1.b", (H,), False, False)
             add("visual.merger.fc2.w", (H, H), True, True)
             add("visual.merger.fc2.b", (H,), False, False)
-            add("visual.newline", (H,), True, False)
+            if c.llava_family != "llava":
+                add("visual.newline", (H,), True, False)
         else:
             add("visual.patch_embed", (vh, c.patch_dim), True, True)
         for i in range(0 if c.is_llava else c.v_depth):
@@ -521,7 +579,12 @@ class ParamStore:
         pe = torch.zeros(vh, c.patch_dim_pad)
         pe[:, : c.patch_dim] = t(pre + "embeddings.patch_embedding.weight").reshape(vh, -1)
         self._assign("visual.patch_embed", pe)
-        self._assign("visual.patch_embed.b", t(pre + "embeddings.patch_embedding.bias"))
+        if c.v_arch == "clip":
+            self._assign("visual.cls", t(pre + "embeddings.class_embedding"))
+            self._assign("visual.pre_ln", t(pre + "pre_layrnorm.weight"))
+            self._assign("visual.pre_ln.b", t(pre + "pre_layrnorm.bias"))
+        else:
+            self._assign("visual.patch_embed.b", t(pre + "embeddings.patch_embedding.bias"))
         self._assign("visual.pos", t(pre + "embeddings.position_embedding.weight"))
 
         def pad_rows(w):          # [nh*d, K] -> [nh*dp, K], zero rows for the padded dims of every head
@@ -529,7 +592,7 @@ class ParamStore:
             out[:, :d] = w.reshape(nh, d, *w.shape[1:])
             return out.reshape(nh * dp, *w.shape[1:])
 
-        for i in range(c.v_depth):
+        for i in range(c.v_run_depth):      # (the blocks past the feature layer stay in `extra`)
             s_, b = f"{pre}encoder.layers.{i}.", f"visual.blocks.{i}."
             self._assign(b + "norm1", t(s_ + "layer_norm1.weight"))
             self._assign(b + "norm1.b", t(s_ + "layer_norm1.bias"))
@@ -547,7 +610,8 @@ class ParamStore:
         self._assign("visual.merger.fc1.b", t("multi_modal_projector.linear_1.bias"))
         self._assign("visual.merger.fc2.w", t("multi_modal_projector.linear_2.weight"))
         self._assign("visual.merger.fc2.b", t("multi_modal_projector.linear_2.bias"))
-        self._assign("visual.newline", t("image_newline"))
+        if c.llava_family != "llava":
+            self._assign("visual.newline", t("image_newline"))
         lm = "language_model.model."
         self._assign("embed", t(lm + "embed_tokens.weight"))
         slots_t, Dr, Dk = torch.from_numpy(c.head_slots), c.head_dim_real, c.head_dim
@@ -565,7 +629,10 @@ class ParamStore:
             self._assign(b + "ln1", t(s_ + "input_layernorm.weight"))
             self._assign(b + "ln2", t(s_ + "post_attention_layernorm.weight"))
             self._assign(b + "qkv.w", torch.cat([pad_heads(t(s_ + f"self_attn.{z}_proj.weight")) for z in "qkv"], 0))
-            self._assign(b + "qkv.b", torch.cat([pad_heads(t(s_ + f"self_attn.{z}_proj.bias")) for z in "qkv"], 0))
+            if c.qkv_bias:
+                self._assign(b + "qkv.b", torch.cat([pad_heads(t(s_ + f"self_attn.{z}_proj.bias")) for z in "qkv"], 0))
+            else:
+                self.w(b + "qkv.b").zero_()
             self._assign(b + "o.w", pad_heads(t(s_ + "self_attn.o_proj.weight").t().contiguous()).t().contiguous())
             self._assign(b + "gu.w", torch.cat([t(s_ + "mlp.gate_proj.weight"), t(s_ + "mlp.up_proj.weight")], 0))
             self._assign(b + "down.w", t(s_ + "mlp.down_proj.weight"))
@@ -584,9 +651,13 @@ class ParamStore:
         unpad = lambda w: w.reshape(nh, dp, *w.shape[1:])[:, :d].reshape(nh * d, *w.shape[1:]).clone()
         pre, out = "vision_tower.vision_model.", {}
         out[pre + "embeddings.patch_embedding.weight"] = get("visual.patch_embed")[:, : c.patch_dim].reshape(vh, c.v_in_channels, c.v_patch, c.v_patch).clone()
-        out[pre + "embeddings.patch_embedding.bias"] = get("visual.patch_embed.b")
+        if c.v_arch == "clip":
+            out[pre + "embeddings.class_embedding"] = get("visual.cls")
+            out[pre + "pre_layrnorm.weight"], out[pre + "pre_layrnorm.bias"] = get("visual.pre_ln"), get("visual.pre_ln.b")
+        else:
+            out[pre + "embeddings.patch_embedding.bias"] = get("visual.patch_embed.b")
         out[pre + "embeddings.position_embedding.weight"] = get("visual.pos")
-        for i in range(c.v_depth):
+        for i in range(c.v_run_depth):
             s_, b = f"{pre}encoder.layers.{i}.", f"visual.blocks.{i}."
             out[s_ + "layer_norm1.weight"], out[s_ + "layer_norm1.bias"] = get(b + "norm1"), get(b + "norm1.b")
             out[s_ + "layer_norm2.weight"], out[s_ + "layer_norm2.bias"] = get(b + "norm2"), get(b + "norm2.b")
@@ -600,7 +671,8 @@ class ParamStore:
             out[s_ + "mlp.fc2.weight"], out[s_ + "mlp.fc2.bias"] = get(b + "fc2.w"), get(b + "fc2.b")
         out["multi_modal_projector.linear_1.weight"], out["multi_modal_projector.linear_1.bias"] = get("visual.merger.fc1.w"), get("visual.merger.fc1.b")
         out["multi_modal_projector.linear_2.weight"], out["multi_modal_projector.linear_2.bias"] = get("visual.merger.fc2.w"), get("visual.merger.fc2.b")
-        out["image_newline"] = get("visual.newline")
+        if c.llava_family != "llava":
+            out["image_newline"] = get("visual.newline")
         lm = "language_model.model."
         out[lm + "embed_tokens.weight"] = get("embed")
         hq, hk = c.num_attention_heads * c.head_dim, c.num_key_value_heads * c.head_dim
@@ -611,7 +683,8 @@ class ParamStore:
             out[s_ + "input_layernorm.weight"], out[s_ + "post_attention_layernorm.weight"] = get(b + "ln1"), get(b + "ln2")
             qw, qb = get(b + "qkv.w"), get(b + "qkv.b")
             out[s_ + "self_attn.q_proj.weight"], out[s_ + "self_attn.k_proj.weight"], out[s_ + "self_attn.v_proj.weight"] = unpad_heads(qw[:hq]), unpad_heads(qw[hq: hq + hk]), unpad_heads(qw[hq + hk:])
-            out[s_ + "self_attn.q_proj.bias"], out[s_ + "self_attn.k_proj.bias"], out[s_ + "self_attn.v_proj.bias"] = unpad_heads(qb[:hq]), unpad_heads(qb[hq: hq + hk]), unpad_heads(qb[hq + hk:])
+            if c.qkv_bias:
+                out[s_ + "self_attn.q_proj.bias"], out[s_ + "self_attn.k_proj.bias"], out[s_ + "self_attn.v_proj.bias"] = unpad_heads(qb[:hq]), unpad_heads(qb[hq: hq + hk]), unpad_heads(qb[hq + hk:])
             out[s_ + "self_attn.o_proj.weight"] = unpad_heads(get(b + "o.w").t().contiguous()).t().contiguous()
             gu = get(b + "gu.w")
             out[s_ + "mlp.gate_proj.weight"], out[s_ + "mlp.up_proj.weight"] = gu[: c.intermediate_size].clone(), gu[c.intermediate_size:].clone()
@@ -774,7 +847,7 @@ class ParamStore:
         if c.is_llava:       # zero padding: the 592 - 588 extra patch columns and the 80 - 72 padded dims of every vision head
             d, dp, nh = c.v_hidden // c.v_heads, c.v_head_pad, c.v_heads
             self.w("visual.patch_embed")[:, c.patch_dim:].zero_()
-            for i in range(c.v_depth):
+            for i in range(c.v_run_depth):
                 b = f"visual.blocks.{i}."
                 self.w(b + "qkv.w").view(3 * nh, dp, -1)[:, d:].zero_()
                 self.w(b + "qkv.b").view(3 * nh, dp)[:, d:].zero_()

@@ -194,11 +194,12 @@ def prepare_batch(processing_class, inputs: list[dict]) -> dict:
         images += [Image.open(i) if isinstance(i, str) else i for i in im]
     enc = processing_class(text=prompts_text, images=images if images else None, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
     out = {"input_ids": np.asarray(enc["input_ids"]), "attention_mask": np.asarray(enc["attention_mask"]), "pixel_values": enc["pixel_values"], "images_per_prompt": per_prompt}
-    if "image_sizes" in enc:            # LLaVA-OneVision processor: crops [images, max crops, 3, S, S] + original (height, width) per image
+    if "image_sizes" in enc:            # LLaVA-OneVision / LLaVA-NeXT processors: crops [images, max crops, 3, S, S] + original (height, width) per image
         out["image_sizes"] = np.asarray(enc["image_sizes"]).reshape(-1, 2).tolist()
-    else:
+    elif "image_grid_thw" in enc:       # Qwen2-VL / Qwen2.5-VL processors: patch rows + (t, h, w) grids
         grid = enc["image_grid_thw"]
         out["image_grid_thw"] = grid.tolist() if hasattr(grid, "tolist") else [tuple(g) for g in grid]
+    # (LLaVA-1.5 processor: one resized crop per image [images, 3, S, S], nothing else)
     return out
 
 
@@ -234,9 +235,11 @@ class SCGRPOTrainer:
                     raise ValueError("Invalid `torch_dtype` passed to `GRPOConfig`. Expected either 'auto' or a string representing "
                                      f"a `torch.dtype` (e.g., 'float32'), but got {td}.")  # REF:108-111
             mid = model.lower()
-            if not any(t in mid for t in ("qwen2.5-vl", "qwen2.5_vl", "qwen2.5vl", "qwen2-vl", "qwen2_vl", "qwen2vl", "llava-ov", "llava_ov", "llava_si")):
-                raise ValueError(f"{model}: this engine implements the Qwen2-VL, Qwen2.5-VL and LLaVA-OneVision branches of the reference's model switch "
-                                 "(REF:116-137; which one is read from the checkpoint's config.json, not from the path); LLaVA-1.5 / LLaVA-NeXT are not built")
+            if not any(t in mid for t in ("qwen2.5-vl", "qwen2.5_vl", "qwen2.5vl", "qwen2-vl", "qwen2_vl", "qwen2vl", "llava-ov", "llava_ov", "llava_si",
+                                          "llava-next", "llava_next", "llava_1_6", "llava-1_5", "llava_1_5")):
+                raise ValueError(f"{model}: the reference's model switch (REF:116-137) knows Qwen2-VL, Qwen2.5-VL, LLaVA-OneVision, LLaVA-NeXT and LLaVA-1.5 ids; "
+                                 "every other id falls to its AutoModelForCausalLM branch (text-only models), which is not part of this path.  Which family a "
+                                 "directory holds is read from its config.json, not from the path")
         elif mik:
             raise ValueError("You passed `model_init_kwargs` to the `GRPOConfig`, but your model is already instantiated. "
                              "This argument can only be used when the `model` argument is a string.")  # REF:141-145

@@ -53,6 +53,12 @@ class SiglipPlan:
     n_tokens: int
     lens: list
     crops: list
+    # CLIP towers (class token in front of every crop's patch tokens): `assemble` builds the tower's input rows from [patch-embedding rows ; class embedding],
+    # `select` drops the class rows again in front of the projector; each with its transpose for the backward pass.  None for SigLIP.
+    assemble: tuple = None
+    assemble_t: tuple = None
+    select: tuple = None
+    select_t: tuple = None
 
 
 @dataclass
@@ -123,7 +129,11 @@ class Engine:
         or the crops already concatenated [total crops, 3, S, S]."""
         c = self.cfg
         if c.is_llava:
-            sizes = [(int(h), int(w)) for h, w in np.asarray(batch["image_sizes"]).reshape(-1, 2)]
+            if c.llava_family == "llava":     # LLaVA-1.5: one crop per image [images, 3, S, S], no sizes (the processor resized / centre-cropped to S x S)
+                n_img = len(batch["pixel_values"]) if isinstance(batch["pixel_values"], (list, tuple)) else int(torch.as_tensor(batch["pixel_values"]).shape[0])
+                sizes = [(c.v_image_size, c.v_image_size)] * n_img
+            else:
+                sizes = [(int(h), int(w)) for h, w in np.asarray(batch["image_sizes"]).reshape(-1, 2)]
             plan_v = self.vision_plan(sizes)
             px = batch["pixel_values"]
             if isinstance(px, (list, tuple)):
@@ -147,6 +157,8 @@ class Engine:
         if c.is_llava:
             cache = self.__dict__.setdefault("_ov_tokens", {})
             key = (int(g[0]), int(g[1]))
+            if c.llava_family == "llava":
+                return c.v_tokens
             if key not in cache:
                 cache[key] = llava_ov.num_image_tokens(key, c.image_grid_pinpoints, c.v_image_size, c.v_side, c.anyres_max)
             return cache[key]
@@ -154,13 +166,28 @@ class Engine:
 
     def _siglip_plan_build(self, sizes) -> SiglipPlan:
         c = self.cfg
-        plan = llava_ov.pack_plan(sizes, c.image_grid_pinpoints, c.v_image_size, c.v_side, c.anyres_max)
-        tp = llava_ov.transpose_plan(plan)
-        nc, per = sum(plan["crops"]), c.v_tokens
         dev = self.dev
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        return SiglipPlan(nc, nc * per, ops.Segments.from_cu(np.arange(nc + 1) * per, dev), up(np.tile(np.arange(per, dtype=np.int64), nc)),
-                          (up(plan["ptr"]), up(plan["idx"]), up(plan["w"])), (up(tp["ptr"]), up(tp["idx"]), up(tp["w"])), len(plan["ptr"]) - 1, plan["lens"], plan["crops"])
+        per, seq = c.v_tokens, c.v_seq
+        if c.llava_family == "llava":         # one crop per image, its patch features ARE the image tokens: no packing map
+            crops, lens, pack, pack_t, n_tok = [1] * len(sizes), [per] * len(sizes), None, None, len(sizes) * per
+        else:
+            plan = llava_ov.pack_plan(sizes, c.image_grid_pinpoints, c.v_image_size, c.v_side, c.anyres_max)
+            tp = llava_ov.transpose_plan(plan)
+            crops, lens, n_tok = plan["crops"], plan["lens"], len(plan["ptr"]) - 1
+            pack, pack_t = (up(plan["ptr"]), up(plan["idx"]), up(plan["w"])), (up(tp["ptr"]), up(tp["idx"]), up(tp["w"]))
+        nc = sum(crops)
+        extra = {}
+        if c.v_cls:
+            # tower row (crop k, position j): j == 0 -> the class-embedding row (index nc * per of the source), j > 0 -> patch row k * per + j - 1
+            j = np.tile(np.arange(seq), nc)
+            k = np.repeat(np.arange(nc), seq)
+            asm = {"ptr": np.arange(nc * seq + 1, dtype=np.int32), "idx": np.where(j == 0, nc * per, k * per + j - 1).astype(np.int32), "w": np.ones(nc * seq, np.float32), "n_src": nc * per + 1}
+            sel = {"ptr": np.arange(nc * per + 1, dtype=np.int32), "idx": (np.repeat(np.arange(nc), per) * seq + 1 + np.tile(np.arange(per), nc)).astype(np.int32),
+                   "w": np.ones(nc * per, np.float32), "n_src": nc * seq}
+            tri = lambda m: (up(m["ptr"]), up(m["idx"]), up(m["w"]))
+            extra = dict(assemble=tri(asm), assemble_t=tri(llava_ov.transpose_plan(asm)), select=tri(sel), select_t=tri(llava_ov.transpose_plan(sel)))
+        return SiglipPlan(nc, nc * seq, ops.Segments.from_cu(np.arange(nc + 1) * seq, dev), up(np.tile(np.arange(seq, dtype=np.int64), nc)), pack, pack_t, n_tok, lens, crops, **extra)
 
     def _vision_plan_build(self, grids) -> VisionPlan:
         c = self.cfg
@@ -367,43 +394,68 @@ class Engine:
         return ops.cast_f32_to_bf16(rows.to(F32).contiguous(), cpad=c.patch_dim_pad)
 
     def _vision_forward_siglip(self, crops, plan: SiglipPlan, save: bool):
-        """crops: [n_crops, 3, S, S] on device (all images of the batch, base image first per image) -> packed image tokens [n_tokens, H] bf16."""
+        """crops: [n_crops, 3, S, S] on device (all images of the batch, base image first per image) -> image tokens [n_tokens, H] bf16 in the order the
+        placeholders consume them.  SigLIP tower (LLaVA-OneVision) or CLIP tower (LLaVA-1.5 / NeXT: class token, pre-LayerNorm, QuickGELU, the blocks up to the
+        feature layer, class token dropped in front of the projector; transformers models/clip/modeling_clip.py:141-200,  models/llava/modeling_llava.py:144-189)."""
         c, P = self.cfg, self.p
         vh, nh, dp, H = c.v_hidden, c.v_heads, c.v_head_pad, c.hidden_size
         N, seg, eps = plan.n_patches, plan.seg, c.v_ln_eps
-        scale = (vh // nh) ** -0.5          # the TRUE head width (72), not the padded one
+        clip = c.v_arch == "clip"
+        scale = (vh // nh) ** -0.5          # the TRUE head width (72 / 64), not the padded one
         px = self._siglip_patches(crops)
-        assert px.shape[0] == N, (px.shape, N)
-        res = ops.gemm_nt(px, P.w("visual.patch_embed"), bias=P.w("visual.patch_embed.b"))
-        branch = ops.embed_fwd(plan.pos_ids, None, P.w("visual.pos"), None)                    # learned positions, one row per patch
+        n_pe = plan.n_crops * c.v_tokens
+        assert px.shape[0] == n_pe, (px.shape, n_pe)
+        if clip:
+            srcA = torch.empty(n_pe + 1, vh, dtype=BF16, device=self.dev)
+            ops.gemm_nt(px, P.w("visual.patch_embed"), out=srcA[:n_pe])
+            srcA[n_pe].copy_(P.w("visual.cls"))
+            res = ops.rows_gather_sum(srcA, plan.assemble[0], plan.assemble[1], N, weights=plan.assemble[2])       # [class ; patches] per crop
+        else:
+            res = ops.gemm_nt(px, P.w("visual.patch_embed"), bias=P.w("visual.patch_embed.b"))
+        branch = ops.embed_fwd(plan.pos_ids, None, P.w("visual.pos"), None)                    # learned positions, one row per tower row
         ctx = {"px": px, "layers": []} if save else None
+        if clip:       # pre_layrnorm on (embeddings + positions): its output is the residual stream the blocks start from
+            x_pre = torch.empty_like(res) if save else res
+            h0, mu0, rs0 = ops.layernorm_fwd(branch, P.w("visual.pre_ln"), P.w("visual.pre_ln.b"), eps, res=res, res_out=x_pre, want_stats=save)
+            if save:
+                ctx["pre"] = (x_pre, mu0, rs0)
+            res, branch = h0, None
         w3 = nh * dp
-        for i in range(c.v_depth):
+        act = ops.quick_gelu_fwd if clip else ops.gelu_tanh_fwd
+        for i in range(c.v_run_depth):
             b = f"visual.blocks.{i}."
-            x_in = torch.empty_like(res) if save else res
-            h1, mu1, rs1 = ops.layernorm_fwd(branch, P.w(b + "norm1"), P.w(b + "norm1.b"), eps, res=res, res_out=x_in, want_stats=save)
+            if branch is None:
+                x_in = res
+                h1, mu1, rs1 = ops.layernorm_fwd(res, P.w(b + "norm1"), P.w(b + "norm1.b"), eps, want_stats=save)
+            else:
+                x_in = torch.empty_like(res) if save else res
+                h1, mu1, rs1 = ops.layernorm_fwd(branch, P.w(b + "norm1"), P.w(b + "norm1.b"), eps, res=res, res_out=x_in, want_stats=save)
             qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"))
             o, lse = ops.attn_fwd(qkv[:, :w3], qkv[:, w3: 2 * w3], qkv[:, 2 * w3:], seg, nh, nh, dp, False, scale, want_lse=save)
             ab = ops.gemm_nt(o, P.w(b + "proj.w"), bias=P.w(b + "proj.b"))
             x_mid = torch.empty_like(x_in) if save else x_in
             h2, mu2, rs2 = ops.layernorm_fwd(ab, P.w(b + "norm2"), P.w(b + "norm2.b"), eps, res=x_in, res_out=x_mid, want_stats=save)
             z = ops.gemm_nt(h2, P.w(b + "fc1.w"), bias=P.w(b + "fc1.b"))
-            a = ops.gelu_tanh_fwd(z)
+            a = act(z)
             branch = ops.gemm_nt(a, P.w(b + "fc2.w"), bias=P.w(b + "fc2.b"))
             res = x_mid
             if save:
                 ctx["layers"].append((x_in, mu1, rs1, h1, qkv, o, lse, x_mid, mu2, rs2, h2, z, a))
-        # hidden state of the last encoder layer (vision_feature_layer = -1: before post_layernorm): residual + MLP branch
+        # hidden state of the feature layer (before any post_layernorm): residual + MLP branch
         feat = torch.empty_like(res)
         ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, feat, P.w("visual.blocks.0.norm1"), None, None, N, vh, vh, vh, vh, 1e-6, None)
-        z = ops.gemm_nt(feat, P.w("visual.merger.fc1.w"), bias=P.w("visual.merger.fc1.b"))
+        featp = ops.rows_gather_sum(feat, plan.select[0], plan.select[1], n_pe, weights=plan.select[2]) if clip else feat      # "default" strategy: without the class rows
+        z = ops.gemm_nt(featp, P.w("visual.merger.fc1.w"), bias=P.w("visual.merger.fc1.b"))
         ga = ops.gelu_fwd(z)                                                                  # exact GELU (projector_hidden_act "gelu")
-        src = torch.empty(N + 1, H, dtype=BF16, device=self.dev)
-        ops.gemm_nt(ga, P.w("visual.merger.fc2.w"), bias=P.w("visual.merger.fc2.b"), out=src[:N])
-        src[N].copy_(P.w("visual.newline"))
-        out = ops.rows_gather_sum(src, plan.pack[0], plan.pack[1], plan.n_tokens, weights=plan.pack[2])
+        if plan.pack is None:             # LLaVA-1.5: the projector rows are the image tokens
+            out = ops.gemm_nt(ga, P.w("visual.merger.fc2.w"), bias=P.w("visual.merger.fc2.b"))
+        else:
+            src = torch.empty(n_pe + 1, H, dtype=BF16, device=self.dev)
+            ops.gemm_nt(ga, P.w("visual.merger.fc2.w"), bias=P.w("visual.merger.fc2.b"), out=src[:n_pe])
+            src[n_pe].copy_(P.w("visual.newline"))
+            out = ops.rows_gather_sum(src, plan.pack[0], plan.pack[1], plan.n_tokens, weights=plan.pack[2])
         if save:
-            ctx.update(feat=feat, z=z, ga=ga, plan=plan)
+            ctx.update(feat=featp, z=z, ga=ga, plan=plan)
         return out, ctx
 
     def _vision_backward_siglip(self, d_out, ctx):
@@ -411,25 +463,33 @@ class Engine:
         vh, nh, dp, H = c.v_hidden, c.v_heads, c.v_head_pad, c.hidden_size
         plan: SiglipPlan = ctx["plan"]
         N, seg = plan.n_patches, plan.seg
+        clip = c.v_arch == "clip"
+        n_pe = plan.n_crops * c.v_tokens
         scale = (vh // nh) ** -0.5
         w3 = nh * dp
-        dsrc = ops.rows_gather_sum(d_out.contiguous(), plan.pack_t[0], plan.pack_t[1], N + 1, weights=plan.pack_t[2])
-        ops.colsum_acc(dsrc[N: N + 1], P.g("visual.newline"))
-        dmo = dsrc[:N]
+        if plan.pack is None:
+            dmo = d_out.contiguous()
+        else:
+            dsrc = ops.rows_gather_sum(d_out.contiguous(), plan.pack_t[0], plan.pack_t[1], n_pe + 1, weights=plan.pack_t[2])
+            ops.colsum_acc(dsrc[n_pe: n_pe + 1], P.g("visual.newline"))
+            dmo = dsrc[:n_pe]
         ops.colsum_acc(dmo, P.g("visual.merger.fc2.b"))
         dga = ops.gemm_nt(dmo, P.wT("visual.merger.fc2.w"))
         self._wgrad("visual.merger.fc2.w", dmo, ctx["ga"])
         dz = ops.gelu_bwd(dga, ctx["z"])
         ops.colsum_acc(dz, P.g("visual.merger.fc1.b"))
-        dres = ops.gemm_nt(dz, P.wT("visual.merger.fc1.w"))        # gradient of the last hidden state = of the residual stream AND of the last MLP branch
+        dres = ops.gemm_nt(dz, P.wT("visual.merger.fc1.w"))        # gradient of the feature layer's hidden state = of the residual stream AND of the last MLP branch
         self._wgrad("visual.merger.fc1.w", dz, ctx["feat"])
-        for i in reversed(range(c.v_depth)):
+        if clip:       # back to the tower's rows: the class rows carry no gradient from the projector
+            dres = ops.rows_gather_sum(dres, plan.select_t[0], plan.select_t[1], N, weights=plan.select_t[2])
+        act_bwd = ops.quick_gelu_bwd if clip else ops.gelu_tanh_bwd
+        for i in reversed(range(c.v_run_depth)):
             b = f"visual.blocks.{i}."
             x_in, mu1, rs1, h1, qkv, o, lse, x_mid, mu2, rs2, h2, z, a = ctx["layers"][i]
             ops.colsum_acc(dres, P.g(b + "fc2.b"))
             da = ops.gemm_nt(dres, P.wT(b + "fc2.w"))
             self._wgrad(b + "fc2.w", dres, a)
-            dz = ops.gelu_tanh_bwd(da, z)
+            dz = act_bwd(da, z)
             ops.colsum_acc(dz, P.g(b + "fc1.b"))
             dh2 = ops.gemm_nt(dz, P.wT(b + "fc1.w"))
             self._wgrad(b + "fc1.w", dz, h2)
@@ -443,10 +503,18 @@ class Engine:
             dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"))
             self._wgrad(b + "qkv.w", dqkv, h1)
             dres = ops.layernorm_bwd(dh1, x_in, P.w(b + "norm1"), mu1, rs1, dres=dx_mid, dw=P.g(b + "norm1"), db=P.g(b + "norm1.b"))
-        # dres = gradient of (patch embedding + position embedding)
+        if clip:
+            x_pre, mu0, rs0 = ctx["pre"]
+            dres = ops.layernorm_bwd(dres, x_pre, P.w("visual.pre_ln"), mu0, rs0, dw=P.g("visual.pre_ln"), db=P.g("visual.pre_ln.b"))
+        # dres = gradient of (patch / class embedding + position embedding)
         ops.embed_bwd(plan.pos_ids, None, dres, P.g("visual.pos"), None)
-        ops.colsum_acc(dres, P.g("visual.patch_embed.b"))
-        self._wgrad("visual.patch_embed", dres, ctx["px"])
+        if clip:
+            dsrcA = ops.rows_gather_sum(dres, plan.assemble_t[0], plan.assemble_t[1], n_pe + 1, weights=plan.assemble_t[2])
+            ops.colsum_acc(dsrcA[n_pe: n_pe + 1], P.g("visual.cls"))
+            self._wgrad("visual.patch_embed", dsrcA[:n_pe], ctx["px"])
+        else:
+            ops.colsum_acc(dres, P.g("visual.patch_embed.b"))
+            self._wgrad("visual.patch_embed", dres, ctx["px"])
         self.join_wgrads()
 
     def _vision_forward_q2(self, px, plan: VisionPlan, save: bool):
@@ -749,7 +817,8 @@ class Engine:
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, do, lse, plan.seg, Hq, Hkv, D, True, c.attn_scale,
                          dqkv[:, :qw], dqkv[:, qw: qw + kw], dqkv[:, qw + kw:])
             ops.rope_(dqkv, plan.cos, plan.sin, Hq + Hkv, D, backward=True)
-            ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
+            if c.qkv_bias:           # (LLaMA / Mistral: no q/k/v biases -- the fused bias row stays zero and receives no gradient)
+                ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
             self._wgrad(b + "qkv.w", dqkv, h1)
             dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"))
             dres = ops.rmsnorm_bwd(dh1, x_in, P.w(b + "ln1"), rstd1, dres=dx_mid, dw=P.g(b + "ln1"))

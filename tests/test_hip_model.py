@@ -1082,3 +1082,129 @@ def test_llava_onevision_64_wide_heads_train_and_roll_out():
     out = pol.export_named()
     assert tuple(out["language_model.model.layers.0.self_attn.q_proj.weight"].shape) == (256, 256) and tuple(out["language_model.model.layers.0.self_attn.k_proj.bias"].shape) == (128,)
     assert tuple(out["language_model.model.layers.1.self_attn.o_proj.weight"].shape) == (256, 256)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# LLaVA-1.5 / LLaVA-NeXT branches of the reference's model switch (REF sc_grpo_trainer.py:130-135)
+# ------------------------------------------------------------------------------------------------------------------------------------
+_LLAVA = {"llava": ("TINY_LLAVA15", "llava15.npz", "sc_grpo_llava15.npz"), "llava_next": ("TINY_LLAVA_NEXT", "llava_next.npz", "sc_grpo_llava_next.npz")}
+
+
+def _llava_store(cfg_d, weights, trainable):
+    s_ = ParamStore(VLMConfig.from_dict(cfg_d), DEV, trainable=trainable)
+    s_.load_named(weights)
+    return s_
+
+
+def _llava_batch(cfg_d, g, meta, ids, mask):
+    b = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_crops(meta["crops"], cfg_d, meta["seed"])}
+    if cfg_d["family"] == "llava_next":
+        b["image_sizes"] = [tuple(x) for x in meta["sizes"]]
+    return b
+
+
+@pytest.mark.parametrize("family", ["llava", "llava_next"])
+def test_llava15_and_next_forward_matches_hf_golden(golden_dir, family):
+    """CLIP tower (64-wide heads zero-padded to 80, class token assembled / dropped through the sparse row maps, pre-LayerNorm, QuickGELU, the blocks up to the feature
+    layer), projector, NeXT's packing without the shrink step, bias-free LLaMA (MHA) / Mistral (GQA) decoder on the HIP kernels vs tiny HF models; the checkpoint names
+    round-trip including the tensors this path never touches (the last CLIP block, post_layernorm)."""
+    cfg_name, gname, _ = _LLAVA[family]
+    cfg_d = getattr(fx, cfg_name)
+    g = load(golden_dir, gname)
+    meta = json.loads(str(g["meta"]))
+    w = fx.make_weights_llava(cfg_d, 0)
+    st = _llava_store(cfg_d, w, False)
+    assert st.cfg.v_arch == "clip" and st.cfg.v_run_depth == cfg_d["vision"]["depth"] - 1 and not st.cfg.qkv_bias
+    back = st.export_named()
+    assert set(back) == set(w)
+    for k, v_ in w.items():
+        assert np.array_equal(back[k].numpy().reshape(-1), v_.reshape(-1)), k
+    e = Engine(st)
+    ids, mask = g["input_ids"], g["attention_mask"]
+    batch = _llava_batch(cfg_d, g, meta, ids, mask)
+    sizes, plan_v, px, rows = e.vision_inputs(batch)
+    assert plan_v.lens == g["feature_lens"].tolist()
+    img, _ = e.vision_forward(px, plan_v, save=False)
+    assert relerr(img.float().cpu().numpy(), g["image_features"]) < 3e-2
+    plan = e.text_plan(ids, mask, [[s_] for s_ in sizes], [[int(r)] for r in rows[:-1]])
+    hf, _ = e.text_forward(plan, img, save=False)
+    B, S = ids.shape
+    valid = (mask[:, 1:] * mask[:, :-1]).astype(bool)
+    rr = (np.arange(B)[:, None] * S + np.arange(S - 1)[None, :])[valid]
+    lp, _ = e.logprobs(hf, torch.from_numpy(rr).to(DEV), torch.from_numpy(ids[:, 1:][valid].astype(np.int64)).to(DEV), save=False)
+    err = np.abs(lp.cpu().numpy() - g["per_token_logps"][valid]).max()
+    assert err < 0.08, err
+
+
+@pytest.mark.parametrize("family", ["llava", "llava_next"])
+def test_llava15_and_next_sc_grpo_matches_reference_golden(golden_dir, family):
+    """The reference's compute_loss under its llava_1_5 / llava_next model ids (both pass through `_ensure_left_padding_data`) vs the HIP engine: log-probs, advantages,
+    loss / KL relative, gradient norms and directions incl. the class embedding and the pre-LayerNorm; the bias-free decoder's fused q|k|v bias receives no gradient."""
+    cfg_name, _, gname = _LLAVA[family]
+    cfg_d = getattr(fx, cfg_name)
+    g = load(golden_dir, gname)
+    meta = json.loads(str(g["meta"]))
+    G, C, seed = meta["G"], meta["C"], meta["seed"]
+    w_ref = fx.make_weights_llava(cfg_d, 0)
+    pol, ref = _llava_store(cfg_d, fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"]), True), _llava_store(cfg_d, w_ref, False)
+    eng = SCGRPOEngine(pol.cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=16))
+    P = g["prompt_completion_ids"].shape[1] - C
+    batch = _llava_batch(cfg_d, g, meta, g["prompt_completion_ids"][:1, :P], g["attention_mask"][:1, :P])
+    comps = fx.synth_completions(G, C, cfg_d, seed + 100, {int(k): v for k, v in meta["eos_rows"].items()})
+    out = eng.loss_and_grads(batch, comps, g["rewards_per_func"])
+    assert np.array_equal(out["ids"], g["prompt_completion_ids"]) and np.array_equal(out["completion_mask"], g["completion_mask"])
+    m = g["completion_mask"].astype(bool)
+    dlp = np.abs(out["logps"].cpu().numpy()[m] - g["per_token_logps"][m]).max()
+    dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - g["ref_per_token_logps"][m]).max()
+    gl, gk = float(g["loss"]), float(g["metric_kl"])
+    mt = out["metrics"]
+    print(f"[parity] {family}: loss hip={mt['loss']:.6e} ref={gl:.6e}  kl hip={mt['kl']:.6e} ref={gk:.6e} ({100 * abs(mt['kl'] - gk) / gk:.1f}%)  |dlogp|max={dlp:.4f}/{dlr:.4f}")
+    assert dlp < 0.08 and dlr < 0.08, (dlp, dlr)
+    np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=1e-5, atol=1e-6)
+    assert abs(mt["kl"] - gk) <= 0.10 * gk and abs(mt["loss"] - gl) <= 0.04 * 0.10 * gk + 2e-6
+    grads = pol.export_named(source="grad")
+    for n, ref_norm in zip([str(n) for n in g["grad_norm_names"]], g["grad_norms"]):
+        if n == "language_model.lm_head.weight" or ref_norm < 1e-7 or n not in grads:      # (a key bias shifts every score of a row alike: its gradient is 0 up to rounding)
+            continue
+        got = float(grads[n].norm())
+        assert abs(got - ref_norm) <= 0.10 * ref_norm + 1e-7, (n, got, ref_norm)
+    for k in g.files:
+        if k.startswith("grad::"):
+            a, b = grads[k[6:]].numpy().reshape(-1).astype(np.float64), g[k].reshape(-1).astype(np.float64)
+            cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+            assert cos > 0.99, (k, cos)
+    assert float(pol.g("layers.0.qkv.b").abs().max()) == 0.0 and float(pol.w("layers.1.qkv.b").abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("family", ["llava", "llava_next"])
+def test_llava15_and_next_rollout_and_step(family):
+    """Group rollout (hipGraph == eager) and one full SC-GRPO step on both structures: finite loss, KL exactly 0 for policy == reference, both towers move."""
+    cfg_name = _LLAVA[family][0]
+    cfg_d = getattr(fx, cfg_name)
+    w = fx.make_weights_llava(cfg_d, 0)
+    pol, ref = _llava_store(cfg_d, w, True), _llava_store(cfg_d, w, False)
+    cfg = pol.cfg
+    e0 = Engine(ref)
+    sizes = [(56, 56), (56, 56)] if family == "llava" else [(80, 100), (150, 60)]
+    rs, rows = np.random.RandomState(7), []
+    for sz, nt in zip(sizes, (5, 12)):
+        rows.append(rs.randint(3, 600, 3).tolist() + [cfg.image_token_id] * e0.n_image_tokens(sz) + rs.randint(3, 600, nt).tolist())
+    ids, mask = fx.left_pad(rows, cfg.pad_token_id)
+    from iadr1_amd import llava_ov as lo
+    ncrops = 2 if family == "llava" else sum(lo.num_crops(s_, cfg_d["image_grid_pinpoints"], cfg_d["vision"]["image_size"]) for s_ in sizes)
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_crops(ncrops, cfg_d, 9)}
+    if family == "llava_next":
+        batch["image_sizes"] = sizes
+    G, C = 4, 8
+    eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, suppress_eos=True, learning_rate=1e-3, seed=3))
+    toks = eng.rollout(batch, greedy=True)
+    eager = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, suppress_eos=True, use_hip_graph=False))
+    assert np.array_equal(toks, eager.rollout(batch, greedy=True)) and toks.shape == (2 * G, C)
+    before = pol.flat.clone()
+    mt = eng.step(batch, lambda comp: np.stack([(np.asarray(comp)[:, 0] % 5).astype(np.float32), (np.asarray(comp)[:, 1] % 3).astype(np.float32)], 1))
+    assert np.isfinite(mt["loss"]) and mt["kl"] == 0.0 and eng.grad_norm() > 0
+    moved = pol.flat != before
+    for name in ("visual.blocks.0.fc1.w", "visual.cls", "layers.0.qkv.w"):
+        sl = pol.slots[name]
+        assert bool(moved[sl.offset: sl.offset + min(100, int(np.prod(sl.shape)))].any()), name
+    assert float(pol.w("layers.0.qkv.b").abs().max()) == 0.0
