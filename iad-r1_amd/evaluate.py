@@ -166,8 +166,10 @@ class GreedyGenerator:
         plan = e.text_plan(ids, mask, gpr, off)
         B, P = ids.shape
         r = self._rollout
-        if r is None or r.N != B or r.max_pages * 32 < P + self.max_new:
-            self._rollout = r = Rollout(e, B, P, self.max_new, max_prompts=B, use_graph=True)
+        if r is None or r.N != B or r.max_prompt < P:        # grow only: pool, block table and captured graph are sized for a prompt length
+            grow = max(P, r.max_prompt if r is not None else 0)
+            self._rollout = r = None
+            self._rollout = r = Rollout(e, B, grow, self.max_new, max_prompts=B, use_graph=True)
         return r.generate(plan, img, 1, self.max_new, temperature=0.0, top_k=1, top_p=1.0, seed=0).cpu().numpy()
 
 

@@ -30,10 +30,10 @@ class Rollout:
         self.e = engine
         c = engine.cfg
         dev = engine.dev
-        self.N, self.max_new, self.use_graph = max_seqs, max_new, use_graph
+        self.N, self.max_new, self.use_graph, self.max_prompt = max_seqs, max_new, use_graph, max_prompt
         L, H, D, Hq, Hkv, I, V = c.num_hidden_layers, c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads, c.intermediate_size, c.vocab_size
         max_prompts = max_prompts or max_seqs
-        self.max_pages = (max_prompt + max_new + PAGE - 1) // PAGE + 1
+        self.max_pages = max_prompt // PAGE + (PAGE - 1 + max_new + PAGE - 1) // PAGE + 1      # full prompt pages + the private pages of the worst remainder (generate())
         # page pool: shared prompt pages + private pages (tail of the prompt + completion) per sequence
         self.n_pages = max_prompts * ((max_prompt + PAGE - 1) // PAGE) + max_seqs * ((max_new + 2 * PAGE - 1) // PAGE + 1) + 1
         self.kc = torch.zeros(L, self.n_pages, Hkv, PAGE, D, dtype=BF16, device=dev)

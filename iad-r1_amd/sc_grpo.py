@@ -257,8 +257,12 @@ class SCGRPOEngine:
         plan = self.pol.text_plan(ids, mask, gpr, off)
         Bp = ids.shape[0]
         N = Bp * a.num_generations
-        if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_pages * 32 < ids.shape[1] + a.max_completion_length:
-            self._rollout = Rollout(self.pol, N, ids.shape[1], a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph)
+        # the KV pool, the block table and the captured graph are sized for a prompt length: a longer padded prompt than any seen so far rebuilds them (grow only;
+        # prompt lengths vary from batch to batch with the image sizes of the any-resolution families)
+        if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_prompt < ids.shape[1]:
+            grow = max(ids.shape[1], self._rollout.max_prompt if self._rollout is not None else 0)
+            self._rollout = None        # release the old pool before the new one is allocated
+            self._rollout = Rollout(self.pol, N, grow, a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph)
         c, st = self.cfg, self.pol.p
         # decode steps that also fill the training arena (no policy forward over the completions afterwards): needs the fused decode kernels that carry
         # the side outputs (q|k|v + rotary + cache append, persistent fused-SwiGLU gate|up GEMM)

@@ -241,7 +241,75 @@ def qwen2_vl_turn_texts(messages, system: Optional[str] = None):
 llava_next_qwen_turn_texts = qwen2_vl_turn_texts
 
 
+class _Special:
+    """A special-token element of a template ({"bos_token"} / {"eos_token"} in llamafactory's slot lists): resolved against the tokenizer, dropped when it has none."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return f"<{self.name}>"
+
+
+BOS, EOS = _Special("bos_token"), _Special("eos_token")
+LLAVA_DEFAULT_SYSTEM = ("A chat between a curious user and an artificial intelligence assistant. "
+                        "The assistant gives helpful, detailed, and polite answers to the user's questions.")
+
+
+def llava_turn_texts(messages, system: Optional[str] = None):
+    """The "llava" template (llamafactory template.py:832-841, "copied from vicuna template", the LLaVA-1.5 script): turn 0 = the system text as its own piece,
+    then "USER: {content} ASSISTANT:"; the answer is the content followed by the EOS token."""
+    if len(messages) % 2:
+        raise ValueError("a conversation is user / assistant pairs")
+    system = system or LLAVA_DEFAULT_SYSTEM
+    rendered = []
+    for i, m in enumerate(messages):
+        pieces = [system] if i == 0 and system else []
+        if m["role"] in ("user", "observation"):
+            pieces.append("USER: " + m["content"] + " ASSISTANT:")
+        elif m["role"] == "assistant":
+            pieces += [m["content"], EOS]
+        else:
+            raise NotImplementedError("Unexpected role: %s (tool calls are not part of the IAD-R1 data)" % m["role"])
+        rendered.append(pieces)
+    return [(rendered[i], rendered[i + 1]) for i in range(0, len(rendered), 2)]
+
+
+def llava_next_mistral_turn_texts(messages, system: Optional[str] = None):
+    """The "llava_next_mistral" template (llamafactory template.py:885-896 with Llama2Template._encode :165-203, the LLaVA-1.6 script): turn 0 = BOS, then
+    "[INST] " + (system + two newlines, when the row has a system prompt; there is no default one) + content + "[/INST]"; the answer is " " + content + EOS."""
+    if len(messages) % 2:
+        raise ValueError("a conversation is user / assistant pairs")
+    rendered = []
+    for i, m in enumerate(messages):
+        pieces = [BOS] if i == 0 else []
+        system_text = (system + "\n\n") if (i == 0 and system) else ""
+        if m["role"] == "user":
+            pieces.append("[INST] " + system_text + m["content"] + "[/INST]")
+        elif m["role"] == "assistant":
+            pieces += [" " + m["content"], EOS]
+        elif m["role"] == "observation":
+            pieces.append("[TOOL_RESULTS] {\"content\": " + m["content"] + "}[/TOOL_RESULTS]")
+        else:
+            raise NotImplementedError("Unexpected role: %s (tool calls are not part of the IAD-R1 data)" % m["role"])
+        rendered.append(pieces)
+    return [(rendered[i], rendered[i + 1]) for i in range(0, len(rendered), 2)]
+
+
+TURN_TEXTS = {"qwen2_vl": qwen2_vl_turn_texts, "llava_next_qwen": llava_next_qwen_turn_texts, "llava": llava_turn_texts, "llava_next_mistral": llava_next_mistral_turn_texts}
+
+
 def encode_turns(tokenizer, turn_texts):
-    """[(prompt_pieces, answer_pieces)] -> [(prompt_ids, answer_ids)], each piece through tokenizer.encode(piece, add_special_tokens=False)."""
-    enc = lambda pieces: [t for p in pieces if p for t in tokenizer.encode(p, add_special_tokens=False)]
+    """[(prompt_pieces, answer_pieces)] -> [(prompt_ids, answer_ids)]: every text piece through tokenizer.encode(piece, add_special_tokens=False), BOS / EOS elements
+    as the tokenizer's ids (llamafactory template.py:141-160)."""
+    def enc(pieces):
+        out = []
+        for p in pieces:
+            if isinstance(p, _Special):
+                tid = getattr(tokenizer, p.name + "_id", None)
+                if tid is not None:
+                    out.append(tid)
+            elif p:
+                out += tokenizer.encode(p, add_special_tokens=False)
+        return out
     return [(enc(s), enc(t)) for s, t in turn_texts]

@@ -468,3 +468,39 @@ def make_weights_llava(cfg: dict, seed: int = 0, std: float = 0.05) -> dict[str,
             x = std * x
         out[name] = _bf16_round(x)
     return out
+
+
+LLAVA_SPECIAL = ["<unk>", "<s>", "</s>", "<image>", "<pad>"]
+LLAVA15_CHAT_TEMPLATE = (      # llava-1.5-hf chat template's structure: "USER: <image>\n<text> ASSISTANT:"
+    "{% for message in messages %}{% if message['role'] != 'system' %}{{ message['role'].upper() + ': '}}{% endif %}"
+    "{% for content in message['content'] | selectattr('type', 'equalto', 'image') %}{{ '<image>\n' }}{% endfor %}"
+    "{% if message['role'] == 'system' %}{{ message['content'][0]['text'] if message['content'] is not string else message['content'] }}{{ ' ' }}{% else %}"
+    "{% for content in message['content'] | selectattr('type', 'equalto', 'text') %}{{ content['text'] + ' '}}{% endfor %}{% endif %}{% endfor %}"
+    "{% if add_generation_prompt %}{{ 'ASSISTANT:' }}{% endif %}"
+)
+LLAVA_NEXT_CHAT_TEMPLATE = (   # llava-v1.6-mistral-7b-hf: "[INST] <image>\n<text> [/INST]"
+    "{% for message in messages %}{% if message['role'] == 'user' %}{{ '[INST] ' }}{% for content in message['content'] | selectattr('type', 'equalto', 'image') %}{{ '<image>\n' }}{% endfor %}"
+    "{% for content in message['content'] | selectattr('type', 'equalto', 'text') %}{{ content['text'] }}{% endfor %}{{ ' [/INST]' }}{% endif %}{% endfor %}"
+)
+
+
+def local_llava_processor(cfg: dict):
+    """Offline transformers LlavaProcessor (cfg family "llava": CLIP image processor, one resized / centre-cropped crop per image) or LlavaNextProcessor ("llava_next":
+    any-resolution crops) with a character-level tokenizer (bos <s>, eos </s>); every `<image>` is expanded by the processor to the image token count of the family."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import CLIPImageProcessorPil, LlavaNextImageProcessorPil, PreTrainedTokenizerFast
+    from transformers.models.llava.processing_llava import LlavaProcessor
+    from transformers.models.llava_next.processing_llava_next import LlavaNextProcessor
+
+    v = cfg["vision"]
+    words = LLAVA_SPECIAL + [chr(c) for c in range(32, 127)] + ["\n"]
+    tok = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Split("", "isolated")
+    t = PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", pad_token="<pad>", unk_token="<unk>", additional_special_tokens=["<image>"])
+    size, crop = {"shortest_edge": v["image_size"]}, {"height": v["image_size"], "width": v["image_size"]}
+    if cfg["family"] == "llava":
+        return LlavaProcessor(image_processor=CLIPImageProcessorPil(size=size, crop_size=crop), tokenizer=t, patch_size=v["patch_size"], vision_feature_select_strategy="default",
+                              chat_template=LLAVA15_CHAT_TEMPLATE, num_additional_image_tokens=1)
+    ip = LlavaNextImageProcessorPil(size=size, crop_size=crop, image_grid_pinpoints=[list(p) for p in cfg["image_grid_pinpoints"]])
+    return LlavaNextProcessor(image_processor=ip, tokenizer=t, patch_size=v["patch_size"], vision_feature_select_strategy="default", chat_template=LLAVA_NEXT_CHAT_TEMPLATE,
+                              num_additional_image_tokens=1)

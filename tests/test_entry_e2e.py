@@ -198,3 +198,83 @@ def test_pa_sft_entry_point_end_to_end_llava_onevision(tmp_path, monkeypatch):
     assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
     cfg2, s2 = load_checkpoint(out, DEV, trainable=False)
     assert cfg2.is_llava and not torch.equal(s2.flat, s0.flat) and bool(torch.isfinite(s2.flat.float()).all())
+
+
+def _llava_config_json(d):
+    """config.json of a LLaVA-1.5 (`llava`) / LLaVA-NeXT (`llava_next`) checkpoint in the published layout: a text_config that names its model type and lists
+    only what differs from that class's defaults would do; the tiny structures list everything."""
+    t, v = d["text"], d["vision"]
+    c = {"model_type": d["family"], "architectures": ["LlavaForConditionalGeneration" if d["family"] == "llava" else "LlavaNextForConditionalGeneration"],
+         "image_token_index": d["image_token_id"], "pad_token_id": d["pad_token_id"], "projector_hidden_act": "gelu", "vision_feature_layer": -2, "vision_feature_select_strategy": "default",
+         "tie_word_embeddings": False,
+         "text_config": {"model_type": "llama" if d["family"] == "llava" else "mistral", "vocab_size": t["vocab_size"], "hidden_size": t["hidden_size"],
+                         "intermediate_size": t["intermediate_size"], "num_hidden_layers": t["num_hidden_layers"], "num_attention_heads": t["num_attention_heads"],
+                         "num_key_value_heads": t["num_key_value_heads"], "rms_norm_eps": t["rms_norm_eps"], "rope_theta": t["rope_theta"], "eos_token_id": d["eos_token_id"], "sliding_window": None},
+         "vision_config": {"model_type": "clip_vision_model", "hidden_size": v["hidden_size"], "image_size": v["image_size"], "intermediate_size": v["intermediate_size"],
+                           "num_attention_heads": v["num_heads"], "num_hidden_layers": v["depth"], "patch_size": v["patch_size"], "projection_dim": 64}}
+    if d["family"] == "llava_next":
+        c["image_grid_pinpoints"] = [list(p) for p in d["image_grid_pinpoints"]]
+    return c
+
+
+@pytest.mark.parametrize("family,model_dir,template", [("llava", "llava_1_5-tiny-hf", "llava"), ("llava_next", "llava_next-mistral-tiny-hf", "llava_next_mistral")])
+def test_llava15_and_next_entry_points_end_to_end(tmp_path, monkeypatch, capsys, family, model_dir, template):
+    """scripts/train/SC_GRPO/SC_GRPO_LLaVA_1_5.sh / _1_6.sh and scripts/train/PA_SFT/PA_SFT_LLaVA_1_5.sh / _1_6.sh, paths swapped: checkpoint directory in the published
+    config layout (model id containing the substring the reference's switch looks for), offline transformers Llava / LlavaNext processor, manifest + image files;
+    two optimizer steps each; the saved checkpoints load back (incl. the CLIP block and post_layernorm this path never touches) and differ from the start."""
+    cfg0 = fx.TINY_LLAVA15 if family == "llava" else fx.TINY_LLAVA_NEXT
+    proc = fx.local_llava_processor(cfg0)
+    proc.save_pretrained = lambda *a, **k: None
+    import transformers
+    monkeypatch.setattr(transformers.AutoProcessor, "from_pretrained", classmethod(lambda cls, *a, **k: proc))
+    tok = proc.tokenizer
+    d = dict(cfg0, image_token_id=tok.convert_tokens_to_ids("<image>"), eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id, vision_start_token_id=-1, vision_end_token_id=-1)
+    src = str(tmp_path / model_dir)
+    cfg = VLMConfig.from_dict(d)
+    s0 = ParamStore(cfg, DEV, trainable=False)
+    w0 = fx.make_weights_llava(d, 0)
+    s0.load_named(w0)
+    save_checkpoint(s0, src, _llava_config_json(d))
+    cfg_l, s1 = load_checkpoint(src, DEV, trainable=False)
+    assert cfg_l == cfg
+    back = s1.export_named()
+    assert set(back) == set(w0) and all(np.array_equal(back[k].float().numpy().reshape(-1), v_.reshape(-1)) for k, v_ in w0.items())
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    rl_rows, sft_rows = [], []
+    for i, (w_, h_) in enumerate(((100, 80), (100, 120), (150, 60), (90, 90))):
+        fx.synth_pil_image(w_, h_, 80 + i).save(str(img_dir / f"p_{i}.png"))
+        rl_rows.append({"image": f"p_{i}.png", "problem": "Are there any defects in the query image?", "solution": "<answer>Yes</answer>" if i % 2 else "<answer>No</answer>"})
+        sft_rows.append({"messages": [{"role": "user", "content": "<image>Are there any defects in the query image?"},
+                                      {"role": "assistant", "content": "<think>a scratch</think><answer>Yes</answer>" if i % 2 else "<answer>No</answer>"}], "images": [f"p_{i}.png"]})
+    # ---- SC-GRPO
+    manifest = tmp_path / "rl.json"
+    manifest.write_text(json.dumps(rl_rows))
+    from iadr1_amd import rewards
+    monkeypatch.setitem(rewards.REWARD_FUNCS, "format", lambda prompts, completions, **kw: [float(sum(map(ord, c[0]["content"])) % 7) for c in completions])
+    out_rl = str(tmp_path / "out_rl")
+    _load("train/stage_rl/grpo_ad.py").main(["--model_name_or_path", src, "--dataset_name", str(manifest), "--image_path", str(img_dir), "--output_dir", out_rl, "--max_prompt_length", "1024",
+                                             "--max_completion_length", "8", "--num_generations", "4", "--per_device_train_batch_size", "1", "--gradient_accumulation_steps", "2",
+                                             "--learning_rate", "1e-3", "--num_train_epochs", "1", "--logging_steps", "1", "--save_steps", "100", "--bf16", "--reward_funcs", "accuracy", "format",
+                                             "--use_vllm_for_gen", "true", "--use_system_prompt", "false", "--single_img", "1", "--deepspeed", "zero3.json"])
+    logs = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert [r["step"] for r in logs] == [1, 2] and all(np.isfinite(r["loss"]) and r["grad_norm"] > 0 for r in logs)
+    cfg2, s2 = load_checkpoint(out_rl, DEV, trainable=False)
+    assert cfg2 == cfg and not torch.equal(s2.flat, s0.flat) and bool(torch.isfinite(s2.flat.float()).all())
+    kept = "vision_tower.vision_model.post_layernorm.weight"
+    assert np.array_equal(s2.export_named()[kept].float().numpy(), w0[kept])          # untouched tensors travel through load -> train -> save
+    # ---- PA-SFT
+    data_dir = tmp_path / "data"
+    data_dir.mkdir()
+    (data_dir / "expert_ad.json").write_text(json.dumps(sft_rows))
+    (data_dir / "dataset_info.json").write_text(json.dumps({"Expert_AD_Stage_1": {"file_name": "expert_ad.json", "formatting": "sharegpt", "columns": {"messages": "messages", "images": "images"},
+                                                                                  "tags": {"role_tag": "role", "content_tag": "content", "user_tag": "user", "assistant_tag": "assistant"}}}))
+    out_sft = str(tmp_path / "out_sft")
+    _load("train/stage_sft/train.py").main(["--stage", "sft", "--do_train", "--model_name_or_path", src, "--dataset", "Expert_AD_Stage_1", "--dataset_dir", str(data_dir), "--image_dir", str(img_dir),
+                                            "--template", template, "--finetuning_type", "full", "--output_dir", out_sft, "--overwrite_output_dir", "--warmup_steps", "1",
+                                            "--per_device_train_batch_size", "1", "--gradient_accumulation_steps", "2", "--learning_rate", "1e-3", "--lr_scheduler_type", "cosine",
+                                            "--logging_steps", "1", "--cutoff_len", "4096", "--save_steps", "500", "--num_train_epochs", "1", "--bf16", "--deepspeed", "zero3.json"])
+    log = [json.loads(l) for l in open(os.path.join(out_sft, "trainer_log.jsonl"))]
+    assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
+    cfg3, s3 = load_checkpoint(out_sft, DEV, trainable=False)
+    assert cfg3 == cfg and not torch.equal(s3.flat, s0.flat) and bool(torch.isfinite(s3.flat.float()).all())

@@ -309,3 +309,48 @@ def test_pa_sft_llava_next_qwen_template_matches_the_reference():
     assert sup == proc.tokenizer.encode("<answer>No</answer><|im_end|>\n", add_special_tokens=False) and len(ids) == len(labels)
     with pytest.raises(ValueError, match="truncates image placeholder"):
         m.encode_example(proc, row, 60, image_token_id=image_id, template="llava_next_qwen", cfg=cfg)
+
+
+@pytest.mark.parametrize("template,cfg_name", [("llava", "TINY_LLAVA15"), ("llava_next_mistral", "TINY_LLAVA_NEXT")])
+def test_pa_sft_llava_and_llava_next_mistral_templates_match_the_reference(template, cfg_name):
+    """The text path of scripts/train/PA_SFT/PA_SFT_LLaVA_1_5.sh (--template llava: vicuna turns, fixed image_seqlen per image) and PA_SFT_LLaVA_1_6.sh
+    (--template llava_next_mistral: BOS + [INST] turns with the system prompt folded into the first one, any-resolution feature counts) against the reference's own
+    template / plugin code on offline transformers Llava / LlavaNext processors (tests/golden/sft_llava.json "other_templates")."""
+    import re
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import llava_ov as lo
+    from iadr1_amd import sft_data as sd
+    from iadr1_amd.params import VLMConfig
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "sft_llava.json")))["other_templates"][template]
+    cfg_d = getattr(fx, cfg_name)
+    cfg = VLMConfig.from_dict(cfg_d)
+    proc = fx.local_llava_processor(cfg_d)
+    if template == "llava":
+        assert g["default_system"] == sd.LLAVA_DEFAULT_SYSTEM
+        tokens_of = lambda size: cfg.v_tokens
+    else:
+        assert g["default_system"] == ""
+        tokens_of = lambda size: lo.num_image_tokens(size, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
+    collapse = lambda s: re.sub(r"(?:<image>)+", lambda m: "<image*%d>" % (len(m.group(0)) // 7), s)
+    char_tok = type("T", (), {"encode": staticmethod(lambda text, add_special_tokens=False: [ord(c) for c in text]), "bos_token_id": 1, "eos_token_id": 2})
+    for c in g["cases"]:
+        pil = [sd.regularize_image_base(fx.synth_pil_image(w, h, seed), c["image_resolution"]) for w, h, seed in c["images"]]
+        sizes = [(cfg.v_image_size, cfg.v_image_size)] * len(pil)
+        if pil:
+            feats = proc.image_processor(images=pil, return_tensors="pt")
+            assert list(feats["pixel_values"].shape) == c["pixel_shape"] and abs(float(feats["pixel_values"].double().abs().sum()) - c["pixel_abs_sum"]) <= 1e-6 * c["pixel_abs_sum"]
+            if template != "llava":
+                sizes = [list(map(int, s)) for s in feats["image_sizes"].tolist()]
+                assert sizes == c["image_sizes"]
+        msgs = sd.expand_image_placeholders_llava(c["messages"], sizes, tokens_of)
+        assert [{**m, "content": collapse(m["content"])} for m in msgs] == c["expanded"]
+        pairs = sd.encode_turns(char_tok, sd.TURN_TEXTS[template]([{**m, "content": collapse(m["content"])} for m in msgs], c["system"]))
+        assert [[list(s), list(t)] for s, t in pairs] == c["pairs_collapsed"]
+    m = _load("train/stage_sft/train.py")
+    image_id = proc.tokenizer.convert_tokens_to_ids("<image>")
+    row = {"prompt": [{"role": "user", "content": "<image>Any defect?"}], "response": [{"role": "assistant", "content": "No"}], "system": "", "images": [fx.synth_pil_image(100, 80, 1)]}
+    ids, labels, pixels, grids = m.encode_example(proc, row, 4096, image_token_id=image_id, template=template, cfg=cfg)
+    assert ids.count(image_id) == (16 if template == "llava" else 70) and len(pixels) == 1 and tuple(pixels[0].shape) == ((1, 3, 56, 56) if template == "llava" else (5, 3, 56, 56))
+    sup = [t for t in labels if t != -100]
+    assert sup[-1] == proc.tokenizer.eos_token_id and len(ids) == len(labels) and (template == "llava" or ids[0] == proc.tokenizer.bos_token_id)

@@ -1208,3 +1208,20 @@ def test_llava15_and_next_rollout_and_step(family):
         sl = pol.slots[name]
         assert bool(moved[sl.offset: sl.offset + min(100, int(np.prod(sl.shape)))].any()), name
     assert float(pol.w("layers.0.qkv.b").abs().max()) == 0.0
+
+
+def test_rollout_regrows_for_longer_prompts():
+    """Prompt lengths change from batch to batch (image sizes of the any-resolution families, text lengths): a prompt longer than any seen so far -- including one
+    whose last partial page plus the completion needs one block-table column more -- rebuilds the KV pool / block table / graph instead of overrunning them."""
+    w = fx.make_weights(fx.TINY, 0)
+    pol, ref = store(w, True), store(w, False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=8, suppress_eos=True))
+    grid = (1, 16, 12)                       # 48 image tokens
+    last = None
+    for n_text in (9, 40, 47, 48, 100, 20):  # padded prompt lengths on both sides of page boundaries, then a shorter one (no rebuild)
+        ids, mask = fx.left_pad([fx.synth_prompt(grid, n_text, fx.TINY, 3)], fx.TINY["pad_token_id"])
+        batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=3), "image_grid_thw": [grid]}
+        toks = eng.rollout(batch, greedy=True)
+        assert toks.shape == (4, 8) and eng._rollout.max_prompt >= ids.shape[1]
+        last = eng._rollout
+    assert eng._rollout is last and last.max_prompt >= 100

@@ -67,7 +67,40 @@ for res, imgs, system, msgs in (
                   "pixel_shape": list(mm["pixel_values"].shape) if pil else [],
                   "pixel_abs_sum": float(mm["pixel_values"].double().abs().sum()) if pil else 0.0,
                   "pairs_collapsed": [[list(s), list(t)] for s, t in pairs]})
-json.dump({"meta": {"generator": "tools/make_golden_sft_llava.py", "template": "llava_next_qwen", "default_system": tpl.default_system, "image_token": tpl.mm_plugin.image_token,
+# ---- the LLaVA-1.5 / LLaVA-1.6 scripts: templates "llava" (vicuna format, LlavaPlugin: a fixed image_seqlen per image) and "llava_next_mistral"
+# (Llama2Template: BOS prefix, system folded into the first [INST], LlavaNextPlugin) -----------------------------------------------------------------
+class CharTokSpecial(CharTok):
+    eos_token_id, bos_token_id = 2, 1
+
+
+other = {}
+for tname, cfg_d in (("llava", fx.TINY_LLAVA15), ("llava_next_mistral", fx.TINY_LLAVA_NEXT)):
+    t2 = TEMPLATES[tname]
+    proc2 = fx.local_llava_processor(cfg_d)
+    side = cfg_d["vision"]["image_size"] // cfg_d["vision"]["patch_size"]
+    proc2.image_seqlen = side * side                      # llamafactory model/patcher.py:81 <- model_utils/visual.py:177-191 (strategy "default")
+    if hasattr(proc2, "_get_number_of_features"):
+        _g2 = proc2._get_number_of_features
+        proc2._get_number_of_features = lambda oh, ow, h, w, _g=_g2: _g(int(oh), int(ow), int(h), int(w))
+    rows = []
+    for res, imgs, system, msgs in (
+            (512 * 512, [(100, 80, 1)], None, [u("<image>\nAre there any defects in the query image?"), a_("<think>clean</think><answer>No</answer>")]),
+            (512 * 512, [(100, 120, 2), (150, 60, 3)], "You are an inspector.", [u("ref <image> query <image>"), a_("x"), u("again"), a_("y")]),
+            (512 * 512, [], None, [u("no picture"), a_("fine")])):
+        proc2.image_resolution = res
+        pil = [fx.synth_pil_image(w, h, seed) for w, h, seed in imgs]
+        expanded = t2.mm_plugin.process_messages(msgs, pil, [], proc2)
+        mm = t2.mm_plugin.get_mm_inputs(pil, [], [len(pil)], [0], [[0]], proc2) if pil else {}
+        pairs = t2.encode_multiturn(CharTokSpecial(), [{**m, "content": collapse(m["content"])} for m in expanded], system, None)
+        rows.append({"image_resolution": res, "images": [list(i) for i in imgs], "system": system, "messages": msgs,
+                     "expanded": [{**m, "content": collapse(m["content"])} for m in expanded],
+                     "image_sizes": [list(map(int, s_)) for s_ in mm["image_sizes"].tolist()] if "image_sizes" in mm else [],
+                     "pixel_shape": list(mm["pixel_values"].shape) if pil else [], "pixel_abs_sum": float(mm["pixel_values"].double().abs().sum()) if pil else 0.0,
+                     "pairs_collapsed": [[list(s_), list(t_)] for s_, t_ in pairs]})
+    other[tname] = {"default_system": t2.default_system, "cases": rows}
+    print(tname, [r["expanded"][0]["content"][:50] for r in rows])
+
+json.dump({"other_templates": other, "meta": {"generator": "tools/make_golden_sft_llava.py", "template": "llava_next_qwen", "default_system": tpl.default_system, "image_token": tpl.mm_plugin.image_token,
                     "processor": "tests/fixture_util.py::local_llava_ov_processor (transformers LlavaOnevisionProcessor, 56-pixel crops)"}, "cases": cases},
           open(os.path.join(ROOT, "tests", "golden", "sft_llava.json"), "w"))
 print("sft_llava.json:", len(cases), "cases;", [c["expanded"][0]["content"][:60] for c in cases])

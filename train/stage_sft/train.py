@@ -77,37 +77,43 @@ def load_sharegpt(name: str, dataset_dir: str, image_dir: str | None = None):
     return [r for r in rows if r["prompt"]]      # the reference filters out the rows its aligner emptied (odd turn counts, roles out of order)
 
 
-TEMPLATES = ("qwen2_vl", "llava_next_qwen")
+TEMPLATES = ("qwen2_vl", "llava_next_qwen", "llava", "llava_next_mistral")
+# template -> model family it belongs to (VLMConfig.llava_family; "" = Qwen2-VL / Qwen2.5-VL)
+TEMPLATE_FAMILY = {"qwen2_vl": "", "llava_next_qwen": "onevision", "llava": "llava", "llava_next_mistral": "next"}
 
 
 def encode_example(proc, row, cutoff_len, train_on_prompt=False, mask_history=False, image_token_id=151655, image_resolution=512 * 512, template="qwen2_vl", cfg=None):
     """Aligned row -> (input_ids, labels, pixel_values, grids), the reference's supervised preprocessing end to end (iadr1_amd.sft_data).
     "qwen2_vl": images regularised (mm_plugin.py:108-123,810-824), "<image>" expanded to the vision tokens of its patch grid (mm_plugin.py:850-896), ChatML
     turns tokenised piecewise (template.py:85-160,1120-1133), per-turn budget and label mask (processors/supervised.py:33-87); grids = [t, h, w] per image.
-    "llava_next_qwen" (the LLaVA-OneVision scripts): the base plugin's area cap only, the LLaVA-OneVision image processor's any-resolution crops, "<image>" ->
-    packed feature count copies of the image token (mm_plugin.py:327-366); pixel_values = list of per-image crop stacks, grids = (height, width) per image."""
-    from iadr1_amd.sft_data import (encode_turns, expand_image_placeholders, expand_image_placeholders_llava, llava_next_qwen_turn_texts, qwen2_vl_turn_texts, regularize_image,
-                                    regularize_image_base, supervised_labels)
-    llava = template == "llava_next_qwen"
+    The llava* templates (the LLaVA scripts): the base plugin's area cap only; "llava_next_qwen" / "llava_next_mistral": the any-resolution image processor's crops,
+    "<image>" -> packed feature count copies of the image token (LlavaNextPlugin, mm_plugin.py:327-366); "llava": one crop per image, "<image>" -> image_seqlen =
+    (image_size / patch_size)^2 copies (LlavaPlugin, mm_plugin.py:287-311).  pixel_values = list of per-image crop stacks, grids = (height, width) per image."""
+    from iadr1_amd.sft_data import TURN_TEXTS, encode_turns, expand_image_placeholders, expand_image_placeholders_llava, regularize_image, regularize_image_base, supervised_labels
+    family = TEMPLATE_FAMILY[template]
     images = []
     for im in row["images"] or []:
         if isinstance(im, str):
             from PIL import Image
             im = Image.open(im)
-        images.append(regularize_image_base(im, image_resolution) if llava else regularize_image(im, image_resolution))
+        images.append(regularize_image_base(im, image_resolution) if family else regularize_image(im, image_resolution))
     feats = proc.image_processor(images=images, return_tensors="pt") if images else None
-    if llava:
+    if family:
         from iadr1_amd import llava_ov
-        grids = [tuple(int(v) for v in s) for s in feats["image_sizes"].tolist()] if images else []
-        tokens_of = lambda size: llava_ov.num_image_tokens(size, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
+        if family == "llava":
+            grids = [(cfg.v_image_size, cfg.v_image_size)] * len(images)
+            tokens_of = lambda size: cfg.v_tokens
+            pixels = [feats["pixel_values"][i: i + 1] for i in range(len(images))] if images else None
+        else:
+            grids = [tuple(int(v) for v in s) for s in feats["image_sizes"].tolist()] if images else []
+            tokens_of = lambda size: llava_ov.num_image_tokens(size, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
+            pixels = [feats["pixel_values"][i, : llava_ov.num_crops(g, cfg.image_grid_pinpoints, cfg.v_image_size)] for i, g in enumerate(grids)] if images else None
         msgs = expand_image_placeholders_llava(row["prompt"] + row["response"], grids, tokens_of)
-        turns = encode_turns(proc.tokenizer, llava_next_qwen_turn_texts(msgs, row["system"]))
-        pixels = [feats["pixel_values"][i, : llava_ov.num_crops(g, cfg.image_grid_pinpoints, cfg.v_image_size)] for i, g in enumerate(grids)] if images else None
     else:
         grids = feats["image_grid_thw"].tolist() if images else []
         msgs = expand_image_placeholders(row["prompt"] + row["response"], grids, merge_size=getattr(proc.image_processor, "merge_size", 2))
-        turns = encode_turns(proc.tokenizer, qwen2_vl_turn_texts(msgs, row["system"]))
         pixels = feats["pixel_values"] if images else None
+    turns = encode_turns(proc.tokenizer, TURN_TEXTS[template](msgs, row["system"]))
     ids, labels = supervised_labels(turns, cutoff_len, train_on_prompt=train_on_prompt, mask_history=mask_history)
     if images and ids.count(image_token_id) != sum(part.count(image_token_id) for tn in turns for part in tn):
         raise ValueError("cutoff_len=%d truncates image placeholder tokens; raise --cutoff_len" % cutoff_len)
@@ -119,8 +125,7 @@ def main(argv=None):
     if a.stage != "sft" or a.finetuning_type != "full":
         raise ValueError("only --stage sft --finetuning_type full is part of the IAD-R1 PA-SFT path")
     if a.template not in TEMPLATES:
-        raise ValueError(f"--template {a.template}: built here are {TEMPLATES} (Qwen2-VL / Qwen2.5-VL and LLaVA-OneVision); the `llava` / `llava_next_mistral` templates "
-                         "(llamafactory data/template.py:833-841,886-897) belong to model families this engine does not run yet")
+        raise ValueError(f"--template {a.template}: the IAD-R1 PA-SFT scripts use {TEMPLATES}; other llamafactory templates are not part of this path")
     import numpy as np
     import torch
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,7 +143,7 @@ def main(argv=None):
     from iadr1_amd.trainer import last_checkpoint, load_checkpoint, load_training_state, save_checkpoint, save_training_state
 
     cfg, store = load_checkpoint(a.model_name_or_path, dev, trainable=True)
-    if cfg.is_llava != (a.template == "llava_next_qwen"):
+    if cfg.llava_family != TEMPLATE_FAMILY[a.template]:
         raise ValueError(f"--template {a.template} does not belong to the model family of {a.model_name_or_path}")
     proc = AutoProcessor.from_pretrained(a.model_name_or_path)
     eng = SFTEngine(cfg, store, SFTArgs(learning_rate=a.learning_rate, weight_decay=a.weight_decay, max_grad_norm=a.max_grad_norm,
@@ -181,6 +186,8 @@ def main(argv=None):
             if cfg.is_llava:     # per-image crop stacks + original (height, width) of every image
                 batch = {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": [c for e in enc if e[2] is not None for c in e[2]], "image_sizes": grids,
                          "images_per_row": [len(e[3]) for e in enc]}
+                if cfg.llava_family == "llava":
+                    del batch["image_sizes"]       # LLaVA-1.5: one S x S crop per image, no sizes
             else:
                 pv = torch.cat([e[2] for e in enc if e[2] is not None], 0)
                 batch = {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": pv, "image_grid_thw": grids, "images_per_row": [len(e[3]) for e in enc]}
