@@ -278,3 +278,45 @@ def test_llava15_and_next_entry_points_end_to_end(tmp_path, monkeypatch, capsys,
     assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
     cfg3, s3 = load_checkpoint(out_sft, DEV, trainable=False)
     assert cfg3 == cfg and not torch.equal(s3.flat, s0.flat) and bool(torch.isfinite(s3.flat.float()).all())
+
+
+def test_evaluation_script_end_to_end(tmp_path, offline_processor, monkeypatch):
+    """scripts/Inference/IAD-R1-Inference/hip_qwen_detect_format.py (the reference's vLLM_Qwen_detect_format.py with the rollout engine as the generator): checkpoint
+    directory + MMAD-format question file + image files -> greedy answers -> answers json (one entry per image, letters from `get_ans`) + the accuracy csv, in the
+    reference's `result/<name>/<dataset>/` layout; a second run resumes from the answers file (nothing left to do) unless --reproduce."""
+    d = _tiny_with_processor_ids(offline_processor)
+    src = str(tmp_path / "Qwen2.5-VL-tiny-Instruct")
+    _write_checkpoint(src, d)
+    data = tmp_path / "Industrial_test"
+    (data / "MVTec" / "bottle").mkdir(parents=True)
+    chat = {}
+    for i in range(3):
+        rel = f"MVTec/bottle/{'good' if i == 0 else 'broken'}_{i}.png"
+        fx.synth_pil_image(112, 84 + 28 * (i % 2), 90 + i).save(str(data / rel))
+        chat[rel] = {"conversation": [{"Question": "Is there any defect in the object?", "Answer": "B" if i == 0 else "A", "Options": {"A": "Yes.", "B": "No."}, "type": "Anomaly Detection"}],
+                     "similar_templates": [], "random_templates": []}
+    qfile = tmp_path / "test_data_format.json"
+    qfile.write_text(json.dumps(chat))
+    monkeypatch.chdir(tmp_path)
+    m = _load("scripts/Inference/IAD-R1-Inference/hip_qwen_detect_format.py")
+    argv = ["x", "--model-path", src, "--test_dataset", "test_data", "--json_path", str(qfile), "--data_path", str(data), "--batch_size", "2", "--name", "QwenTiny"]
+    monkeypatch.setattr(sys, "argv", argv)
+    monkeypatch.setattr("iadr1_amd.evaluate.GreedyGenerator.__init__", _short_generator_init(), raising=True)
+    m.main()
+    out_dir = tmp_path / "result" / "QwenTiny" / "test_data"
+    ans_path = out_dir / "answers_0_shot_Qwen2.5-VL-tiny-Instruct_vllm.json"
+    answers = json.load(open(ans_path))
+    assert [a["image"] for a in answers] == list(chat) and all(a["gpt_answer"] for a in answers) and all(a["question_type"] == "Anomaly Detection" for a in answers)
+    assert os.path.exists(str(ans_path).replace(".json", "_accuracy.csv"))
+    m.main()                                                   # resume: every image already answered
+    assert json.load(open(ans_path)) == answers
+
+
+def _short_generator_init():
+    """The script decodes up to 512 tokens per answer; a random-weight model never stops early, so the test caps the length (same code path)."""
+    from iadr1_amd import evaluate
+    orig = evaluate.GreedyGenerator.__init__
+
+    def init(self, cfg, store, max_new_tokens=512):
+        orig(self, cfg, store, max_new_tokens=12)
+    return init
