@@ -1225,3 +1225,20 @@ def test_rollout_regrows_for_longer_prompts():
         assert toks.shape == (4, 8) and eng._rollout.max_prompt >= ids.shape[1]
         last = eng._rollout
     assert eng._rollout is last and last.max_prompt >= 100
+
+
+def test_sc_grpo_loop_learns_the_rewarded_behaviour():
+    """The whole loop as a learner (rollout -> rewards -> group advantages -> clipped-ratio-free GRPO gradient with the KL term -> AdamW -> updated weights in the next
+    rollout): reward = fraction of completion tokens with an id in the lower half of the vocabulary.  From 0.29 at the start, the mean reward of the sampled groups
+    reaches > 0.9 within 10 optimizer steps while the KL to the frozen reference grows from exactly 0 (tools/grpo_learns.py prints the curve)."""
+    w = fx.make_weights(fx.TINY, 0)
+    pol, ref = store(w, True), store(w, False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=8, max_prompt_length=4096, max_completion_length=8, learning_rate=3e-3, beta=0.04, suppress_eos=True, seed=11))
+    grid = (1, 16, 12)
+    ids, mask = fx.left_pad([fx.synth_prompt(grid, 9, fx.TINY, 3), fx.synth_prompt(grid, 9, fx.TINY, 4)], fx.TINY["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid, grid], fx.TINY, seed=3), "image_grid_thw": [grid, grid]}
+    reward = lambda comp: (np.asarray(comp) < fx.TINY["text"]["vocab_size"] // 2).mean(1, keepdims=True).astype(np.float32)
+    hist = [eng.step(batch, reward) for _ in range(10)]
+    rewards, kls = [h["reward"] for h in hist], [h["kl"] for h in hist]
+    assert rewards[0] < 0.5 and min(rewards[-3:]) > 0.9, rewards
+    assert kls[0] == 0.0 and kls[-1] > 1e-3, kls
