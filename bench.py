@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="3b", choices=["3b", "7b", "qwen2vl_2b", "llava_ov_7b", "tiny"])
+    ap.add_argument("--model", default="3b", choices=["3b", "7b", "qwen2vl_2b", "llava_ov_7b", "llava15_7b", "llava_next_7b", "tiny"])
     ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the rollout streams gate|up / down / lm_head as e4m3 + per-row scales (opt-in, BASELINE config 5; NOT the headline precision)")
     ap.add_argument("--prompts", type=int, default=8)
@@ -102,12 +102,18 @@ def synth_batch_llava(cfg, n_prompts, n_text, seed, image_hw=(448, 448)):
     5 crops of 384 x 384 -> 729 + 54 x 55 = 3699 packed image tokens) + 3 prefix ids + n_text text ids."""
     from iadr1_amd import llava_ov as lo
     rs = np.random.RandomState(seed)
-    n_img = lo.num_image_tokens(image_hw, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
-    nc = lo.num_crops(image_hw, cfg.image_grid_pinpoints, cfg.v_image_size)
+    if cfg.llava_family == "llava":       # LLaVA-1.5: the processor resizes / centre-crops to one 336 x 336 crop: 576 image tokens
+        n_img, nc = cfg.v_tokens, 1
+    else:
+        n_img = lo.num_image_tokens(image_hw, cfg.image_grid_pinpoints, cfg.v_image_size, cfg.v_side, cfg.anyres_max)
+        nc = lo.num_crops(image_hw, cfg.image_grid_pinpoints, cfg.v_image_size)
     rows = [rs.randint(1000, 150000, 3).tolist() + [cfg.image_token_id] * n_img + rs.randint(1000, 150000, n_text).tolist() for _ in range(n_prompts)]
     ids = np.array(rows, dtype=np.int64)
     px = rs.standard_normal((n_prompts * nc, 3, cfg.v_image_size, cfg.v_image_size)).astype(np.float32)
-    return {"input_ids": ids, "attention_mask": np.ones_like(ids), "pixel_values": torch.from_numpy(px), "image_sizes": [image_hw] * n_prompts}
+    out = {"input_ids": ids, "attention_mask": np.ones_like(ids), "pixel_values": torch.from_numpy(px)}
+    if cfg.llava_family != "llava":
+        out["image_sizes"] = [image_hw] * n_prompts
+    return out
 
 
 def synth_batch(cfg, n_prompts, prompt_len, seed):
@@ -436,16 +442,20 @@ def main():
         cfg = VLMConfig.qwen2vl_2b()      # BASELINE config 1 (Qwen2-VL-2B PA-SFT): LayerNorm / QuickGELU ViT, no window attention
     elif a.model == "llava_ov_7b":
         cfg = VLMConfig.llava_ov_7b()     # BASELINE config 5 (LLaVA-OneVision-SI-7B SC-GRPO): SigLIP tower + any-resolution packing + Qwen2-7B decoder
+    elif a.model == "llava15_7b":
+        cfg = VLMConfig.llava15_7b()      # SC_GRPO_LLaVA_1_5.sh: CLIP tower, one 336-pixel crop (576 image tokens), vicuna-7b decoder
+    elif a.model == "llava_next_7b":
+        cfg = VLMConfig.llava_next_7b()   # SC_GRPO_LLaVA_1_6.sh: CLIP tower, any-resolution crops, Mistral-7B decoder
     else:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import fixture_util as fx
         cfg = VLMConfig.from_dict(fx.TINY)
     if a.workload == "pa_sft":
         return run_pa_sft(a, cfg, dev, rank, world)
-    llava = a.model == "llava_ov_7b"
+    llava = a.model in ("llava_ov_7b", "llava15_7b", "llava_next_7b")
     if a.micro_batch <= 0:
         # llava_ov_7b: 3699 image tokens per prompt -> one group (prompt + its 8 completions) per pass keeps the saved activations at ~26 GB
-        a.micro_batch = 32 if a.model == "7b" else (a.group if llava else 64)
+        a.micro_batch = 32 if a.model in ("7b", "llava15_7b") else (a.group if llava else 64)
     pol = ParamStore(cfg, dev, trainable=True)
     pol.init_random(seed=0)
     N = a.prompts * a.group
@@ -454,8 +464,10 @@ def main():
     for step_id in range(a.warmup + a.steps + 1):
         if llava:
             b = synth_batch_llava(cfg, a.prompts, 253, seed=1234 + 7919 * rank + step_id)
-            batches.append({"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"].to(dev),
-                            "image_sizes": torch.tensor(b["image_sizes"])})
+            bb = {"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"].to(dev)}
+            if "image_sizes" in b:
+                bb["image_sizes"] = torch.tensor(b["image_sizes"])
+            batches.append(bb)
             continue
         b = synth_batch(cfg, a.prompts, a.prompt_len, seed=1234 + 7919 * rank + step_id)
         batches.append({"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"].to(dev),
@@ -544,13 +556,19 @@ def main():
                          "source": "profiles/r02_mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, separate profiled pass)"}
         except Exception:
             pass
+        model_name = ({"llava_ov_7b": "LLaVA-OneVision-SI-7B", "llava15_7b": "LLaVA-1.5-7B", "llava_next_7b": "LLaVA-NeXT-Mistral-7B"}[a.model] if llava
+                      else ("Qwen2-VL-2B" if a.model == "qwen2vl_2b" else "Qwen2.5-VL-" + a.model.upper()))
+        image_note = ("448x448 image through the family's processor geometry (model_note) + 256 text positions" if llava
+                      else f"448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions")
         out = {
             "metric": "GRPO samples/sec (img448+512tok, group=8) Qwen2.5-VL-3B" if a.model == "3b" else f"GRPO samples/sec {a.model}",
-            "model_note": ("LLaVA-OneVision-SI-7B shapes (BASELINE config 5): 448x448 image -> 5 crops of 384x384 through the SigLIP tower -> 3699 packed image tokens + 256 text positions per prompt"
+            "model_note": ({"llava_ov_7b": "LLaVA-OneVision-SI-7B shapes (BASELINE config 5): 448x448 image -> 5 crops of 384x384 through the SigLIP tower -> 3699 packed image tokens + 256 text positions per prompt",
+                            "llava15_7b": "llava-1.5-7b shapes: one 336x336 crop through the CLIP tower -> 576 image tokens + 256 text positions per prompt",
+                            "llava_next_7b": "llava-v1.6-mistral-7b shapes: 448x448 image -> 5 crops of 336x336 through the CLIP tower -> 2928 packed image tokens + 256 text positions per prompt"}.get(a.model)
                            if llava else None),
             "value": world * N * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{'LLaVA-OneVision-SI-7B' if llava else ('Qwen2-VL-2B' if a.model == 'qwen2vl_2b' else 'Qwen2.5-VL-' + a.model.upper())} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {'448x448 image (any-resolution: 5 crops of 384x384 -> 3699 packed image tokens) + 256 text positions' if llava else f'448x448 image (1024 patches -> 256 tokens) + {a.prompt_len} prompt positions'}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
+            "config": {"workload": f"{model_name} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {image_note}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
                        "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "grad_exchange": ({"wire": eng.reducer.wire, "bytes_per_step": getattr(eng.reducer, "last_bytes_on_wire", 0), "buckets_per_step": getattr(eng.reducer, "last_n_buckets", 0)}

@@ -864,6 +864,250 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, S
     STAMP(3);
 }
 
+// Group-shared form of the decode attention for LONG shared prompts (LLaVA families: 3000-4000 prompt tokens; MHA decoders): the G sequences of a prompt group
+// share their full prompt pages through the block table, so ONE block per (group, kv head) reads those pages once for all G * (Hq / Hkv) query rows (up to NT
+// MFMA column tiles of 16) instead of every (sequence, kv head) block reading its own copy -- G times less K/V traffic for the prompt part, which is nearly all
+// of it (15 GB of 29 GB per decode step at LLaVA-OneVision-7B shapes).  Phase 1: the 8 waves walk the shared pages; their partial softmax states are combined
+// through LDS into one state per query row.  Phase 2: wave s takes sequence s of the group: its private pages (prompt remainder + completion), then the merge
+// with the shared state of its rows and the output / side-output stores.  No cross-block exchange; grid = (groups, Hkv).
+struct DecodeGroupArgs {
+    DecodeArgs a;
+    const int* shared_pages;  // [B / G]: leading block-table entries (full prompt pages) shared by the G sequences of a group
+    int G;
+    // Few (group, kv head) pairs and very long prompts (LLaVA-OneVision-7B: 8 x 4 blocks for 3900 shared tokens): the shared pages are split over `chunks` blocks
+    // (grid.z) in a first launch (mode 1) that leaves one partial state per (group, kv head, chunk, row) in `ws`; a second launch (mode 2, grid (groups, Hkv))
+    // merges them and runs phase 2.  mode 0: both phases in one launch.
+    int mode, chunks;
+    float* ws;                // [groups][Hkv][chunks][RMAX][D + 2]: o[D], m, l per row
+};
+
+template <int D, int NT>
+__global__ __launch_bounds__(512) void attn_decode_group_kernel(DecodeGroupArgs gp, SideOut so) {
+    constexpr int KS = D / 32, DT = D / 16, PAGE = 32, WAVES = 8, RMAX = 16 * NT, GS = 17;
+    const DecodeArgs& p = gp.a;
+    extern __shared__ float dsm[];
+    float* red_m = dsm;                                 // [WAVES][16]
+    float* red_l = red_m + WAVES * 16;                  // [WAVES][16]
+    float* red_o = red_l + WAVES * 16;                  // [WAVES][D][GS]
+    float* sh_m = red_o + WAVES * D * GS;               // [RMAX] state of the shared part per query row (log2 domain, like m / l below)
+    float* sh_l = sh_m + RMAX;
+    float* sh_o = sh_l + RMAX;                          // [RMAX][D]
+    const int gi = blockIdx.x, kvh = blockIdx.y, group = p.Hq / p.Hkv, G = gp.G;
+    const int rows = G * group;                         // <= RMAX (host checks)
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
+    const long long sb = side_base(so);
+    const int b0 = gi * G;
+    const int ns = gp.shared_pages[gi];
+    const float c = p.scale * LOG2E;
+
+    // ---- phase 1: shared pages, all query rows of the group ----------------------------------------------------------------------------------
+    // Q fragments of the NT column tiles live in LDS in fragment order (one conflict-free 16-byte read per fragment and page): 64 VGPRs less than keeping
+    // them in registers, which with the 128 accumulator registers of NT = 4 spilled to scratch
+    bf16_t* qs = (bf16_t*)(sh_o + RMAX * D);            // [NT][KS][64 lanes][8]
+    for (int t = w; t < NT; t += WAVES) {
+        const int r = t * 16 + li, sq = r / group, j = r - sq * group;
+        const bool ok = r < rows;
+        const bf16_t* src = p.q + (long long)(b0 + (ok ? sq : 0)) * p.ldq + (kvh * group + (ok ? j : 0)) * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) *(bf16x8_t*)(qs + ((t * KS + ks) * 64 + l) * 8) = ld_frag_g(src + ks * 32 + g * 8, ok);
+    }
+    __syncthreads();
+    float m[NT], lsum[NT];
+    f32x4_t acc[NT][DT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        m[t] = -INFINITY;
+        lsum[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[t][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const int per = gp.mode == 1 ? (ns + gp.chunks - 1) / gp.chunks : ns;           // pages of this block's chunk (mode 1: blockIdx.z)
+    const int pg0 = gp.mode == 1 ? (int)blockIdx.z * per : 0, pg1 = gp.mode == 2 ? 0 : min(ns, pg0 + per);
+    float* wsb = gp.ws + (((long long)gi * p.Hkv + kvh) * gp.chunks) * RMAX * (D + 2);
+    for (int pg = pg0 + w; pg < pg1; pg += WAVES) {
+        asm volatile("" ::: "memory");      // keeps the (loop-invariant) Q fragment reads inside the loop: hoisted, they are 64 registers again
+        const int phys = p.block_table[(long long)b0 * p.max_pages + pg];
+        const bf16_t* kp = p.kcache + ((long long)phys * p.Hkv + kvh) * PAGE * D;
+        const bf16_t* vp = p.vcache + ((long long)phys * p.Hkv + kvh) * D * PAGE;
+        bf16x8_t kfr[KS][2], vfr[DT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) kfr[ks][t2] = ld_frag_g(kp + ((ks * 2 + t2) * 64 + l) * 8, true);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vfr[dt] = ld_frag_g(vp + (dt * 16 + li) * PAGE + g * 8, true);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {      // every key of a shared page is a prompt token of every sequence of the group: no masking
+            f32x4_t sc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+                    sc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[ks][t2], *(const bf16x8_t*)(qs + ((t * KS + ks) * 64 + l) * 8), sc[t2], 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[t2][e] *= c; mx = fmaxf(mx, sc[t2][e]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            const float mn = fmaxf(m[t], mx);
+            const float alpha = fast_exp2(m[t] - mn);           // m = -inf on the first page: exp2(-inf) = 0
+            float ps = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[t2][e] = fast_exp2(sc[t2][e] - mn); ps += sc[t2][e]; }
+            lsum[t] = lsum[t] * alpha + ps;
+            m[t] = mn;
+            const bf16x8_t pf = pack_frag(sc[0], sc[1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                acc[t][dt] *= alpha;
+                acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pf, acc[t][dt], 0, 0, 0);
+            }
+        }
+    }
+    // combine the 8 waves' states, one column tile at a time, into the per-row shared state (LDS; mode 1: this chunk's slot of the workspace)
+#pragma unroll
+    for (int t = 0; t < NT && gp.mode != 2; ++t) {
+        float ls = lsum[t];
+        ls += __shfl_xor(ls, 16, WAVE);
+        ls += __shfl_xor(ls, 32, WAVE);
+        if (g == 0) { red_m[w * 16 + li] = m[t]; red_l[w * 16 + li] = ls; }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red_o[(w * D + dt * 16 + g * 4 + e) * GS + li] = acc[t][dt][e];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 16 * D; idx += WAVES * 64) {
+            const int j = idx / D, d = idx - j * D;
+            float M = red_m[j];
+#pragma unroll
+            for (int ww = 1; ww < WAVES; ++ww) M = fmaxf(M, red_m[ww * 16 + j]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) {
+                const float f = (red_m[ww * 16 + j] == -INFINITY) ? 0.f : fast_exp2(red_m[ww * 16 + j] - M);
+                num += f * red_o[(ww * D + d) * GS + j];
+                den += f * red_l[ww * 16 + j];
+            }
+            if (gp.mode == 1) {
+                float* dst = wsb + ((long long)blockIdx.z * RMAX + t * 16 + j) * (D + 2);
+                dst[d] = num;
+                if (d == 0) { dst[D] = M; dst[D + 1] = den; }
+            } else {
+                sh_o[(t * 16 + j) * D + d] = num;
+                if (d == 0) { sh_m[t * 16 + j] = M; sh_l[t * 16 + j] = den; }
+            }
+        }
+        __syncthreads();
+    }
+    if (gp.mode == 1) return;
+    if (gp.mode == 2) {      // merge the chunks' partial states of the first launch (fixed order: reproducible)
+        for (int idx = threadIdx.x; idx < rows * D; idx += WAVES * 64) {
+            const int r = idx / D, d = idx - r * D;
+            float M = -INFINITY;
+            for (int cc = 0; cc < gp.chunks; ++cc) M = fmaxf(M, wsb[((long long)cc * RMAX + r) * (D + 2) + D]);
+            float num = 0.f, den = 0.f;
+            for (int cc = 0; cc < gp.chunks; ++cc) {
+                const float* src = wsb + ((long long)cc * RMAX + r) * (D + 2);
+                const float f = (src[D] == -INFINITY) ? 0.f : fast_exp2(src[D] - M);
+                num += f * src[d];
+                den += f * src[D + 1];
+            }
+            sh_o[r * D + d] = num;
+            if (d == 0) { sh_m[r] = M; sh_l[r] = den; }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: wave s <- sequence s of the group: private pages, merge with the shared state, stores ----------------------------------------
+    for (int sq = w; sq < G; sq += WAVES) {
+        const int b = b0 + sq;
+        const int n = p.ctx_len[b];
+        const int npage = (n + PAGE - 1) / PAGE;
+        bf16x8_t q1[KS];
+        {
+            const bool ok = li < group;
+            const bf16_t* src = p.q + (long long)b * p.ldq + (kvh * group + (ok ? li : 0)) * D;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) q1[ks] = ld_frag_g(src + ks * 32 + g * 8, ok);
+        }
+        float m1 = -INFINITY, l1 = 0.f;
+        f32x4_t a1[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) a1[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int pg = ns; pg < npage; ++pg) {
+            const int phys = p.block_table[(long long)b * p.max_pages + pg];
+            const bf16_t* kp = p.kcache + ((long long)phys * p.Hkv + kvh) * PAGE * D;
+            const bf16_t* vp = p.vcache + ((long long)phys * p.Hkv + kvh) * D * PAGE;
+            bf16x8_t kfr[KS][2], vfr[DT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) kfr[ks][t2] = ld_frag_g(kp + ((ks * 2 + t2) * 64 + l) * 8, true);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vfr[dt] = ld_frag_g(vp + (dt * 16 + li) * PAGE + g * 8, true);
+            f32x4_t sc[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) sc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[ks][t2], q1[ks], sc[t2], 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = pg * PAGE + g * 8 + t2 * 4 + e;
+                    const float tv = key < n ? sc[t2][e] * c : -INFINITY;
+                    sc[t2][e] = tv;
+                    mx = fmaxf(mx, tv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            const float mn = fmaxf(m1, mx);
+            const float alpha = (mn == -INFINITY) ? 1.f : fast_exp2(m1 - mn);
+            const float mref = (mn == -INFINITY) ? 0.f : mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[t2][e] = fast_exp2(sc[t2][e] - mref); ps += sc[t2][e]; }
+            l1 = l1 * alpha + ps;
+            m1 = mn;
+            const bf16x8_t pf = pack_frag(sc[0], sc[1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                a1[dt] *= alpha;
+                a1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pf, a1[dt], 0, 0, 0);
+            }
+        }
+        l1 += __shfl_xor(l1, 16, WAVE);
+        l1 += __shfl_xor(l1, 32, WAVE);
+        if (li < group) {       // lane (li = head j of the group, g): dims dt * 16 + g * 4 + e
+            const int r = sq * group + li;
+            const float ms = sh_m[r], lsh = sh_l[r];
+            const float M = fmaxf(ms, m1);
+            const float fs = (ms == -INFINITY) ? 0.f : fast_exp2(ms - M), f1 = (m1 == -INFINITY) ? 0.f : fast_exp2(m1 - M);
+            const float den = fs * lsh + f1 * l1;
+            const float inv = den > 0.f ? 1.f / den : 0.f;
+            const int col0 = (kvh * group + li) * D;
+            const long long rr = sb >= 0 ? sb + (long long)b * so.seq_stride : 0;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + g * 4;
+                const f32x4_t so4 = *(const f32x4_t*)(sh_o + (long long)r * D + d);
+                const u32x2_t ov = {pack2bf((fs * so4[0] + f1 * a1[dt][0]) * inv, (fs * so4[1] + f1 * a1[dt][1]) * inv),
+                                    pack2bf((fs * so4[2] + f1 * a1[dt][2]) * inv, (fs * so4[3] + f1 * a1[dt][3]) * inv)};
+                *(u32x2_t*)(p.o + (p.ldo ? (long long)b * p.ldo + col0 + d : xpk_off(b, col0 + d, p.Hq * D))) = ov;
+                if (sb >= 0) *(u32x2_t*)((bf16_t*)so.p0 + rr * so.ld0 + col0 + d) = ov;
+            }
+            if (sb >= 0 && g == 0) ((float*)so.p1)[(long long)(kvh * group + li) * so.ld1 + rr] = den > 0.f ? (M + log2f(den)) * LN2 : -INFINITY;
+        }
+    }
+}
+
 // Write K/V rows of `T` tokens into the paged cache (prefill: many tokens; decode: one per sequence).
 // slot[t] = physical page * 32 + offset, or < 0 to skip (padding).
 template <int D>
@@ -1076,6 +1320,36 @@ extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* 
         hipLaunchKernelGGL((attn_decode_kernel<128, 8>), dim3(B, Hkv), dim3(512), smem, stream, p, so);
     }
     return iadr1_check_launch("attn_decode");
+}
+
+extern "C" int iadr1_attn_decode_group(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len, const int* shared_pages, void* o,
+                                       int B, int G, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, int chunks, float* ws,
+                                       const void* side, hipStream_t stream) {
+    IADR1_REQUIRE(D == 128, "attn_decode_group: head dim %d not built (128 is)", D);
+    IADR1_REQUIRE(B > 0 && G >= 1 && (B % G) == 0 && Hq % Hkv == 0 && Hq / Hkv <= 16 && G * (Hq / Hkv) <= 64 && shared_pages != nullptr,
+                  "attn_decode_group: B must be a multiple of the group size and a group may hold at most 64 query rows per kv head (G=%d, heads per kv head=%d)", G, Hkv ? Hq / Hkv : 0);
+    IADR1_REQUIRE((ldq % 8) == 0 && (ldo % 4) == 0, "attn_decode_group: ldq must be a multiple of 8, ldo of 4");
+    IADR1_REQUIRE(chunks >= 1 && chunks <= 64 && (chunks == 1 || ws != nullptr), "attn_decode_group: 1 <= chunks <= 64, and chunks > 1 needs the workspace");
+    DecodeGroupArgs p{{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale}, shared_pages, G, 0, chunks, ws};
+    SideOut so, none{};
+    if (int e = iadr1_side_arg(side, &so)) return e;
+    const int rows = G * (Hq / Hkv), nt = rows <= 16 ? 1 : (rows <= 32 ? 2 : 4);
+    const int smem = (2 * 8 * 16 + 8 * 128 * 17 + 2 * 16 * nt + 16 * nt * 128) * 4 + nt * 4 * 64 * 8 * 2;       // reduction scratch, shared-part state, Q fragments
+    const dim3 block(512);
+    auto launch = [&](dim3 grid, const SideOut& s_) {
+        if (nt == 1) { set_smem(attn_decode_group_kernel<128, 1>, smem); hipLaunchKernelGGL((attn_decode_group_kernel<128, 1>), grid, block, smem, stream, p, s_); }
+        else if (nt == 2) { set_smem(attn_decode_group_kernel<128, 2>, smem); hipLaunchKernelGGL((attn_decode_group_kernel<128, 2>), grid, block, smem, stream, p, s_); }
+        else { set_smem(attn_decode_group_kernel<128, 4>, smem); hipLaunchKernelGGL((attn_decode_group_kernel<128, 4>), grid, block, smem, stream, p, s_); }
+    };
+    if (chunks == 1) {
+        launch(dim3(B / G, Hkv), so);
+    } else {
+        p.mode = 1;
+        launch(dim3(B / G, Hkv, chunks), none);
+        p.mode = 2;
+        launch(dim3(B / G, Hkv), so);
+    }
+    return iadr1_check_launch("attn_decode_group");
 }
 
 extern "C" int iadr1_kv_store(const void* k, long long ldk, const void* v, long long ldv, const long long* slot, void* kcache, void* vcache,

@@ -467,6 +467,27 @@ def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=
     return o
 
 
+def attn_decode_group_ws(B, G, Hq, Hkv, D, chunks, device):
+    """fp32 workspace of attn_decode_group(chunks > 1)."""
+    rows = G * (Hq // Hkv)
+    rmax = 16 if rows <= 16 else (32 if rows <= 32 else 64)
+    return torch.empty((B // G) * Hkv * chunks * rmax * (D + 2), dtype=F32, device=device)
+
+
+def attn_decode_group(q, kcache, vcache, block_table, ctx_len, shared_pages, G, Hq, Hkv, D, scale, out=None, side=None, chunks=1, ws=None):
+    """Decode attention with the full prompt pages of every group of G sequences read once (include/iadr1_hip.h iadr1_attn_decode_group); chunks > 1 splits
+    the shared pages over that many blocks per (group, kv head) (two launches, partial states through `ws`)."""
+    B = q.shape[0]
+    o = out if out is not None else torch.empty(B, Hq * D, dtype=BF16, device=q.device)
+    ob, ldo = _xarg(o)
+    assert shared_pages.dtype == torch.int32 and shared_pages.numel() == B // G
+    if chunks > 1 and ws is None:
+        ws = attn_decode_group_ws(B, G, Hq, Hkv, D, chunks, q.device)
+    hip.call("attn_decode_group", q, kcache, vcache, block_table, ctx_len, shared_pages, ob, B, G, Hq, Hkv, D, block_table.shape[1], _ld(q), ldo, float(scale), int(chunks), ws,
+             _side(side))
+    return o
+
+
 def kv_store(k, v, slot, kcache, vcache, Hkv, D):
     hip.call("kv_store", k, _ld(k), v, _ld(v), slot, kcache, vcache, k.shape[0], Hkv, D)
 

@@ -304,6 +304,28 @@ def _llava_ov_7b() -> VLMConfig:
 VLMConfig.llava_ov_7b = staticmethod(_llava_ov_7b)
 
 
+def _llava15_7b() -> VLMConfig:
+    """llava-1.5-7b-hf shapes (public config.json): CLIP ViT-L/14-336 tower, vicuna-7b (LLaMA: 32 layers, width 4096, 32 heads, MLP 11008, vocabulary 32064)."""
+    return VLMConfig.from_hf_config({
+        "model_type": "llava", "image_token_index": 32000, "pad_token_id": 32001, "projector_hidden_act": "gelu", "vision_feature_layer": -2, "vision_feature_select_strategy": "default",
+        "text_config": {"model_type": "llama", "max_position_embeddings": 4096, "rms_norm_eps": 1e-05, "vocab_size": 32064},
+        "vision_config": {"model_type": "clip_vision_model", "hidden_size": 1024, "image_size": 336, "intermediate_size": 4096, "num_attention_heads": 16, "num_hidden_layers": 24, "patch_size": 14}})
+
+
+def _llava_next_7b() -> VLMConfig:
+    """llava-v1.6-mistral-7b-hf shapes (public config.json): the same CLIP tower, Mistral-7B (GQA 32 / 8, MLP 14336), five any-resolution pinpoints."""
+    return VLMConfig.from_hf_config({
+        "model_type": "llava_next", "image_token_index": 32000, "projector_hidden_act": "gelu", "vision_feature_layer": -2, "vision_feature_select_strategy": "default",
+        "image_grid_pinpoints": [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]],
+        "text_config": {"model_type": "mistral", "intermediate_size": 14336, "max_position_embeddings": 32768, "num_key_value_heads": 8, "rms_norm_eps": 1e-05, "rope_theta": 1000000.0,
+                        "sliding_window": None, "vocab_size": 32064},
+        "vision_config": {"model_type": "clip_vision_model", "hidden_size": 1024, "image_size": 336, "intermediate_size": 4096, "num_attention_heads": 16, "num_hidden_layers": 24, "patch_size": 14}})
+
+
+VLMConfig.llava15_7b = staticmethod(_llava15_7b)
+VLMConfig.llava_next_7b = staticmethod(_llava_next_7b)
+
+
 @dataclass
 class _Slot:
     name: str

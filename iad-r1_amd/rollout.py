@@ -41,6 +41,8 @@ class Rollout:
         N = max_seqs
         i32, i64 = torch.int32, torch.int64
         self.block_table = torch.zeros(N, self.max_pages, dtype=i32, device=dev)
+        self.shared_pages = torch.zeros(max_prompts, dtype=i32, device=dev)     # full prompt pages every sequence of a group shares (attn_decode_group)
+        self.group_attn, self.G, self.group_chunks, self.group_ws = False, 1, 1, None
         self.pos = torch.zeros(N, dtype=i32, device=dev)
         self.ctx_len = torch.zeros(N, dtype=i32, device=dev)
         self.slot = torch.zeros(N, dtype=i64, device=dev)
@@ -130,8 +132,7 @@ class Rollout:
                 assert tr is None
                 ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
                 ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
-            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o,
-                            side=side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
+            self._attention(i, side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), c.hidden_size, out=self.part_o, ksplit=self.ks_o)
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h,
                             side=side(p0=T_("x_mid", i), p1=T_("h2", i), p2=T_("rstd2", i)))
@@ -147,6 +148,18 @@ class Rollout:
                         side=side(p0=None if tr is None else tr["x_last"], p1=None if tr is None else tr["hf"], p2=None if tr is None else tr["rstdf"]))
         ops.gemm_skinny(self.h, P.wpk(P.lm_head_name()), c.vocab_size, out=self.logits)
         self._sample_and_advance()
+
+    def _attention(self, i, side):
+        """Decode attention of layer i.  Long shared prompts / many kv heads: one block per (prompt group, kv head) reads the group's full prompt pages once for all
+        its sequences (iadr1_attn_decode_group); otherwise one block per (sequence, kv head)."""
+        c = self.e.cfg
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        q = self.qkv[:, : Hq * D]
+        if self.group_attn:
+            ops.attn_decode_group(q, self.kc[i], self.vc[i], self.block_table, self.ctx_len, self.shared_pages[: self.N // self.G], self.G, Hq, Hkv, D, c.attn_scale, out=self.o, side=side,
+                                  chunks=self.group_chunks, ws=self.group_ws)
+        else:
+            ops.attn_decode(q, self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o, side=side)
 
     def _decode_step_folded(self):
         """The decode step with RMSNorm launches folded into the GEMMs around them (ops.NormFold).  ln2 (default): the o projection adds itself INTO the
@@ -202,8 +215,7 @@ class Rollout:
                 assert tr is None
                 ops.gemm_skinny(xin, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv, fold=nf1)
                 ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
-            ops.attn_decode(self.qkv[:, :qw], self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o,
-                            side=side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
+            self._attention(i, side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
             ops.gemm_skinny(self.o, P.wpk(b + "o.w"), H, resid=self.x, ksplit=self.ks_o, side=side(p0=T_("x_mid", i)),
                             fold=producer(self.ssq_b, self.part_o, self.ks_o, None if f1 else self.xp))
             xg, nf2 = (self.x if f1 or self.xp is None else self.xp), consumer(self.ssq_b)
@@ -291,6 +303,26 @@ class Rollout:
                     slot_tail[gi, b * S + first + j] = pages[j // PAGE] * PAGE + j % PAGE
                     any_tail = True
         self.block_table.copy_(torch.from_numpy(bt))
+        # group-shared decode attention when it pays.  Measured on MI355X (decode step, 64 sequences, 7B-class shapes, profiles/r02_group_attention.txt):
+        #   LLaVA-1.5 (MHA, 32 kv heads, 832 shared tokens: 2048 per-sequence blocks)      9.30 -> 6.30 ms
+        #   LLaVA-NeXT (8 kv heads, 3168 shared tokens: 512 per-sequence blocks)           8.47 -> 6.70 ms (6.53 with the shared part split over 4 blocks)
+        #   LLaVA-OneVision (4 kv heads, 3936 shared tokens: 256 per-sequence blocks)      6.71 -> 6.98 ms (7.40 split over 8): the 8 sequences of a group already
+        #   meet in L2 when all their blocks are resident at once, so the per-sequence form stays.
+        # Rule: more per-sequence blocks than one resident round (N * Hkv >= 512) and at least 256 shared tokens.  IADR1_DECODE_GROUP_ATTN=0|1 forces it.
+        shared_tok = np.array([int(lengths[b]) // PAGE * PAGE for b in range(Bp)])
+        self.shared_pages[:Bp].copy_(torch.from_numpy((shared_tok // PAGE).astype(np.int32)))
+        want = os.environ.get("IADR1_DECODE_GROUP_ATTN")
+        rows_ok = G * (c.num_attention_heads // c.num_key_value_heads) <= 64
+        use = rows_ok and G > 1 and N * c.num_key_value_heads >= 512 and int(shared_tok.min()) >= 256
+        use = rows_ok and (use if want is None else want == "1")
+        # few (group, kv head) blocks for a long shared part: split it over chunks of >= 8 pages until ~256 blocks stream (two launches, partial states through a workspace)
+        chunks = 1
+        if use:
+            blocks = Bp * c.num_key_value_heads
+            chunks = int(os.environ.get("IADR1_DECODE_GROUP_CHUNKS", max(1, min(256 // max(blocks, 1), int(shared_tok.min()) // PAGE // 8, 16))))
+        if use != self.group_attn or (use and (G != self.G or chunks != self.group_chunks)):
+            self.group_attn, self.G, self.group_chunks, self.graph = use, G, chunks, None
+            self.group_ws = ops.attn_decode_group_ws(self.N, G, c.num_attention_heads, c.num_key_value_heads, c.head_dim, chunks, dev) if (use and chunks > 1) else None
         slot_shared_d = torch.from_numpy(slot_shared).to(dev)
         slot_tail_d = torch.from_numpy(slot_tail).to(dev) if any_tail else None
         Hkv, D = c.num_key_value_heads, c.head_dim

@@ -216,6 +216,14 @@ int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
 int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len,
                       void* o, int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale,
                       const iadr1_side_out_t* side, iadr1_stream_t stream);
+/* The same attention for prompt GROUPS with long shared prompts (LLaVA families, MHA decoders): sequences [g*G, (g+1)*G) share their first shared_pages[g] block-table
+ * entries (the full prompt pages, as the rollout lays them out); one block per (group, kv head) reads those pages ONCE for all G * Hq/Hkv (<= 64) query rows, then
+ * every sequence's private pages, and merges.  Same results as iadr1_attn_decode up to fp32 summation order; G times less K/V traffic for the shared part.
+ * chunks > 1 (few groups x kv heads, very long prompts): the shared pages are split over `chunks` blocks in a first launch whose partial states go through
+ * `ws` (fp32 [B/G][Hkv][chunks][64 or 32 or 16 rows][D + 2], rows = the tile-rounded G * Hq/Hkv) to a second launch that merges them in chunk order. */
+int iadr1_attn_decode_group(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len, const int* shared_pages,
+                            void* o, int B, int G, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, int chunks, float* ws,
+                            const iadr1_side_out_t* side, iadr1_stream_t stream);
 int iadr1_kv_store(const void* k, long long ldk, const void* v, long long ldv, const long long* slot, void* kcache,
                    void* vcache, int T, int Hkv, int D, iadr1_stream_t stream);
 /* decode-step fusion of iadr1_rope_inplace (q,k heads) + iadr1_kv_store for one new token per sequence */

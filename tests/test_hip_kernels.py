@@ -810,3 +810,73 @@ def test_fp8_weight_gemm_fused_swiglu(M, I, K):
         ref = torch.nn.functional.silu(gu[:, :I].float()).to(BF).float() * gu[:, I:].float()
         a = ops.gemm_skinny(ops.pack_act(x), (w8, sc), 2 * I, swiglu=True, out=ops.PackedAct(M, I, DEV)).unpack()
         close(a, ref, 2e-2, 2e-2 * math.sqrt(K) * 0.3, f"fp8w swiglu {M}x{I}x{K}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Hq,Hkv,G,prompts,extra", [(16, 2, 8, [512, 777], [0, 5, 130, 31, 64, 1, 255, 200]), (32, 32, 8, [832], [3, 60, 0, 128, 7, 33, 90, 255]),
+                                                    (32, 8, 8, [3184, 40], [1, 2, 3, 4, 5, 6, 7, 8]), (28, 4, 8, [100], [9, 19, 29, 39, 49, 59, 69, 79]),
+                                                    (2, 1, 4, [7, 64, 31], [0, 1, 32, 40]), (16, 16, 3, [300], [5, 6, 7])])
+def test_decode_attention_group_equals_per_sequence(Hq, Hkv, G, prompts, extra):
+    """iadr1_attn_decode_group (one block per (prompt group, kv head): the group's full prompt pages read once for all of its query rows, then every sequence's
+    private pages, merged) against iadr1_attn_decode (one block per (sequence, kv head)) on the rollout's page layout -- shared full prompt pages, private pages for the
+    prompt remainder + completion -- and against fp32 torch; GQA groups of 8 / 4 / 7 / 2, MHA, prompts shorter than a page (no shared page), 1..4 column tiles."""
+    D, PAGE = 128, 32
+    Bp = len(prompts)
+    B = Bp * G
+    ctx = [prompts[b // G] + extra[b % G] + 1 for b in range(B)]                    # prompt + generated so far (+ the current token)
+    n_shared = [p // PAGE for p in prompts]
+    maxp = max((c_ + PAGE - 1) // PAGE for c_ in ctx) + 1
+    bt = np.zeros((B, maxp), dtype=np.int32)
+    nxt = 1
+    shared = []
+    for b in range(Bp):
+        shared.append(list(range(nxt, nxt + n_shared[b])))
+        nxt += n_shared[b]
+    for r in range(B):
+        priv = (ctx[r] + PAGE - 1) // PAGE - n_shared[r // G]
+        pages = shared[r // G] + list(range(nxt, nxt + priv))
+        nxt += priv
+        bt[r, : len(pages)] = pages
+    kc = torch.zeros(nxt + 1, Hkv, 32, D, dtype=BF, device=DEV)
+    vc = torch.zeros(nxt + 1, Hkv, D, 32, dtype=BF, device=DEV)
+    keys, vals = {}, {}
+    for b in range(Bp):                                                              # prompt K/V: identical for the sequences of a group
+        pk, pv = rnd(prompts[b], Hkv * D, seed=100 + b), rnd(prompts[b], Hkv * D, seed=200 + b)
+        for s_ in range(G):
+            r = b * G + s_
+            n_own = ctx[r] - prompts[b]
+            keys[r] = torch.cat([pk, rnd(n_own, Hkv * D, seed=300 + r)])
+            vals[r] = torch.cat([pv, rnd(n_own, Hkv * D, seed=400 + r)])
+            pos = torch.arange(ctx[r])
+            slot = torch.from_numpy(bt[r])[pos // PAGE].long() * PAGE + pos % PAGE
+            ops.kv_store(keys[r], vals[r], slot.to(DEV), kc, vc, Hkv, D)            # (shared pages are written G times with the same values)
+    q = rnd(B, Hq * D, seed=5)
+    btd, ctxd = torch.from_numpy(bt).to(DEV), torch.tensor(ctx, dtype=torch.int32, device=DEV)
+    sp = torch.tensor(n_shared, dtype=torch.int32, device=DEV)
+    o_seq = ops.attn_decode(q, kc, vc, btd, ctxd, Hq, Hkv, D, D ** -0.5)
+    o_grp = ops.attn_decode_group(q, kc, vc, btd, ctxd, sp, G, Hq, Hkv, D, D ** -0.5)
+    close(o_grp, o_seq, 1e-2, 4e-3, "group vs per-sequence decode attention")        # same arithmetic, different fp32 summation order: a bf16 ulp
+    op = ops.attn_decode_group(q, kc, vc, btd, ctxd, sp, G, Hq, Hkv, D, D ** -0.5, out=ops.PackedAct(B, Hq * D, DEV))
+    assert torch.equal(op.unpack(), o_grp)
+    for chunks in (2, 5):       # shared pages split over `chunks` blocks per (group, kv head): two launches, partial states merged in chunk order
+        o_ch = ops.attn_decode_group(q, kc, vc, btd, ctxd, sp, G, Hq, Hkv, D, D ** -0.5, chunks=chunks)
+        close(o_ch, o_seq, 1e-2, 4e-3, f"chunked group attention ({chunks})")
+        assert torch.equal(o_ch, ops.attn_decode_group(q, kc, vc, btd, ctxd, sp, G, Hq, Hkv, D, D ** -0.5, chunks=chunks))       # reproducible
+    for r in (0, B // 2, B - 1):
+        n = ctx[r]
+        qf = q[r].float().view(Hq, 1, D)
+        kf = keys[r].float().view(n, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+        vf = vals[r].float().view(n, Hkv, D).transpose(0, 1).repeat_interleave(Hq // Hkv, 0)
+        ref = (torch.softmax(qf @ kf.transpose(1, 2) * D ** -0.5, -1) @ vf).reshape(Hq * D)
+        close(o_grp[r], ref, 2e-2, 2e-2, f"group decode r={r} n={n}")
+    # side outputs: the attention rows and log-sum-exp land in the training arena exactly as the per-sequence kernel writes them
+    step = torch.tensor([3], dtype=torch.int32, device=DEV)
+    T = B * 8 + 10
+    arena_o, arena_l = torch.zeros(T, Hq * D, dtype=BF, device=DEV), torch.zeros(Hq, T, dtype=F32, device=DEV)
+    so = ops.SideOut.make(step, 2, 8, p0=arena_o, p1=arena_l, ld1=T)
+    ops.attn_decode_group(q, kc, vc, btd, ctxd, sp, G, Hq, Hkv, D, D ** -0.5, side=so)
+    rows = 2 + torch.arange(B, device=DEV) * 8 + 3
+    assert torch.equal(arena_o[rows], o_grp)
+    arena_o2, arena_l2 = torch.zeros_like(arena_o), torch.zeros_like(arena_l)
+    ops.attn_decode(q, kc, vc, btd, ctxd, Hq, Hkv, D, D ** -0.5, side=ops.SideOut.make(step, 2, 8, p0=arena_o2, p1=arena_l2, ld1=T))
+    close(arena_l[:, rows], arena_l2[:, rows], 1e-5, 1e-5, "log-sum-exp side output")
