@@ -748,6 +748,7 @@ struct DecodeArgs {
     long long ldq, ldo;
     int B, Hq, Hkv, max_pages;
     float scale;
+    int gseq;                 // > 1: sequences [g * gseq, (g + 1) * gseq) share their prompt pages (group rollout) -> XCD-aware block order, see the kernel
 };
 
 template <int D, int WAVES>
@@ -758,7 +759,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, S
     float* red_m = dsm;                                // [WAVES][16]
     float* red_l = dsm + WAVES * 16;                   // [WAVES][16]
     float* red_o = dsm + 2 * WAVES * 16;               // [WAVES][D][GS]
-    const int b = blockIdx.x, kvh = blockIdx.y, group = p.Hq / p.Hkv;
+    // Block -> (sequence, kv head).  Plain: grid (B, Hkv).  Group rollout (gseq > 1, 1-D grid): workgroup ids go round-robin over the 8 XCDs, each with its own
+    // L2, so the plain order scatters the gseq sequences that share a prompt's K/V pages over all XCDs and every copy is an L2 miss.  Here XCD x takes the prompt
+    // groups x, x + 8, ... and ALL blocks of a group (its sequences x kv heads) run on that one XCD: the pages come from HBM once and from L2 gseq - 1 times.
+    int b = blockIdx.x, kvh = blockIdx.y;
+    if (p.gseq > 1) {
+        const int id = blockIdx.x, npg = p.gseq * p.Hkv, k = id >> 3;
+        const int gi = (id & 7) + 8 * (k / npg), mem = k - (k / npg) * npg;
+        if (gi * p.gseq >= p.B) return;
+        kvh = mem / p.gseq;
+        b = gi * p.gseq + (mem - kvh * p.gseq);
+    }
+    const int group = p.Hq / p.Hkv;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
     const long long sb = side_base(so);
     STAMP(0);
@@ -1299,11 +1311,15 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
 }
 
 extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len, void* o,
-                                 int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, const void* side, hipStream_t stream) {
+                                 int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, int seqs_per_group, const void* side, hipStream_t stream) {
     IADR1_REQUIRE(D == 128, "attn_decode: head dim %d not built (128 is)", D);
     IADR1_REQUIRE(B > 0 && Hq % Hkv == 0 && Hq / Hkv <= 16, "attn_decode: GQA group must be <= 16");
     IADR1_REQUIRE((ldq % 8) == 0, "attn_decode: ldq must be a multiple of 8");
-    DecodeArgs p{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale};
+    IADR1_REQUIRE(seqs_per_group >= 0 && (seqs_per_group <= 1 || B % seqs_per_group == 0), "attn_decode: B must be a multiple of seqs_per_group");
+    static const int xcd_groups = iadr1_env_int("IADR1_DECODE_ATTN_XCD_GROUPS", 1);
+    const int gseq = (xcd_groups && seqs_per_group > 1) ? seqs_per_group : 0;
+    DecodeArgs p{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale, gseq};
+    const dim3 grid = gseq ? dim3(8 * ((B / gseq + 7) / 8) * gseq * Hkv) : dim3(B, Hkv);
     // 16 waves per (sequence, kv head) block: a wave then walks ~1.5 pages instead of ~3 at ctx ~ 640 (the kernel is a chain of dependent
     // page loads on only B*Hkv = 128 CUs); IADR1_DECODE_ATTN_WAVES=8 keeps the 8-wave form
     static const int waves = iadr1_env_int("IADR1_DECODE_ATTN_WAVES", 16) == 8 ? 8 : 16;
@@ -1313,11 +1329,11 @@ extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* 
     if (waves == 16) {
         const int smem = (2 * 16 * 16 + 16 * 128 * gs) * 4;
         set_smem(attn_decode_kernel<128, 16>, smem);
-        hipLaunchKernelGGL((attn_decode_kernel<128, 16>), dim3(B, Hkv), dim3(1024), smem, stream, p, so);
+        hipLaunchKernelGGL((attn_decode_kernel<128, 16>), grid, dim3(1024), smem, stream, p, so);
     } else {
         const int smem = (2 * 8 * 16 + 8 * 128 * gs) * 4;
         set_smem(attn_decode_kernel<128, 8>, smem);
-        hipLaunchKernelGGL((attn_decode_kernel<128, 8>), dim3(B, Hkv), dim3(512), smem, stream, p, so);
+        hipLaunchKernelGGL((attn_decode_kernel<128, 8>), grid, dim3(512), smem, stream, p, so);
     }
     return iadr1_check_launch("attn_decode");
 }
@@ -1330,7 +1346,7 @@ extern "C" int iadr1_attn_decode_group(const void* q, const void* kcache, const 
                   "attn_decode_group: B must be a multiple of the group size and a group may hold at most 64 query rows per kv head (G=%d, heads per kv head=%d)", G, Hkv ? Hq / Hkv : 0);
     IADR1_REQUIRE((ldq % 8) == 0 && (ldo % 4) == 0, "attn_decode_group: ldq must be a multiple of 8, ldo of 4");
     IADR1_REQUIRE(chunks >= 1 && chunks <= 64 && (chunks == 1 || ws != nullptr), "attn_decode_group: 1 <= chunks <= 64, and chunks > 1 needs the workspace");
-    DecodeGroupArgs p{{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale}, shared_pages, G, 0, chunks, ws};
+    DecodeGroupArgs p{{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale, 0}, shared_pages, G, 0, chunks, ws};
     SideOut so, none{};
     if (int e = iadr1_side_arg(side, &so)) return e;
     const int rows = G * (Hq / Hkv), nt = rows <= 16 ? 1 : (rows <= 32 ? 2 : 4);

@@ -459,11 +459,12 @@ def attn_bwd(q, k, v, o, dout, lse, seg: Segments, Hq, Hkv, D, causal, scale, dq
              _ld(q), _ld(k), _ld(v), _ld(o), _ld(dout), _ld(dq), _ld(dk), _ld(dv), 1 if causal else 0, float(scale))
 
 
-def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=None, side=None):
+def attn_decode(q, kcache, vcache, block_table, ctx_len, Hq, Hkv, D, scale, out=None, side=None, seqs_per_group=0):
+    """seqs_per_group: sequences [g*n, (g+1)*n) share prompt pages (placement hint: one XCD per prompt group; same results)."""
     B = q.shape[0]
     o = out if out is not None else torch.empty(B, Hq * D, dtype=BF16, device=q.device)
     ob, ldo = _xarg(o)
-    hip.call("attn_decode", q, kcache, vcache, block_table, ctx_len, ob, B, Hq, Hkv, D, block_table.shape[1], _ld(q), ldo, float(scale), _side(side))
+    hip.call("attn_decode", q, kcache, vcache, block_table, ctx_len, ob, B, Hq, Hkv, D, block_table.shape[1], _ld(q), ldo, float(scale), int(seqs_per_group), _side(side))
     return o
 
 

@@ -43,6 +43,7 @@ class Rollout:
         self.block_table = torch.zeros(N, self.max_pages, dtype=i32, device=dev)
         self.shared_pages = torch.zeros(max_prompts, dtype=i32, device=dev)     # full prompt pages every sequence of a group shares (attn_decode_group)
         self.group_attn, self.G, self.group_chunks, self.group_ws = False, 1, 1, None
+        self.G_seq = 0          # sequences per prompt group of the current rollout (placement hint of attn_decode)
         self.pos = torch.zeros(N, dtype=i32, device=dev)
         self.ctx_len = torch.zeros(N, dtype=i32, device=dev)
         self.slot = torch.zeros(N, dtype=i64, device=dev)
@@ -159,7 +160,7 @@ class Rollout:
             ops.attn_decode_group(q, self.kc[i], self.vc[i], self.block_table, self.ctx_len, self.shared_pages[: self.N // self.G], self.G, Hq, Hkv, D, c.attn_scale, out=self.o, side=side,
                                   chunks=self.group_chunks, ws=self.group_ws)
         else:
-            ops.attn_decode(q, self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o, side=side)
+            ops.attn_decode(q, self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o, side=side, seqs_per_group=self.G_seq)
 
     def _decode_step_folded(self):
         """The decode step with RMSNorm launches folded into the GEMMs around them (ops.NormFold).  ln2 (default): the o projection adds itself INTO the
@@ -309,6 +310,8 @@ class Rollout:
         #   LLaVA-OneVision (4 kv heads, 3936 shared tokens: 256 per-sequence blocks)      6.71 -> 6.98 ms (7.40 split over 8): the 8 sequences of a group already
         #   meet in L2 when all their blocks are resident at once, so the per-sequence form stays.
         # Rule: more per-sequence blocks than one resident round (N * Hkv >= 512) and at least 256 shared tokens.  IADR1_DECODE_GROUP_ATTN=0|1 forces it.
+        if self.G_seq != G:
+            self.G_seq, self.graph = G, None
         shared_tok = np.array([int(lengths[b]) // PAGE * PAGE for b in range(Bp)])
         self.shared_pages[:Bp].copy_(torch.from_numpy((shared_tok // PAGE).astype(np.int32)))
         want = os.environ.get("IADR1_DECODE_GROUP_ATTN")

@@ -214,8 +214,10 @@ int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
  * 343-358,667).  Pages hold 32 keys: K page [Hkv][32 x D in the MFMA-fragment order
  * attn_decode reads, private to these three entry points], V page [Hkv][D][32].  slot = page*32 + offset. */
 int iadr1_attn_decode(const void* q, const void* kcache, const void* vcache, const int* block_table, const int* ctx_len,
-                      void* o, int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale,
+                      void* o, int B, int Hq, int Hkv, int D, int max_pages, long long ldq, long long ldo, float scale, int seqs_per_group,
                       const iadr1_side_out_t* side, iadr1_stream_t stream);
+/* seqs_per_group > 1 (a hint, results do not depend on it): sequences [g*n, (g+1)*n) share their prompt pages through the block table (group rollout); the blocks of
+ * one prompt group are then placed on ONE XCD so that its L2 serves all but the first reader of a shared page. */
 /* The same attention for prompt GROUPS with long shared prompts (LLaVA families, MHA decoders): sequences [g*G, (g+1)*G) share their first shared_pages[g] block-table
  * entries (the full prompt pages, as the rollout lays them out); one block per (group, kv head) reads those pages ONCE for all G * Hq/Hkv (<= 64) query rows, then
  * every sequence's private pages, and merges.  Same results as iadr1_attn_decode up to fp32 summation order; G times less K/V traffic for the shared part.

@@ -880,3 +880,21 @@ def test_decode_attention_group_equals_per_sequence(Hq, Hkv, G, prompts, extra):
     arena_o2, arena_l2 = torch.zeros_like(arena_o), torch.zeros_like(arena_l)
     ops.attn_decode(q, kc, vc, btd, ctxd, Hq, Hkv, D, D ** -0.5, side=ops.SideOut.make(step, 2, 8, p0=arena_o2, p1=arena_l2, ld1=T))
     close(arena_l[:, rows], arena_l2[:, rows], 1e-5, 1e-5, "log-sum-exp side output")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Hq,Hkv,G,Bp", [(16, 2, 8, 8), (28, 4, 8, 3), (2, 1, 4, 11), (16, 16, 2, 9)])
+def test_decode_attention_group_placement_hint_does_not_change_results(Hq, Hkv, G, Bp):
+    """seqs_per_group re-orders the blocks of iadr1_attn_decode (one XCD per prompt group); outputs are bit-identical with and without it, for group counts that are and are
+    not multiples of the 8 XCDs."""
+    D, B = 128, Bp * G
+    lens = [40 + 13 * (b % 7) + 64 * (b // G % 3) for b in range(B)]
+    maxp = (max(lens) + 31) // 32
+    kc = rnd(B * maxp + 2, Hkv * 32 * D, seed=1).view(-1, Hkv, 32, D)
+    vc = rnd(B * maxp + 2, Hkv * D * 32, seed=2).view(-1, Hkv, D, 32)
+    bt = torch.randperm(B * maxp + 2, generator=torch.Generator().manual_seed(0))[: B * maxp].view(B, maxp).to(torch.int32).to(DEV)
+    ctx = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    q = rnd(B, Hq * D, seed=5)
+    a = ops.attn_decode(q, kc, vc, bt, ctx, Hq, Hkv, D, D ** -0.5)
+    b_ = ops.attn_decode(q, kc, vc, bt, ctx, Hq, Hkv, D, D ** -0.5, seqs_per_group=G)
+    assert torch.equal(a, b_)
