@@ -304,19 +304,20 @@ class Rollout:
                     slot_tail[gi, b * S + first + j] = pages[j // PAGE] * PAGE + j % PAGE
                     any_tail = True
         self.block_table.copy_(torch.from_numpy(bt))
-        # group-shared decode attention when it pays.  Measured on MI355X (decode step, 64 sequences, 7B-class shapes, profiles/r02_group_attention.txt):
-        #   LLaVA-1.5 (MHA, 32 kv heads, 832 shared tokens: 2048 per-sequence blocks)      9.30 -> 6.30 ms
-        #   LLaVA-NeXT (8 kv heads, 3168 shared tokens: 512 per-sequence blocks)           8.47 -> 6.70 ms (6.53 with the shared part split over 4 blocks)
-        #   LLaVA-OneVision (4 kv heads, 3936 shared tokens: 256 per-sequence blocks)      6.71 -> 6.98 ms (7.40 split over 8): the 8 sequences of a group already
-        #   meet in L2 when all their blocks are resident at once, so the per-sequence form stays.
-        # Rule: more per-sequence blocks than one resident round (N * Hkv >= 512) and at least 256 shared tokens.  IADR1_DECODE_GROUP_ATTN=0|1 forces it.
+        # group-shared decode attention when it pays.  Measured on MI355X (decode step, 64 sequences, 7B-class shapes, profiles/r02_group_attention.txt; the
+        # per-sequence kernel with its blocks placed one prompt group per XCD, the group kernel with one block per (group, kv head)):
+        #   LLaVA-1.5 (MHA, 32 kv heads, 832 shared tokens: 2048 per-sequence blocks)      7.69 vs 6.30 ms   -> group kernel
+        #   LLaVA-NeXT (8 kv heads, 3168 shared tokens: 512 per-sequence blocks)           6.48 vs 6.53 ms   -> per-sequence kernel
+        #   LLaVA-OneVision (4 kv heads, 3936 shared tokens: 256 per-sequence blocks)      5.61 vs 6.98 ms   -> per-sequence kernel
+        # Rule: N * Hkv >= 1024 per-sequence blocks (several resident rounds: the copies of a page are then read at different times) and >= 256 shared tokens.
+        # IADR1_DECODE_GROUP_ATTN=0|1 forces it.
         if self.G_seq != G:
             self.G_seq, self.graph = G, None
         shared_tok = np.array([int(lengths[b]) // PAGE * PAGE for b in range(Bp)])
         self.shared_pages[:Bp].copy_(torch.from_numpy((shared_tok // PAGE).astype(np.int32)))
         want = os.environ.get("IADR1_DECODE_GROUP_ATTN")
         rows_ok = G * (c.num_attention_heads // c.num_key_value_heads) <= 64
-        use = rows_ok and G > 1 and N * c.num_key_value_heads >= 512 and int(shared_tok.min()) >= 256
+        use = rows_ok and G > 1 and N * c.num_key_value_heads >= 1024 and int(shared_tok.min()) >= 256
         use = rows_ok and (use if want is None else want == "1")
         # few (group, kv head) blocks for a long shared part: split it over chunks of >= 8 pages until ~256 blocks stream (two launches, partial states through a workspace)
         chunks = 1
