@@ -36,7 +36,17 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: 
 
 
 def _skinny_pmc():
-    """HBM-side bytes of the decode step's heaviest kernel (gate|up stream) from the PMC passes recorded under profiles/."""
+    """HBM-side bytes of the decode step from the PMC passes recorded under profiles/ (3B shapes): every kernel of the step (r02_decode_pmc.json: FETCH / WRITE per
+    kernel, summed over the launches of one step), else the heaviest kernel alone (r01_skinny_pmc.json)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_decode_pmc.json")))
+        attn = next(k for k in d["kernels"] if "attn_decode" in k["kernel"])
+        steps = attn["launches"] / 36.0
+        total = sum((k["read_bytes_corrected"] + k["write_bytes"]) * k["launches"] for k in d["kernels"]) / steps
+        return {"kernel": "all kernels of one decode step (Qwen2.5-VL-3B shapes, 64 sequences, context ~520)", "bytes_per_launch": total, "algorithmic_bytes_per_launch": None,
+                "source": "profiles/r02_decode_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"}
+    except Exception:
+        pass
     try:
         k = json.load(open(os.path.join(ROOT, "profiles", "r01_skinny_pmc.json")))
         return {"kernel": k["kernel"], "bytes_per_launch": k["traffic_bytes"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"], "MNK": k["MNK"], "source": "profiles/r01_skinny_pmc.json"}
@@ -52,14 +62,15 @@ def decode_roofline(cfg, pol, events, n_seq, gen_len):
         return None
     ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in events)
     steps = sum(n for _, _, n, _ in events)
-    w_bytes = pol.flat_pk.numel() * 2
+    w_bytes = pol.flat_pk.numel() * 2 + (pol.flat_pk8.numel() if getattr(pol, "decode_fp8", False) else 0)
     kv_tok = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2
     # context read by decode step j (1-based) = prompt length + j tokens (the new token's own K/V included)
     kv_bytes = sum(kv_tok * (plen * n + n_seq * n * (n + 1) // 2) for _, _, n, plen in events) / max(steps, 1)
     ach = (w_bytes + kv_bytes) / (ms / steps * 1e-3) / 1e9
+    pmc = _skinny_pmc() if (cfg.hidden_size, cfg.num_hidden_layers, cfg.v_arch) == (2048, 36, "qwen2_5_vl") else None      # the PMC record is of the 3B shapes
     return {"bound": "hbm", "kernel": "decode step (hipGraph: skinny GEMMs on decode-packed weights + paged attention + RMSNorm + sampling)", "achieved": ach,
             "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "ms_per_decode_step": ms / steps, "decode_steps": steps,
-            "algorithmic_bytes_per_step": {"weights": w_bytes, "kv": kv_bytes}, "traffic": (_skinny_pmc() or {}).get("bytes_per_launch"), "traffic_detail": _skinny_pmc()}
+            "algorithmic_bytes_per_step": {"weights": w_bytes, "kv": kv_bytes}, "traffic": (pmc or {}).get("bytes_per_launch"), "traffic_detail": pmc}
 
 
 def parse():
