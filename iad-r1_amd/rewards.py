@@ -75,6 +75,17 @@ class TypeMatcher:
                 self.group_terms[normalize(a)] = group
 
     def best_category(self, text: str):
+        """(category, confidence) of a free-text defect type.  A pure function of the string; the fuzzy pass is a difflib ratio against every vocabulary term
+        (0.3 ms per call), and training batches repeat the same few type strings, so results are memoised per matcher."""
+        memo = self.__dict__.setdefault("_best_memo", {})
+        hit = memo.get(text)
+        if hit is None:
+            if len(memo) > 65536:
+                memo.clear()
+            hit = memo[text] = self._best_category(text)
+        return hit
+
+    def _best_category(self, text: str):
         n = normalize(text)
         hit = self.term_category.get(n)
         if hit is not None:
@@ -98,6 +109,16 @@ class TypeMatcher:
         return self.group_terms.get(normalize(text)) if text else None
 
     def score(self, predicted: str, actual: str) -> float:
+        memo = self.__dict__.setdefault("_score_memo", {})
+        key = (predicted, actual)
+        hit = memo.get(key)
+        if hit is None:
+            if len(memo) > 65536:
+                memo.clear()
+            hit = memo[key] = self._score(predicted, actual)
+        return hit
+
+    def _score(self, predicted: str, actual: str) -> float:
         if not predicted or not actual:
             return S_NONE
         p, a = normalize(predicted), normalize(actual)
