@@ -1242,3 +1242,64 @@ def test_sc_grpo_loop_learns_the_rewarded_behaviour():
     rewards, kls = [h["reward"] for h in hist], [h["kl"] for h in hist]
     assert rewards[0] < 0.5 and min(rewards[-3:]) > 0.9, rewards
     assert kls[0] == 0.0 and kls[-1] > 1e-3, kls
+
+
+def test_trainer_level_traced_path_with_gradient_accumulation():
+    """The fast path at the reference's API with the trainer's own loop: `SCGRPOTrainer.train()` at the 3B widths (2 layers), gradient_accumulation_steps = 2 -- two
+    compute_loss calls per optimizer step, each with its own rollout whose prefill / decode steps fill the SAME training arena (captured graph, arena pointers
+    frozen) -- against the same trainer with the hand-over switched off (the policy forward runs after the rollout).  The first optimizer step of both runs sees the same
+    tokens (same seeds, same decode kernels): same rewards, gradient norms within 1 %, parameters after the step pointing the same way (AdamW's first update is
+    +-lr per element, so near-zero gradients may flip); the second step runs on (sampling diverges with the weights), and the hand-over really was active in all four
+    micro-steps."""
+    import dataclasses
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
+    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
+    G, C, Bp = 4, 12, 2
+    b = bench.synth_batch(cfg, Bp, 300, seed=5)
+    batch = {"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"], "image_grid_thw": torch.tensor(b["image_grid_thw"])}
+    rows = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "q"}]}], "image": [object()], "solution": "s"}] * (Bp * 4)
+
+    def token_reward(prompts, completions, **kw):
+        return [float(sum(map(ord, c[0]["content"])) % 5) for c in completions]
+
+    class Proc(_FakeProcessor):
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [" ".join(str(int(t) % 97) for t in row) for row in np.asarray(ids)]      # text that depends on the sampled ids -> rewards that separate the group
+
+    finals, traced = {}, {}
+    for reuse in (True, False):
+        pol = ParamStore(cfg, DEV, trainable=True)
+        pol.init_random(seed=0)
+        tr = SCGRPOTrainer((cfg, pol), [token_reward], args=GRPOConfig(output_dir="/tmp/iadr1_traced_test", num_generations=G, max_completion_length=C, max_prompt_length=None,
+                                                                        per_device_train_batch_size=Bp, gradient_accumulation_steps=2, learning_rate=1e-4, max_steps=2, save_steps=0,
+                                                                        shuffle=False, micro_batch_seqs=64, seed=7),
+                           train_dataset=rows, processing_class=Proc(batch, None))
+        tr.engine.args.reuse_decode = reuse
+        tr.engine.args.suppress_eos = True
+        seen = []
+        orig = tr.engine.step
+
+        def step(*a, _o=orig, _s=seen, _e=tr.engine, **k):
+            out = _o(*a, **k)
+            _s.append(bool(_e.last_step_traced))
+            return out
+        tr.engine.step = step
+        first = {}
+        orig_opt = tr.engine.optimizer_step
+
+        def opt(_o=orig_opt, _p=pol, _f=first):
+            _o()
+            _f.setdefault("flat", _p.flat.float().clone())
+        tr.engine.optimizer_step = opt
+        hist = tr.train()
+        assert len(hist) == 2 and all(np.isfinite(h["loss"]) and h["grad_norm"] > 0 for h in hist)
+        finals[reuse], traced[reuse] = (first["flat"], hist[0]), seen
+        del tr, pol
+    assert traced[True] == [True] * 4 and traced[False] == [False] * 4                     # 2 optimizer steps x 2 micro-steps, hand-over active in every one
+    (a, ha), (b_, hb) = finals[True], finals[False]
+    assert ha["reward"] == hb["reward"] and ha["reward_std"] == hb["reward_std"] and abs(ha["grad_norm"] - hb["grad_norm"]) <= 0.01 * hb["grad_norm"]
+    a, b_ = a.double(), b_.double()
+    assert float((a - b_).abs().max()) <= 2.5e-4 and float((a @ b_) / (a.norm() * b_.norm())) > 0.9999
