@@ -284,7 +284,7 @@ class SCGRPOEngine:
                 and N2 % 128 == 0 and N2 // 32 >= 2 * ncu and N <= 256)
 
     # ---- loss + gradients for given completions ------------------------------------------------------------------
-    def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None, train_carry=None):
+    def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None, train_carry=None, defer_metrics: bool = False):
         """completions: list of Bp*G id lists (prompt-major) or an [N,C] array already padded;
         rewards_per_func: [N, n_funcs] float tensor/array.  Accumulates gradients into policy.grad."""
         a, c = self.args, self.cfg
@@ -391,13 +391,17 @@ class SCGRPOEngine:
             self.pol.vision_backward(dimg, vctx)
             self.accum += 1
         st = advantages()
-        metrics = {
-            "loss": float(row_loss.mean()),
-            "completion_length": float(cmask.sum(1).mean()),
-            "reward": float(st["rewards"].mean()),
-            "reward_std": float(st["std"].mean()),
-            "kl": float(row_kl.mean()),
-        }
+        metrics = {"completion_length": float(cmask.sum(1).mean()), "reward": float(st["rewards"].mean()), "reward_std": float(st["std"].mean())}
+        dev_means = torch.stack([row_loss.mean(), row_kl.mean()])       # one device -> host read for both
+
+        def finalize():
+            lk = dev_means.tolist()
+            metrics.update(loss=lk[0], kl=lk[1])
+            return metrics
+        if defer_metrics:      # the caller enqueues more work (the optimizer) before it reads the two device-side means: no idle GPU while the host comes back from the sync
+            metrics["finalize"] = finalize
+        else:
+            finalize()
         return {"metrics": metrics, "logps": logp_all, "ref_logps": ref_all, "kl": kl_all, "advantages": st["adv"], "completion_mask": cmask,
                 "rewards_per_func": st["rpf"], "ids": ids, "mask": mask}
 
@@ -421,7 +425,7 @@ class SCGRPOEngine:
         return float(self.norm2.sqrt().item()) * getattr(self, "grad_scale", 1.0)
 
     # ---- the whole micro-step ----------------------------------------------------------------------------------------
-    def step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False):
+    def step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False, defer_metrics=False):
         """One SC-GRPO micro-step: vision tower -> group rollout -> rewards -> reference / policy passes + backward (-> optimizer).  This is the path
         `SCGRPOTrainer.compute_loss` (the reference's API, REF:586) runs and the one bench.py times.
         reward_fn(completion_ids: np.ndarray [N,C]) -> [N, n_funcs] rewards (decode + plugin functions live with the caller, which owns the tokenizer).
@@ -451,10 +455,12 @@ class SCGRPOEngine:
         t3 = mark()
         self.last_step_traced = bool(carry and carry.get("traced"))     # the decode steps filled the completion rows of the training arena
         last = do_optimizer_step if last_micro_step is None else last_micro_step
-        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=last, vis=vis, train_carry=carry)
+        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=last, vis=vis, train_carry=carry, defer_metrics=defer_metrics or do_optimizer_step)
         t4 = mark()
         if do_optimizer_step:
             self.optimizer_step()
+        if not defer_metrics and "finalize" in out["metrics"]:
+            out["metrics"].pop("finalize")()
         t5 = mark()
         if timing:
             print(f"[iadr1 timing] vision {1e3*(t1-t0):.1f} ms | rollout {1e3*(t2-t1):.1f} | rewards {1e3*(t3-t2):.1f} | ref+policy fwd/bwd {1e3*(t4-t3):.1f} | optimizer {1e3*(t5-t4):.1f}", flush=True)

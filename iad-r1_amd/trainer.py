@@ -310,15 +310,17 @@ class SCGRPOTrainer:
         return np.stack(cols, 1)
 
     # ---- reference API ---------------------------------------------------------------------------------------------
-    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, last_micro_step=True):
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, last_micro_step=True, _defer=False):
         """One SC-GRPO micro-step on `inputs` (list of dataset rows).  Returns the loss value; gradients are
-        accumulated inside the engine (there is no autograd graph to hand back)."""
+        accumulated inside the engine (there is no autograd graph to hand back).
+        _defer (training_step, last micro-batch): returns a callable that yields the loss once called -- the two device-side means (loss, KL) are then read
+        AFTER the optimizer has been enqueued, so the GPU does not idle while the host returns from the read."""
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")  # REF:587-588
         batch = self._prepare(inputs)
         # the engine's whole micro-step (SCGRPOEngine.step): vision tower once per image, rollout whose prefill / decode steps double as the policy's
         # training forward when the micro-batch holds whole groups, rewards evaluated on the host while the reference pass is in the GPU queue
-        out = self.engine.step(batch, lambda comp: self._rewards(inputs, comp), do_optimizer_step=False, last_micro_step=last_micro_step, return_outputs=True)
+        out = self.engine.step(batch, lambda comp: self._rewards(inputs, comp), do_optimizer_step=False, last_micro_step=last_micro_step, return_outputs=True, defer_metrics=_defer)
         m = out["metrics"]
         self._metrics["completion_length"].append(m["completion_length"])
         rp = out["rewards_per_func"].mean(0)
@@ -326,8 +328,13 @@ class SCGRPOTrainer:
             self._metrics[f"rewards/{f.__name__}"].append(float(rp[i]))
         self._metrics["reward"].append(m["reward"])
         self._metrics["reward_std"].append(m["reward_std"])
-        self._metrics["kl"].append(m["kl"])
-        return m["loss"]
+
+        def finish():
+            if "finalize" in m:
+                m.pop("finalize")()
+            self._metrics["kl"].append(m["kl"])
+            return m["loss"]
+        return finish if _defer else finish()
 
     def log(self, logs: dict, start_time=None):
         metrics = {k: sum(v) / len(v) for k, v in self._metrics.items()}
@@ -348,8 +355,10 @@ class SCGRPOTrainer:
         """One optimizer step = gradient_accumulation_steps micro-batches through compute_loss (the data-parallel gradient buckets leave during the
         last one's backward) + clip / AdamW / weight-copy refresh.  What transformers.Trainer.training_step + the optimizer block of its inner loop do
         around the reference's compute_loss (TF:trainer.py:1892-1961, :1785); train() and bench.py both go through here."""
-        losses = [self.compute_loss(None, inputs, last_micro_step=(k == len(micro_batches) - 1)) for k, inputs in enumerate(micro_batches)]
+        last = len(micro_batches) - 1
+        losses = [self.compute_loss(None, inputs, last_micro_step=(k == last), _defer=(k == last)) for k, inputs in enumerate(micro_batches)]
         self.engine.optimizer_step()
+        losses[last] = losses[last]()       # the last micro-batch's loss / KL means are read after the optimizer launches are in the queue
         self.state.global_step += 1
         return losses
 
