@@ -203,6 +203,62 @@ def prepare_batch(processing_class, inputs: list[dict]) -> dict:
     return out
 
 
+def resolve_reward_funcs(reward_funcs, reward_processing_classes, model_init_kwargs: Optional[dict] = None, device=None):
+    """The reference's reward-function set-up (REF:228-262, 303-305): a string is a sequence-classification checkpoint (`num_labels=1`), a torch
+    module is a reward MODEL that needs a tokenizer (default: the one of its checkpoint; pad token defaults to EOS; the model's `pad_token_id` is set to
+    the tokenizer's, because such models score the last non-pad token), everything else is the callable plug-in API of SURVEY section 8(b).3.
+    Reward models are the caller's torch modules: they run through torch on `device`, in eval mode, outside the HIP hot path."""
+    funcs = list(reward_funcs) if isinstance(reward_funcs, (list, tuple)) else [reward_funcs]
+    for i, f in enumerate(funcs):
+        if isinstance(f, str):
+            from transformers import AutoModelForSequenceClassification
+            funcs[i] = AutoModelForSequenceClassification.from_pretrained(f, num_labels=1, **(model_init_kwargs or {}))
+    if reward_processing_classes is None:
+        classes = [None] * len(funcs)
+    elif not isinstance(reward_processing_classes, list):
+        classes = [reward_processing_classes]
+    else:
+        classes = list(reward_processing_classes)
+        if len(classes) != len(funcs):
+            raise ValueError("The number of reward processing classes must match the number of reward functions.")  # REF:246-247
+    if len(classes) != len(funcs):       # (a single class with several functions: the reference's zip() silently drops the rest; refuse instead)
+        raise ValueError("The number of reward processing classes must match the number of reward functions.")
+    for i, (c, f) in enumerate(zip(classes, funcs)):
+        if isinstance(f, torch.nn.Module):
+            if c is None:
+                from transformers import AutoTokenizer
+                c = AutoTokenizer.from_pretrained(f.config._name_or_path)
+            if c.pad_token_id is None:
+                c.pad_token = c.eos_token
+            f.config.pad_token_id = c.pad_token_id
+            classes[i] = c
+            f.eval()
+            if device is not None:
+                f.to(device)
+        elif not callable(f):
+            raise ValueError(f"reward function {i}: expected a callable, a torch module (reward model) or a checkpoint path, got {type(f).__name__}")
+    return funcs, classes
+
+
+def reward_func_name(f) -> str:
+    """metric key of a reward function (REF:804-809)"""
+    return f.config._name_or_path.split("/")[-1] if isinstance(f, torch.nn.Module) else f.__name__
+
+
+def reward_model_scores(model, tokenizer, prompts: list, completions: list, conversational: bool) -> np.ndarray:
+    """REF:760-772: the reward model reads prompt + completion as one text (conversational rows: the tokenizer's chat template over the prompt's messages +
+    the assistant turn, trl/trl/data_utils.py:71-169 "messages" case), right-padded, no special tokens added; reward = logits[:, 0]."""
+    if conversational:
+        texts = [tokenizer.apply_chat_template(p + c, tools=None, tokenize=False) for p, c in zip(prompts, completions)]
+    else:
+        texts = [p + c for p, c in zip(prompts, completions)]
+    enc = tokenizer(texts, return_tensors="pt", padding=True, padding_side="right", add_special_tokens=False)
+    dev = next(model.parameters()).device
+    enc = {k: v.to(dev) for k, v in enc.items()}
+    with torch.inference_mode():
+        return model(**enc).logits[:, 0].float().cpu().numpy().astype(np.float32)
+
+
 class SCGRPOTrainer:
     def __init__(
         self,
@@ -274,10 +330,7 @@ class SCGRPOTrainer:
         if self.cfg.is_llava and hasattr(processing_class, "tokenizer"):
             processing_class.tokenizer.padding_side = "left"              # REF:218-219
         self.processing_class = processing_class
-        self.reward_funcs = list(reward_funcs) if isinstance(reward_funcs, (list, tuple)) else [reward_funcs]
-        for f in self.reward_funcs:
-            if not callable(f):
-                raise ValueError("reward model checkpoints as reward functions are not part of this path; pass callables")
+        self.reward_funcs, self.reward_processing_classes = resolve_reward_funcs(reward_funcs, reward_processing_classes, mik if isinstance(model, str) else None, self.device)
         self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
         self.use_vllm = use_vllm_for_gen
         group = None
@@ -305,8 +358,11 @@ class SCGRPOTrainer:
         prompts = [ex["prompt"] for ex in inputs for _ in range(G)]
         kw = {k: [ex[k] for ex in inputs for _ in range(G)] for k in inputs[0] if k not in ("prompt", "completion")}
         cols = []
-        for f in self.reward_funcs:
-            cols.append(np.asarray(f(prompts=prompts, completions=completions, current_step=self.state.global_step, **kw), dtype=np.float32))
+        for f, c in zip(self.reward_funcs, self.reward_processing_classes):
+            if isinstance(f, torch.nn.Module):
+                cols.append(reward_model_scores(f, c, prompts, completions, conversational))
+            else:
+                cols.append(np.asarray(f(prompts=prompts, completions=completions, current_step=self.state.global_step, **kw), dtype=np.float32))
         return np.stack(cols, 1)
 
     # ---- reference API ---------------------------------------------------------------------------------------------
@@ -325,7 +381,7 @@ class SCGRPOTrainer:
         self._metrics["completion_length"].append(m["completion_length"])
         rp = out["rewards_per_func"].mean(0)
         for i, f in enumerate(self.reward_funcs):
-            self._metrics[f"rewards/{f.__name__}"].append(float(rp[i]))
+            self._metrics[f"rewards/{reward_func_name(f)}"].append(float(rp[i]))
         self._metrics["reward"].append(m["reward"])
         self._metrics["reward_std"].append(m["reward_std"])
 

@@ -132,6 +132,63 @@ def test_trainer_constructor_errors_match_reference():
         SCGRPOTrainer("/x/llava-1.5-7b", [], args=GRPOConfig())
 
 
+def test_reward_model_as_reward_function_matches_the_reference():
+    """"a PreTrainedModel reward is also accepted" (sc_grpo_trainer.py:228-262 set-up, :760-772 scoring, :804-809 metric key).
+    tests/golden/reward_model.npz holds what the reference's compute_loss fed a tiny sequence classifier (texts rendered by the reward tokenizer's chat
+    template over prompt + completion, right padding, no added special tokens) and the rewards it got back; the trainer's host path must reproduce both."""
+    import types
+    import numpy as np
+    import torch
+    from transformers import Qwen2Config, Qwen2ForSequenceClassification
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import rewards as R
+    from iadr1_amd.trainer import SCGRPOTrainer, resolve_reward_funcs, reward_func_name
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reward_model.npz"))
+    tok = fx.local_qwen2vl_processor().tokenizer
+    tok.chat_template = fx.QWEN2VL_CHAT_TEMPLATE
+    cfg = Qwen2Config(vocab_size=len(tok), hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      max_position_embeddings=512, num_labels=1, pad_token_id=None, tie_word_embeddings=False)
+    rm = Qwen2ForSequenceClassification(cfg).float()
+    rm.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("rm::")})
+    rm.config._name_or_path = "local/tiny-reward-model"
+    funcs, classes = resolve_reward_funcs([R.accuracy_reward, rm], [None, tok])
+    assert rm.config.pad_token_id == tok.pad_token_id and not rm.training and classes[1] is tok
+    assert [reward_func_name(f) for f in funcs] == ["accuracy_reward", "tiny-reward-model"]
+    assert sorted("rewards/" + reward_func_name(f) for f in funcs) == g["metric_names"].tolist()
+    with pytest.raises(ValueError, match="must match the number of reward functions"):
+        resolve_reward_funcs([R.accuracy_reward, rm], [tok])
+    with pytest.raises(ValueError, match="expected a callable"):
+        resolve_reward_funcs([3], None)
+
+    texts = g["completions_text"].tolist()
+    t = SCGRPOTrainer.__new__(SCGRPOTrainer)
+    t.args = types.SimpleNamespace(num_generations=len(texts))
+    t.state = types.SimpleNamespace(global_step=0)
+    t.processing_class = types.SimpleNamespace(batch_decode=lambda ids, skip_special_tokens=True: list(texts))
+    t.reward_funcs, t.reward_processing_classes = funcs, classes
+    seen = {}
+    orig = tok.__class__.__call__
+
+    def spy(self, text=None, *a, **kw):
+        out = orig(self, text, *a, **kw)
+        seen["texts"], seen["ids"], seen["mask"] = list(text), out["input_ids"].numpy().copy(), out["attention_mask"].numpy().copy()
+        return out
+    tok.__class__.__call__ = spy
+    try:
+        inputs = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "Is there a defect?"}]}], "image": [object()], "solution": str(g["solution"])}]
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            got = t._rewards(inputs, np.zeros((len(texts), 3), np.int64))
+    finally:
+        tok.__class__.__call__ = orig
+    assert seen["texts"] == g["texts"].tolist()
+    assert np.array_equal(seen["ids"], g["input_ids"]) and np.array_equal(seen["mask"], g["attention_mask"])
+    assert got.dtype == np.float32 and got.shape == g["rewards_per_func"].shape
+    assert np.array_equal(got[:, 0], g["rewards_per_func"][:, 0])
+    np.testing.assert_allclose(got[:, 1], g["rewards_per_func"][:, 1], rtol=1e-5, atol=1e-6)
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it."""
     import re

@@ -460,6 +460,71 @@ def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed, perturb_scale
     print(f"{name}: loss={loss.item():.8f} reward={t._metrics['reward'][0]:.4f} kl={t._metrics['kl'][0]:.6f} len={t._metrics['completion_length'][0]}")
 
 
+def tiny_reward_model(tokenizer, seed=5):
+    """A 2-layer Qwen2 sequence classifier (num_labels=1) on the character-level test tokenizer: the `PreTrainedModel` kind of reward function."""
+    from transformers import Qwen2Config, Qwen2ForSequenceClassification
+    torch.manual_seed(seed)
+    cfg = Qwen2Config(vocab_size=len(tokenizer), hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      max_position_embeddings=512, num_labels=1, pad_token_id=None, tie_word_embeddings=False)
+    m = Qwen2ForSequenceClassification(cfg)
+    m.config._name_or_path = "local/tiny-reward-model"
+    return m.float().eval()
+
+
+def gen_reward_model(SCGRPOTrainer, reward):
+    """The reference's compute_loss with a reward MODEL among the reward functions (sc_grpo_trainer.py:760-772): records what the model was fed (texts through
+    the reward tokenizer's chat template, right padding) and the rewards it returned, plus the model's weights so the test can rebuild it."""
+    G, C = 4, 10
+    cfg = fx.TINY
+    w_ref = fx.make_weights(cfg, seed=0)
+    ref = build_hf_model(cfg, w_ref).eval()
+    pol = build_hf_model(cfg, fx.perturb_weights(w_ref, seed=1, scale=0.25)).train()
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    grid = (1, 16, 12)
+    batch = tiny_batch(cfg, [grid], [9], 31)
+    comps = fx.synth_completions(G, C, cfg, 131, {1: 6})
+    texts = [CANNED[i % len(CANNED)] for i in range(G)]
+    t = make_trainer(SCGRPOTrainer, reward, cfg, ref, batch, comps, texts, G, C)
+    tok = fx.local_qwen2vl_processor().tokenizer
+    tok.chat_template = fx.QWEN2VL_CHAT_TEMPLATE           # (the processor holds the template; a reward tokenizer carries its own)
+    rm = tiny_reward_model(tok)
+    # what the reference's constructor does to a reward model / its tokenizer (sc_grpo_trainer.py:250-261)
+    if tok.pad_token_id is None:
+        tok.pad_token = tok.eos_token
+    rm.config.pad_token_id = tok.pad_token_id
+    t.reward_funcs = [reward.accuracy_reward, rm]
+    t.reward_processing_classes = [None, tok]
+    seen = {}
+    orig = tok.__class__.__call__
+
+    def spy(self, text=None, *a, **kw):
+        out = orig(self, text, *a, **kw)
+        seen["texts"], seen["ids"], seen["mask"] = list(text), out["input_ids"].numpy().copy(), out["attention_mask"].numpy().copy()
+        return out
+    tok.__class__.__call__ = spy
+    inputs = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "Is there a defect?"}]}], "image": [object()], "solution": SOLUTION}]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss, loc = capture_locals(lambda: t.compute_loss(pol, inputs), "compute_loss")
+    finally:
+        tok.__class__.__call__ = orig
+    out = {
+        "meta": json.dumps({**meta(), "G": G, "C": C, "reward_model": "tools/make_golden.py tiny_reward_model (Qwen2ForSequenceClassification, weights stored here)",
+                            "tokenizer": "fixture_util.local_qwen2vl_processor().tokenizer with chat_template = QWEN2VL_CHAT_TEMPLATE"}),
+        "rewards_per_func": loc["rewards_per_func"].numpy(),
+        "advantages": loc["advantages"].numpy(),
+        "texts": np.array(seen["texts"]), "input_ids": seen["ids"], "attention_mask": seen["mask"],
+        "completions_text": np.array(texts), "solution": np.array(SOLUTION),
+        "metric_names": np.array(sorted(k for k in t._metrics if k.startswith("rewards/"))),
+        "loss": np.float64(loss.item()),
+    }
+    for k, v in rm.state_dict().items():
+        out["rm::" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "reward_model.npz"), **out)
+    print("reward_model:", loc["rewards_per_func"].numpy().tolist(), out["metric_names"].tolist())
+
+
 def gen_logps_padded(SCGRPOTrainer):
     """_get_per_token_logps on two different left-padded prompts with two different grids + the
     intermediate activations used to pin the oracle layer by layer."""
@@ -671,6 +736,8 @@ def main():
     if not only or "grpo_far" in only:
         gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={1: 9, 4: 2, 6: 5}, name="sc_grpo_g8_far.npz", seed=23, perturb_scale=0.25)
         gen_sc_grpo(SCGRPOTrainer, reward, G=4, C=10, eos_rows={0: 4, 2: 8}, name="sc_grpo_trunc.npz", seed=24, perturb_scale=0.25, truncate=2)
+    if not only or "reward_model" in only:
+        gen_reward_model(SCGRPOTrainer, reward)
     if not only or "logps" in only:
         gen_logps_padded(SCGRPOTrainer)
     if not only or "logps7" in only:
