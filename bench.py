@@ -181,6 +181,24 @@ class GemmTimer:
 
         ops.gemm_swiglu_fused = timed_f
 
+        # lm_head through the linear_logprob kernels: gemm_nt_256's main loop with the log-sum-exp / dlogits epilogues (the forward pair's second launch,
+        # a per-row merge of ~0.1 ms, sits inside its interval)
+        def wrap_head(name, tag):
+            orig_h = getattr(ops, name)
+
+            def timed_h(h, w, *a, **kw):
+                if not timer.enabled:
+                    return orig_h(h, w, *a, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = orig_h(h, w, *a, **kw)
+                e1.record()
+                timer.records.append((e0, e1, 2.0 * h.shape[0] * w.shape[0] * h.shape[1], (h.shape[0], w.shape[0], h.shape[1], tag)))
+                return r
+            setattr(ops, name, timed_h)
+        wrap_head("linear_logprob", "lse epilogue")
+        wrap_head("linear_logprob_dlogits", "dlogits epilogue")
+
     def summary(self):
         t = sum(r[0].elapsed_time(r[1]) for r in self.records) * 1e-3
         fl = sum(r[2] for r in self.records)

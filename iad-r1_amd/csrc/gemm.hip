@@ -40,9 +40,16 @@ struct GemmArgs {
     int band;  // tile rows per rasterisation band (gemm_nt_256)
     bf16_t* C2;      // OUT_SWIGLU: a[M, N/2] = silu(gate) * up (C = the gate|up matrix itself, or null when only `a` is wanted)
     long long ldc2;
+    // OUT_LSE / OUT_DLOGITS (linear_logprob: the lm_head contraction whose logits never reach HBM)
+    const long long* targets;   // [M] column of the row's target (< 0: ignored row)
+    float* part;                // OUT_LSE: [M][nparts] pairs (max, sum of exp(x - max)) over each wave's 64-column slice
+    float* tgt_logit;           // OUT_LSE: [M] the logit at the target column (rows with a target in range)
+    const float* lse;           // OUT_DLOGITS: [M] log-sum-exp of the row
+    const float* g;             // OUT_DLOGITS: [M] dLoss/dlogp of the row
+    int nparts;
 };
 
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_SWIGLU = 3 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_SWIGLU = 3, OUT_LSE = 4, OUT_DLOGITS = 5 };
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -478,11 +485,69 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) *(u32x4_t*)(dst0 + (long long)it * 16 * p.ldc2) = rv[it];
         }
-    } else if constexpr (OUT == OUT_BF16) {
+    } else if constexpr (OUT == OUT_LSE) {
+        // linear_logprob forward: per row and 64-column wave slice the pair (max, sum exp(x - max)) and the logit at the row's target column; the
+        // logits themselves are never stored.  Lane (lm, lq) holds columns j*16 + lq*4 + e of rows i*16 + lm: in-lane over (j, e), then over lq.
+        const int cbase = n0 + wn * 64;
+        const bool full = cbase + 64 <= p.N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wm * 128 + i * 16 + lm;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (full || cbase + j * 16 + lq * 4 + e < p.N) mx = fmaxf(mx, acc[i][j][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (full || cbase + j * 16 + lq * 4 + e < p.N) sm += __expf(acc[i][j][e] - mx);
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (row < p.M) {
+                if (lq == 0) *(f32x2_t*)(p.part + ((long long)row * p.nparts + tn * 4 + wn) * 2) = (f32x2_t){mx, sm};
+                const long long tg = p.targets[row];
+                if (tg >= cbase && tg < cbase + 64) {
+                    const int d = (int)(tg - cbase) - lq * 4;     // this lane holds d = j*16 + e, e in 0..3
+                    float tv = 0.f;
+                    bool hit = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (d == j * 16 + e) { tv = acc[i][j][e]; hit = true; }
+                    if (hit) p.tgt_logit[row] = tv;
+                }
+            }
+        }
+    } else if constexpr (OUT == OUT_BF16 || OUT == OUT_DLOGITS) {
         __syncthreads();  // every wave is done with the operand buffers
         bf16_t* slab = (bf16_t*)smem + (size_t)w * 128 * EP_LD;
+        if constexpr (OUT == OUT_DLOGITS) {
+            // linear_logprob backward: the recomputed logits leave as dlogits = g * (onehot(target) - exp(x - lse)) in bf16 (iadr1_dlogits_rows's arithmetic)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = min(m0 + wm * 128 + i * 16 + lm, p.M - 1);
+                const float rl = p.lse[row], rg = p.g[row];
+                const long long tg = p.targets[row];
+                const int d = (tg >= 0 && tg < p.N) ? (int)tg - (n0 + wn * 64) - lq * 4 : -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = -rg * __expf(acc[i][j][e] - rl) + (d == j * 16 + e ? rg : 0.f);
+                    *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + j * 16 + lq * 4) = (u32x2_t){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if constexpr (OUT == OUT_DLOGITS) break;
             const int nl = j * 16 + lq * 4;
             const int gn = n0 + wn * 64 + nl;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -591,6 +656,33 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
                 }
             }
         }
+    }
+}
+
+// linear_logprob, second launch: one wave per row merges the row's (max, sum) pairs in a fixed order -> lse, logp = logit[target] - lse (0 for ignored rows).
+__global__ __launch_bounds__(256) void lse_combine_kernel(const float* part, const float* tgt_logit, const long long* targets, float* logp, float* lse_out, int R, int V,
+                                                          int nparts) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (row >= R) return;
+    const f32x2_t* pp = (const f32x2_t*)part + (long long)row * nparts;
+    float m = -INFINITY, s = 0.f;
+    for (int i = l; i < nparts; i += 64) {
+        const f32x2_t v = pp[i];
+        if (v[0] > m) { s *= __expf(m - v[0]); m = v[0]; }
+        if (v[0] != -INFINITY) s += v[1] * __expf(v[0] - m);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+        const float mm = fmaxf(m, m2);
+        s = (m == -INFINITY ? 0.f : s * __expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mm));
+        m = mm;
+    }
+    if (l == 0) {
+        const float lse = m + logf(s);
+        if (lse_out) lse_out[row] = lse;
+        const long long tg = targets[row];
+        logp[row] = (tg >= 0 && tg < V) ? tgt_logit[row] - lse : 0.f;
     }
 }
 
@@ -1452,6 +1544,50 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     else if (out_mode == 1) hipLaunchKernelGGL(gemm_nt_128<OUT_F32>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     else hipLaunchKernelGGL(gemm_nt_128<OUT_F32_ACC>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     return iadr1_check_launch("gemm_nt_bf16");
+}
+
+// linear_logprob: logp[r] = log_softmax(H[r] . W^T)[targets[r]] and lse[r] without the [M, V] logits ever reaching HBM (gemm_nt_256 with the OUT_LSE
+// epilogue + lse_combine_kernel), and its backward's first half: dlogits (bf16) from the recomputed logits (OUT_DLOGITS epilogue).
+extern "C" long long iadr1_linear_logprob_workspace_bytes(int M, int V) {
+    if (M <= 0 || V <= 0) return 0;
+    const long long nparts = (long long)((V + T2 - 1) / T2) * 4;
+    return (long long)M * nparts * 8 + (long long)M * 4;
+}
+
+static int linear_logprob_args(const char* what, const void* H, const void* W, int M, int V, int K, long long ldh, long long ldw) {
+    IADR1_REQUIRE(M > 0 && V > 0 && K > 0, "%s: empty problem M=%d V=%d K=%d", what, M, V, K);
+    IADR1_REQUIRE((K % 8) == 0 && (ldh % 8) == 0 && (ldw % 8) == 0, "%s: K, ldh, ldw must be multiples of 8 (16-byte chunks); K=%d ldh=%lld ldw=%lld", what, K, ldh, ldw);
+    IADR1_REQUIRE((((uintptr_t)H) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "%s: H/W must be 16-byte aligned", what);
+    return 0;
+}
+
+extern "C" int iadr1_linear_logprob_fwd(const void* H, const void* W, const long long* targets, float* logp, float* lse, void* workspace, int M, int V, int K,
+                                        long long ldh, long long ldw, hipStream_t stream) {
+    if (int rc = linear_logprob_args("linear_logprob_fwd", H, W, M, V, K, ldh, ldw)) return rc;
+    IADR1_REQUIRE(targets && logp && workspace && (((uintptr_t)workspace) & 7) == 0, "linear_logprob_fwd: targets, logp and an 8-byte aligned workspace are required");
+    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    const int tiles_n = (V + T2 - 1) / T2, nparts = tiles_n * 4;
+    float* part = (float*)workspace;
+    float* tgt_logit = part + (long long)M * nparts * 2;
+    GemmArgs p{(const bf16_t*)H, (const bf16_t*)W, nullptr, nullptr, zeros_ptr(), M, V, K, ldh, ldw, 0, 0, band_rows, nullptr, 0, targets, part, tgt_logit, nullptr, nullptr, nparts};
+    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_LSE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
+    (void)attr_done;
+    hipLaunchKernelGGL(gemm_nt_256<OUT_LSE>, dim3(((M + T2 - 1) / T2) * tiles_n), dim3(NT2), SMEM2_BYTES, stream, p);
+    if (int rc = iadr1_check_launch("linear_logprob_fwd")) return rc;
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, part, tgt_logit, targets, logp, lse, M, V, nparts);
+    return iadr1_check_launch("linear_logprob_fwd (combine)");
+}
+
+extern "C" int iadr1_linear_logprob_dlogits(const void* H, const void* W, const long long* targets, const float* lse, const float* g, void* dl, long long ldd, int M, int V,
+                                            int K, long long ldh, long long ldw, hipStream_t stream) {
+    if (int rc = linear_logprob_args("linear_logprob_dlogits", H, W, M, V, K, ldh, ldw)) return rc;
+    IADR1_REQUIRE(targets && lse && g && dl, "linear_logprob_dlogits: targets, lse, g and dl are required");
+    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    GemmArgs p{(const bf16_t*)H, (const bf16_t*)W, dl, nullptr, zeros_ptr(), M, V, K, ldh, ldw, ldd, 0, band_rows, nullptr, 0, targets, nullptr, nullptr, lse, g, 0};
+    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_DLOGITS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
+    (void)attr_done;
+    hipLaunchKernelGGL(gemm_nt_256<OUT_DLOGITS>, dim3(((M + T2 - 1) / T2) * ((V + T2 - 1) / T2)), dim3(NT2), SMEM2_BYTES, stream, p);
+    return iadr1_check_launch("linear_logprob_dlogits");
 }
 
 // gate|up projection with the SwiGLU fused into the epilogue of gemm_nt_256 (training / prefill shapes): GU[M, 2I] = A . W^T (stored when GU != null:

@@ -508,6 +508,35 @@ def dlogits_rows(logits32, targets, lse, g, out=None):
     return dl
 
 
+def linear_logprob(h, w, targets, logp=None, lse=None, ws=None):
+    """logp[r] = log_softmax(h[r] @ w^T)[targets[r]] (0 for targets < 0) and lse[r], without materialising the [R, V] logits
+    (include/iadr1_hip.h iadr1_linear_logprob_fwd).  ws: uint8 workspace of linear_logprob_ws_bytes(R, V) bytes (allocated when None)."""
+    R, K = h.shape
+    V, K2 = w.shape
+    assert K == K2 and h.dtype == BF16 and w.dtype == BF16 and targets.dtype == torch.int64 and targets.numel() == R
+    logp = logp if logp is not None else torch.empty(R, dtype=F32, device=h.device)
+    lse = lse if lse is not None else torch.empty(R, dtype=F32, device=h.device)
+    need = linear_logprob_ws_bytes(R, V)
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.uint8, device=h.device)
+    assert ws.numel() * ws.element_size() >= need and ws.is_contiguous()
+    hip.call("linear_logprob_fwd", h, w, targets, logp, lse, ws, R, V, K, _ld(h), _ld(w))
+    return logp, lse
+
+
+def linear_logprob_ws_bytes(R, V):
+    return int(hip.lib().iadr1_linear_logprob_workspace_bytes(R, V))
+
+
+def linear_logprob_dlogits(h, w, targets, lse, g, out=None):
+    """dl[R, V] (bf16) = g[r] * (onehot(targets[r]) - softmax(h[r] @ w^T)) from recomputed logits (iadr1_linear_logprob_dlogits)."""
+    R, K = h.shape
+    V = w.shape[0]
+    dl = out if out is not None else torch.empty(R, V, dtype=BF16, device=h.device)
+    hip.call("linear_logprob_dlogits", h, w, targets, lse, g, dl, _ld(dl), R, V, K, _ld(h), _ld(w))
+    return dl
+
+
 def grpo_loss(logp, ref_logp, adv, mask, beta, n_total_rows=None):
     N, C = logp.shape
     dev = logp.device

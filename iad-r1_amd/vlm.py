@@ -94,6 +94,12 @@ class Engine:
         # (torch priority -1; the range here is (0, -1)): 1294-1306 ms/step against 1272 -- the starved wgrad queue lengthens the join at the end
         self.wgrad_stream = torch.cuda.Stream() if (self.dev.type == "cuda" and os.environ.get("IADR1_WGRAD_STREAM", "1") != "0") else None
         self.keep_logits_bytes = 24 << 30
+        # lm_head + log-softmax + gather.  "fused" (default): the linear_logprob kernels -- logits never reach HBM, the backward recomputes them straight into
+        # dlogits; "logits": the two-step form (fp32 logit chunks + row kernels; a differentiated pass keeps its logits when they fit `keep_logits_bytes`).
+        # Measured on the 3B bench shape: 1261.9 (fused) vs 1263.2 ms per step, and 10 GB of kept logits less.  Policy and frozen reference always run the
+        # same form, so a policy that equals the reference has KL == 0 exactly (bit-equal log-probs).
+        self.head_mode = os.environ.get("IADR1_HEAD", "fused")
+        assert self.head_mode in ("fused", "logits"), self.head_mode
         self._ws = {}
 
     def _workspace(self, key, shape, dtype):
@@ -858,15 +864,24 @@ class Engine:
         V = W.shape[0]
         # with `save`, the fp32 logits of all R rows are kept for the backward (10 GB for 16384 x 151936: nothing on a 288 GB part)
         # instead of being recomputed chunk by chunk; without it only one chunk is ever alive
-        keep = save and R * V * 4 <= self.keep_logits_bytes
+        fused = self.head_mode == "fused"
+        # fused: one linear_logprob launch pair over all R rows (GEMM epilogue -> (max, sum exp) per 64-column slice + target logit, then a per-row merge)
+        keep = save and R * V * 4 <= self.keep_logits_bytes and not fused
         lg_all = self._workspace("lm_logits_all", (R, V), F32) if keep else None
-        lg_buf = None if keep else self._workspace("lm_logits", (min(R, self.lm_chunk), V), F32)
-        for r0 in range(0, R, self.lm_chunk):
-            r1 = min(R, r0 + self.lm_chunk)
-            lg = ops.gemm_nt(hsel[r0:r1], W, out=lg_all[r0:r1] if keep else lg_buf[: r1 - r0])
-            lp, ls = ops.logprob_rows(lg, targets[r0:r1])
-            logp[r0:r1] = lp
-            lse[r0:r1] = ls
+        if fused:
+            need = ops.linear_logprob_ws_bytes(R, V)
+            ws = self._ws.get("lm_logprob_ws")
+            if ws is None or ws.numel() < need:                     # grow-only: the row count changes from batch to batch
+                ws = self._ws["lm_logprob_ws"] = torch.empty(need + need // 4, dtype=torch.uint8, device=self.dev)
+            ops.linear_logprob(hsel, W, targets, logp=logp, lse=lse, ws=ws)
+        else:
+            lg_buf = None if keep else self._workspace("lm_logits", (min(R, self.lm_chunk), V), F32)
+            for r0 in range(0, R, self.lm_chunk):
+                r1 = min(R, r0 + self.lm_chunk)
+                lg = ops.gemm_nt(hsel[r0:r1], W, out=lg_all[r0:r1] if keep else lg_buf[: r1 - r0])
+                lp, ls = ops.logprob_rows(lg, targets[r0:r1])
+                logp[r0:r1] = lp
+                lse[r0:r1] = ls
         ctx = None
         if save:
             ptr, idx = self.scatter_plan(rows_host if rows_host is not None else rows.cpu().numpy(), hf.shape[0], self.dev)
@@ -884,14 +899,18 @@ class Engine:
         V = W.shape[0]
         nc = min(R, self.lm_chunk)
         kept = ctx.get("logits")
-        lg_buf = None if kept is not None else self._workspace("lm_logits", (nc, V), F32)
+        fused = kept is None and self.head_mode == "fused"
+        lg_buf = None if kept is not None or fused else self._workspace("lm_logits", (nc, V), F32)
         dl_buf = self._workspace("lm_dlogits", (nc, V), BF16)
         dlT_buf = self._workspace("lm_dlogits_t", (V, (nc + 7) // 8 * 8), BF16)
         for r0 in range(0, R, self.lm_chunk):
             r1 = min(R, r0 + self.lm_chunk)
             n = r1 - r0
-            lg = kept[r0:r1] if kept is not None else ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[:n])
-            dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1], out=dl_buf[:n])
+            if fused:
+                dl = ops.linear_logprob_dlogits(hsel[r0:r1], W, targets[r0:r1], lse[r0:r1], g[r0:r1], out=dl_buf[:n])
+            else:
+                lg = kept[r0:r1] if kept is not None else ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[:n])
+                dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1], out=dl_buf[:n])
             ops.gemm_nt(dl, WT, out=dhsel[r0:r1])
             np8 = (n + 7) // 8 * 8
             dlT = dlT_buf[:, :np8]

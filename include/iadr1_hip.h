@@ -240,6 +240,17 @@ int iadr1_logprob_rows(const float* logits, long long ld, const long long* targe
                        iadr1_stream_t stream);
 int iadr1_dlogits_rows(const float* logits, long long ld, const long long* targets, const float* lse, const float* g,
                        void* dl, long long ldd, int R, int V, iadr1_stream_t stream);
+/* linear_logprob -- SURVEY section 8(b).5 "fused K15+K16, returns per-token logp and lse" (and linear_ce: logp = -CE, target < 0 ignored):
+ *   logp[r] = log_softmax(H[r,:K] . W[V,K]^T)[targets[r]],  lse[r] = logsumexp of that row    (REF:505-513 lm_head + log_softmax + gather; PA-SFT CE TF:loss/loss_utils.py:32-71)
+ * without the [M, V] logits reaching HBM: the GEMM's epilogue reduces every 64-column slice to (max, sum exp) and picks the target logit, a second launch
+ * merges the slices in a fixed order (deterministic).  `workspace`: iadr1_linear_logprob_workspace_bytes(M, V) bytes, caller-owned, 8-byte aligned.
+ * iadr1_linear_logprob_dlogits: the backward's first half -- the logits are recomputed and leave as dl[M, V] = g[r] * (onehot(target) - exp(x - lse[r])) in bf16
+ * (the arithmetic of iadr1_dlogits_rows); dH = dl . W and dW += dl^T . H are iadr1_gemm_nt_bf16 calls.  K, ldh, ldw multiples of 8, ldd multiple of 8. */
+long long iadr1_linear_logprob_workspace_bytes(int M, int V);
+int iadr1_linear_logprob_fwd(const void* H, const void* W, const long long* targets, float* logp, float* lse, void* workspace, int M, int V, int K,
+                             long long ldh, long long ldw, iadr1_stream_t stream);
+int iadr1_linear_logprob_dlogits(const void* H, const void* W, const long long* targets, const float* lse, const float* g, void* dl, long long ldd,
+                                 int M, int V, int K, long long ldh, long long ldw, iadr1_stream_t stream);
 /* n_total_rows: number of sequences the batch mean runs over (>= N when the step is micro-batched) */
 int iadr1_grpo_loss(const float* logp, const float* ref_logp, const float* adv, const int* mask, float beta, int n_total_rows,
                     float* dlogp, float* kl, float* row_loss, float* row_kl, int N, int C, iadr1_stream_t stream);

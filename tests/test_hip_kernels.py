@@ -57,6 +57,34 @@ def test_gemm_nt(M, N, K, mode):
         close(out, ref + base.float(), 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"gemm f32 acc {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("R,V,K", [(20, 1000, 64), (300, 152064 // 8, 256), (513, 4096 + 128, 128), (1024, 151936, 512), (4096, 32064, 256)])
+def test_linear_logprob_matches_gemm_then_logprob_rows(R, V, K):
+    """iadr1_linear_logprob_fwd / _dlogits (logits never stored) against the two-step form they replace (gemm_nt fp32 logits -> logprob_rows / dlogits_rows)
+    and against fp32 torch log_softmax; ragged row / vocabulary tiles, ignored rows (target -100), targets in the first and the last column."""
+    h, w = rnd(R, K, seed=1), rnd(V, K, seed=2, scale=0.6)
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    tg = torch.randint(0, V, (R,), generator=gen)
+    tg[0], tg[1], tg[R // 2] = 0, V - 1, -100
+    tg = tg.to(DEV)
+    g = rnd(R, seed=4, dtype=F32)
+    g[R // 2] = 0.0
+    logits = ops.gemm_nt(h, w, out_dtype=F32)
+    lp0, lse0 = ops.logprob_rows(logits, tg)
+    lp, lse = ops.linear_logprob(h, w, tg)
+    close(lse, lse0, 1e-6, 2e-5, f"linear_logprob lse {R}x{V}x{K}")
+    close(lp, lp0, 1e-6, 2e-5, f"linear_logprob logp {R}x{V}x{K}")
+    assert float(lp[R // 2]) == 0.0
+    ref = torch.log_softmax(h.float() @ w.float().t(), -1)
+    keep = tg >= 0
+    close(lp[keep], ref[keep].gather(1, tg[keep][:, None])[:, 0], 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"linear_logprob vs torch {R}x{V}x{K}")
+    lp2, lse2 = ops.linear_logprob(h, w, tg)      # deterministic
+    assert torch.equal(lp, lp2) and torch.equal(lse, lse2)
+    if V % 8 == 0:
+        dl0 = ops.dlogits_rows(logits, tg, lse0, g)
+        dl = ops.linear_logprob_dlogits(h, w, tg, lse0, g)
+        assert torch.equal(dl, dl0), f"dlogits {R}x{V}x{K}: {(dl.float() - dl0.float()).abs().max().item()}"
+
+
 def test_gemm_nt_strided_views():
     # operands / outputs that are column slices of wider buffers (the fused qkv / gate|up layouts)
     big_a, big_b = rnd(300, 512, seed=5), rnd(260, 512, seed=6)
