@@ -300,7 +300,9 @@ class SCGRPOTrainer:
             raise ValueError("You passed `model_init_kwargs` to the `GRPOConfig`, but your model is already instantiated. "
                              "This argument can only be used when the `model` argument is a string.")  # REF:141-145
         if peft_config is not None:
-            raise ValueError("peft_config: LoRA is not part of this path (the reference scripts train full parameters)")
+            raise ValueError("peft_config: LoRA is not part of this path.  The reference wraps the policy with get_peft_model (REF:149-150) but pushes the wrapped "
+                             "state_dict -- base_model.model.* / lora_A / lora_B names, adapters not merged -- into vLLM's load_weights (REF:569-579), and generation "
+                             "without vLLM raises (REF:720): its LoRA branch cannot complete a step, and none of its launch scripts asks for it")
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         self.hf_config = None
         if isinstance(model, str):

@@ -130,6 +130,10 @@ def test_trainer_constructor_errors_match_reference():
         SCGRPOTrainer((None, {}), [], args=GRPOConfig(model_init_kwargs={"a": 1}))
     with pytest.raises(ValueError, match="Qwen2.5-VL"):
         SCGRPOTrainer("/x/llava-1.5-7b", [], args=GRPOConfig())
+    with pytest.raises(ValueError, match="LoRA is not part of this path"):
+        SCGRPOTrainer((None, {}), [], args=GRPOConfig(), peft_config=object())
+    with pytest.raises(ValueError, match="LoRA is not part of this path"):
+        _load("train/stage_rl/grpo_ad.py").main(["--model_name_or_path", "/x", "--output_dir", "o", "--dataset_name", "d.json", "--use_peft"])
 
 
 def test_reward_model_as_reward_function_matches_the_reference():

@@ -91,6 +91,8 @@ def build_parser():
     p.add_argument("--decode_weights", default="bf16", choices=["bf16", "fp8"],
                    help="fp8: the rollout streams the gate|up / down / lm_head weights as e4m3 + per-row scales (BASELINE config 5); the loss and its gradients stay bf16")
     p.add_argument("--run_name", default=None)
+    # ModelConfig's LoRA switch: refused with the reason (the trainer's peft_config error), not silently ignored
+    p.add_argument("--use_peft", nargs="?", default=False, const=True)
     # accepted for script compatibility, no effect here
     for flag in ("--deepspeed", "--report_to", "--gradient_checkpointing", "--bf16", "--ddp_timeout", "--push_to_hub"):
         p.add_argument(flag, nargs="?", default=None, const=True)
@@ -157,10 +159,17 @@ def load_rows(path: str):
     return json.loads(txt) if txt.startswith("[") else [json.loads(l) for l in txt.splitlines() if l.strip()]
 
 
+PEFT_UNSUPPORTED = ("--use_peft / peft_config: LoRA is not part of this path.  In the reference it cannot run either: SCGRPOTrainer wraps the policy with get_peft_model "
+                    "(sc_grpo_trainer.py:149-150) but _move_model_to_vllm (:569-579) hands the wrapped state_dict (base_model.model.* / lora_A / lora_B names, adapters not "
+                    "merged) to vLLM's load_weights, and generation without vLLM raises (:720); none of its launch scripts passes --use_peft")
+
+
 def main(argv=None):
     a = parse_args_and_config(build_parser(), argv)
     if a.single_img not in (0, 1):
         raise ValueError("The single_img parameter can only be 0 or 1")
+    if str2bool(a.use_peft):
+        raise ValueError(PEFT_UNSUPPORTED)
     if not a.dataset_name.endswith((".json", ".jsonl")):
         raise ValueError("dataset_name must be a .json/.jsonl manifest (the reference loads it with load_dataset('json'))")
     import torch
