@@ -527,6 +527,9 @@ def main():
         step_id += 1
     barrier()
     ms0 = torch.cuda.memory_stats()
+    alloc_trace = os.environ.get("IADR1_ALLOC_TRACE") == "1"     # who asks the device for memory inside the timed region (stderr; a diagnosis switch)
+    if alloc_trace:
+        torch.cuda.memory._record_memory_history(enabled="all", context="alloc", stacks="python", max_entries=200000)
     timer.enabled = True
     if eng._rollout is not None:
         eng._rollout.decode_events = []
@@ -537,6 +540,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    if alloc_trace:
+        snap = torch.cuda.memory._snapshot()
+        torch.cuda.memory._record_memory_history(enabled=None)
+        import collections
+        print("[alloc-trace] events by action:", dict(collections.Counter(ev["action"] for tr_ in snap["device_traces"] for ev in tr_)), file=sys.stderr)
+        for tr_ in snap["device_traces"]:
+            for ev in tr_:
+                if ev["action"] in ("segment_alloc", "segment_free"):
+                    fr = [f"{os.path.basename(f['filename'])}:{f['line']}:{f['name']}" for f in ev.get("frames", []) if "iad-r1_amd" in f["filename"] or "bench.py" in f["filename"]][:4]
+                    print(f"[alloc-trace] {ev['action']:13s} {ev['size'] / 2**20:9.1f} MiB  {' <- '.join(fr)}", file=sys.stderr)
     metrics = {k: (sum(v) / len(v) if v else None) for k, v in tr._metrics.items()}
     traced = bool(getattr(eng, "last_step_traced", False))      # read now: the extra (untimed) leg below runs the other layout
     dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
