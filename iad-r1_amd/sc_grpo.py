@@ -311,7 +311,9 @@ class SCGRPOEngine:
                 rpf = rewards_per_func() if callable(rewards_per_func) else rewards_per_func
                 rpf = torch.as_tensor(np.asarray(rpf), dtype=F32)
                 adv, std = group_advantages(rpf.sum(1), G)
-                state.update(rpf=rpf, rewards=rpf.sum(1), adv=adv, std=std, adv_d=adv.to(self.dev))
+                # pinned + non-blocking: a pageable host-to-device copy synchronises the stream, i.e. would make the host wait here for the reference and policy
+                # forwards it has just enqueued (and leave the GPU idle for the ~1 ms the host then needs to launch the loss kernel)
+                state.update(rpf=rpf, rewards=rpf.sum(1), adv=adv, std=std, adv_d=adv.pin_memory().to(self.dev, non_blocking=True))
             return state
 
         if vis is None or (backward and vis["ctx"] is None):
