@@ -303,7 +303,7 @@ class Rollout:
                 for j in range(full * PAGE, n):
                     slot_tail[gi, b * S + first + j] = pages[j // PAGE] * PAGE + j % PAGE
                     any_tail = True
-        self.block_table.copy_(torch.from_numpy(bt))
+        self.block_table.copy_(torch.from_numpy(bt).pin_memory(), non_blocking=True)      # (pinned: a pageable upload synchronises the stream, ops.h2d)
         # group-shared decode attention when it pays.  Measured on MI355X (decode step, 64 sequences, 7B-class shapes, profiles/r02_group_attention.txt; the
         # per-sequence kernel with its blocks placed one prompt group per XCD, the group kernel with one block per (group, kv head)):
         #   LLaVA-1.5 (MHA, 32 kv heads, 832 shared tokens: 2048 per-sequence blocks)      7.69 vs 6.30 ms   -> group kernel
@@ -314,7 +314,7 @@ class Rollout:
         if self.G_seq != G:
             self.G_seq, self.graph = G, None
         shared_tok = np.array([int(lengths[b]) // PAGE * PAGE for b in range(Bp)])
-        self.shared_pages[:Bp].copy_(torch.from_numpy((shared_tok // PAGE).astype(np.int32)))
+        self.shared_pages[:Bp].copy_(torch.from_numpy((shared_tok // PAGE).astype(np.int32)).pin_memory(), non_blocking=True)
         want = os.environ.get("IADR1_DECODE_GROUP_ATTN")
         rows_ok = G * (c.num_attention_heads // c.num_key_value_heads) <= 64
         use = rows_ok and G > 1 and N * c.num_key_value_heads >= 1024 and int(shared_tok.min()) >= 256
@@ -327,8 +327,8 @@ class Rollout:
         if use != self.group_attn or (use and (G != self.G or chunks != self.group_chunks)):
             self.group_attn, self.G, self.group_chunks, self.graph = use, G, chunks, None
             self.group_ws = ops.attn_decode_group_ws(self.N, G, c.num_attention_heads, c.num_key_value_heads, c.head_dim, chunks, dev) if (use and chunks > 1) else None
-        slot_shared_d = torch.from_numpy(slot_shared).to(dev)
-        slot_tail_d = torch.from_numpy(slot_tail).to(dev) if any_tail else None
+        slot_shared_d = ops.h2d(slot_shared, dev)
+        slot_tail_d = ops.h2d(slot_tail, dev) if any_tail else None
         Hkv, D = c.num_key_value_heads, c.head_dim
 
         def kv_sink(i, k, v):
@@ -374,8 +374,8 @@ class Rollout:
         # ---- device state for the first generated token ----------------------------------------------------
         rep = lambda a: np.repeat(a, G)
         first_pos = rep(lengths + plan.rope_deltas)                         # M-RoPE position of the first new token
-        self.pos.copy_(torch.from_numpy((first_pos - 1).astype(np.int32)))
-        self.ctx_len.copy_(torch.from_numpy(rep(lengths).astype(np.int32)))
+        self.pos.copy_(torch.from_numpy((first_pos - 1).astype(np.int32)).pin_memory(), non_blocking=True)
+        self.ctx_len.copy_(torch.from_numpy(rep(lengths).astype(np.int32)).pin_memory(), non_blocking=True)
         self.finished.zero_()
         self.step.zero_()
         self.out_tokens.fill_(c.pad_token_id)

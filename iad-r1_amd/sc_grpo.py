@@ -301,7 +301,7 @@ class SCGRPOEngine:
         ids = np.concatenate([np.repeat(ids_p, G, 0), comp], 1)
         mask = np.concatenate([np.repeat(mask_p, G, 0), cmask.astype(mask_p.dtype)], 1)
         S = P + C
-        cmask_d = torch.from_numpy(cmask).to(self.dev)
+        cmask_d = ops.h2d(cmask, self.dev)
         state = {}
 
         def advantages():
@@ -313,7 +313,7 @@ class SCGRPOEngine:
                 adv, std = group_advantages(rpf.sum(1), G)
                 # pinned + non-blocking: a pageable host-to-device copy synchronises the stream, i.e. would make the host wait here for the reference and policy
                 # forwards it has just enqueued (and leave the GPU idle for the ~1 ms the host then needs to launch the loss kernel)
-                state.update(rpf=rpf, rewards=rpf.sum(1), adv=adv, std=std, adv_d=adv.pin_memory().to(self.dev, non_blocking=True))
+                state.update(rpf=rpf, rewards=rpf.sum(1), adv=adv, std=std, adv_d=ops.h2d(adv, self.dev))
             return state
 
         if vis is None or (backward and vis["ctx"] is None):
@@ -362,8 +362,8 @@ class SCGRPOEngine:
                             sel[r - r0, t_] = (r - r0) * S + hi
                         tgt[r - r0, t_] = ids[r, qi]
                 sel = sel.reshape(-1)
-            rows_d = torch.from_numpy(sel.astype(np.int64)).to(self.dev)
-            tgt_d = torch.from_numpy(tgt.reshape(-1)).to(self.dev)
+            rows_d = ops.h2d(sel.astype(np.int64), self.dev)
+            tgt_d = ops.h2d(tgt.reshape(-1), self.dev)
             hf, _ = self.ref.text_forward(plan, img_ref, save=False)
             rl, _ = self.ref.logprobs(hf, rows_d, tgt_d, save=False)
             del hf

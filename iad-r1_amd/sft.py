@@ -68,8 +68,8 @@ class SFTEngine:
             sel = np.flatnonzero(tgt[r0:r1].reshape(-1) != -100)
             if len(sel) == 0:
                 continue
-            rows_d = torch.from_numpy(sel.astype(np.int64)).to(self.dev)
-            tgt_d = torch.from_numpy(tgt[r0:r1].reshape(-1)[sel]).to(self.dev)
+            rows_d = ops.h2d(sel.astype(np.int64), self.dev)
+            tgt_d = ops.h2d(tgt[r0:r1].reshape(-1)[sel], self.dev)
             hf, ctx = e.text_forward(plan, img, save=backward)
             lp, lctx = e.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel)
             total += -lp.sum()

@@ -173,7 +173,7 @@ class Engine:
     def _siglip_plan_build(self, sizes) -> SiglipPlan:
         c = self.cfg
         dev = self.dev
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        up = lambda a: ops.h2d(np.ascontiguousarray(a), dev)
         per, seq = c.v_tokens, c.v_seq
         if c.llava_family == "llava":         # one crop per image, its patch features ARE the image tokens: no packing map
             crops, lens, pack, pack_t, n_tok = [1] * len(sizes), [per] * len(sizes), None, None, len(sizes) * per
@@ -204,7 +204,7 @@ class Engine:
         if c.v_arch == "qwen2_vl":   # no window reorder, every block attends over the whole image (TF:qwen2_vl ::690-720)
             cu_full = indexing.vision_cu_seqlens(grids)
             pos = indexing.vision_position_ids(grids, c.v_merge).astype(np.float32)
-            rot_t = torch.from_numpy((pos[:, :, None] * self.v_inv_freq[None, None, :]).reshape(pos.shape[0], -1)).to(self.dev)
+            rot_t = ops.h2d((pos[:, :, None] * self.v_inv_freq[None, None, :]).reshape(pos.shape[0], -1), self.dev)
             seg = ops.Segments.from_cu(cu_full, self.dev)
             return VisionPlan(pos.shape[0], None, None, seg, seg, rot_t.cos().contiguous(), rot_t.sin().contiguous())
         win, cu_win = indexing.vision_window_index(grids, c.v_merge, c.v_window, c.v_patch)
@@ -213,9 +213,9 @@ class Engine:
         n = pos.shape[0]
         rot = (pos[:, :, None] * self.v_inv_freq[None, None, :]).reshape(n, -1)     # [N, d/2]: h freqs then w freqs
         rot = rot.reshape(n // m2, m2, -1)[win].reshape(n, -1)
-        rot_t = torch.from_numpy(rot).to(self.dev)
-        win_t = torch.from_numpy(win).to(self.dev)
-        rev = torch.from_numpy(np.argsort(win)).to(self.dev)
+        rot_t = ops.h2d(rot, self.dev)
+        win_t = ops.h2d(win, self.dev)
+        rev = ops.h2d(np.argsort(win), self.dev)
         return VisionPlan(n, win_t, rev, ops.Segments.from_cu(cu_win, self.dev), ops.Segments.from_cu(cu_full, self.dev), rot_t.cos().contiguous(), rot_t.sin().contiguous())
 
     def _positions(self, input_ids, attention_mask, flat_grids):
@@ -258,10 +258,10 @@ class Engine:
                 raise ValueError("attention_mask rows must be one contiguous run of ones (left padding / post-EOS padding only)")
             starts.append(b * S + first)
             ends.append(b * S + last)
-        pos_t = torch.from_numpy(pos.reshape(3, B * S)).to(self.dev)
+        pos_t = ops.h2d(pos.reshape(3, B * S), self.dev)
         sel = pos_t[self.mrope_comp]                                   # [D/2, T]: component per frequency
         ang = sel.t().to(F32) * self.inv_freq[None, :]                  # [T, D/2] fp32, as TF::525-538
-        return TextPlan(B, S, torch.from_numpy(input_ids.reshape(-1).astype(np.int64)).to(self.dev), torch.from_numpy(img_index.reshape(-1)).to(self.dev),
+        return TextPlan(B, S, ops.h2d(input_ids.reshape(-1).astype(np.int64), self.dev), ops.h2d(img_index.reshape(-1), self.dev),
                         ops.Segments(starts, ends, self.dev), ang.cos().contiguous(), ang.sin().contiguous(), deltas, lengths)
 
     def text_plan_shared(self, ids_p: np.ndarray, mask_p: np.ndarray, comp: np.ndarray, cmask: np.ndarray, G: int, grids_per_prompt, img_off_per_prompt) -> TextPlan:
@@ -313,9 +313,9 @@ class Engine:
             ends.append(base + r * C + int(clen[r]))
             prefix.append([starts[b], ends[b] - starts[b], 0, 0])
         ids_flat = np.concatenate([ids_p.reshape(-1), comp.reshape(-1)]).astype(np.int64)
-        pos_t = torch.from_numpy(pos_flat).to(self.dev)
+        pos_t = ops.h2d(pos_flat, self.dev)
         ang = pos_t[self.mrope_comp].t().to(F32) * self.inv_freq[None, :]
-        plan = TextPlan(n, P + C, torch.from_numpy(ids_flat).to(self.dev), torch.from_numpy(img_index).to(self.dev),
+        plan = TextPlan(n, P + C, ops.h2d(ids_flat, self.dev), ops.h2d(img_index, self.dev),
                         ops.Segments(starts, ends, self.dev, prefix=prefix), ang.cos().contiguous(), ang.sin().contiguous(), deltas, mask_full.sum(1).astype(np.int64))
         plan.shared = (ng, P, n, C, G)
         # the completion rows alone (two-phase forward: the prompt rows were already run by the rollout's prefill); segment indices stay absolute
@@ -848,7 +848,7 @@ class Engine:
         order = np.argsort(rows_host, kind="stable").astype(np.int32)
         ptr = np.zeros(T + 1, dtype=np.int32)
         np.cumsum(np.bincount(rows_host, minlength=T), out=ptr[1:])
-        return torch.from_numpy(ptr).to(device), torch.from_numpy(order).to(device)
+        return ops.h2d(ptr, device), ops.h2d(order, device)
 
     def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool, dup=None, rows_host=None):
         """logp[r] = log_softmax(lm_head(hf[rows[r]]))[targets[r]]  (targets < 0 -> 0).  The [R,V] logits exist
