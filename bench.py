@@ -626,6 +626,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
                          "mfma_busy": mfma_busy,
+                         "power_limit": {"source": "profiles/r02_gemm_power.txt (tools/gemm_power.py: rocm-smi during a 6 s back-to-back gemm_nt stream, separate run)",
+                                         "sclk_mhz_under_gemm_stream": 1900, "sclk_mhz_idle": 2400, "socket_power_w": 1388,
+                                         "dense_bf16_peak_at_that_clock_tflops": MFMA_BF16_DENSE_PEAK_TFLOPS * 1900 / 2400},
                          "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt,
                          "timing": "sum of algorithmic FLOPs of the launches / length of the union of their HIP-event intervals (weight-gradient GEMMs run on a side stream "
                                    "concurrently with the dgrad GEMMs; equals FLOPs / sum of launch durations when nothing overlaps: IADR1_WGRAD_STREAM=0)",
