@@ -343,7 +343,11 @@ def run_pa_sft(a, cfg, dev, rank, world):
     from iadr1_amd.sft import SFTArgs, SFTEngine
     p = ParamStore(cfg, dev, trainable=True, with_decode_pack=False)
     p.init_random(seed=0)
-    eng = SFTEngine(cfg, p, SFTArgs(learning_rate=1e-5, weight_decay=0.1, micro_batch_seqs=a.sft_batch))
+    # the trainable set of the reference's PA-SFT (LLaMA-Factory defaults): Qwen2-VL (a registered composite family) trains with its vision tower and projector frozen,
+    # Qwen2.5-VL (not registered in the vendored LLaMA-Factory) trains whole -- iadr1_amd.sft.frozen_parameter_rule
+    from iadr1_amd.sft import frozen_parameter_rule
+    frozen = frozen_parameter_rule("qwen2_vl" if cfg.v_arch == "qwen2_vl" else "qwen2_5_vl")
+    eng = SFTEngine(cfg, p, SFTArgs(learning_rate=1e-5, weight_decay=0.1, micro_batch_seqs=a.sft_batch, frozen=frozen))
     timer = GemmTimer()
     timer.install()
     B, P, C = a.sft_batch, a.prompt_len, a.gen_len
@@ -398,7 +402,8 @@ def run_pa_sft(a, cfg, dev, rank, world):
         print(json.dumps({
             "metric": f"PA-SFT samples/sec (bs={B}, img448, {P}+{C} tok) {model_name}", "value": world * B * a.steps / dt, "unit": "samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic", "config": {"workload": f"{model_name} PA-SFT step (BASELINE config {1 if a.model == 'qwen2vl_2b' else 2}): {B} sequences x (448x448 image + {P} prompt positions + {C} supervised tokens), forward(labels) + backward + AdamW, random-init weights", "parallelism": f"dp{world}"},
+            "data": "synthetic", "config": {"workload": f"{model_name} PA-SFT step (BASELINE config {1 if a.model == 'qwen2vl_2b' else 2}): {B} sequences x (448x448 image + {P} prompt positions + {C} supervised tokens), forward(labels) + backward + AdamW, random-init weights", "parallelism": f"dp{world}",
+                                            "trainable": ("language model (vision tower + projector frozen: LLaMA-Factory's defaults for the registered qwen2_vl family)" if frozen is not None else "all parameters (qwen2_5_vl is not a registered composite family of the reference's LLaMA-Factory: nothing is frozen)")},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
             "last_loss": loss, "tokens_per_s": world * B * (P + C) * a.steps / dt, "cpu_baseline": None,

@@ -781,6 +781,35 @@ class ParamStore:
             self.sync_master_from_bf16()
         self.refresh_shadows()
 
+    def optimizer_segments(self, frozen=None):
+        """[(lo, hi, decays)]: the contiguous ranges of the flat parameter buffer an optimizer step visits -- everything (the decayed group, then the rest) when
+        nothing is frozen; with `frozen(name) -> bool` the runs of adjacent trainable tensors inside each group (frozen tensors take part in neither the update
+        nor the weight decay, like parameters without requires_grad under an HF optimizer)."""
+        if frozen is None:
+            return [(lo, hi, d) for lo, hi, d in ((0, self.n_decay, True), (self.n_decay, self.n_total, False)) if hi > lo]
+        segs = []
+        for s in sorted(self.slots.values(), key=lambda s: s.offset):
+            if frozen(s.name):
+                continue
+            lo, hi = s.offset, s.offset + _rup(int(np.prod(s.shape)), 64)
+            if segs and segs[-1][1] == lo and segs[-1][2] == s.decay:
+                segs[-1] = (segs[-1][0], hi, s.decay)
+            else:
+                segs.append((lo, hi, s.decay))
+        return segs
+
+    def frozen_ranges(self, frozen):
+        """[(lo, hi)] of the flat buffer held by frozen tensors (merged)."""
+        out = []
+        for s in sorted(self.slots.values(), key=lambda s: s.offset):
+            if frozen(s.name):
+                lo, hi = s.offset, s.offset + _rup(int(np.prod(s.shape)), 64)
+                if out and out[-1][1] == lo:
+                    out[-1] = (out[-1][0], hi)
+                else:
+                    out.append((lo, hi))
+        return out
+
     def refresh_shadows(self):
         """After any change of the bf16 parameters (load / optimizer step): transposed + decode-packed copies.
         For a trainable store on the GPU the ~450 small launches (one per tensor) are captured into a hipGraph at the first call and replayed: every

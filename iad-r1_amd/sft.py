@@ -5,6 +5,7 @@ decay on >=2-D parameters (HF Trainer parameter groups)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
+from typing import Callable, Optional
 
 import numpy as np
 import torch
@@ -27,6 +28,30 @@ class SFTArgs:
     max_grad_norm: float = 1.0
     gradient_accumulation_steps: int = 1
     micro_batch_seqs: int = 16
+    frozen: Optional[Callable[[str], bool]] = None      # parameter-store names that do not train (frozen_parameter_rule); None: everything trains
+
+
+# Families the reference's LLaMA-Factory registers as composite models (model/model_utils/visual.py:236-288), by HF `model_type`.  For these -- and only
+# these -- full fine-tuning freezes the vision tower and the projector unless told otherwise (hparams/finetuning_args.py:416-423: both default to True;
+# no launch script overrides them).  `qwen2_5_vl` and `llava_onevision` are NOT registered there: their whole model trains.
+_COMPOSITE = ("qwen2_vl", "llava", "llava_next")
+
+
+def frozen_parameter_rule(model_type: str, freeze_vision_tower: bool = True, freeze_multi_modal_projector: bool = True) -> Optional[Callable[[str], bool]]:
+    """Which tensors of the parameter store PA-SFT leaves untouched: `_setup_full_tuning` (llamafactory/model/adapter.py:39-55) clears requires_grad of every
+    parameter whose name contains a key of `get_forbidden_modules` (model_utils/visual.py:153-171) -- qwen2_vl: `visual.patch_embed`, `visual.blocks` (tower),
+    `visual.merger` (projector); llava / llava_next: `vision_tower`, `multi_modal_projector` (`image_newline` and the language model train).  Restated on the
+    store's names (tower: visual.patch_embed*, visual.blocks.*, visual.pos, visual.cls, visual.pre_ln*; projector: visual.merger.*); pinned to the reference's
+    function by tests/golden/sft_freeze.json."""
+    if model_type not in _COMPOSITE or not (freeze_vision_tower or freeze_multi_modal_projector):
+        return None
+    tower = ("visual.patch_embed", "visual.blocks.", "visual.pos", "visual.cls", "visual.pre_ln")
+
+    def frozen(name: str) -> bool:
+        if name.startswith("visual.merger."):
+            return freeze_multi_modal_projector
+        return freeze_vision_tower and name.startswith(tower)
+    return frozen
 
 
 class SFTEngine:
@@ -39,6 +64,15 @@ class SFTEngine:
         self.accum = 0
         self.norm2 = torch.zeros(1, dtype=F32, device=self.dev)
         self.norm_scratch = torch.zeros(2048, dtype=F32, device=self.dev)
+        # frozen tensors: no optimizer visit, and no backward work that only they would need
+        fz = args.frozen
+        vis = [n for n in params.slots if n.startswith("visual.")]
+        self.segments = params.optimizer_segments(fz)
+        self.frozen_ranges = params.frozen_ranges(fz) if fz is not None else []
+        live = [n for n in vis if fz is None or not fz(n)]
+        # "all": the tower / projector backward runs; "newline": only the row the any-resolution packing inserts trains (LLaVA-NeXT with a frozen tower and
+        # projector), its gradient needs the transposed packing map alone; "none": the image embeddings are constants of the step
+        self.vision_grads = "all" if any(n != "visual.newline" for n in live) else ("newline" if live else "none")
 
     def loss_and_grads(self, batch, backward=True, num_items_in_batch=None, last_micro_step=True):
         """batch: input_ids, attention_mask, labels [B,S] (numpy), pixel_values [n,patch_dim], image_grid_thw [n_img,3],
@@ -47,7 +81,7 @@ class SFTEngine:
         ids, mask, labels = (np.asarray(batch[k]) for k in ("input_ids", "attention_mask", "labels"))
         B, S = ids.shape
         grids, plan_v, px, rows = e.vision_inputs(batch)
-        img, vctx = e.vision_forward(px, plan_v, save=backward)
+        img, vctx = e.vision_forward(px, plan_v, save=backward and self.vision_grads == "all")
         ipr = batch.get("images_per_row") or [1] * B
         gpr, off, k = [], [], 0
         for n in ipr:
@@ -58,7 +92,7 @@ class SFTEngine:
         tgt = np.full((B, S), -100, dtype=np.int64)
         tgt[:, :-1] = labels[:, 1:]
         n_items = int((tgt != -100).sum()) if num_items_in_batch is None else int(num_items_in_batch)
-        dimg32 = torch.zeros(img.shape, dtype=F32, device=self.dev) if backward else None
+        dimg32 = torch.zeros(img.shape, dtype=F32, device=self.dev) if (backward and self.vision_grads != "none") else None
         total = torch.zeros((), dtype=F32, device=self.dev)
         mb = max(1, min(self.args.micro_batch_seqs, B))
         starts = list(range(0, B, mb))
@@ -79,7 +113,10 @@ class SFTEngine:
                 hook = self.reducer.layer_ready if (last_micro_step and si == len(starts) - 1) else None
                 e.text_backward(dhf, ctx, dimg32, layer_done=hook)
         if backward:
-            e.vision_backward(ops.f32_bias_to_bf16(dimg32, None), vctx)
+            if self.vision_grads == "all":
+                e.vision_backward(ops.f32_bias_to_bf16(dimg32, None), vctx)
+            elif self.vision_grads == "newline":
+                e.vision_backward(ops.f32_bias_to_bf16(dimg32, None), {"plan": plan_v}, only_newline=True)
             self.accum += 1
             if last_micro_step:
                 # a slice without supervised tokens ran no backward and fired no hook: send the layer buckets it skipped now, in the same order,
@@ -92,12 +129,14 @@ class SFTEngine:
         self.reducer.finish()
         self.opt_step += 1
         scale = 1.0 / (self.reducer.world * max(1, self.accum))
-        hip.call("sumsq", st.grad, st.n_total, self.norm_scratch, self.norm2)
+        if self.vision_grads == "all":
+            for lo, hi in self.frozen_ranges:      # a partly frozen vision side: the backward wrote gradients of frozen tensors too; they count in no norm and no update
+                st.grad[lo:hi].zero_()
+        hip.call("sumsq", st.grad, st.n_total, self.norm_scratch, self.norm2)      # (frozen ranges hold zeros)
         self.grad_scale = scale          # grad_norm() = sqrt(norm2) * scale: the norm of the averaged gradient, before clipping (HF's `grad_norm` log key)
-        for lo, hi, wd in ((0, st.n_decay, a.weight_decay), (st.n_decay, st.n_total, 0.0)):
-            if hi > lo:
-                hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,
-                         a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd, self.opt_step, scale, self.norm2, a.max_grad_norm)
+        for lo, hi, decays in self.segments:
+            hip.call("adamw_flat", st.master[lo:hi], st.m[lo:hi], st.v[lo:hi], st.grad[lo:hi], st.flat[lo:hi], hi - lo, a.learning_rate,
+                     a.adam_beta1, a.adam_beta2, a.adam_epsilon, a.weight_decay if decays else 0.0, self.opt_step, scale, self.norm2, a.max_grad_norm)
         st.refresh_shadows()
         self.accum = 0
 

@@ -464,7 +464,7 @@ class Engine:
             ctx.update(feat=featp, z=z, ga=ga, plan=plan)
         return out, ctx
 
-    def _vision_backward_siglip(self, d_out, ctx):
+    def _vision_backward_siglip(self, d_out, ctx, only_newline=False):
         c, P = self.cfg, self.p
         vh, nh, dp, H = c.v_hidden, c.v_heads, c.v_head_pad, c.hidden_size
         plan: SiglipPlan = ctx["plan"]
@@ -479,6 +479,8 @@ class Engine:
             dsrc = ops.rows_gather_sum(d_out.contiguous(), plan.pack_t[0], plan.pack_t[1], n_pe + 1, weights=plan.pack_t[2])
             ops.colsum_acc(dsrc[n_pe: n_pe + 1], P.g("visual.newline"))
             dmo = dsrc[:n_pe]
+        if only_newline:
+            return
         ops.colsum_acc(dmo, P.g("visual.merger.fc2.b"))
         dga = ops.gemm_nt(dmo, P.wT("visual.merger.fc2.w"))
         self._wgrad("visual.merger.fc2.w", dmo, ctx["ga"])
@@ -617,11 +619,14 @@ class Engine:
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
-    def vision_backward(self, d_out: torch.Tensor, ctx):
-        """d_out: [N/m2, H] bf16 gradient of the merged image embeds (raster order)."""
+    def vision_backward(self, d_out: torch.Tensor, ctx, only_newline: bool = False):
+        """d_out: [N/m2, H] bf16 gradient of the merged image embeds (raster order).
+        only_newline (PA-SFT of the any-resolution LLaVA families with a frozen tower and projector, sft.frozen_parameter_rule): the one trainable tensor of the
+        vision side is the row the packing inserts; its gradient needs ctx["plan"] alone."""
         c, P = self.cfg, self.p
         if c.is_llava:
-            return self._vision_backward_siglip(d_out, ctx)
+            return self._vision_backward_siglip(d_out, ctx, only_newline)
+        assert not only_newline
         vh, nh, d, m2 = c.v_hidden, c.v_heads, c.v_head_dim, c.v_merge**2
         plan: VisionPlan = ctx["plan"]
         N = plan.n_patches

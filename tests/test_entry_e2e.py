@@ -278,6 +278,14 @@ def test_llava15_and_next_entry_points_end_to_end(tmp_path, monkeypatch, capsys,
     assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
     cfg3, s3 = load_checkpoint(out_sft, DEV, trainable=False)
     assert cfg3 == cfg and not torch.equal(s3.flat, s0.flat) and bool(torch.isfinite(s3.flat.float()).all())
+    # the reference's PA-SFT of these two registered families trains the language model (and `image_newline`) with the CLIP tower and the projector frozen
+    # (LLaMA-Factory defaults, tests/golden/sft_freeze.json)
+    for n in s3.slots:
+        same = torch.equal(s3.w(n), s0.w(n))
+        if n.startswith("visual.") and n != "visual.newline":
+            assert same, n
+        elif len(s3.slots[n].shape) >= 2:
+            assert not same, n
 
 
 def test_evaluation_script_end_to_end(tmp_path, offline_processor, monkeypatch):

@@ -193,6 +193,60 @@ def test_reward_model_as_reward_function_matches_the_reference():
     np.testing.assert_allclose(got[:, 1], g["rewards_per_func"][:, 1], rtol=1e-5, atol=1e-6)
 
 
+def test_pa_sft_frozen_parameter_rule_matches_the_reference():
+    """iadr1_amd.sft.frozen_parameter_rule vs tests/golden/sft_freeze.json -- the output of the reference's own get_forbidden_modules + the name test of
+    _setup_full_tuning (llamafactory/model/model_utils/visual.py:153-171, model/adapter.py:39-55) on the HF parameter names of the tiny fixture models, for the
+    default flags (what every launch script runs) and the three other vision-tower / projector combinations.  A store tensor is frozen iff every HF parameter
+    it is built from is frozen (fused q|k|v, gate|up: all members fall on the same side)."""
+    import torch
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.params import ParamStore, VLMConfig
+    from iadr1_amd.sft import frozen_parameter_rule
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "sft_freeze.json")))["cases"]
+    fixtures = {"qwen2_vl": (fx.TINY_Q2, fx.make_weights), "qwen2_5_vl": (fx.TINY, fx.make_weights), "llava_onevision": (fx.TINY_OV, fx.make_weights_ov),
+                "llava": (fx.TINY_LLAVA15, fx.make_weights_llava), "llava_next": (fx.TINY_LLAVA_NEXT, fx.make_weights_llava)}
+    seen = set()
+    for c in cases:
+        fl = c["flags"]
+        if fl["train_mm_proj_only"]:
+            continue            # (refused by the entry point: what it freezes follows the transformers version's parameter naming)
+        mt = c["model_type"]
+        seen.add(mt)
+        rule = frozen_parameter_rule(mt, fl["freeze_vision_tower"], fl["freeze_multi_modal_projector"])
+        cfgd, mk = fixtures[mt]
+        cfg = VLMConfig.from_dict(cfgd)
+        store = ParamStore(cfg, torch.device("cpu"), trainable=False, with_decode_pack=False)
+        # frozen HF names of the golden, normalised to the classic checkpoint naming the fixtures use
+        def norm(n):
+            n = n[len("model."):] if n.startswith(("model.visual.", "model.vision_tower.", "model.multi_modal_projector.", "model.image_newline")) else n
+            return "model." + n[len("model.language_model."):] if n.startswith("model.language_model.") else n
+        frozen_hf = {norm(n) for n in c["frozen"]}
+        if rule is None:
+            assert not frozen_hf, (mt, fl)
+            continue
+        fz_store = {n for n in store.slots if rule(n)}
+        vis_store = {n for n in store.slots if n.startswith("visual.")}
+        assert fz_store <= vis_store
+        tower = {n for n in vis_store if not n.startswith("visual.merger.") and n != "visual.newline"}
+        proj = {n for n in vis_store if n.startswith("visual.merger.")}
+        assert fz_store == (tower if fl["freeze_vision_tower"] else set()) | (proj if fl["freeze_multi_modal_projector"] else set())
+        # the same partition on the reference's side: every frozen HF name belongs to the tower / projector, the language model and image_newline never do
+        keys = {"qwen2_vl": (("visual.patch_embed", "visual.blocks"), ("visual.merger",))}.get(mt, (("vision_tower",), ("multi_modal_projector",)))
+        for n in frozen_hf:
+            assert any(k in n for k in keys[0] + keys[1]), n
+        assert bool(fz_store & tower) == any(any(k in n for k in keys[0]) for n in frozen_hf)
+        assert bool(fz_store & proj) == any(any(k in n for k in keys[1]) for n in frozen_hf)
+        assert not any("image_newline" in n or "lm_head" in n or "embed_tokens" in n for n in frozen_hf)
+    assert seen == set(fixtures)
+    # the entry point: defaults as LLaMA-Factory's, --train_mm_proj_only refused
+    m = _load("train/stage_sft/train.py")
+    a = m.build_parser().parse_args(["--model_name_or_path", "/m", "--dataset", "d", "--output_dir", "o"])
+    assert a.freeze_vision_tower is True and a.freeze_multi_modal_projector is True and a.train_mm_proj_only is False
+    a = m.build_parser().parse_args(["--model_name_or_path", "/m", "--dataset", "d", "--output_dir", "o", "--freeze_vision_tower", "false"])
+    assert a.freeze_vision_tower is False
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it."""
     import re

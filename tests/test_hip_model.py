@@ -447,6 +447,56 @@ def test_qwen2vl_variant_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-2, atol=2e-2)
 
 
+def test_pa_sft_default_freezes_vision_tower_and_projector_like_the_reference(golden_dir):
+    """The reference's PA-SFT of a registered composite family (Qwen2-VL = BASELINE config 1) runs with LLaMA-Factory's defaults: vision tower and projector
+    frozen (tests/golden/sft_freeze.json from its own get_forbidden_modules).  3-step AdamW curve, gradient norms and selected tensors after the steps vs a tiny HF
+    Qwen2VLForConditionalGeneration with exactly that trainable set (tests/golden/qwen2vl_sft_frozen.npz); frozen tensors must come back bit-identical."""
+    from iadr1_amd.sft import frozen_parameter_rule
+    g0, g = load(golden_dir, "qwen2vl_sft.npz"), load(golden_dir, "qwen2vl_sft_frozen.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = VLMConfig.from_dict(fx.TINY_Q2)
+    w = fx.make_weights(fx.TINY_Q2, 0)
+    p = ParamStore(cfg, DEV, trainable=True)
+    p.load_named(w)
+    rule = frozen_parameter_rule("qwen2_vl")
+    eng = SFTEngine(cfg, p, SFTArgs(learning_rate=meta["lr"], weight_decay=meta["wd"], max_grad_norm=0.0, frozen=rule))
+    assert eng.vision_grads == "none" and all(rule(n) == n.startswith("visual.") for n in p.slots)
+    batch = {k: g0[k] for k in ("input_ids", "attention_mask", "labels", "pixel_values")}
+    batch["image_grid_thw"] = [tuple(int(z) for z in r) for r in g0["image_grid_thw"]]
+    losses, norms = [], []
+    for _ in range(3):
+        losses.append(eng.loss_and_grads(batch))
+        eng.optimizer_step()
+        norms.append(eng.grad_norm())
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=8e-2)
+    back = p.export_named()
+    for k, v in w.items():
+        moved = not np.array_equal(back[k].numpy(), v.reshape(back[k].shape))
+        assert moved == (not k.startswith("visual.")), k                        # frozen: untouched, not even by weight decay; everything else moved
+    for k in (f for f in g.files if f.startswith("after::")):
+        want = g[k]
+        got = back[k[7:]].numpy().reshape(want.shape)
+        # three Adam steps move an element by <= 3 lr; where the bf16 gradient of a near-zero element has the other sign than the fp32 one, twice that apart
+        # (+ the bf16 rounding of the exported parameter)
+        assert np.abs(got - want).max() <= 2 * 3 * meta["lr"] + np.abs(want).max() * 2.0 ** -8, k
+    # both unfrozen: the whole model trains and this is the unfrozen golden's curve
+    p2 = ParamStore(cfg, DEV, trainable=True)
+    p2.load_named(w)
+    assert frozen_parameter_rule("qwen2_vl", False, False) is None and frozen_parameter_rule("qwen2_5_vl") is None and frozen_parameter_rule("llava_onevision") is None
+    # projector trained, tower frozen: the vision backward runs, the tower's gradients are discarded
+    eng3 = SFTEngine(cfg, p2, SFTArgs(learning_rate=meta["lr"], weight_decay=meta["wd"], max_grad_norm=1.0, frozen=frozen_parameter_rule("qwen2_vl", True, False)))
+    assert eng3.vision_grads == "all"
+    eng3.loss_and_grads(batch)
+    eng3.optimizer_step()
+    back3 = p2.export_named()
+    for k, v in w.items():
+        moved = not np.array_equal(back3[k].numpy(), v.reshape(back3[k].shape))
+        fz = k.startswith("visual.patch_embed") or k.startswith("visual.blocks.")
+        assert not (fz and moved), k
+        assert moved or fz or v.ndim < 2, k          # (one step of 1e-3 on a gain near 1 stays inside its bf16 rounding interval: matrices must move)
+
+
 def test_eval_harness_greedy_generator_matches_hf_generate(golden_dir):
     """iadr1_amd.evaluate.GreedyGenerator (the eval scripts' decoding path, G = 1) reproduces HF `generate(do_sample=False)` token ids."""
     from iadr1_amd.evaluate import GreedyGenerator

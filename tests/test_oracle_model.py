@@ -189,6 +189,38 @@ def test_qwen2vl_variant(golden_dir):
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
 
 
+def test_qwen2vl_pa_sft_with_the_reference_trainable_set(golden_dir):
+    """PA-SFT as the reference runs it for a registered composite family: vision tower + projector frozen (LLaMA-Factory defaults; tests/golden/sft_freeze.json).
+    Oracle 3-step AdamW curve and gradient norms over exactly the golden's trainable tensors vs the tiny HF model (tests/golden/qwen2vl_sft_frozen.npz)."""
+    g0, g = _load(golden_dir, "qwen2vl_sft.npz"), _load(golden_dir, "qwen2vl_sft_frozen.npz")
+    meta = json.loads(str(g["meta"]))
+    cfg = fx.TINY_Q2
+    m = oq.Qwen25VLOracle(cfg, fx.make_weights(cfg, 0), requires_grad=True)
+    frozen = {n[len("model."):] if n.startswith("model.visual.") else n for n in meta["frozen_hf_names"]}
+    params = {k: p for k, p in dict(m.parameters()).items()}
+    assert frozen and frozen <= set(params) and all(k.startswith("visual.") for k in frozen) and all(k in frozen for k in params if k.startswith("visual."))
+    train = {k: p for k, p in params.items() if k not in frozen}
+    for k in frozen:
+        params[k].requires_grad_(False)
+    grids = [tuple(int(z) for z in r) for r in g0["image_grid_thw"]]
+    ids, mask, labels = (torch.from_numpy(g0[k]) for k in ("input_ids", "attention_mask", "labels"))
+    pv = torch.from_numpy(g0["pixel_values"])
+    opt = torch.optim.AdamW([{"params": [p for p in train.values() if p.ndim >= 2], "weight_decay": meta["wd"]},
+                             {"params": [p for p in train.values() if p.ndim < 2], "weight_decay": 0.0}], lr=meta["lr"])
+    losses, norms = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = m.sft_loss(ids, mask, labels, pv, grids)
+        loss.backward()
+        norms.append(float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in train.values()))))
+        opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3)
+    for k in (f for f in g.files if f.startswith("after::")):
+        np.testing.assert_allclose(params[k[7:]].detach().numpy().reshape(g[k].shape), g[k], rtol=2e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize("cfg_name,golden", [("TINY_OV", "llava_ov.npz"), ("TINY_OV64", "llava_ov_hd64.npz")])
 def test_llava_onevision_forward(golden_dir, cfg_name, golden):
     """(second case: 64-wide decoder heads, the Qwen2-0.5B structure of LLaVA-OneVision-0.5B)  oracle/llava_ov.py (SigLIP tower, projector, any-resolution packing incl. the bilinear shrink, Qwen2 decoder) vs a tiny HF

@@ -46,6 +46,11 @@ def build_parser():
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--disable_shuffling", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     p.add_argument("--micro_batch_seqs", type=int, default=16)
+    # llamafactory hparams/finetuning_args.py:416-427 (defaults kept: no launch script passes them, so the registered families train with a frozen tower + projector)
+    tf = lambda v: str(v).lower() in ("1", "true", "yes")
+    p.add_argument("--freeze_vision_tower", nargs="?", const=True, default=True, type=tf)
+    p.add_argument("--freeze_multi_modal_projector", nargs="?", const=True, default=True, type=tf)
+    p.add_argument("--train_mm_proj_only", nargs="?", const=True, default=False, type=tf)
     p.add_argument("--image_resolution", type=int, default=512 * 512)
     p.add_argument("--resume_from_checkpoint", default=None, help="checkpoint-N directory with a training state; default: the last one under output_dir unless --overwrite_output_dir")
     p.add_argument("--train_on_prompt", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
@@ -139,15 +144,24 @@ def main(argv=None):
     import iadr1_amd  # noqa: F401
     from transformers import AutoProcessor
 
-    from iadr1_amd.sft import SFTArgs, SFTEngine
+    from iadr1_amd.sft import SFTArgs, SFTEngine, frozen_parameter_rule
     from iadr1_amd.trainer import last_checkpoint, load_checkpoint, load_training_state, save_checkpoint, save_training_state
 
     cfg, store = load_checkpoint(a.model_name_or_path, dev, trainable=True)
     if cfg.llava_family != TEMPLATE_FAMILY[a.template]:
         raise ValueError(f"--template {a.template} does not belong to the model family of {a.model_name_or_path}")
     proc = AutoProcessor.from_pretrained(a.model_name_or_path)
+    if a.train_mm_proj_only:
+        raise ValueError("--train_mm_proj_only: not part of this path (no launch script uses it; the reference's rule matches parameter NAMES against 'model' / "
+                         "'language_model', so what it freezes depends on the transformers version's naming)")
+    with open(os.path.join(a.model_name_or_path, "config.json")) as f:
+        model_type = json.load(f).get("model_type")
+    frozen = frozen_parameter_rule(model_type, a.freeze_vision_tower, a.freeze_multi_modal_projector)
+    if frozen is not None and rank == 0:
+        n_fz = sum(1 for n in store.slots if frozen(n))
+        print(f"[pa-sft] model_type {model_type}: {n_fz} of {len(store.slots)} parameter tensors frozen (vision tower: {a.freeze_vision_tower}, projector: {a.freeze_multi_modal_projector})", flush=True)
     eng = SFTEngine(cfg, store, SFTArgs(learning_rate=a.learning_rate, weight_decay=a.weight_decay, max_grad_norm=a.max_grad_norm,
-                                        gradient_accumulation_steps=a.gradient_accumulation_steps, micro_batch_seqs=a.micro_batch_seqs), group=group)
+                                        gradient_accumulation_steps=a.gradient_accumulation_steps, micro_batch_seqs=a.micro_batch_seqs, frozen=frozen), group=group)
     from iadr1_amd import schedule
     if a.lr_scheduler_type not in schedule.SCHEDULES:
         raise ValueError(f"--lr_scheduler_type {a.lr_scheduler_type}: supported {schedule.SCHEDULES}")
