@@ -33,7 +33,7 @@ class GRPOConfig:
     the SC-GRPO scripts set (scripts/train/SC_GRPO/*.sh:40-63) or whose defaults matter.  Unknown / unused
     reference flags are accepted by the CLI and ignored."""
     output_dir: str = "outputs"
-    per_device_train_batch_size: int = 1
+    per_device_train_batch_size: int = 8     # (transformers TrainingArguments; every launch script passes 1)
     gradient_accumulation_steps: int = 1
     num_generations: int = 8
     max_prompt_length: Optional[int] = 512
@@ -48,10 +48,10 @@ class GRPOConfig:
     max_grad_norm: float = 1.0
     lr_scheduler_type: str = "linear"
     warmup_steps: int = 0
-    num_train_epochs: float = 1.0
+    num_train_epochs: float = 3.0       # (transformers TrainingArguments; the launch scripts do not override it)
     max_steps: int = -1
-    logging_steps: int = 1
-    save_steps: int = 100
+    logging_steps: int = 500
+    save_steps: int = 500
     seed: int = 42
     bf16: bool = True
     gradient_checkpointing: bool = False   # accepted; 288 GB HBM holds the activations of a micro-batch, nothing is recomputed

@@ -247,6 +247,27 @@ def test_pa_sft_frozen_parameter_rule_matches_the_reference():
     assert a.freeze_vision_tower is False
 
 
+def test_entry_point_defaults_are_the_references():
+    """Flags a launch script does not pass take the reference's defaults: transformers TrainingArguments (SC-GRPO inherits them through trl's GRPOConfig; its
+    scripts pass no --num_train_epochs, so the reference trains THREE epochs with the linear schedule laid over all of them) and LLaMA-Factory's
+    DataArguments / ModelArguments (hparams/data_args.py:41-57, model_args.py:62)."""
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.trainer import GRPOConfig
+    rl = _load("train/stage_rl/grpo_ad.py").build_parser().parse_args(["--model_name_or_path", "/m", "--output_dir", "o", "--dataset_name", "d.json"])
+    want_rl = dict(num_train_epochs=3.0, per_device_train_batch_size=8, gradient_accumulation_steps=1, learning_rate=1e-6, weight_decay=0.0, max_grad_norm=1.0,
+                   lr_scheduler_type="linear", warmup_steps=0, logging_steps=500, save_steps=500, seed=42, max_steps=-1, num_generations=8, max_prompt_length=512,
+                   max_completion_length=256, beta=0.04, temperature=0.9)
+    for k, v in want_rl.items():
+        assert getattr(rl, k) == v, (k, getattr(rl, k))
+        assert getattr(GRPOConfig(), k) == v, (k, getattr(GRPOConfig(), k))
+    sft = _load("train/stage_sft/train.py").build_parser().parse_args(["--model_name_or_path", "/m", "--dataset", "d", "--output_dir", "o"])
+    want_sft = dict(num_train_epochs=3.0, per_device_train_batch_size=8, gradient_accumulation_steps=1, learning_rate=5e-5, weight_decay=0.0, max_grad_norm=1.0,
+                    lr_scheduler_type="linear", warmup_steps=0, logging_steps=500, save_steps=500, seed=42, max_steps=-1, cutoff_len=2048, dataset_dir="data",
+                    image_resolution=512 * 512, train_on_prompt=False, mask_history=False, freeze_vision_tower=True, freeze_multi_modal_projector=True)
+    for k, v in want_sft.items():
+        assert getattr(sft, k) == v, (k, getattr(sft, k))
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it."""
     import re

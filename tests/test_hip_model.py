@@ -247,7 +247,7 @@ def test_trainer_api_runs_two_optimizer_steps():
     rows = [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "q"}]}], "image": [object()],
              "solution": "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"}] * 4
     cfgT = GRPOConfig(output_dir="/tmp/iadr1_trainer_test", num_generations=4, max_completion_length=8, max_prompt_length=4096, learning_rate=1e-3,
-                      gradient_accumulation_steps=2, max_steps=2, save_steps=0)
+                      per_device_train_batch_size=1, gradient_accumulation_steps=2, max_steps=2, logging_steps=1, save_steps=0)
     tr = SCGRPOTrainer((CFG, fx.make_weights(fx.TINY, 0)), [rewards.accuracy_reward, rewards.consistency_reward], args=cfgT, train_dataset=rows,
                        processing_class=_FakeProcessor(batch, texts))
     before = tr.policy.flat.clone()
@@ -1041,7 +1041,7 @@ def test_llava_onevision_through_the_trainer_api_and_checkpoint_roundtrip(tmp_pa
 
     tr = SCGRPOTrainer(src, [rewards.accuracy_reward, rewards.consistency_reward, text_checksum_reward],
                        args=GRPOConfig(output_dir=out_dir, num_generations=4, max_completion_length=8, max_prompt_length=None, learning_rate=1e-3, per_device_train_batch_size=2,
-                                       max_steps=1, save_steps=0, shuffle=False),
+                                       max_steps=1, logging_steps=1, save_steps=0, shuffle=False),
                        train_dataset=rows, processing_class=proc)
     assert tr.cfg.is_llava and proc.tokenizer.padding_side == "left"
     before = tr.policy.flat.clone()
@@ -1324,7 +1324,7 @@ def test_trainer_level_traced_path_with_gradient_accumulation():
         pol = ParamStore(cfg, DEV, trainable=True)
         pol.init_random(seed=0)
         tr = SCGRPOTrainer((cfg, pol), [token_reward], args=GRPOConfig(output_dir="/tmp/iadr1_traced_test", num_generations=G, max_completion_length=C, max_prompt_length=None,
-                                                                        per_device_train_batch_size=Bp, gradient_accumulation_steps=2, learning_rate=1e-4, max_steps=2, save_steps=0,
+                                                                        per_device_train_batch_size=Bp, gradient_accumulation_steps=2, learning_rate=1e-4, max_steps=2, logging_steps=1, save_steps=0,
                                                                         shuffle=False, micro_batch_seqs=64, seed=7),
                            train_dataset=rows, processing_class=Proc(batch, None))
         tr.engine.args.reuse_decode = reuse

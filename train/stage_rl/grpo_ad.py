@@ -68,9 +68,10 @@ def build_parser():
     p.add_argument("--model_name_or_path", required=True)
     p.add_argument("--attn_implementation", default="flash_attention_2")
     p.add_argument("--torch_dtype", default=None)
-    # GRPOConfig / TrainingArguments subset
+    # GRPOConfig / TrainingArguments subset; defaults = theirs (trl/trl/trainer/grpo_config.py, transformers TrainingArguments: 3 epochs, batch 8, logging / saving every 500
+    # steps, linear schedule without warm-up) -- the launch scripts do NOT pass --num_train_epochs, so the reference runs three epochs
     p.add_argument("--output_dir", required=True)
-    p.add_argument("--per_device_train_batch_size", type=int, default=1)
+    p.add_argument("--per_device_train_batch_size", type=int, default=8)
     p.add_argument("--gradient_accumulation_steps", type=int, default=1)
     p.add_argument("--num_generations", type=int, default=8)
     p.add_argument("--max_prompt_length", type=int, default=512)
@@ -82,10 +83,10 @@ def build_parser():
     p.add_argument("--max_grad_norm", type=float, default=1.0)
     p.add_argument("--lr_scheduler_type", default="linear")
     p.add_argument("--warmup_steps", type=int, default=0)
-    p.add_argument("--num_train_epochs", type=float, default=1.0)
+    p.add_argument("--num_train_epochs", type=float, default=3.0)
     p.add_argument("--max_steps", type=int, default=-1)
-    p.add_argument("--logging_steps", type=int, default=1)
-    p.add_argument("--save_steps", type=int, default=100)
+    p.add_argument("--logging_steps", type=int, default=500)
+    p.add_argument("--save_steps", type=int, default=500)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--micro_batch_seqs", type=int, default=64)
     p.add_argument("--decode_weights", default="bf16", choices=["bf16", "fp8"],

@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 def build_parser():
     p = argparse.ArgumentParser(allow_abbrev=False)
+    # defaults = the reference's (transformers TrainingArguments / LLaMA-Factory DataArguments: data_args.py:41-57, model_args.py:62); the launch scripts override most of them
     p.add_argument("--stage", default="sft")
     p.add_argument("--do_train", nargs="?", const=True, default=True)
     p.add_argument("--model_name_or_path", required=True)
@@ -31,17 +32,17 @@ def build_parser():
     p.add_argument("--template", default="qwen2_vl")
     p.add_argument("--finetuning_type", default="full")
     p.add_argument("--output_dir", required=True)
-    p.add_argument("--per_device_train_batch_size", type=int, default=1)
-    p.add_argument("--gradient_accumulation_steps", type=int, default=2)
-    p.add_argument("--learning_rate", type=float, default=1e-5)
-    p.add_argument("--weight_decay", type=float, default=0.1)
-    p.add_argument("--lr_scheduler_type", default="cosine")
-    p.add_argument("--warmup_steps", type=int, default=100)
-    p.add_argument("--num_train_epochs", type=float, default=1.0)
+    p.add_argument("--per_device_train_batch_size", type=int, default=8)
+    p.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    p.add_argument("--learning_rate", type=float, default=5e-5)
+    p.add_argument("--weight_decay", type=float, default=0.0)
+    p.add_argument("--lr_scheduler_type", default="linear")
+    p.add_argument("--warmup_steps", type=int, default=0)
+    p.add_argument("--num_train_epochs", type=float, default=3.0)
     p.add_argument("--max_steps", type=int, default=-1)
-    p.add_argument("--cutoff_len", type=int, default=4096)
+    p.add_argument("--cutoff_len", type=int, default=2048)
     p.add_argument("--max_grad_norm", type=float, default=1.0)
-    p.add_argument("--logging_steps", type=int, default=1)
+    p.add_argument("--logging_steps", type=int, default=500)
     p.add_argument("--save_steps", type=int, default=500)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--disable_shuffling", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
