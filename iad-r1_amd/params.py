@@ -386,14 +386,19 @@ class ParamStore:
                 add("visual.newline", (H,), True, False)
         else:
             add("visual.patch_embed", (vh, c.patch_dim), True, True)
+        # Weight-decay group = transformers.Trainer.get_decay_parameter_names (both trainers of the reference create their optimizer through it): parameters of
+        # nn.LayerNorm modules and names matching bias / layernorm / rmsnorm / .norm. / _norm. are exempt, everything else decays -- including the RMSNorm gains of
+        # the Qwen2.5-VL vision tower (`norm1`, `norm2`, `merger.ln_q`: a Qwen2RMSNorm under names the patterns miss), `image_newline` and CLIP's
+        # `class_embedding`.  Pinned per family by tests/golden/sft_freeze.json (decay_parameters).
+        rms_gain_decays = not q2
         for i in range(0 if c.is_llava else c.v_depth):
             b = f"visual.blocks.{i}."
-            add(b + "norm1", (vh,), False, False)
+            add(b + "norm1", (vh,), rms_gain_decays, False)
             add(b + "qkv.w", (3 * vh, vh), True, True)
             add(b + "qkv.b", (3 * vh,), False, False)
             add(b + "proj.w", (vh, vh), True, True)
             add(b + "proj.b", (vh,), False, False)
-            add(b + "norm2", (vh,), False, False)
+            add(b + "norm2", (vh,), rms_gain_decays, False)
             if q2:
                 add(b + "norm1.b", (vh,), False, False)
                 add(b + "norm2.b", (vh,), False, False)
@@ -408,7 +413,7 @@ class ParamStore:
             add(b + "down.b", (vh,), False, False)
         mu = c.v_merge**2
         if not c.is_llava:
-            add("visual.merger.ln_q", (vh,), False, False)
+            add("visual.merger.ln_q", (vh,), rms_gain_decays, False)
             if q2:
                 add("visual.merger.ln_q.b", (vh,), False, False)
             add("visual.merger.fc1.w", (vh * mu, vh * mu), True, True)

@@ -247,6 +247,49 @@ def test_pa_sft_frozen_parameter_rule_matches_the_reference():
     assert a.freeze_vision_tower is False
 
 
+def test_weight_decay_group_is_the_hf_trainers():
+    """Both trainers of the reference build their optimizer in transformers.Trainer.create_optimizer: the weight-decay group is get_decay_parameter_names(model)
+    (tests/golden/sft_freeze.json: decay_parameters, from the installed transformers on the tiny HF models of all five families).  Every tensor of the parameter
+    store must sit on the same side as the HF parameters it is built from -- e.g. the RMSNorm gains of the Qwen2.5-VL vision tower DO decay (their names escape
+    HF's norm patterns), image_newline and CLIP's class embedding do, LayerNorm gains and every bias do not."""
+    import numpy as np
+    import torch
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.params import ParamStore, VLMConfig
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "sft_freeze.json")))
+    fixtures = {"qwen2_vl": fx.TINY_Q2, "qwen2_5_vl": fx.TINY, "llava_onevision": fx.TINY_OV, "llava": fx.TINY_LLAVA15, "llava_next": fx.TINY_LLAVA_NEXT}
+
+    def norm(n):            # checkpoint naming differs between transformers generations (model.language_model.layers / language_model.model.layers / model.layers ...)
+        while n.startswith(("model.", "language_model.")):
+            n = n.split(".", 1)[1]
+        return n.replace("vision_tower.vision_model.", "vision_tower.")
+    for mt, cfgd in fixtures.items():
+        cfg = VLMConfig.from_dict(cfgd)
+        store = ParamStore(cfg, torch.device("cpu"), trainable=False, with_decode_pack=False, with_transposes=False)
+        slots = sorted(store.slots.values(), key=lambda s: s.offset)
+        assert len(slots) < 250
+        store.flat.zero_()
+        for i, sl in enumerate(slots):          # every element of slot i holds i + 1 (exact in bf16 below 256)
+            store.w(sl.name).fill_(float(i + 1))
+        exported = store.export_named()
+        canon = {k: v for k, v in exported.items()}
+        decay_hf = {norm(n) for n in d["decay_parameters"][mt]}
+        all_hf = {norm(n) for n in d["parameters"][mt]}
+        seen = set()
+        for name, t in canon.items():
+            key = norm(name)
+            ids = {int(v) for v in np.unique(t.float().numpy()) if v != 0}       # (zero: padding rows / lanes of the fused layouts, tensors the store does not hold)
+            if key not in all_hf or not ids:
+                continue
+            assert len(ids) == 1, (mt, name, ids)
+            sl = slots[ids.pop() - 1]
+            assert sl.decay == (key in decay_hf), (mt, name, sl.name, sl.decay)
+            seen.add(sl.name)
+        missing = {sl.name for sl in slots} - seen      # every tensor of the store was placed (bias-free decoders keep an all-zero fused bias row no checkpoint holds)
+        assert all(n.endswith(".qkv.b") and n.startswith("layers.") and not cfg.qkv_bias for n in missing), (mt, sorted(missing))
+
+
 def test_entry_point_defaults_are_the_references():
     """Flags a launch script does not pass take the reference's defaults: transformers TrainingArguments (SC-GRPO inherits them through trl's GRPOConfig; its
     scripts pass no --num_train_epochs, so the reference trains THREE epochs with the linear schedule laid over all of them) and LLaMA-Factory's

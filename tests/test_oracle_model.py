@@ -126,6 +126,18 @@ def test_greedy_rollout_token_ids(golden_dir):
     # full-recompute loop feeds pads back into the context while the cached one does not attend differently: only row 0's prefix is compared)
 
 
+def _hf_groups(golden_dir, model_type, params):
+    """(decay, no_decay) lists of the oracle's parameters as transformers.Trainer forms them for the family's HF model (tests/golden/sft_freeze.json:
+    decay_parameters = Trainer.get_decay_parameter_names; names brought back to the classic checkpoint naming the fixtures use)."""
+    d = json.load(open(os.path.join(golden_dir, "sft_freeze.json")))
+    def norm(n):
+        n = n[len("model."):] if n.startswith("model.visual.") else n
+        return "model." + n[len("model.language_model."):] if n.startswith("model.language_model.") else n
+    names = {norm(n) for n in d["decay_parameters"][model_type]}
+    assert {norm(n) for n in d["parameters"][model_type]} == set(params), sorted(set(params) ^ {norm(n) for n in d["parameters"][model_type]})[:6]
+    return [p for n, p in params.items() if n in names], [p for n, p in params.items() if n not in names]
+
+
 def test_sft_loss_curve(golden_dir):
     g = _load(golden_dir, "sft.npz")
     meta = json.loads(str(g["meta"]))
@@ -135,8 +147,8 @@ def test_sft_loss_curve(golden_dir):
     ids, mask, labels = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels"))
     pv = torch.from_numpy(g["pixel_values"])
     params = dict(m.parameters())
-    decay = [p for n, p in params.items() if p.ndim >= 2]
-    no_decay = [p for n, p in params.items() if p.ndim < 2]
+    decay, no_decay = _hf_groups(golden_dir, "qwen2_5_vl", params)
+    assert any(p.ndim < 2 for p in decay)          # the vision tower's RMSNorm gains decay under HF's name rule
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": meta["wd"]}, {"params": no_decay, "weight_decay": 0.0}], lr=meta["lr"])
     losses = []
     for _ in range(3):
@@ -177,8 +189,8 @@ def test_qwen2vl_variant(golden_dir):
     valid = (mask[:, 1:] * mask[:, :-1]).bool().numpy()
     np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=3e-4)
     params = dict(m.parameters())
-    opt = torch.optim.AdamW([{"params": [p for p in params.values() if p.ndim >= 2], "weight_decay": meta["wd"]},
-                             {"params": [p for p in params.values() if p.ndim < 2], "weight_decay": 0.0}], lr=meta["lr"])
+    decay, no_decay = _hf_groups(golden_dir, "qwen2_vl", params)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": meta["wd"]}, {"params": no_decay, "weight_decay": 0.0}], lr=meta["lr"])
     losses = []
     for _ in range(3):
         opt.zero_grad()
@@ -205,8 +217,10 @@ def test_qwen2vl_pa_sft_with_the_reference_trainable_set(golden_dir):
     grids = [tuple(int(z) for z in r) for r in g0["image_grid_thw"]]
     ids, mask, labels = (torch.from_numpy(g0[k]) for k in ("input_ids", "attention_mask", "labels"))
     pv = torch.from_numpy(g0["pixel_values"])
-    opt = torch.optim.AdamW([{"params": [p for p in train.values() if p.ndim >= 2], "weight_decay": meta["wd"]},
-                             {"params": [p for p in train.values() if p.ndim < 2], "weight_decay": 0.0}], lr=meta["lr"])
+    decay, no_decay = _hf_groups(golden_dir, "qwen2_vl", params)
+    keep = {id(p) for p in train.values()}
+    opt = torch.optim.AdamW([{"params": [p for p in decay if id(p) in keep], "weight_decay": meta["wd"]},
+                             {"params": [p for p in no_decay if id(p) in keep], "weight_decay": 0.0}], lr=meta["lr"])
     losses, norms = [], []
     for _ in range(3):
         opt.zero_grad()

@@ -619,6 +619,15 @@ def gen_greedy():
     print("greedy.npz:", out[:, P:].tolist(), "min margin", float((top2[..., 0] - top2[..., 1]).min()))
 
 
+def hf_param_groups(model):
+    """(decay, no_decay) parameter lists exactly as transformers.Trainer.create_optimizer forms them (get_decay_parameter_names of the installed version)."""
+    from transformers import Trainer
+    names = set(Trainer.get_decay_parameter_names(Trainer.__new__(Trainer), model))
+    decay = [p for n, p in model.named_parameters() if n in names and p.requires_grad]
+    no_decay = [p for n, p in model.named_parameters() if n not in names and p.requires_grad]
+    return decay, no_decay
+
+
 def gen_sft():
     """PA-SFT numeric oracle: HF forward(labels) loss + 3 AdamW steps (lr 1e-3 for visible motion,
     wd 0.1 as PA_SFT_*.sh:38-44, betas/eps = torch defaults = HF Trainer defaults)."""
@@ -632,9 +641,7 @@ def gen_sft():
     labels = ids.clone()
     labels[:, : b["input_ids"].shape[1]] = -100  # prompt tokens masked (llamafactory supervised.py:34-87)
     inputs = dict(input_ids=ids, attention_mask=mask, pixel_values=b["pixel_values"], image_grid_thw=b["image_grid_thw"], mm_token_type_ids=(ids == cfg["image_token_id"]).int(), labels=labels)
-    decay, no_decay = [], []
-    for n, p in model.named_parameters():
-        (no_decay if (p.ndim < 2 or "norm" in n or "ln_q" in n or n.endswith(".bias")) else decay).append(p)
+    decay, no_decay = hf_param_groups(model)
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
     losses = []
     for _ in range(3):
@@ -644,7 +651,7 @@ def gen_sft():
         opt.step()
         losses.append(loss.item())
     np.savez_compressed(
-        os.path.join(OUT, "sft.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 11, "lr": 1e-3, "wd": 0.1, "no_decay": "ndim<2 (norm gains, biases)"}),
+        os.path.join(OUT, "sft.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 11, "lr": 1e-3, "wd": 0.1, "no_decay": "transformers.Trainer.get_decay_parameter_names (tests/golden/sft_freeze.json: decay_parameters)"}),
         input_ids=ids.numpy(), attention_mask=mask.numpy(), labels=labels.numpy(), pixel_values=b["pixel_values"].numpy(),
         image_grid_thw=b["image_grid_thw"].numpy(), losses=np.array(losses, dtype=np.float64),
     )
@@ -672,9 +679,7 @@ def gen_qwen2vl(SCGRPOTrainer):
     labels[:, : b["input_ids"].shape[1]] = -100
     inputs = dict(input_ids=ids, attention_mask=mask, pixel_values=b["pixel_values"], image_grid_thw=b["image_grid_thw"], mm_token_type_ids=mm, labels=labels)
     model.train()
-    decay, no_decay = [], []
-    for n, p in model.named_parameters():
-        (no_decay if (p.ndim < 2 or "norm" in n or "ln_q" in n or n.endswith(".bias")) else decay).append(p)
+    decay, no_decay = hf_param_groups(model)
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
     losses = []
     for _ in range(3):

@@ -10,6 +10,7 @@ import importlib.machinery, json, os, sys, types
 
 import numpy as np
 import torch
+from transformers import Trainer  # noqa: F401  (before the peft stub below: transformers probes for the real package)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -82,8 +83,16 @@ def main():
         for fl in FLAGS:
             forb, frozen = frozen_names(mt, names, **fl)
             cases.append({"model_type": mt, "flags": fl, "forbidden_modules": forb, "n_parameters": len(names), "frozen": frozen})
-    json.dump({"meta": {**mg.meta(), "source": "llamafactory/model/model_utils/visual.py:153-171,236-288 + model/adapter.py:39-55 through tools/make_golden_sft_freeze.py"},
-               "cases": cases}, open(os.path.join(OUT, "sft_freeze.json"), "w"), indent=0)
+    # the optimizer's parameter groups: transformers.Trainer.get_decay_parameter_names of the installed version (the weight-decay group; everything else gets 0) --
+    # LLaMA-Factory's CustomSeq2SeqTrainer and trl's GRPOTrainer both fall through to Trainer.create_optimizer
+    decay = {mt: sorted(Trainer.get_decay_parameter_names(Trainer.__new__(Trainer), model)) for mt, model in models.items()}
+    allp = {mt: [n for n, _ in model.named_parameters()] for mt, model in models.items()}
+    json.dump({"meta": {**mg.meta(), "source": "llamafactory/model/model_utils/visual.py:153-171,236-288 + model/adapter.py:39-55 through tools/make_golden_sft_freeze.py; "
+                                              "decay_parameters: transformers.Trainer.get_decay_parameter_names on the tiny fixture models"},
+               "cases": cases, "decay_parameters": decay, "parameters": allp}, open(os.path.join(OUT, "sft_freeze.json"), "w"), indent=0)
+    for mt in decay:
+        nd = [n for n in allp[mt] if n not in set(decay[mt])]
+        print(mt, "decay", len(decay[mt]), "no-decay", len(nd), "| 1-D decayed:", [n for n, p in models[mt].named_parameters() if p.ndim < 2 and n in set(decay[mt])][:6])
     for c in cases:
         print(c["model_type"], c["flags"], c["forbidden_modules"], "frozen", None if c["frozen"] is None else len(c["frozen"]), "of", c["n_parameters"])
 
@@ -98,10 +107,11 @@ def main():
     ids, mask, labels = (torch.from_numpy(g0[k]) for k in ("input_ids", "attention_mask", "labels"))
     inputs = dict(input_ids=ids, attention_mask=mask, pixel_values=torch.from_numpy(g0["pixel_values"]), image_grid_thw=torch.from_numpy(g0["image_grid_thw"]),
                   mm_token_type_ids=(ids == cfg["image_token_id"]).int(), labels=labels)
+    dnames = set(Trainer.get_decay_parameter_names(Trainer.__new__(Trainer), model))
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         if p.requires_grad:
-            (no_decay if (p.ndim < 2 or "norm" in n or "ln_q" in n or n.endswith(".bias")) else decay).append(p)
+            (decay if n in dnames else no_decay).append(p)
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     losses, gnorms = [], []
