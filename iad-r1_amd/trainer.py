@@ -440,6 +440,8 @@ class SCGRPOTrainer:
         sampler = schedule.RankSampler(len(rows), rank, world, seed=a.seed, shuffle=a.shuffle)
         t0 = time.time()
         i = start * bs * ga
+        steps_per_epoch = max(1, schedule.total_steps(len(rows), world, bs, ga, 1.0, -1))
+        window_loss, window_from = 0.0, start
         for step in range(start, total):
             self.engine.args.learning_rate = self._lr(step, total)
             micro = []
@@ -447,9 +449,14 @@ class SCGRPOTrainer:
                 micro.append([rows[sampler.index(i + j)] for j in range(bs)])
                 i += bs
             losses = self.training_step(micro)
+            window_loss += float(np.mean(losses))
             if self.state.global_step % a.logging_steps == 0:
-                self.log({"loss": float(np.mean(losses)), "grad_norm": self.engine.grad_norm(), "learning_rate": self.engine.args.learning_rate, "step": self.state.global_step,
+                # transformers.Trainer._maybe_log_save_evaluate: the mean step loss since the last log line, rounded to 4 places; the scheduler has already stepped,
+                # so `learning_rate` is the NEXT step's; `epoch` = fraction of the data seen
+                self.log({"loss": round(window_loss / (self.state.global_step - window_from), 4), "grad_norm": self.engine.grad_norm(),
+                          "learning_rate": self._lr(step + 1, total), "epoch": round(self.state.global_step / steps_per_epoch, 2), "step": self.state.global_step,
                           "elapsed_s": round(time.time() - t0, 2)})
+                window_loss, window_from = 0.0, self.state.global_step
             if a.save_steps and self.state.global_step % a.save_steps == 0 and rank == 0:
                 ck = os.path.join(a.output_dir, f"checkpoint-{self.state.global_step}")
                 self.save_model(ck)

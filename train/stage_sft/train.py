@@ -183,6 +183,8 @@ def main(argv=None):
         eng.opt_step, start = st["opt_step"], st["global_step"]
         print(f"resuming from {ck} at step {start}", flush=True)
     i, t0 = start * bs * ga, time.time()
+    steps_per_epoch = max(1, schedule.total_steps(len(rows), world, bs, ga, 1.0, -1))
+    window_loss, window_from = 0.0, start
     for step in range(start, total):
         lr = schedule.lr_at(step, total, a.learning_rate, a.warmup_steps, a.lr_scheduler_type)
         eng.args.learning_rate = lr
@@ -208,9 +210,18 @@ def main(argv=None):
                 batch = {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": pv, "image_grid_thw": grids, "images_per_row": [len(e[3]) for e in enc]}
             losses.append(eng.loss_and_grads(batch, last_micro_step=(k == ga - 1)))
         eng.optimizer_step()
-        if log and (step + 1) % a.logging_steps == 0:
-            log.write(json.dumps({"current_steps": step + 1, "total_steps": total, "loss": float(np.mean(losses)), "lr": lr, "elapsed_time": round(time.time() - t0, 1)}) + "\n")
-            log.flush()
+        window_loss += float(np.mean(losses))
+        if (step + 1) % a.logging_steps == 0:
+            # the record LLaMA-Factory's LogCallback writes (train/callbacks.py:279-318) from transformers.Trainer's log line: mean step loss since the last line
+            # (4 places), the scheduler's NEXT learning rate, the epoch fraction, progress
+            if log:
+                el = time.time() - t0
+                rec = {"current_steps": step + 1, "total_steps": total, "loss": round(window_loss / (step + 1 - window_from), 4),
+                       "lr": schedule.lr_at(step + 1, total, a.learning_rate, a.warmup_steps, a.lr_scheduler_type), "epoch": round((step + 1) / steps_per_epoch, 2),
+                       "percentage": round((step + 1) / total * 100, 2), "elapsed_time": round(el, 1), "remaining_time": round(el / (step + 1 - start) * (total - step - 1), 1)}
+                log.write(json.dumps(rec) + "\n")
+                log.flush()
+            window_loss, window_from = 0.0, step + 1
         if rank == 0 and a.save_steps and (step + 1) % a.save_steps == 0:
             save_checkpoint(store, os.path.join(a.output_dir, f"checkpoint-{step + 1}"), json.load(open(os.path.join(a.model_name_or_path, "config.json"))))
             save_training_state(store, os.path.join(a.output_dir, f"checkpoint-{step + 1}"), eng.opt_step, step + 1)
