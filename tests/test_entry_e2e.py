@@ -276,6 +276,10 @@ def test_llava15_and_next_entry_points_end_to_end(tmp_path, monkeypatch, capsys,
                                             "--logging_steps", "1", "--cutoff_len", "4096", "--save_steps", "500", "--num_train_epochs", "1", "--bf16", "--deepspeed", "zero3.json"])
     log = [json.loads(l) for l in open(os.path.join(out_sft, "trainer_log.jsonl"))]
     assert [r["current_steps"] for r in log] == [1, 2] and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in log)
+    assert {"lr", "epoch", "percentage", "total_steps", "elapsed_time", "remaining_time"} <= set(log[-1]) and log[-1]["percentage"] == 100.0 and log[-1]["lr"] == 0.0
+    res, state = json.load(open(os.path.join(out_sft, "train_results.json"))), json.load(open(os.path.join(out_sft, "trainer_state.json")))
+    assert res == json.load(open(os.path.join(out_sft, "all_results.json"))) and abs(res["train_loss"] - np.mean([r["loss"] for r in log])) < 1e-3
+    assert state["global_step"] == 2 and [h["step"] for h in state["log_history"]] == [1, 2, 2]
     cfg3, s3 = load_checkpoint(out_sft, DEV, trainable=False)
     assert cfg3 == cfg and not torch.equal(s3.flat, s0.flat) and bool(torch.isfinite(s3.flat.float()).all())
     # the reference's PA-SFT of these two registered families trains the language model (and `image_newline`) with the CLIP tower and the projector frozen

@@ -185,6 +185,7 @@ def main(argv=None):
     i, t0 = start * bs * ga, time.time()
     steps_per_epoch = max(1, schedule.total_steps(len(rows), world, bs, ga, 1.0, -1))
     window_loss, window_from = 0.0, start
+    run_loss, history = 0.0, []
     for step in range(start, total):
         lr = schedule.lr_at(step, total, a.learning_rate, a.warmup_steps, a.lr_scheduler_type)
         eng.args.learning_rate = lr
@@ -211,6 +212,7 @@ def main(argv=None):
             losses.append(eng.loss_and_grads(batch, last_micro_step=(k == ga - 1)))
         eng.optimizer_step()
         window_loss += float(np.mean(losses))
+        run_loss += float(np.mean(losses))
         if (step + 1) % a.logging_steps == 0:
             # the record LLaMA-Factory's LogCallback writes (train/callbacks.py:279-318) from transformers.Trainer's log line: mean step loss since the last line
             # (4 places), the scheduler's NEXT learning rate, the epoch fraction, progress
@@ -221,6 +223,7 @@ def main(argv=None):
                        "percentage": round((step + 1) / total * 100, 2), "elapsed_time": round(el, 1), "remaining_time": round(el / (step + 1 - start) * (total - step - 1), 1)}
                 log.write(json.dumps(rec) + "\n")
                 log.flush()
+                history.append({"epoch": rec["epoch"], "learning_rate": rec["lr"], "loss": rec["loss"], "step": step + 1})
             window_loss, window_from = 0.0, step + 1
         if rank == 0 and a.save_steps and (step + 1) % a.save_steps == 0:
             save_checkpoint(store, os.path.join(a.output_dir, f"checkpoint-{step + 1}"), json.load(open(os.path.join(a.model_name_or_path, "config.json"))))
@@ -228,6 +231,18 @@ def main(argv=None):
     if rank == 0:
         save_checkpoint(store, a.output_dir, json.load(open(os.path.join(a.model_name_or_path, "config.json"))))
         proc.save_pretrained(a.output_dir)
+        # what run_sft leaves beside the model (llamafactory/train/sft/workflow.py:108-110 -> transformers.Trainer.save_metrics / save_state): the run's metrics and
+        # the log history (`--plot_loss` would draw training_loss.png from the latter; no plotting library here)
+        done = max(1, total - start)
+        runtime = time.time() - t0
+        metrics = {"epoch": round(total / steps_per_epoch, 2), "train_loss": run_loss / done, "train_runtime": round(runtime, 4),
+                   "train_samples_per_second": round(done * bs * ga * world / runtime, 3), "train_steps_per_second": round(done / runtime, 3)}
+        for name in ("train_results.json", "all_results.json"):
+            with open(os.path.join(a.output_dir, name), "w") as f:
+                json.dump(metrics, f, indent=4, sort_keys=True)
+        with open(os.path.join(a.output_dir, "trainer_state.json"), "w") as f:
+            json.dump({"epoch": metrics["epoch"], "global_step": total, "max_steps": total, "logging_steps": a.logging_steps, "save_steps": a.save_steps,
+                       "num_train_epochs": a.num_train_epochs, "train_batch_size": bs, "log_history": history + [{**metrics, "step": total}]}, f, indent=2)
 
 
 if __name__ == "__main__":
