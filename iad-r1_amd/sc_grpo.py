@@ -120,6 +120,8 @@ class GradReducer:
     either way, so the replicas' parameters stay bit-identical.  The bucket sequence depends on the parameter layout only, never on a rank's
     data.  Works on CPU / gloo too (tests)."""
 
+    RING = 3        # bf16 staging buffers of one bucket each: one being cast into, one on the wire, one being cast back
+
     def __init__(self, store: ParamStore, group=None, bucket_bytes: int = 256 << 20, wire: str | None = None):
         import torch.distributed as dist
         self.dist, self.store, self.group = dist, store, group
@@ -131,8 +133,13 @@ class GradReducer:
         self.wire = (wire or os.environ.get("IADR1_REDUCE_DTYPE", "bf16")).lower()
         if self.wire not in ("bf16", "fp32"):
             raise ValueError("IADR1_REDUCE_DTYPE must be bf16 or fp32")
-        self.bucket_elems = max(1, int(bucket_bytes) // (2 if self.wire == "bf16" else 4))
-        self.stage = torch.empty(store.n_total, dtype=BF16, device=store.grad.device) if (self.active and self.wire == "bf16") else None
+        self.bucket_elems = max(1, min(int(bucket_bytes) // (2 if self.wire == "bf16" else 4), store.n_total))
+        # staging: a RING of bucket-sized bf16 buffers (<= 768 MB), not a second copy of the model (16.6 GB at 7B, which the 7B / LLaVA-OneVision
+        # configurations do not have to spare next to 245 GB of training state).  A buffer is reused only after its previous bucket has been cast
+        # back into the fp32 gradient buffer -- stream order on the side stream guarantees it (the cast-back is enqueued before the next cast-in)
+        self.ring = [torch.empty(self.bucket_elems, dtype=BF16, device=store.grad.device) for _ in range(self.RING)] if (self.active and self.wire == "bf16") else None
+        self.pending = [None] * self.RING
+        self.slot = 0
         self.bytes_on_wire = 0          # per step, for the bench line
         self.n_buckets = 0
         c = store.cfg
@@ -145,27 +152,48 @@ class GradReducer:
         self.first_layer_off = s["layers.0.qkv.w"].offset
         self.reset()
 
+    def staging_bytes(self) -> int:
+        """Device memory the exchange adds to the training state."""
+        return 0 if self.ring is None else sum(r.numel() * r.element_size() for r in self.ring)
+
     def reset(self):
         self.done = []
 
-    def _bucket(self, lo, hi):
-        g = self.store.grad[lo:hi]
-        if self.stage is None:
-            self.dist.all_reduce(g, group=self.group)
+    def _complete(self, k):
+        """Bucket in ring slot k: wait for its collective (stream-ordered on RCCL: the side stream waits, the host does not), cast the sum back."""
+        p = self.pending[k]
+        if p is None:
             return
-        st = self.stage[lo:hi]
-        if self.cuda:   # fp32 -> bf16 (round to nearest even) and back through the library's cast kernels
-            hip.call("cast_f32_to_bf16", g, hi - lo, st, hi - lo, 1, hi - lo, hi - lo)
-        else:
-            st.copy_(g)
-        self.dist.all_reduce(st, group=self.group)
+        work, st, lo, hi = p
+        work.wait()
+        g = self.store.grad[lo:hi]
         if self.cuda:
             hip.call("cast_bf16_to_f32", st, g, hi - lo)
         else:
             g.copy_(st)
+        self.pending[k] = None
 
-    def _reduce(self, lo, hi):
-        if not self.active or hi <= lo:
+    def _bucket(self, lo, hi):
+        g = self.store.grad[lo:hi]
+        if self.ring is None:
+            self.dist.all_reduce(g, group=self.group)
+            return
+        k = self.slot
+        self.slot = (k + 1) % self.RING
+        self._complete(k)                  # the slot's previous bucket (RING buckets ago) leaves the buffer first
+        st = self.ring[k][: hi - lo]
+        if self.cuda:   # fp32 -> bf16 (round to nearest even) and back through the library's cast kernels
+            hip.call("cast_f32_to_bf16", g, hi - lo, st, hi - lo, 1, hi - lo, hi - lo)
+        else:
+            st.copy_(g)
+        self.pending[k] = (self.dist.all_reduce(st, group=self.group, async_op=True), st, lo, hi)
+
+    def _drain(self):
+        for i in range(self.RING):         # oldest first
+            self._complete((self.slot + i) % self.RING)
+
+    def _reduce(self, lo, hi, drain=False):
+        if not self.active or (hi <= lo and not drain):
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -173,10 +201,13 @@ class GradReducer:
         with ctx:
             for b0 in range(lo, hi, self.bucket_elems):
                 b1 = min(hi, b0 + self.bucket_elems)
-                self._bucket(b0, b1)      # on NCCL the collective is enqueued behind this stream's work and the stream waits for it: no host block
+                self._bucket(b0, b1)      # on RCCL the collective is enqueued behind this stream's work: no host block
                 self.bytes_on_wire += (b1 - b0) * (2 if self.wire == "bf16" else 4)
                 self.n_buckets += 1
-        self.done.append((lo, hi))
+            if drain:
+                self._drain()
+        if hi > lo:
+            self.done.append((lo, hi))
 
     def layer_ready(self, i):
         self._reduce(*self.layer_range[i])
@@ -198,6 +229,7 @@ class GradReducer:
             if lo > cur:
                 self._reduce(cur, lo)
             cur = max(cur, hi)
+        self._reduce(0, 0, drain=True)      # the buckets still in the ring: wait + cast back
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         self.last_bytes_on_wire, self.last_n_buckets = self.bytes_on_wire, self.n_buckets

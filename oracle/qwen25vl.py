@@ -138,12 +138,16 @@ def _segment_attention(q, k, v, cu, scale):
 class Qwen25VLOracle:
     """Functional fp32 model over a {checkpoint-name: tensor} dict."""
 
-    def __init__(self, cfg: dict, weights: dict, requires_grad: bool = False, dtype=torch.float32):
+    def __init__(self, cfg: dict, weights: dict, requires_grad=False, dtype=torch.float32, copy: bool = True):
+        """requires_grad: bool, or a collection of checkpoint names (gradients for those tensors only).  copy=False adopts the given tensors
+        (full-size models: 15 GB of fp32 for the 3B shapes -- tests/test_hip_model.py full-depth parity)."""
         self.cfg = cfg
         self.w = {}
         for k, a in weights.items():
-            t = torch.as_tensor(a).to(dtype).clone()
-            t.requires_grad_(requires_grad)
+            t = torch.as_tensor(a).to(dtype)
+            if copy:
+                t = t.clone()
+            t.requires_grad_(requires_grad if isinstance(requires_grad, bool) else k in requires_grad)
             self.w[k] = t
         if cfg.get("tie_word_embeddings", False):
             self.w["lm_head.weight"] = self.w["model.embed_tokens.weight"]

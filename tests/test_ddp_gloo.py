@@ -39,6 +39,8 @@ def _worker(rank, world, port, q, wire="fp32"):
     mine = st.grad.clone()
     red = GradReducer(st, wire=wire, bucket_bytes=1 << 16)      # small buckets: every range is split into several collectives
     assert red.world == world
+    # the bf16 wire stages through a RING of bucket-sized buffers (reused many times here: ~50 buckets through 3 slots), never a second copy of the model
+    assert red.staging_bytes() == (3 * (1 << 16) if wire == "bf16" else 0)
     # backward order: last layer first; only some layers fire the hook (the rest must be swept by finish())
     for i in reversed(range(cfg.num_hidden_layers)):
         if i % 2 == 1:
@@ -77,6 +79,17 @@ def test_grad_reducer_world2_gloo(wire):
         assert p.exitcode == 0
     for rank, ok, ok2, nonzero_first in res:
         assert ok and ok2 and nonzero_first, (rank, ok, ok2)
+
+
+def test_reducer_staging_is_bucket_sized_not_model_sized():
+    """a full-model bf16 staging buffer (16.6 GB at 7B) would not fit next to the 7B training state.  The ring holds RING buckets of
+    at most 256 MB each, whatever the model size (checked on the class constants; the 2-rank run above checks the tiny model's actual allocation)."""
+    sys.path.insert(0, ROOT)
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.sc_grpo import GradReducer
+    import inspect
+    default_bucket = inspect.signature(GradReducer.__init__).parameters["bucket_bytes"].default
+    assert GradReducer.RING * default_bucket <= 1 << 30
 
 
 def test_layer_buckets_are_disjoint_and_cover_decoder_weights():

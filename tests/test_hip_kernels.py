@@ -323,6 +323,11 @@ ATTN_CASES = [
     (80, 2, 2, False, [(0, 64), (64, 128), (128, 176), (176, 192)]),
     (80, 3, 3, False, [(0, 300), (300, 364), (364, 1388)]),
     (128, 2, 2, False, [(0, 100)]),
+    # head geometries of BASELINE configs 4 / 5 and the LLaVA decoders (REF sc_grpo_trainer.py:116-137): Qwen2.5-VL-7B / Qwen2-7B 28:4 (group 7),
+    # LLaMA-7B MHA 32:32, Mistral-7B 32:8
+    (128, 28, 4, True, [(0, 200), (205, 333), (340, 341), (400, 777)]),
+    (128, 32, 32, True, [(0, 130), (130, 131), (140, 397)]),
+    (128, 32, 8, True, [(5, 261), (261, 300), (300, 556)]),
 ]
 
 
@@ -360,6 +365,10 @@ PREFIX_CASES = [
     (4, 2, [(3, 103), (110, 174)], [[(200, 230), (232, 233), (240, 337)], [(340, 404), (404, 450)]]),
     (16, 2, [(0, 512)], [[(512 + 256 * i, 512 + 256 * i + n) for i, n in enumerate([256, 17, 200, 64])]]),
     (2, 1, [(0, 37)], [[(40, 41)]]),
+    # group 7 (28:4: Qwen2.5-VL-7B, LLaVA-OneVision-7B), MHA (LLaVA-1.5) and 32:8 (LLaVA-NeXT-Mistral) in the shared-prefix form
+    (28, 4, [(0, 160), (160, 224)], [[(256 + 64 * i, 256 + 64 * i + n) for i, n in enumerate([64, 9, 50])], [(480, 544), (544, 545)]]),
+    (32, 32, [(2, 98)], [[(100, 140), (140, 141), (150, 214)]]),
+    (32, 8, [(0, 128)], [[(128, 192), (192, 230)]]),
 ]
 
 

@@ -68,23 +68,30 @@ def test_forward_matches_reference_golden(golden_dir):
     assert pos_ref.shape[0] == 3
 
 
-@pytest.mark.parametrize("name,mb", [("sc_grpo_g4.npz", 16), ("sc_grpo_g8.npz", 16), ("sc_grpo_g8.npz", 3), ("sc_grpo_g8_far.npz", 16), ("sc_grpo_trunc.npz", 16)])
+@pytest.mark.parametrize("name,mb", [("sc_grpo_g4.npz", 16), ("sc_grpo_g8.npz", 16), ("sc_grpo_g8.npz", 3), ("sc_grpo_g8_far.npz", 16), ("sc_grpo_trunc.npz", 16),
+                                     ("sc_grpo_7b_like.npz", 16), ("sc_grpo_7b_like.npz", 3)])
 def test_sc_grpo_step_matches_reference_golden(golden_dir, name, mb):
     """HIP engine vs the reference's own compute_loss (tests/golden/sc_grpo_*.npz).  g4 / g8: policy close to the frozen reference (KL ~ 3e-3,
     loss ~ 1e-4); g8_far: policy far from it (KL ~ 0.2, loss ~ 8e-3), where loss and KL tolerances are RELATIVE; trunc: the reference's left
-    truncation of the prompt (max_prompt_length = P - 2, REF:630-634)."""
+    truncation of the prompt (max_prompt_length = P - 2, REF:630-634); 7b_like: the reference's compute_loss on TINY7 -- untied lm_head and 7 query heads
+    per kv head, the structure of BASELINE config 4 (Qwen2.5-VL-7B, 28:4) and of config 5's decoder -- forward AND backward, in both layouts
+    (mb = 16: shared prefix, mb = 3: repeated rows, micro-batches cutting the group)."""
     g = load(golden_dir, name)
     meta = json.loads(str(g["meta"]))
     G, C, seed = meta["G"], meta["C"], meta["seed"]
-    w_ref = fx.make_weights(fx.TINY, 0)
-    pol, ref = store(fx.perturb_weights(w_ref, 1, scale=meta.get("perturb_scale", 0.02)), True), store(w_ref, False)
+    cfg_d = getattr(fx, meta.get("config", "fixture_util.TINY").split(".")[-1])
+    cfg = VLMConfig.from_dict(cfg_d)
+    w_ref = fx.make_weights(cfg_d, 0)
+    pol, ref = ParamStore(cfg, DEV, trainable=True), ParamStore(cfg, DEV, trainable=False)
+    pol.load_named(fx.perturb_weights(w_ref, 1, scale=meta.get("perturb_scale", 0.02)))
+    ref.load_named(w_ref)
     mpl = meta["max_prompt_length"] if meta.get("truncate") else 4096
-    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=mpl, max_completion_length=C, beta=0.04, micro_batch_seqs=mb))
+    eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=mpl, max_completion_length=C, beta=0.04, micro_batch_seqs=mb))
     grid = tuple(meta["grid"])
-    ids, mask = fx.left_pad([fx.synth_prompt(grid, meta["n_text"], fx.TINY, seed)], fx.TINY["pad_token_id"])
-    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=seed), "image_grid_thw": [grid]}
+    ids, mask = fx.left_pad([fx.synth_prompt(grid, meta["n_text"], cfg_d, seed)], cfg_d["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], cfg_d, seed=seed), "image_grid_thw": [grid]}
     eos_rows = {int(k): v for k, v in meta["eos_rows"].items()}
-    comps = fx.synth_completions(G, C, fx.TINY, seed + 100, eos_rows)
+    comps = fx.synth_completions(G, C, cfg_d, seed + 100, eos_rows)
     out = eng.loss_and_grads(batch, comps, g["rewards_per_func"])
     assert np.array_equal(out["completion_mask"], g["completion_mask"])             # integer work: bit-exact
     assert np.array_equal(out["ids"], g["prompt_completion_ids"])
@@ -105,14 +112,14 @@ def test_sc_grpo_step_matches_reference_golden(golden_dir, name, mb):
     gl, gk = float(g["loss"]), float(g["metric_kl"])
     dk, dl = abs(mt["kl"] - gk), abs(mt["loss"] - gl)
     print(f"[parity] {name} mb={mb}: loss hip={mt['loss']:.6e} ref={gl:.6e} (d={dl:.2e})  kl hip={mt['kl']:.6e} ref={gk:.6e} (d={dk:.2e}, {100 * dk / gk:.1f}%)  |dlogp|max={dlp:.4f}/{dlr:.4f}")
-    rel_kl = 0.10 if meta.get("perturb_scale", 0.02) > 0.1 else 0.25
+    rel_kl = 0.10 if gk > 0.05 else 0.25
     assert dk <= rel_kl * gk, (mt["kl"], gk)
     assert dl <= 0.04 * rel_kl * gk + 2e-6, (mt["loss"], gl)              # beta = 0.04; never looser than the north star's 1e-3
     assert dl < 1e-3
     grads = pol.export_named(source="grad")
     names = [str(n) for n in g["grad_norm_names"]]
     for n, ref_norm in zip(names, g["grad_norms"]):
-        if n == "lm_head.weight" or ref_norm < 1e-9:
+        if (n == "lm_head.weight" and cfg.tie_word_embeddings) or ref_norm < 1e-9:
             continue
         got = float(grads[n].norm())
         assert abs(got - ref_norm) <= 0.08 * ref_norm + 1e-7, (n, got, ref_norm)
@@ -569,6 +576,79 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
     a, b = g1.double(), g0.double()
     assert float((a @ b) / (a.norm() * b.norm())) > 0.999
     assert torch.isfinite(g1).all() and torch.isfinite(g0).all()
+
+
+def test_full_depth_3b_sc_grpo_step_vs_oracle():
+    """The UNREDUCED Qwen2.5-VL-3B (36 decoder layers, 32 ViT blocks, 151 936-token vocabulary; BASELINE configs 2 / 3) against the fp32 CPU oracle on
+    the same weights: what bf16 storage costs over the real depth (every other oracle comparison runs <= 4 layers).  1 prompt x G = 2, one 8 x 8-patch
+    image (16 image tokens) + 64 text tokens, C = 8, policy = reference x (1 + 5 % element-wise noise), EOS inside one completion.  Checked: per-token
+    log-probs of both models, KL and loss relative, gradients of five named tensors (two of them at the bottom of the decoder stack / in the ViT).
+    REF sc_grpo_trainer.py:116-137 (model), :384-514 (log-probs), :746-798 (loss).  Tolerances picked from the measured values printed below."""
+    import time
+    from oracle import qwen25vl as oq
+    from oracle import sc_grpo as og
+    t0 = time.time()
+    cfg = VLMConfig.qwen25vl_3b()
+    d3 = {"text": {"vocab_size": 151936, "hidden_size": 2048, "intermediate_size": 11008, "num_hidden_layers": 36, "num_attention_heads": 16, "num_key_value_heads": 2,
+                   "rms_norm_eps": 1e-6, "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
+          "vision": {"depth": 32, "hidden_size": 1280, "intermediate_size": 3420, "num_heads": 16, "in_channels": 3, "patch_size": 14, "spatial_merge_size": 2,
+                     "temporal_patch_size": 2, "window_size": 112, "out_hidden_size": 2048, "fullatt_block_indexes": [7, 15, 23, 31]},
+          "image_token_id": cfg.image_token_id, "video_token_id": 151656, "vision_start_token_id": cfg.vision_start_token_id, "vision_end_token_id": cfg.vision_end_token_id,
+          "eos_token_id": cfg.eos_token_id, "pad_token_id": cfg.pad_token_id, "tie_word_embeddings": True}
+    pol, ref = ParamStore(cfg, DEV, trainable=True), ParamStore(cfg, DEV, trainable=False)
+    ref.init_random(seed=0)
+    ref.w("embed").mul_(2.0)            # logits std ~ 1.8 instead of 0.9: a distribution with real structure over the vocabulary
+    ref.finalize()
+    pol.flat.copy_(ref.flat)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    for lo in range(0, pol.flat.numel(), 1 << 28):
+        v = pol.flat[lo: lo + (1 << 28)]
+        v.copy_((v.float() * (1.0 + 0.05 * torch.randn(v.shape, generator=gen, device=DEV))).to(torch.bfloat16))     # zero padding / zero biases stay zero
+    pol.finalize()
+    G, C = 2, 8
+    grid = (1, 8, 8)
+    rs = np.random.RandomState(5)
+    row = rs.randint(1000, 150000, 3).tolist() + [cfg.vision_start_token_id] + [cfg.image_token_id] * 16 + [cfg.vision_end_token_id] + rs.randint(1000, 150000, 64).tolist()
+    ids = np.array([row], dtype=np.int64)
+    mask = np.ones_like(ids)
+    px = rs.standard_normal((64, cfg.patch_dim)).astype(np.float32)
+    comps = [rs.randint(1000, 150000, C).tolist(), rs.randint(1000, 150000, 5).tolist() + [cfg.eos_token_id]]
+    rew = np.array([[1.0, 0.5], [0.2, 0.0]], dtype=np.float32)
+    eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=G))
+    out = eng.loss_and_grads({"input_ids": ids, "attention_mask": mask, "pixel_values": torch.from_numpy(px), "image_grid_thw": [grid]}, comps, rew)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    names = ["model.norm.weight", "model.layers.35.post_attention_layernorm.weight", "model.layers.0.input_layernorm.weight", "model.layers.17.self_attn.k_proj.bias",
+             "visual.merger.ln_q.weight", "visual.blocks.0.norm1.weight"]
+    grads = pol.export_named(source="grad")
+    grads = {n: grads[n].numpy().reshape(-1).astype(np.float64) for n in names}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    o_pol = oq.Qwen25VLOracle(d3, pol.export_named(), requires_grad=set(names), copy=False)
+    o_ref = oq.Qwen25VLOracle(d3, ref.export_named(), copy=False)
+    t2 = time.time()
+    want = og.sc_grpo_step(o_pol, o_ref, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(px), [grid], comps, torch.from_numpy(rew), G, 0.04,
+                           cfg.eos_token_id, cfg.pad_token_id)
+    want["loss"].backward()
+    t3 = time.time()
+    m = want["completion_mask"].bool().numpy()
+    assert np.array_equal(out["completion_mask"], want["completion_mask"].numpy()) and int(m.sum()) == C + 6
+    dlp = np.abs(out["logps"].cpu().numpy()[m] - want["logps"].detach().numpy()[m]).max()
+    dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - want["ref_logps"].numpy()[m]).max()
+    wl, wk = float(want["loss"]), float(want["metrics"]["kl"])
+    mt = out["metrics"]
+    dk, dl = abs(mt["kl"] - wk), abs(mt["loss"] - wl)
+    cos = {}
+    for n in names:
+        a, b = grads[n], o_pol.w[n].grad.numpy().reshape(-1).astype(np.float64)
+        cos[n] = (float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)), float(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30)))
+    print(f"[full depth 3B] |dlogp|max policy={dlp:.4f} ref={dlr:.4f}  logp range [{want['logps'].min().item():.2f}, {want['logps'].max().item():.2f}]  "
+          f"kl hip={mt['kl']:.5e} oracle={wk:.5e} ({100 * dk / wk:.2f}%)  loss hip={mt['loss']:.6e} oracle={wl:.6e} (d={dl:.2e})  "
+          f"grad (cos, norm ratio)={ {k: (round(c, 4), round(r, 3)) for k, (c, r) in cos.items()} }  "
+          f"seconds: hip {t1 - t0:.0f}, export {t2 - t1:.0f}, oracle {t3 - t2:.0f}")
+    assert dlp < 0.1 and dlr < 0.1, (dlp, dlr)
+    assert dk <= 0.10 * wk and dl <= 0.04 * 0.10 * wk + 2e-6 and dl < 1e-3, (mt, wk, wl)
+    for n, (c, r) in cos.items():
+        assert c > 0.97 and 0.85 < r < 1.15, (n, c, r)
 
 
 def test_two_images_per_prompt_one_shot_template_vs_oracle():

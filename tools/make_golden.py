@@ -400,11 +400,12 @@ GRAD_FULL = [
 ]
 
 
-def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed, perturb_scale=0.02, truncate=0):
+def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed, perturb_scale=0.02, truncate=0, cfg=None, cfg_name="fixture_util.TINY", grad_full=None):
     """perturb_scale: distance policy <-> frozen reference (0.02: KL ~ 3e-3; 0.25: KL ~ 0.1, where a relative tolerance on KL and loss is a real
     check).  truncate > 0: max_prompt_length = P - truncate, i.e. the reference's left truncation (sc_grpo_trainer.py:630-634) cuts that many
-    leading text tokens of the prompt (pixel tensors untouched, M-RoPE positions recomputed on the truncated ids)."""
-    cfg = fx.TINY
+    leading text tokens of the prompt (pixel tensors untouched, M-RoPE positions recomputed on the truncated ids).
+    cfg: the fixture configuration (default TINY; TINY7 = the 7B structure: untied lm_head, GQA group 7 -- BASELINE config 4)."""
+    cfg = cfg or fx.TINY
     w_ref = fx.make_weights(cfg, seed=0)
     w_pol = fx.perturb_weights(w_ref, seed=1, scale=perturb_scale)
     ref = build_hf_model(cfg, w_ref).eval()
@@ -432,7 +433,7 @@ def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed, perturb_scale
     gnorm = {inv[k]: float(g.norm()) for k, g in grads.items() if k in inv}
     out = {
         "meta": json.dumps({**meta(), "G": G, "C": C, "grid": grid, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows or {}, "perturb_scale": perturb_scale, "truncate": truncate,
-                            "max_prompt_length": int(t.max_prompt_length), "weights": f"fixture_util.make_weights(TINY,0) / perturb_weights(.,1,scale={perturb_scale})"}),
+                            "max_prompt_length": int(t.max_prompt_length), "config": cfg_name, "weights": f"fixture_util.make_weights({cfg_name.split('.')[-1]},0) / perturb_weights(.,1,scale={perturb_scale})"}),
         "completion_ids": loc["completion_ids"].numpy(),
         "prompt_completion_ids": loc["prompt_completion_ids"].numpy(),
         "attention_mask": loc["attention_mask"].numpy(),
@@ -454,7 +455,7 @@ def gen_sc_grpo(SCGRPOTrainer, reward, G, C, eos_rows, name, seed, perturb_scale
         "completions_text": np.array(texts),
         "solution": np.array(SOLUTION),
     }
-    for k in GRAD_FULL:
+    for k in (grad_full or GRAD_FULL):
         out["grad::" + k] = grads[hf_name(k)].numpy()
     np.savez_compressed(os.path.join(OUT, name), **out)
     print(f"{name}: loss={loss.item():.8f} reward={t._metrics['reward'][0]:.4f} kl={t._metrics['kl'][0]:.6f} len={t._metrics['completion_length'][0]}")
@@ -741,6 +742,11 @@ def main():
     if not only or "grpo_far" in only:
         gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={1: 9, 4: 2, 6: 5}, name="sc_grpo_g8_far.npz", seed=23, perturb_scale=0.25)
         gen_sc_grpo(SCGRPOTrainer, reward, G=4, C=10, eos_rows={0: 4, 2: 8}, name="sc_grpo_trunc.npz", seed=24, perturb_scale=0.25, truncate=2)
+    if not only or "grpo7" in only:
+        # BASELINE config 4's structure (untied head, 7 query heads per kv head) through the reference's compute_loss: policy far from the reference (KL ~ 0.2)
+        gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={1: 9, 4: 2, 6: 5}, name="sc_grpo_7b_like.npz", seed=25, perturb_scale=0.08, cfg=fx.TINY7, cfg_name="fixture_util.TINY7",
+                    grad_full=["model.norm.weight", "model.layers.1.self_attn.k_proj.bias", "model.layers.1.self_attn.q_proj.bias", "model.layers.0.input_layernorm.weight",
+                               "model.layers.0.self_attn.v_proj.weight", "visual.merger.ln_q.weight", "visual.blocks.1.norm2.weight", "visual.merger.mlp.2.bias"])
     if not only or "reward_model" in only:
         gen_reward_model(SCGRPOTrainer, reward)
     if not only or "logps" in only:
