@@ -101,7 +101,10 @@ def test_sc_grpo_step_matches_reference_golden(golden_dir, name, mb):
     m = g["completion_mask"].astype(bool)
     dlp = np.abs(out["logps"].cpu().numpy()[m] - g["per_token_logps"][m]).max()
     dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - g["ref_per_token_logps"][m]).max()
-    assert dlp < 0.06 and dlr < 0.06, (dlp, dlr)
+    # bf16 storage vs the fp32 reference: 0.06 log-prob units on TINY (hidden 256, logits within +-5); TINY7 (hidden 896, logits within +-10, log-probs down
+    # to -12.8) measured 0.065 / 0.071 -> 0.10 there, the same 1 % of the log-prob range
+    tol_lp = 0.06 if cfg.hidden_size <= 256 else 0.10
+    assert dlp < tol_lp and dlr < tol_lp, (dlp, dlr)
     np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=1e-5, atol=1e-6)
     mt = out["metrics"]
     assert mt["completion_length"] == float(g["metric_completion_length"])
@@ -583,7 +586,9 @@ def test_full_depth_3b_sc_grpo_step_vs_oracle():
     the same weights: what bf16 storage costs over the real depth (every other oracle comparison runs <= 4 layers).  1 prompt x G = 2, one 8 x 8-patch
     image (16 image tokens) + 64 text tokens, C = 8, policy = reference x (1 + 5 % element-wise noise), EOS inside one completion.  Checked: per-token
     log-probs of both models, KL and loss relative, gradients of five named tensors (two of them at the bottom of the decoder stack / in the ViT).
-    REF sc_grpo_trainer.py:116-137 (model), :384-514 (log-probs), :746-798 (loss).  Tolerances picked from the measured values printed below."""
+    REF sc_grpo_trainer.py:116-137 (model), :384-514 (log-probs), :746-798 (loss).
+    The yardstick for the log-probs is the reference's OWN precision: the same oracle run in bf16 (what `--bf16` makes the reference compute, torch CPU kernels)
+    against the fp32 oracle.  The HIP path must not be further from fp32 than 1.5x that (two bf16 implementations with different summation orders)."""
     import time
     from oracle import qwen25vl as oq
     from oracle import sc_grpo as og
@@ -630,22 +635,33 @@ def test_full_depth_3b_sc_grpo_step_vs_oracle():
                            cfg.eos_token_id, cfg.pad_token_id)
     want["loss"].backward()
     t3 = time.time()
+    # the reference's precision: bf16 parameters and activations (log-softmax in fp32 as REF:509), same inputs
+    ids_t = torch.cat([torch.from_numpy(ids).repeat(G, 1), og.right_pad(comps, cfg.pad_token_id)], 1)
+    mask_t = torch.cat([torch.from_numpy(mask).repeat(G, 1), want["completion_mask"].long()], 1)
+    with torch.no_grad():
+        o16 = oq.Qwen25VLOracle(d3, {k: t.detach() for k, t in o_pol.w.items() if not (k == "lm_head.weight")}, dtype=torch.bfloat16)
+        lp16 = o16.per_token_logps(ids_t, mask_t, torch.from_numpy(px).repeat(G, 1), [grid] * G)[:, ids.shape[1] - 1:].float().numpy()
+        del o16
+    t4 = time.time()
     m = want["completion_mask"].bool().numpy()
     assert np.array_equal(out["completion_mask"], want["completion_mask"].numpy()) and int(m.sum()) == C + 6
     dlp = np.abs(out["logps"].cpu().numpy()[m] - want["logps"].detach().numpy()[m]).max()
     dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - want["ref_logps"].numpy()[m]).max()
-    wl, wk = float(want["loss"]), float(want["metrics"]["kl"])
+    d16 = np.abs(lp16[m] - want["logps"].detach().numpy()[m]).max()                 # bf16 oracle vs fp32 oracle (policy weights)
+    dmean = np.abs(out["logps"].cpu().numpy()[m] - want["logps"].detach().numpy()[m]).mean()
+    d16mean = np.abs(lp16[m] - want["logps"].detach().numpy()[m]).mean()
+    wl, wk = float(want["loss"].detach()), float(want["metrics"]["kl"])
     mt = out["metrics"]
     dk, dl = abs(mt["kl"] - wk), abs(mt["loss"] - wl)
     cos = {}
     for n in names:
         a, b = grads[n], o_pol.w[n].grad.numpy().reshape(-1).astype(np.float64)
         cos[n] = (float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)), float(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30)))
-    print(f"[full depth 3B] |dlogp|max policy={dlp:.4f} ref={dlr:.4f}  logp range [{want['logps'].min().item():.2f}, {want['logps'].max().item():.2f}]  "
+    print(f"[full depth 3B] |dlogp|max policy={dlp:.4f} (mean {dmean:.4f}) ref={dlr:.4f}; the bf16 ORACLE vs fp32: max {d16:.4f} mean {d16mean:.4f}  logp range [{want['logps'].min().item():.2f}, {want['logps'].max().item():.2f}]  "
           f"kl hip={mt['kl']:.5e} oracle={wk:.5e} ({100 * dk / wk:.2f}%)  loss hip={mt['loss']:.6e} oracle={wl:.6e} (d={dl:.2e})  "
           f"grad (cos, norm ratio)={ {k: (round(c, 4), round(r, 3)) for k, (c, r) in cos.items()} }  "
-          f"seconds: hip {t1 - t0:.0f}, export {t2 - t1:.0f}, oracle {t3 - t2:.0f}")
-    assert dlp < 0.1 and dlr < 0.1, (dlp, dlr)
+          f"seconds: hip {t1 - t0:.0f}, export {t2 - t1:.0f}, oracle fp32 {t3 - t2:.0f}, bf16 {t4 - t3:.0f}", flush=True)
+    assert dlp <= 1.5 * d16 + 0.02 and dlr <= 1.5 * d16 + 0.02 and dmean <= 1.5 * d16mean + 0.005, (dlp, dlr, d16, dmean, d16mean)
     assert dk <= 0.10 * wk and dl <= 0.04 * 0.10 * wk + 2e-6 and dl < 1e-3, (mt, wk, wl)
     for n, (c, r) in cos.items():
         assert c > 0.97 and 0.85 < r < 1.15, (n, c, r)
