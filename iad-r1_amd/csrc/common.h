@@ -112,14 +112,6 @@ struct SideOut {                   // same layout as iadr1_side_out_t
 };
 // the caller's struct (host memory, may be null) -> the by-value kernel argument; argument checks in runtime.hip
 int iadr1_side_arg(const void* side, SideOut* out);
-// Norm folding of the decode step (include/iadr1_hip.h iadr1_norm_fold_t, same layout)
-struct NormFold {
-    const float* ssq_in; int ssq_in_tiles; float eps;
-    float* ssq_out;
-    void* y_packed;
-    float* slabs;
-    unsigned* counters;
-};
 // IADR1_* A/B switches of the launchers: read ONCE (`static const int x = iadr1_env_int(...)`, thread-safe static initialisation), constant afterwards
 int iadr1_env_int(const char* name, int dflt);
 // read the step counter ONCE, at kernel entry (a dependent global load in an epilogue is a memory latency on the critical path of a latency-bound kernel)

@@ -200,22 +200,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* ids, co
         *(u32x4_t*)(out + t * H + c * 8) = *(const u32x4_t*)(src + c * 8);
     }
 }
-// First kernel of a decode step with folded norms (include/iadr1_hip.h iadr1_norm_fold_t): one block per sequence copies its token's embedding row into
-// the residual stream (row-major or decode-packed) and leaves the row's sum of squares as the single tile partial the first q|k|v GEMM scales by.
-__global__ __launch_bounds__(256) void embed_decode_kernel(const long long* ids, const bf16_t* E, bf16_t* x, long long ldx, float* ssq, int M, int H) {
-    __shared__ float scratch[16];
-    const int row = blockIdx.x;
-    const bf16_t* src = E + ids[row] * (long long)H;
-    float ss = 0.f;
-    for (int c = threadIdx.x; c < (H >> 3); c += 256) {
-        const u32x4_t v = *(const u32x4_t*)(src + c * 8);
-        *(u32x4_t*)(x + (ldx ? (long long)row * ldx + c * 8 : xpk_off(row, c * 8, H))) = v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ss += lo_bf(v[e]) * lo_bf(v[e]) + hi_bf(v[e]) * hi_bf(v[e]);
-    }
-    ss = block_sum<256>(ss, scratch);
-    if (threadIdx.x == 0) ssq[row] = ss;
-}
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* ids, const int* img_index, const bf16_t* dx, float* dE,
                                                         float* dimg, int T, int H) {
     const int cpr = H >> 3;
@@ -438,11 +422,6 @@ extern "C" int iadr1_embed_fwd(const long long* ids, const int* img_index, const
     IADR1_REQUIRE(T > 0 && (H % 8) == 0, "embed_fwd: H must be a multiple of 8");
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)E, (const bf16_t*)img, (bf16_t*)out, T, H);
     return iadr1_check_launch("embed_fwd");
-}
-extern "C" int iadr1_embed_decode(const long long* ids, const void* E, void* x, long long ldx, float* ssq_out, int M, int H, hipStream_t stream) {
-    IADR1_REQUIRE(M > 0 && (H % 8) == 0 && (ldx != 0 || (H % 32) == 0) && ssq_out != nullptr, "embed_decode: H must be a multiple of 8 (32 for the decode-packed layout)");
-    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, stream, ids, (const bf16_t*)E, (bf16_t*)x, ldx, ssq_out, M, H);
-    return iadr1_check_launch("embed_decode");
 }
 extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
                                hipStream_t stream) {

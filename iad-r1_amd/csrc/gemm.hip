@@ -712,148 +712,20 @@ struct SkinnyArgs {
     bf16_t* kcache;
     bf16_t* vcache;
     int Hq, Hkv;
-    SideOut so;                // out_mode 4: p0 = roped q|k|v rows; out_mode 3 (persistent kernel): p0 = gate|up rows, p1 = SwiGLU rows; 5: p0 = residual rows (common.h)
+    SideOut so;                // out_mode 4: p0 = roped q|k|v rows; out_mode 3 (persistent kernel): p0 = gate|up rows, p1 = SwiGLU rows (common.h)
     const float* wscale;       // non-null: W is FP8 (OCP e4m3) decode-packed (iadr1_pack_weight_fp8), wscale[n] = dequantisation scale of output row n
     int xcd_order;             // persistent kernel with side outputs: XCD-aware order of the tile groups (IADR1_PERS_XCD_ORDER=0: plain)
-    NormFold nf;               // norm folding (include/iadr1_hip.h iadr1_norm_fold_t): ssq_in -> every output row is scaled by 1/rms(x row); out_mode 5 -> producer
 };
-
-// ---- norm folding (include/iadr1_hip.h iadr1_norm_fold_t) -------------------------------------------------------------------------------
-// Consumer side.  Wave w adds the tile partials w, w + WAVES, ... of the block's 64 rows (lane = row) into part[w][lane] (LDS, valid after the
-// caller's next barrier); fold_rinv: 1/rms of row m from those WAVES values.  Fixed summation order: the scale is bit-reproducible.
-// The loads are issued at kernel entry into registers (FoldRegs::load) and only consumed after the main loop (FoldRegs::reduce): the L2 round trip
-// hides behind the weight stream (a load-wait-store prologue in front of the weight loads cost 1.4 us of a 7 us kernel).
-template <int WAVES, int MAXT>
-struct FoldRegs {
-    float v[MAXT];
-    __device__ __forceinline__ void load(const SkinnyArgs& p, int m_base) {
-        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-        const long long mpad = (long long)((p.M + 63) & ~63);
-        const int tiles = p.nf.ssq_in_tiles;
-        const float* src = p.nf.ssq_in + m_base + l;
-#pragma unroll
-        for (int u = 0; u < MAXT; ++u) v[u] = src[(long long)min(w + u * WAVES, tiles - 1) * mpad];
-    }
-    // part[w][lane]: this wave's share of the rows' sums of squares (tiles past MAXT * WAVES in a rolled tail: hidden sizes above 16 * MAXT * WAVES)
-    __device__ __forceinline__ void reduce(const SkinnyArgs& p, int m_base, float* part) const {
-        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-        const long long mpad = (long long)((p.M + 63) & ~63);
-        const int tiles = p.nf.ssq_in_tiles;
-        float s = 0.f;
-#pragma unroll
-        for (int u = 0; u < MAXT; ++u) s += (w + u * WAVES < tiles) ? v[u] : 0.f;
-        for (int t = w + MAXT * WAVES; t < tiles; t += WAVES) s += p.nf.ssq_in[(long long)t * mpad + m_base + l];
-        part[w * 64 + l] = s;
-    }
-};
-// rs[m] = 1/rms of row m from the WAVES partial sums (first 64 threads, after the barrier that completes `part`; valid after the next barrier)
-template <int WAVES>
-__device__ __forceinline__ void fold_rinv_rows(const SkinnyArgs& p, const float* part, float* rs) {
-    if (threadIdx.x < 64) {
-        float s = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) s += part[ww * 64 + threadIdx.x];
-        rs[threadIdx.x] = rsqrtf(s / (float)p.K + p.nf.eps);
-    }
-}
-template <int WAVES>
-__device__ __forceinline__ float fold_rinv(const SkinnyArgs& p, const float* part, int m) {
-    float s = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < WAVES; ++ww) s += part[ww * 64 + m];
-    return rsqrtf(s / (float)p.K + p.nf.eps);
-}
-// Producer side (out_mode 5).  `red` ([WAVES][64][RLD] fp32, complete: the caller has passed its barrier) holds this block's partial of the 64 x 16
-// tile at columns n0.. (LDS column offset roff); z of nz = the block's K slice.  nz == 1: the tile is complete.  nz > 1: every slice stores its
-// partial with agent-scope (L2 write-through, `sc1`) stores, releases, and bumps the tile's counter; the block that finds nz - 1 there is the last:
-// it re-reads ALL nz partials (agent-scope loads: the other slices may have run on another XCD, whose L2 is not coherent with this one) and adds
-// them in slice order -- the sum does not depend on which block was last.  Then, for both cases, the reference's rounding points: bf16 branch
-// output, bf16(residual + branch) written back in place (+ the training arena row), and the tile's contribution to the rows' sums of squares.
-template <int WAVES, int RLD>
-__device__ __forceinline__ void fold_finish_tile(const SkinnyArgs& p, const float* red, int roff, int n0, int m_base, int z, int nz, long long side0, unsigned* flag) {
-    constexpr int PER = (64 * 16) / (WAVES * 64);
-    const int t = threadIdx.x;
-    const long long mpad = (long long)((p.M + 63) & ~63);
-    bf16_t* Y = (bf16_t*)p.Y;
-    float v[PER], r[PER];
-    long long yo[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int idx = t + k * WAVES * 64, m = idx >> 4, n = idx & 15, gm = m_base + m, gn = n0 + n;
-        yo[k] = p.ldy ? (long long)gm * p.ldy + gn : xpk_off(gm, gn, p.N);
-        r[k] = gm < p.M ? bf2f(Y[yo[k]]) : 0.f;
-        float a = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) a += red[((size_t)ww * 64 + m) * RLD + roff + n];
-        v[k] = a;
-    }
-    if (nz > 1) {
-        float* slab = p.nf.slabs;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int idx = t + k * WAVES * 64, gm = m_base + (idx >> 4), gn = n0 + (idx & 15);
-            __hip_atomic_store(slab + ((long long)z * mpad + gm) * p.N + gn, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // Every wave waits for its write-through stores to be acknowledged before the barrier lets thread 0 count the block in.  No fence: an agent-scope
-        // release / acquire writes back and invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1 -- measured: the decode step went from 2.9 to
-        // 7.9 ms with them), and nothing here lives in L2: the partials are stored and loaded with sc1, the counter is an atomic.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned* cnt = p.nf.counters + (long long)blockIdx.y * (p.N >> 4) + (n0 >> 4);
-        if (t == 0) *flag = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*flag != (unsigned)(nz - 1)) return;               // block-uniform
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int idx = t + k * WAVES * 64, gm = m_base + (idx >> 4), gn = n0 + (idx & 15);
-            const float* src = slab + (long long)gm * p.N + gn;
-            const long long zs = mpad * p.N;
-            float a = 0.f;
-            int zz = 0;
-            for (; zz + 8 <= nz; zz += 8) {
-                float u[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) u[q] = __hip_atomic_load(src + (zz + q) * zs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) a += u[q];
-            }
-            for (; zz < nz; ++zz) a += __hip_atomic_load(src + zz * zs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v[k] = a;
-        }
-        if (t == 0) *cnt = 0;                                    // left zero for the next launch (visible at the kernel boundary)
-    }
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int idx = t + k * WAVES * 64, m = idx >> 4, n = idx & 15, gm = m_base + m, gn = n0 + n;
-        const bf16_t xn = f2bf(bf2f(f2bf(v[k])) + r[k]);
-        float q = 0.f;
-        if (gm < p.M) {
-            Y[yo[k]] = xn;
-            if (p.nf.y_packed) ((bf16_t*)p.nf.y_packed)[xpk_off(gm, gn, p.N)] = xn;
-            if (side0 >= 0) ((bf16_t*)p.so.p0)[(side0 + (long long)gm * p.so.seq_stride) * p.so.ld0 + gn] = xn;
-            q = bf2f(xn) * bf2f(xn);
-        }
-        q += __shfl_xor(q, 8, WAVE);
-        q += __shfl_xor(q, 4, WAVE);
-        q += __shfl_xor(q, 2, WAVE);
-        q += __shfl_xor(q, 1, WAVE);
-        if (n == 0) p.nf.ssq_out[(long long)(n0 >> 4) * mpad + gm] = q;
-    }
-}
 
 template <int NB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     constexpr int U = 2, BNC = 16 * NB, RLD = BNC + 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [WAVES][64][RLD]
-    float* part = red + (size_t)WAVES * 64 * RLD;   // [WAVES][64] norm folding: partial row sums of squares; + 1 word: the last-arriver flag
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int lm = l & 15, lq = l >> 4;
     const int n0 = blockIdx.x * BNC;
     const int m_base = blockIdx.y * 64;
-    const bool scaled = p.nf.ssq_in != nullptr;
-    FoldRegs<WAVES, 8> fr;
-    if (scaled) fr.load(p, m_base);
     const int nslab = p.K >> 6;  // full 64-wide slabs; a trailing 32-wide half slab (K % 64 == 32) is handled after the loops
     const int per_z = (nslab + gridDim.z - 1) / gridDim.z;
     const int s_begin = blockIdx.z * per_z, s_end = min(nslab, s_begin + per_z);
@@ -868,7 +740,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     // a thread's epilogue column is the same in every round (WAVES*64 is a multiple of BNC): fetch its bias now, not in the tail
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
     const float bias_pre = ((p.out_mode == 0 || p.out_mode == 4) && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
-    const long long side0 = (NB == 1 && (p.out_mode == 4 || p.out_mode == 5)) ? side_base(p.so) : -1;
+    const long long side0 = (NB == 1 && p.out_mode == 4) ? side_base(p.so) : -1;
     // out_mode 4 (one output per thread when WAVES*64 == 64*16): rotary factors and the cache slot are fetched up front as well
     float pre_cos = 1.f, pre_sin = 0.f;
     long long pre_slot = -1;
@@ -931,7 +803,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     }
     // lane owns rows n = j*16 + lq*4 + e of column m = i*16 + lm  (swapped-operand C layout)
     STAMP(1);
-    if (scaled) fr.reduce(p, m_base, part);
     float* mine = red + (size_t)w * 64 * RLD;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -953,7 +824,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             float vs = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WAVES; ++ww) vs += red[((size_t)ww * 64 + m) * RLD + n];
-            if (scaled) vs *= fold_rinv<WAVES>(p, part, m);
             vs = bf2f(f2bf(vs + bias_pre));
             // the rotary partner (column n ^ 8 of the same row) is finished by lane ^ 8 of this wave: take its value instead of summing it again
             const float vp = __shfl_xor(vs, 8, WAVE);
@@ -978,10 +848,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         STAMP(3);
         return;
     }
-    if (p.out_mode == 5) {
-        if constexpr (NB == 1) fold_finish_tile<WAVES, RLD>(p, red, 0, n0, m_base, blockIdx.z, gridDim.z, side0, (unsigned*)(part + WAVES * 64));
-        return;
-    }
     for (int idx = t; idx < 64 * BNC; idx += WAVES * 64) {
         const int m = idx / BNC, n = idx - m * BNC;
         const int gm = m_base + m, gn = n0 + n;
@@ -989,7 +855,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         float v = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
-        if (scaled) v *= fold_rinv<WAVES>(p, part, m);
         if (p.out_mode == 0) {
             v += bias_pre;
             ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
@@ -1021,14 +886,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
     constexpr int RC = 32, RLD = RC + 1;  // columns per reduction round
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [WAVES][64][RLD]
-    float* part = red + (size_t)WAVES * 64 * RLD;   // [WAVES][64] norm folding
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int lm = l & 15, lq = l >> 4;
     const int n0 = blockIdx.x * 16 * NB;
     const int m_base = blockIdx.y * 64;
-    const bool scaled = p.nf.ssq_in != nullptr;
-    FoldRegs<WAVES, 16> fr;
-    if (scaled) fr.load(p, m_base);
     const int nstep = FP8 ? p.K >> 6 : p.K >> 5;
     const int per_z = (nstep + gridDim.z - 1) / gridDim.z;
     const int st_begin = blockIdx.z * per_z, st_end = min(nstep, st_begin + per_z);
@@ -1109,7 +970,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
     int s0 = st_begin + w;
     for (; s0 + (DEPTH - 1) * WAVES < st_end; s0 += WAVES * DEPTH) trip(s0, std::integral_constant<int, DEPTH>{});
     for (; s0 < st_end; s0 += WAVES) trip(s0, std::integral_constant<int, 1>{});
-    if (scaled) fr.reduce(p, m_base, part);
     float* mine = red + (size_t)w * 64 * RLD;
 #pragma unroll
     for (int r = 0; r < NB / 2; ++r) {
@@ -1135,7 +995,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
                     u += red[((size_t)ww * 64 + m) * RLD + 16 + n];
                 }
                 if constexpr (FP8) { g *= p.wscale[gn]; u *= p.wscale[(p.N >> 1) + gn]; }
-                if (scaled) { const float ri = fold_rinv<WAVES>(p, part, m); g *= ri; u *= ri; }
                 g = bf2f(f2bf(g));
                 u = bf2f(f2bf(u));
                 const float sg = bf2f(f2bf(g / (1.f + __expf(-g))));
@@ -1151,7 +1010,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
 #pragma unroll
             for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
             if constexpr (FP8) v *= p.wscale[gn];
-            if (scaled) v *= fold_rinv<WAVES>(p, part, m);
             if (p.out_mode == 0) {
                 if (p.bias) v += bf2f(p.bias[gn]);
                 ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
@@ -1176,11 +1034,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     constexpr int TPI = 2, RLD = 16 * TPI + 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [WAVES][64][RLD]
-    float* part = red + (size_t)WAVES * 64 * RLD;   // [WAVES][64] norm folding
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
     const int b = blockIdx.x, bps = gridDim.x;
     const int m_base = blockIdx.y * 64;
-    const bool scaled = p.nf.ssq_in != nullptr;
     const long long sb = p.out_mode == 3 ? side_base(p.so) : -1;
     STAMP(4);
     const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks)
@@ -1223,15 +1079,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
 #ifdef IADR1_PERS_XFIRST
     if (g < ngroups) loadw(g);
 #endif
-    float* rs = part + WAVES * 64;                              // [64] 1/rms of the block's rows
-    if (scaled) {      // requested after the weights and X (L2 hits, first needed in the first epilogue); one barrier pair before the loop, none in it
-        FoldRegs<WAVES, 16> fr;
-        fr.load(p, m_base);
-        fr.reduce(p, m_base, part);
-        __syncthreads();
-        fold_rinv_rows<WAVES>(p, part, rs);
-        __syncthreads();
-    }
     float* mine = red + (size_t)w * 64 * RLD;
     for (; g < ngroups; gq += gstep, g = group_of(gq)) {
         const int g_next = group_of(gq + gstep);
@@ -1267,7 +1114,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
                     gsum += red[((size_t)ww * 64 + m) * RLD + n];
                     usum += red[((size_t)ww * 64 + m) * RLD + 16 + n];
                 }
-                if (scaled) { const float ri = rs[m]; gsum *= ri; usum *= ri; }
                 gsum = bf2f(f2bf(gsum));
                 usum = bf2f(f2bf(usum));
                 const float sg = bf2f(f2bf(gsum / (1.f + __expf(-gsum))));
@@ -1287,7 +1133,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
                 float v = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
-                if (scaled) v *= rs[m];
                 if (p.out_mode == 0) {
                     if (p.bias) v += bf2f(p.bias[gn]);
                     ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
@@ -1312,10 +1157,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
     constexpr int RLD = 16 + 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [WAVES][64][RLD]
-    unsigned* flag = (unsigned*)(red + (size_t)WAVES * 64 * RLD);   // out_mode 5: last-arriver flag
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
     const int z = blockIdx.x / bps, b = blockIdx.x - z * bps;
-    const long long side0 = p.out_mode == 5 ? side_base(p.so) : -1;
     const int m_base = blockIdx.y * 64;
     const int ksteps = p.K >> 5;
     const int per_z = (ksteps + nz - 1) / nz;
@@ -1369,35 +1212,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
 #pragma unroll
             for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + lq * 4 + e] = acc[i][e];
         __syncthreads();
-        if (p.out_mode == 5) {
-            fold_finish_tile<WAVES, RLD>(p, red, 0, g * 16, m_base, z, nz, side0, flag);
-        } else {
-            for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
-                const int m = idx >> 4, n = idx & 15, gm = m_base + m;
-                if (gm >= p.M) continue;
-                float v = 0.f;
+        for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
+            const int m = idx >> 4, n = idx & 15, gm = m_base + m;
+            if (gm >= p.M) continue;
+            float v = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
-                ((float*)p.Y)[((long long)z * p.M + gm) * p.ldy + g * 16 + n] = v;
-            }
+            for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+            ((float*)p.Y)[((long long)z * p.M + gm) * p.ldy + g * 16 + n] = v;
         }
         __syncthreads();
     }
 }
 
-// 8 weights x the norm gain of their K columns (norm folding, include/iadr1_hip.h): bf16(w * g), one rounding; null gain = copy
-__device__ __forceinline__ u32x4_t scale8(u32x4_t w, const bf16_t* colscale, int k) {
-    if (!colscale) return w;
-    const u32x4_t g = *(const u32x4_t*)(colscale + k);
-    u32x4_t o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack2bf(lo_bf(w[e]) * lo_bf(g[e]), hi_bf(w[e]) * hi_bf(g[e]));
-    return o;
-}
-
 // Decode-packing of a fused gate|up matrix W[2I, K] for the SwiGLU-fused skinny GEMM: packed 16-row tile 2q holds
 // gate rows [16q, 16q+16), tile 2q+1 the matching up rows [I+16q, ...), so one block owns both halves of its columns.
-__global__ __launch_bounds__(256) void pack_gateup_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int I, int K, const bf16_t* colscale) {
+__global__ __launch_bounds__(256) void pack_gateup_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int I, int K) {
     const int ksteps = K >> 5;
     const long long total = (long long)(2 * I >> 4) * ksteps * 64;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1407,13 +1236,13 @@ __global__ __launch_bounds__(256) void pack_gateup_kernel(const bf16_t* W, long 
         const long long tile = ts / ksteps;
         const long long n = (tile & 1 ? I : 0) + (tile >> 1) * 16 + (lane & 15);
         const int k = ks * 32 + (lane >> 4) * 8;
-        *(u32x4_t*)(Wp + i * 8) = scale8(*(const u32x4_t*)(W + n * ldw + k), colscale, k);
+        *(u32x4_t*)(Wp + i * 8) = *(const u32x4_t*)(W + n * ldw + k);
     }
 }
 
 // Repack W[N,K] (row-major) into MFMA-fragment order for the decode stream:
 //   Wp[n/16][k/32][lane = (n%16) + 16*((k%32)/8)][k%8]
-__global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int N, int K, const bf16_t* colscale) {
+__global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* W, long long ldw, bf16_t* Wp, int N, int K) {
     const int ksteps = K >> 5;
     const long long total = (long long)(N >> 4) * ksteps * 64;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1423,15 +1252,14 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* W, long 
         const long long tile = ts / ksteps;
         const long long n = tile * 16 + (lane & 15);
         const int k = ks * 32 + (lane >> 4) * 8;
-        *(u32x4_t*)(Wp + i * 8) = scale8(*(const u32x4_t*)(W + n * ldw + k), colscale, k);
+        *(u32x4_t*)(Wp + i * 8) = *(const u32x4_t*)(W + n * ldw + k);
     }
 }
 
 // Decode-packing of the fused q|k|v matrix for the out_mode-4 epilogue: like pack_weight_kernel, but inside every q and k head
 // the 128 rows are dealt to the 8 column tiles as [8j, 8j+8) ++ [64+8j, 64+8j+8) so a tile holds complete rotary pairs; v heads keep
 // their natural order.  The bias vector is permuted the same way.
-__global__ __launch_bounds__(256) void pack_qkv_rope_kernel(const bf16_t* W, long long ldw, const bf16_t* bias, bf16_t* Wp, bf16_t* bias_p, int n_rope_heads, int N, int K,
-                                                            const bf16_t* colscale) {
+__global__ __launch_bounds__(256) void pack_qkv_rope_kernel(const bf16_t* W, long long ldw, const bf16_t* bias, bf16_t* Wp, bf16_t* bias_p, int n_rope_heads, int N, int K) {
     const int ksteps = K >> 5;
     const long long total = (long long)(N >> 4) * ksteps * 64;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1442,18 +1270,18 @@ __global__ __launch_bounds__(256) void pack_qkv_rope_kernel(const bf16_t* W, lon
         const int head = tile >> 3, j = tile & 7;
         const long long n = head < n_rope_heads ? (long long)head * 128 + (lm < 8 ? 8 * j + lm : 64 + 8 * j + lm - 8) : (long long)tile * 16 + lm;
         const int k = ks * 32 + (lane >> 4) * 8;
-        *(u32x4_t*)(Wp + i * 8) = scale8(*(const u32x4_t*)(W + n * ldw + k), colscale, k);
+        *(u32x4_t*)(Wp + i * 8) = *(const u32x4_t*)(W + n * ldw + k);
         if (ks == 0 && lane < 16 && bias) bias_p[tile * 16 + lm] = bias[n];
     }
 }
 
-// FP8 decode pack, pass 1: dequantisation scale of every output row, scale[n] = max_k |w[n][k] * g[k]| / 448 (448 = largest finite OCP e4m3 value)
-__global__ __launch_bounds__(256) void fp8_row_scale_kernel(const bf16_t* W, long long ldw, const bf16_t* colscale, float* scale, int K) {
+// FP8 decode pack, pass 1: dequantisation scale of every output row, scale[n] = max_k |w[n][k]| / 448 (448 = largest finite OCP e4m3 value)
+__global__ __launch_bounds__(256) void fp8_row_scale_kernel(const bf16_t* W, long long ldw, float* scale, int K) {
     __shared__ float scratch[16];
     const long long n = blockIdx.x;
     float amax = 0.f;
     for (int c = threadIdx.x; c < (K >> 3); c += 256) {
-        const u32x4_t v = scale8(*(const u32x4_t*)(W + n * ldw + c * 8), colscale, c * 8);
+        const u32x4_t v = *(const u32x4_t*)(W + n * ldw + c * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo_bf(v[e])), fabsf(hi_bf(v[e]))));
     }
@@ -1462,7 +1290,7 @@ __global__ __launch_bounds__(256) void fp8_row_scale_kernel(const bf16_t* W, lon
 }
 // pass 2: Wp8[n/16][k/64][lane][16 bytes] (see gemm_skinny_wide_kernel<.., FP8>); I > 0: gate|up matrix, 16-row tiles of gate and up interleaved like
 // pack_gateup_kernel.  Round-to-nearest-even through v_cvt_pk_fp8_f32; |w / scale| <= 448 by construction.
-__global__ __launch_bounds__(256) void pack_fp8_kernel(const bf16_t* W, long long ldw, const bf16_t* colscale, const float* scale, uint32_t* Wp8, int N, int K, int I) {
+__global__ __launch_bounds__(256) void pack_fp8_kernel(const bf16_t* W, long long ldw, const float* scale, uint32_t* Wp8, int N, int K, int I) {
     const int dsteps = K >> 6;
     const long long total = (long long)(N >> 4) * dsteps * 64;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -1476,7 +1304,7 @@ __global__ __launch_bounds__(256) void pack_fp8_kernel(const bf16_t* W, long lon
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = sd * 64 + h * 32 + (lane >> 4) * 8;
-            const u32x4_t v = scale8(*(const u32x4_t*)(W + n * ldw + k), colscale, k);
+            const u32x4_t v = *(const u32x4_t*)(W + n * ldw + k);
             int lo = 0, hi = 0;
             lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[0]) / sc, hi_bf(v[0]) / sc, lo, false);
             lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[1]) / sc, hi_bf(v[1]) / sc, lo, true);
@@ -1606,45 +1434,23 @@ extern "C" int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, vo
     return iadr1_check_launch("gemm_swiglu_bf16");
 }
 
-// the caller's iadr1_norm_fold_t (host memory, may be null) -> the by-value kernel argument
-static int skinny_fold_arg(const void* fold, int out_mode, int ksplit, NormFold* out) {
-    *out = NormFold{};
-    if (!fold) {
-        IADR1_REQUIRE(out_mode != 5, "gemm_skinny: out_mode 5 (residual-stream producer) needs the fold argument");
-        return IADR1_OK;
-    }
-    const NormFold f = *(const NormFold*)fold;
-    if (out_mode == 5) {
-        IADR1_REQUIRE(f.ssq_out != nullptr && f.ssq_in == nullptr, "gemm_skinny: out_mode 5 writes ssq_out and takes no ssq_in");
-        IADR1_REQUIRE(ksplit == 1 || (f.slabs != nullptr && f.counters != nullptr), "gemm_skinny: out_mode 5 with ksplit > 1 needs the slab workspace and the tile counters");
-    } else {
-        IADR1_REQUIRE(out_mode != 2, "gemm_skinny: partial slabs (out_mode 2) cannot be row-scaled");
-        IADR1_REQUIRE(f.ssq_in == nullptr || (f.ssq_in_tiles >= 1 && f.eps >= 0.f), "gemm_skinny: ssq_in needs ssq_in_tiles >= 1");
-    }
-    *out = f;
-    return IADR1_OK;
-}
-
 extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
-                                      long long ldw, long long ldy, int out_mode, int ksplit, const void* side, const void* fold, hipStream_t stream) {
+                                      long long ldw, long long ldy, int out_mode, int ksplit, const void* side, hipStream_t stream) {
     IADR1_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_skinny: empty problem");
     IADR1_REQUIRE((K % 32) == 0 && (N % 16) == 0 && (ldx % 8) == 0, "gemm_skinny: packed weights need K %% 32 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
-    IADR1_REQUIRE(ldy != 0 || (out_mode == 3 && (N % 64) == 0) || (out_mode == 5 && (N % 32) == 0),
-                  "gemm_skinny: a decode-packed output (ldy == 0) exists for the fused-SwiGLU mode and the residual-stream producer only");
+    IADR1_REQUIRE(ldy != 0 || (out_mode == 3 && (N % 64) == 0), "gemm_skinny: a decode-packed output (ldy == 0) exists for the fused-SwiGLU mode only");
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)W) & 15) == 0, "gemm_skinny: X/W must be 16-byte aligned");
     (void)ldw;
-    IADR1_REQUIRE(out_mode >= 0 && out_mode <= 5 && out_mode != 4 && ksplit >= 1 && (ksplit == 1 || out_mode == 2 || out_mode == 5),
-                  "gemm_skinny: out_mode 0-3 or 5; ksplit > 1 needs out_mode 2 (partial slabs) or 5 (residual-stream producer)");
+    IADR1_REQUIRE(out_mode >= 0 && out_mode <= 3 && ksplit >= 1 && (ksplit == 1 || out_mode == 2), "gemm_skinny: out_mode 0-3; ksplit > 1 needs out_mode 2 (partial slabs)");
     IADR1_REQUIRE(out_mode != 3 || (N % 128) == 0, "gemm_skinny: fused SwiGLU needs N (= 2*I) to be a multiple of 128, got %d", N);
     SkinnyArgs p{};
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
     p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.out_mode = out_mode;
-    if (int e = skinny_fold_arg(fold, out_mode, ksplit, &p.nf)) return e;
     static const int xcd_order = iadr1_env_int("IADR1_PERS_XCD_ORDER", 1);
     p.xcd_order = xcd_order;
     const int mz = (M + 63) / 64;
-    // dynamic LDS: the cross-wave reduction buffer [WAVES][64][RLD] + (norm folding) [WAVES][64] partial row sums and one flag word
-    constexpr int SM1 = 16 * 64 * 17 * 4 + 16 * 64 * 4 + 64, SM2 = 8 * 64 * 33 * 4 + 8 * 64 * 4 + 64, SMW = 8 * 64 * 33 * 4 + 8 * 64 * 4 + 64, SMP = SMW + 256, SMS = 8 * 64 * 17 * 4 + 64;
+    // dynamic LDS: the cross-wave reduction buffer [WAVES][64][RLD]
+    constexpr int SM1 = 16 * 64 * 17 * 4, SM2 = 8 * 64 * 33 * 4, SMW = 8 * 64 * 33 * 4, SMP = SMW, SMS = 8 * 64 * 17 * 4;
     // launcher configuration, fixed at first use: A/B switches, the CU count, LDS opt-ins of every kernel this entry point can launch
     static const int wide_nb = iadr1_env_int("IADR1_SKINNY_WIDE_NB", -1);  // -1: 4 with packed X, 8 with row-major X
     static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1);
@@ -1669,9 +1475,8 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     {
         {   // split-K slabs (down projection): <= 6 k-steps per wave in a slice, >= 4 tiles per block
             const int kst = K >> 5, per_z = (kst + ksplit - 1) / ksplit, bps = ksplit > 0 ? ncu / ksplit : 0;
-            if (pers && ksplit > 1 && (out_mode == 2 || out_mode == 5) && per_z <= 48 && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
-                IADR1_REQUIRE(side == nullptr || out_mode == 5, "gemm_skinny: no side outputs in the split-K slab form");
-                if (int e = iadr1_side_arg(side, &p.so)) return e;
+            if (pers && ksplit > 1 && out_mode == 2 && per_z <= 48 && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
+                IADR1_REQUIRE(side == nullptr, "gemm_skinny: no side outputs in the split-K slab form");
                 hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 6>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
                 return iadr1_check_launch("gemm_skinny_bf16");
             }
@@ -1679,12 +1484,8 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         const int ksw = K / 256;
         const bool pers_ok = pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu;
         if (int e = iadr1_side_arg(side, &p.so)) return e;
-        IADR1_REQUIRE(!p.so.step || (out_mode == 3 && pers_ok) || out_mode == 5,
-                      "gemm_skinny: side outputs exist for the fused-SwiGLU projection in the persistent kernel and for the residual-stream producer only (mode %d N=%d K=%d)", out_mode, N, K);
-        if (out_mode == 5) {     // residual-stream producer: the narrow kernel, one 16-column tile per block, K slices over grid.z
-            hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3(N / 16, mz, ksplit), dim3(1024), SM1, stream, p);
-            return iadr1_check_launch("gemm_skinny_bf16");
-        }
+        IADR1_REQUIRE(!p.so.step || (out_mode == 3 && pers_ok),
+                      "gemm_skinny: side outputs exist for the fused-SwiGLU projection in the persistent kernel only (mode %d N=%d K=%d)", out_mode, N, K);
         if (pers_ok) {
             const dim3 grid(ncu, mz, 1), block(512);
             if (ksw == 8) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 8>), grid, block, SMP, stream, p);
@@ -1705,17 +1506,17 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     return iadr1_check_launch("gemm_skinny_bf16");
 }
 
-extern "C" int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, const void* colscale, hipStream_t stream) {
+extern "C" int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, hipStream_t stream) {
     IADR1_REQUIRE(N > 0 && K > 0 && (N % 16) == 0 && (K % 32) == 0 && (ldw % 8) == 0, "pack_weight: need N %% 16 == 0, K %% 32 == 0 (N=%d K=%d)", N, K);
     long long blocks = ((long long)N * K / 8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, N, K, (const bf16_t*)colscale);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, N, K);
     return iadr1_check_launch("pack_weight_bf16");
 }
 
 extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const void* bias_p, void* q_out, const float* rope_cos, const float* rope_sin,
                                            const long long* slot, void* kcache, void* vcache, int M, int Hq, int Hkv, int D, int K, long long ldx,
-                                           long long ldq, const void* side, const void* fold, hipStream_t stream) {
+                                           long long ldq, const void* side, hipStream_t stream) {
     IADR1_REQUIRE(D == 128, "gemm_qkv_rope_kv: head dim %d not built (128 is)", D);
     IADR1_REQUIRE(M > 0 && Hq > 0 && Hkv > 0 && (K % 32) == 0 && (ldx % 8) == 0, "gemm_qkv_rope_kv: need K %% 32 == 0 (K=%d)", K);
     IADR1_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wp) & 15) == 0, "gemm_qkv_rope_kv: X/W must be 16-byte aligned");
@@ -1724,21 +1525,19 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
     p.ldx = ldx; p.ldw = K; p.ldy = ldq; p.out_mode = 4;
     p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.slot = slot; p.kcache = (bf16_t*)kcache; p.vcache = (bf16_t*)vcache; p.Hq = Hq; p.Hkv = Hkv;
     if (int e = iadr1_side_arg(side, &p.so)) return e;
-    if (int e = skinny_fold_arg(fold, 4, 1, &p.nf)) return e;
-    constexpr int SM1 = 16 * 64 * 17 * 4 + 16 * 64 * 4 + 64;
+    constexpr int SM1 = 16 * 64 * 17 * 4;
     static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1); return true; }();
     (void)attr_done;
     hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3(p.N / 16, (M + 63) / 64, 1), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
 }
 
-extern "C" int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, void* Wp, void* bias_p, int Hq, int Hkv, int D, int K, const void* colscale,
-                                        hipStream_t stream) {
+extern "C" int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, void* Wp, void* bias_p, int Hq, int Hkv, int D, int K, hipStream_t stream) {
     IADR1_REQUIRE(D == 128 && K > 0 && (K % 32) == 0 && (ldw % 8) == 0, "pack_qkv_rope: need D == 128, K %% 32 == 0 (D=%d K=%d)", D, K);
     const int N = (Hq + 2 * Hkv) * D;
     long long blocks = ((long long)N * K / 8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pack_qkv_rope_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)Wp, (bf16_t*)bias_p, Hq + Hkv, N, K, (const bf16_t*)colscale);
+    hipLaunchKernelGGL(pack_qkv_rope_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)Wp, (bf16_t*)bias_p, Hq + Hkv, N, K);
     return iadr1_check_launch("pack_qkv_rope_bf16");
 }
 
@@ -1750,17 +1549,17 @@ extern "C" int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M
     return iadr1_check_launch("pack_act_bf16");
 }
 
-extern "C" int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, const void* colscale, hipStream_t stream) {
+extern "C" int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, hipStream_t stream) {
     IADR1_REQUIRE(I > 0 && K > 0 && (I % 64) == 0 && (K % 32) == 0 && (ldw % 8) == 0, "pack_gateup: need I %% 64 == 0, K %% 32 == 0 (I=%d K=%d)", I, K);
     long long blocks = ((long long)2 * I * K / 8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pack_gateup_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, I, K, (const bf16_t*)colscale);
+    hipLaunchKernelGGL(pack_gateup_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (bf16_t*)Wp, I, K);
     return iadr1_check_launch("pack_gateup_bf16");
 }
 
 // Decode-time skinny GEMM on FP8 weights (include/iadr1_hip.h): the wide kernel, 64 output columns per block, K slices over grid.z.
 extern "C" int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const float* wscale, void* Y, const void* bias, int M, int N, int K, long long ldx, long long ldy,
-                                      int out_mode, int ksplit, const void* fold, hipStream_t stream) {
+                                      int out_mode, int ksplit, hipStream_t stream) {
     IADR1_REQUIRE(M > 0 && N > 0 && K > 0 && wscale != nullptr, "gemm_skinny_fp8w: empty problem / no scales");
     IADR1_REQUIRE((K % 64) == 0 && (N % 64) == 0 && (ldx % 8) == 0, "gemm_skinny_fp8w: FP8-packed weights need K %% 64 == 0 and N %% 64 == 0 (K=%d N=%d)", K, N);
     IADR1_REQUIRE(ldy != 0 || (out_mode == 3 && (N % 64) == 0), "gemm_skinny_fp8w: a decode-packed output (ldy == 0) exists for the fused-SwiGLU mode only");
@@ -1770,22 +1569,21 @@ extern "C" int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const floa
     SkinnyArgs p{};
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)Wp8; p.wscale = wscale; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
     p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.out_mode = out_mode;
-    if (int e = skinny_fold_arg(fold, out_mode, ksplit, &p.nf)) return e;
-    constexpr int SMW = 8 * 64 * 33 * 4 + 8 * 64 * 4 + 64;
+    constexpr int SMW = 8 * 64 * 33 * 4;
     static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW); return true; }();
     (void)attr_done;
     hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8, true>), dim3(N / 64, (M + 63) / 64, ksplit), dim3(512), SMW, stream, p);
     return iadr1_check_launch("gemm_skinny_fp8w");
 }
 
-extern "C" int iadr1_pack_weight_fp8(const void* W, long long ldw, void* Wp8, float* scale, int N, int K, int gateup_I, const void* colscale, hipStream_t stream) {
+extern "C" int iadr1_pack_weight_fp8(const void* W, long long ldw, void* Wp8, float* scale, int N, int K, int gateup_I, hipStream_t stream) {
     IADR1_REQUIRE(N > 0 && K > 0 && (N % 16) == 0 && (K % 64) == 0 && (ldw % 8) == 0, "pack_weight_fp8: need N %% 16 == 0, K %% 64 == 0 (N=%d K=%d)", N, K);
     IADR1_REQUIRE(gateup_I == 0 || (2 * gateup_I == N && (gateup_I % 64) == 0), "pack_weight_fp8: gateup_I must be N / 2 and a multiple of 64");
     IADR1_REQUIRE(scale != nullptr && (((uintptr_t)Wp8) & 15) == 0, "pack_weight_fp8: scale buffer / 16-byte aligned destination required");
-    hipLaunchKernelGGL(fp8_row_scale_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)W, ldw, (const bf16_t*)colscale, scale, K);
+    hipLaunchKernelGGL(fp8_row_scale_kernel, dim3(N), dim3(256), 0, stream, (const bf16_t*)W, ldw, scale, K);
     long long blocks = ((long long)N * K / 16 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pack_fp8_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, (const bf16_t*)colscale, scale, (uint32_t*)Wp8, N, K, gateup_I);
+    hipLaunchKernelGGL(pack_fp8_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)W, ldw, scale, (uint32_t*)Wp8, N, K, gateup_I);
     return iadr1_check_launch("pack_weight_fp8");
 }
 

@@ -46,70 +46,31 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
-def pack_weight(w, out=None, colscale=None):
-    """[N,K] row-major -> decode-packed fragment order (flat [N*K]).  colscale [K] bf16: the packed copy holds bf16(w * colscale) (a norm gain folded
-    into the weights, NormFold)."""
+def pack_weight(w, out=None):
+    """[N,K] row-major -> decode-packed fragment order (flat [N*K])."""
     N, K = w.shape
     o = out if out is not None else torch.empty(N * K, dtype=BF16, device=w.device)
-    assert colscale is None or (colscale.dtype == BF16 and colscale.numel() == K and colscale.is_contiguous())
-    hip.call("pack_weight_bf16", w, _ld(w), o, N, K, colscale)
+    hip.call("pack_weight_bf16", w, _ld(w), o, N, K)
     return o
 
 
-def pack_gateup(w, out=None, colscale=None):
+def pack_gateup(w, out=None):
     """[2I,K] gate|up -> decode-packed with gate/up tiles interleaved (for gemm_skinny(..., swiglu=True))."""
     N2, K = w.shape
     o = out if out is not None else torch.empty(N2 * K, dtype=BF16, device=w.device)
-    assert colscale is None or (colscale.dtype == BF16 and colscale.numel() == K and colscale.is_contiguous())
-    hip.call("pack_gateup_bf16", w, _ld(w), o, N2 // 2, K, colscale)
+    hip.call("pack_gateup_bf16", w, _ld(w), o, N2 // 2, K)
     return o
 
 
-def pack_weight_fp8(w, out=None, out_scale=None, colscale=None, gateup=False):
+def pack_weight_fp8(w, out=None, out_scale=None, gateup=False):
     """[N,K] bf16 -> (FP8 e4m3 decode pack: flat uint8 [N*K], fp32 scale per output row [N]) for gemm_skinny (include/iadr1_hip.h iadr1_pack_weight_fp8).
     gateup: w is a gate|up matrix, tiles interleaved for the fused-SwiGLU mode."""
     N, K = w.shape
     out = out if out is not None else torch.empty(N * K, dtype=torch.uint8, device=w.device)
     out_scale = out_scale if out_scale is not None else torch.empty(N, dtype=F32, device=w.device)
     assert out.dtype == torch.uint8 and out.numel() == N * K and out_scale.dtype == F32 and out_scale.numel() == N
-    assert colscale is None or (colscale.dtype == BF16 and colscale.numel() == K and colscale.is_contiguous())
-    hip.call("pack_weight_fp8", w, _ld(w), out, out_scale, N, K, N // 2 if gateup else 0, colscale)
+    hip.call("pack_weight_fp8", w, _ld(w), out, out_scale, N, K, N // 2 if gateup else 0)
     return out, out_scale
-
-
-class NormFold(ctypes.Structure):
-    """include/iadr1_hip.h iadr1_norm_fold_t: the decode step's RMSNorms folded into the GEMMs around them.  `consumer(ssq, eps)`: the GEMM reads the
-    un-normalised residual stream (weights packed with colscale = the norm gain) and scales every output row by 1/rms from the tile partials `ssq`
-    [tiles, Mpad] fp32.  `producer(ssq_out, slabs, counters)`: gemm_skinny(resid=...) adds its output to the residual stream in place and writes
-    the new partials."""
-    _fields_ = [("ssq_in", ctypes.c_void_p), ("ssq_in_tiles", ctypes.c_int), ("eps", ctypes.c_float), ("ssq_out", ctypes.c_void_p), ("y_packed", ctypes.c_void_p),
-                ("slabs", ctypes.c_void_p), ("counters", ctypes.c_void_p)]
-
-    @staticmethod
-    def consumer(ssq, eps, tiles=None):
-        assert ssq.dtype == F32 and ssq.dim() == 2 and ssq.is_contiguous() and ssq.shape[1] % 64 == 0
-        nf = NormFold(ssq.data_ptr(), int(ssq.shape[0] if tiles is None else tiles), float(eps), None, None, None, None)
-        nf._keep = (ssq,)
-        return nf
-
-    @staticmethod
-    def producer(ssq_out, slabs=None, counters=None, packed_copy=None):
-        """packed_copy (PackedAct): the new residual rows are also written there (the next GEMM's input when the residual stream itself is row-major)."""
-        assert ssq_out.dtype == F32 and ssq_out.dim() == 2 and ssq_out.is_contiguous() and ssq_out.shape[1] % 64 == 0
-        assert slabs is None or (slabs.dtype == F32 and slabs.is_contiguous() and counters is not None and counters.dtype == torch.int32)
-        nf = NormFold(None, 0, 0.0, ssq_out.data_ptr(), None if packed_copy is None else packed_copy.buf.data_ptr(), None if slabs is None else slabs.data_ptr(),
-                      None if counters is None else counters.data_ptr())
-        nf._keep = (ssq_out, slabs, counters, packed_copy)
-        return nf
-
-
-def embed_decode(ids, table, out, ssq_out):
-    """out[m] = table[ids[m]] (row-major tensor or PackedAct), ssq_out[0, m] = sum of squares of the row: the entry of a decode step with folded norms."""
-    M, H = out.shape
-    ob, ldo = _xarg(out)
-    assert ids.dtype == torch.int64 and ids.numel() == M and ssq_out.dtype == F32 and ssq_out.shape[-1] >= M
-    hip.call("embed_decode", ids, table, ob, ldo, ssq_out, M, H)
-    return out
 
 
 class SideOut(ctypes.Structure):
@@ -161,21 +122,19 @@ def _xarg(x):
     return (x.buf, 0) if isinstance(x, PackedAct) else (x, _ld(x))
 
 
-def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=False, side=None, fold=None, resid=None):
+def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=False, side=None):
     """out[M,N] = x[M,K] @ W[N,K]^T + bias with W given decode-packed (`pack_weight`); HBM-bound weight stream.
-    x may be a PackedAct.  ksplit > 1: `out` is fp32 [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=...).
-    fold = NormFold.consumer(...): rows scaled by 1/rms of the x rows.  resid (tensor or PackedAct [M, N]) with fold = NormFold.producer(...):
-    resid = bf16(resid + bf16(x @ W^T)) in place, + the tile partials of its rows' sums of squares (C ABI out_mode 5)."""
+    x may be a PackedAct.  ksplit > 1: `out` is fp32 [ksplit, M, N] partial slabs to be summed by rmsnorm_fwd(x32=...)."""
     M, K = x.shape
     xb, ldx = _xarg(x)
     dev = xb.device
     if isinstance(wp, tuple):       # (FP8 pack, per-row scales): ops.pack_weight_fp8 -- the opt-in FP8 weight stream of the rollout
         w8, wscale = wp
-        assert w8.dtype == torch.uint8 and w8.numel() == N * K and wscale.numel() == N and resid is None and side is None
+        assert w8.dtype == torch.uint8 and w8.numel() == N * K and wscale.numel() == N and side is None
         if swiglu:
             out = out if out is not None else torch.empty(M, N // 2, dtype=BF16, device=dev)
             ob, ldo = _xarg(out)
-            hip.call("gemm_skinny_fp8w", xb, w8, wscale, ob, None, M, N, K, ldx, ldo, 3, 1, _side(fold))
+            hip.call("gemm_skinny_fp8w", xb, w8, wscale, ob, None, M, N, K, ldx, ldo, 3, 1)
             return out
         if out is None:
             out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=dev)
@@ -184,20 +143,15 @@ def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=
             mode, ldy = 2, N
         else:
             mode, ldy = (1 if out.dtype == F32 else 0), _ld(out)
-        hip.call("gemm_skinny_fp8w", xb, w8, wscale, out, bias, M, N, K, ldx, ldy, mode, ksplit, _side(fold))
+        hip.call("gemm_skinny_fp8w", xb, w8, wscale, out, bias, M, N, K, ldx, ldy, mode, ksplit)
         return out
     w = wp
     assert wp.numel() == N * K
-    if resid is not None:
-        assert fold is not None and bias is None and out is None and not swiglu and tuple(resid.shape) == (M, N)
-        rb, ldr = _xarg(resid)
-        hip.call("gemm_skinny_bf16", xb, w, rb, None, M, N, K, ldx, K, ldr, 5, ksplit, _side(side), _side(fold))
-        return resid
     if swiglu:
         if out is None:
             out = torch.empty(M, N // 2, dtype=BF16, device=dev)
         ob, ldo = _xarg(out)
-        hip.call("gemm_skinny_bf16", xb, w, ob, None, M, N, K, ldx, K, ldo, 3, 1, _side(side), _side(fold))
+        hip.call("gemm_skinny_bf16", xb, w, ob, None, M, N, K, ldx, K, ldo, 3, 1, _side(side))
         return out
     if out is None:
         out = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), dtype=F32 if ksplit > 1 else out_dtype, device=dev)
@@ -206,25 +160,24 @@ def gemm_skinny(x, wp, N, bias=None, out=None, out_dtype=BF16, ksplit=1, swiglu=
         mode, ldy = 2, N
     else:
         mode, ldy = (1 if out.dtype == F32 else 0), _ld(out)
-    hip.call("gemm_skinny_bf16", xb, w, out, bias, M, N, K, ldx, K, ldy, mode, ksplit, None, _side(fold))
+    hip.call("gemm_skinny_bf16", xb, w, out, bias, M, N, K, ldx, K, ldy, mode, ksplit, None)
     return out
 
 
-def pack_qkv_rope(w, bias, Hq, Hkv, D, out=None, out_bias=None, colscale=None):
+def pack_qkv_rope(w, bias, Hq, Hkv, D, out=None, out_bias=None):
     """q|k|v weight [N, K] (+ bias [N]) -> decode-packed with rotary partners sharing a tile (for gemm_qkv_rope_kv)."""
     N, K = w.shape
     out = out if out is not None else torch.empty(N * K, dtype=BF16, device=w.device)
     out_bias = out_bias if out_bias is not None else torch.empty(N, dtype=BF16, device=w.device)
-    assert colscale is None or (colscale.dtype == BF16 and colscale.numel() == K and colscale.is_contiguous())
-    hip.call("pack_qkv_rope_bf16", w, _ld(w), bias, out, out_bias, Hq, Hkv, D, K, colscale)
+    hip.call("pack_qkv_rope_bf16", w, _ld(w), bias, out, out_bias, Hq, Hkv, D, K)
     return out, out_bias
 
 
-def gemm_qkv_rope_kv(x, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, Hq, Hkv, D, side=None, fold=None):
-    """Decode step: q_out[:, :Hq*D] = rope(x.Wq^T + bq); K / V rows of the new token appended to the paged cache.  fold = NormFold.consumer(...)."""
+def gemm_qkv_rope_kv(x, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, Hq, Hkv, D, side=None):
+    """Decode step: q_out[:, :Hq*D] = rope(x.Wq^T + bq); K / V rows of the new token appended to the paged cache."""
     M, K = x.shape
     xb, ldx = _xarg(x)
-    hip.call("gemm_qkv_rope_kv_bf16", xb, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, M, Hq, Hkv, D, K, ldx, _ld(q_out), _side(side), _side(fold))
+    hip.call("gemm_qkv_rope_kv_bf16", xb, wp, bias_p, q_out, cos, sin, slot, kcache, vcache, M, Hq, Hkv, D, K, ldx, _ld(q_out), _side(side))
     return q_out
 
 

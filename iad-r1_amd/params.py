@@ -26,7 +26,6 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
-_FOLD_NORM = int(os.environ.get("IADR1_DECODE_FOLD_NORM", "0"))
 
 
 def _first_set(*values):
@@ -527,40 +526,18 @@ class ParamStore:
     def qkv_rope_packed(self) -> bool:
         return self.cfg.head_dim == 128
 
-    @property
-    def fold_norm(self) -> tuple:
-        """(ln1, ln2): which RMSNorms of the decode step are folded into the GEMM that follows them (ops.NormFold; include/iadr1_hip.h iadr1_norm_fold_t).
-        A folded norm's gain lives in the decode pack of that GEMM, bf16(w * g) -- q|k|v and lm_head for ln1 / the final norm, gate|up for ln2 -- and the
-        rollout scales rows by 1/rms in the GEMM epilogue instead of launching the norm.  IADR1_DECODE_FOLD_NORM: 0 (default) none; 1 ln2 only -- its
-        producer, the o projection, finishes a tile inside one block; 2 both -- the down projection's K slices then meet through the last-arriving block.
-        Built, parity-tested and MEASURED (profiles/r02_decode_fold.txt): 2.684 / 2.699 / 2.925 ms per decode step for modes 0 / 1 / 2 at 64 sequences of
-        the 3B shapes -- the 5 us norm launch a fold removes comes back as epilogue latency of the producer (+2.8 us on the o projection, +10.7 us for the
-        split-K exchange of the down projection), so the launches stay; the switch is kept for shapes where the balance differs."""
-        mode = _FOLD_NORM if self.cfg.hidden_size % 32 == 0 else 0
-        return (mode >= 2, mode >= 1)
-
     def refresh_decode_pack(self):
         fuse = self.cfg.intermediate_size % 64 == 0
         c = self.cfg
-        fold1, fold2 = self.fold_norm
         for name, (dst8, sc8) in self._pk8.items():
-            gain = ("ln2" if name.endswith(".gu.w") else None) if fold2 else None
-            colscale = self.w(name[:-len("gu.w")] + gain) if gain else (self.w("norm") if (fold1 and name == self.lm_head_name()) else None)
-            ops.pack_weight_fp8(self.w(name), out=dst8, out_scale=sc8, colscale=colscale, gateup=name.endswith(".gu.w") and self.cfg.intermediate_size % 64 == 0)
+            ops.pack_weight_fp8(self.w(name), out=dst8, out_scale=sc8, gateup=name.endswith(".gu.w") and self.cfg.intermediate_size % 64 == 0)
         for name, dst in self._pk.items():
             if self.qkv_rope_packed and name.endswith(".qkv.w"):
                 # rotary partners share a tile: the decode q|k|v GEMM applies rope and appends K/V in its epilogue
-                ops.pack_qkv_rope(self.w(name), self.w(name[:-1] + "b"), c.num_attention_heads, c.num_key_value_heads, c.head_dim, out=dst, out_bias=self._pkb[name],
-                                  colscale=self.w(name[:-len("qkv.w")] + "ln1") if fold1 else None)
-            elif name.endswith(".qkv.w"):
-                ops.pack_weight(self.w(name), out=dst, colscale=self.w(name[:-len("qkv.w")] + "ln1") if fold1 else None)
+                ops.pack_qkv_rope(self.w(name), self.w(name[:-1] + "b"), c.num_attention_heads, c.num_key_value_heads, c.head_dim, out=dst, out_bias=self._pkb[name])
             elif fuse and name.endswith(".gu.w"):
                 # gate/up tiles interleaved: the decode GEMM applies SwiGLU in its epilogue
-                ops.pack_gateup(self.w(name), out=dst, colscale=self.w(name[:-len("gu.w")] + "ln2") if fold2 else None)
-            elif name.endswith(".gu.w"):
-                ops.pack_weight(self.w(name), out=dst, colscale=self.w(name[:-len("gu.w")] + "ln2") if fold2 else None)
-            elif name == self.lm_head_name():
-                ops.pack_weight(self.w(name), out=dst, colscale=self.w("norm") if fold1 else None)
+                ops.pack_gateup(self.w(name), out=dst)
             else:
                 ops.pack_weight(self.w(name), out=dst)
 

@@ -61,29 +61,14 @@ class Rollout:
         self.fuse_swiglu = I % 64 == 0
         act = (lambda k: ops.PackedAct(N, k, dev)) if self.packed else (lambda k: torch.empty(N, k, dtype=BF16, device=dev))
         self.h = act(H)
-        # norm folding (include/iadr1_hip.h iadr1_norm_fold_t; the decode packs carry the norm gains: ParamStore.fold_norm): the residual stream itself is the
-        # GEMM input, its rows' sums of squares travel as per-tile partials from the producer (embedding / o / down projection) to the consumer
-        self.fold1, self.fold2 = engine.p.fold_norm
-        self.fold = self.fold1 or self.fold2
-        if self.fold:
-            Mp = (N + 63) // 64 * 64
-            if self.fold1:
-                self.x = act(H)                                               # the residual stream is a GEMM input at both norms: decode-packed itself
-            else:
-                self.xp = act(H) if self.packed else None                     # row-major stream (the ln1 launch reads it) + a packed copy for gate|up
-            self.ssq_a = torch.zeros(H // 16, Mp, dtype=F32, device=dev)      # rows entering ln1 (and the final norm)
-            self.ssq_b = torch.zeros(H // 16, Mp, dtype=F32, device=dev)      # rows entering ln2
-            self.tile_cnt = torch.zeros(Mp // 64 * (H // 16), dtype=i32, device=dev)
         self.qkv = torch.empty(N, c.qkv_width, dtype=BF16, device=dev)
         self.o = act(Hq * D)
         self.br = torch.empty(N, H, dtype=BF16, device=dev)
         self.ks_o, self.ks_down = (2, 8) if H * Hq * D >= 1 << 20 else (1, 1)   # split-K of the two narrow-N projections
         if os.environ.get("IADR1_DECODE_KS"):
             self.ks_o, self.ks_down = (int(z) for z in os.environ["IADR1_DECODE_KS"].split(","))
-        if self.fold and not os.environ.get("IADR1_DECODE_KS"):
-            self.ks_o = 1            # one K slice: the o projection's tile is complete inside its block (no exchange)
-        self.part_o = torch.empty(self.ks_o, (N + 63) // 64 * 64 if self.fold else N, H, dtype=F32, device=dev)
-        self.part_d = torch.empty(self.ks_down, (N + 63) // 64 * 64 if self.fold1 else N, H, dtype=F32, device=dev)
+        self.part_o = torch.empty(self.ks_o, N, H, dtype=F32, device=dev)
+        self.part_d = torch.empty(self.ks_down, N, H, dtype=F32, device=dev)
         self.gu = torch.empty(N, 2 * I, dtype=BF16, device=dev)
         self.a = act(I) if self.fuse_swiglu else torch.empty(N, I, dtype=BF16, device=dev)
         self.logits = torch.empty(N, V, dtype=F32, device=dev)
@@ -97,8 +82,6 @@ class Rollout:
 
     # ---- one decode step (graph body) -------------------------------------------------------------------------
     def _decode_step(self):
-        if self.fold:
-            return self._decode_step_folded()
         e, c, P = self.e, self.e.cfg, self.e.p
         tr = self.trace      # None, or the training arena the step also fills (Rollout.generate(train_trace=...))
 
@@ -161,83 +144,6 @@ class Rollout:
                                   chunks=self.group_chunks, ws=self.group_ws)
         else:
             ops.attn_decode(q, self.kc[i], self.vc[i], self.block_table, self.ctx_len, Hq, Hkv, D, c.attn_scale, out=self.o, side=side, seqs_per_group=self.G_seq)
-
-    def _decode_step_folded(self):
-        """The decode step with RMSNorm launches folded into the GEMMs around them (ops.NormFold).  ln2 (default): the o projection adds itself INTO the
-        residual stream and leaves the per-tile sums of squares of the new rows, gate|up reads the un-normalised rows (its decode pack carries the gain)
-        and scales by 1/rms in its epilogue: 6 kernels per layer instead of 7.  With ln1 folded as well (IADR1_DECODE_FOLD_NORM=2) the down projection is
-        the second producer and q|k|v / lm_head the consumers: 5 kernels per layer.  Side outputs: residual rows come from the producers; the normalised
-        rows and rstd statistics of a folded norm are recomputed in bulk after the rollout (Engine.text_context_from_trace)."""
-        e, c, P = self.e, self.e.cfg, self.e.p
-        tr = self.trace
-        keep = self._sides = []
-
-        def side(**kw):
-            if tr is None:
-                return None
-            so = ops.SideOut.make(self.step, tr["base"], tr["stride"], **kw)
-            keep.append(so)
-            return so
-
-        def consumer(ssq, tiles=None):
-            nf = ops.NormFold.consumer(ssq, c.rms_norm_eps, tiles)
-            keep.append(nf)
-            return nf
-
-        def producer(ssq, slabs, ks, packed_copy=None):
-            nf = ops.NormFold.producer(ssq, slabs if ks > 1 else None, self.tile_cnt if ks > 1 else None, packed_copy)
-            keep.append(nf)
-            return nf
-
-        D, Hq, Hkv, H, L = c.head_dim, c.num_attention_heads, c.num_key_value_heads, c.hidden_size, c.num_hidden_layers
-        qw = Hq * D
-        f1 = self.fold1
-        T_ = lambda name, i: None if tr is None else tr[name][i]
-        if f1:
-            ops.embed_decode(self.cur_tok, P.w("embed"), self.x, self.ssq_a)    # layer 0's x_in rows of the arena are filled after the rollout
-        else:
-            ops.embed_fwd(self.cur_tok, None, P.w("embed"), None, out=self.x)
-        ops.rope_table(self.pos, e.inv_freq, self.cos, self.sin)
-        for i in range(L):
-            b = f"layers.{i}."
-            if f1:
-                xin, nf1 = self.x, consumer(self.ssq_a, 1 if i == 0 else None)
-            else:
-                xin, nf1 = self.h, None
-                if i == 0:
-                    ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h, side=side(p1=T_("h1", i), p2=T_("rstd1", i)))
-                else:
-                    ops.rmsnorm_fwd(None, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h,
-                                    side=side(p0=T_("x_in", i), p1=T_("h1", i), p2=T_("rstd1", i)))
-            if P.qkv_rope_packed:
-                ops.gemm_qkv_rope_kv(xin, P.wpk(b + "qkv.w"), P.wpk_bias(b + "qkv.w"), self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D,
-                                     side=side(p0=T_("qkv", i)), fold=nf1)
-            else:
-                assert tr is None
-                ops.gemm_skinny(xin, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv, fold=nf1)
-                ops.rope_kv_store(self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D)
-            self._attention(i, side(p0=T_("o", i), p1=T_("lse", i), ld1=None if tr is None else tr["lse"][i].stride(0)))
-            ops.gemm_skinny(self.o, P.wpk(b + "o.w"), H, resid=self.x, ksplit=self.ks_o, side=side(p0=T_("x_mid", i)),
-                            fold=producer(self.ssq_b, self.part_o, self.ks_o, None if f1 else self.xp))
-            xg, nf2 = (self.x if f1 or self.xp is None else self.xp), consumer(self.ssq_b)
-            if self.fuse_swiglu:
-                ops.gemm_skinny(xg, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True, side=side(p0=T_("gu", i), p1=T_("a", i)), fold=nf2)
-            else:
-                assert tr is None
-                ops.gemm_skinny(xg, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.gu, fold=nf2)
-                ops.swiglu_fwd(self.gu, out=self.a)
-            if f1:
-                nxt = None if tr is None else (tr["x_in"][i + 1] if i + 1 < L else tr["x_last"])
-                ops.gemm_skinny(self.a, P.wpk(b + "down.w"), H, resid=self.x, ksplit=self.ks_down, fold=producer(self.ssq_a, self.part_d, self.ks_down), side=side(p0=nxt))
-            else:
-                ops.gemm_skinny(self.a, P.wpk(b + "down.w"), H, out=self.part_d, ksplit=self.ks_down)
-        if f1:
-            ops.gemm_skinny(self.x, P.wpk(P.lm_head_name()), c.vocab_size, out=self.logits, fold=consumer(self.ssq_a))
-        else:
-            ops.rmsnorm_fwd(None, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h,
-                            side=side(p0=None if tr is None else tr["x_last"], p1=None if tr is None else tr["hf"], p2=None if tr is None else tr["rstdf"]))
-            ops.gemm_skinny(self.h, P.wpk(P.lm_head_name()), c.vocab_size, out=self.logits)
-        self._sample_and_advance()
 
     def _sample_and_advance(self):
         s = self.sampling
@@ -364,7 +270,6 @@ class Rollout:
                                 (t_[:, Bp * S:] if (t_.dim() == 2 and t_.shape[0] == c.num_attention_heads and k == "lse") else t_[Bp * S:]).zero_()
                 tr["key"] = key
                 self.trace = tr
-                train_carry["trace_folded"] = (self.fold1, self.fold2)      # the normalised rows / rstd of the completion block are NOT in the arena yet (Engine.text_context_from_trace)
         else:
             hf, _ = e.text_forward(plan, img_embeds, save=False, kv_sink=kv_sink)
         last_rows = torch.arange(Bp, device=dev, dtype=torch.int64) * S + (S - 1)

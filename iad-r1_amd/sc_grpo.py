@@ -99,6 +99,18 @@ def right_pad(rows, pad_value: int) -> np.ndarray:
     return pad([np.asarray(r, dtype=np.int64) for r in rows], pad_value, "right").astype(np.int64).reshape(len(rows), -1)
 
 
+def right_padding_shift(row_ids: np.ndarray, pad_token_id: int) -> int:
+    """The trigger of the reference's `_ensure_left_padding_data` (REF:534-541), on the ids alone: the first pad token of the [prompt | completion] row
+    starts an all-pad suffix -> that many columns are rotated to the front (returned); otherwise (no pad, left padding, a pad inside the text) the row is
+    left alone (0).  Derived from the ids like the reference, not from the EOS mask: a supplied completion that is shorter than C without an EOS is
+    rotated too, and with pad == EOS the EOS itself moves into the padding."""
+    pads = np.flatnonzero(row_ids == pad_token_id)
+    if pads.size == 0:
+        return 0
+    first = int(pads[0])
+    return int(len(row_ids) - first) if bool((row_ids[first:] == pad_token_id).all()) else 0
+
+
 def group_advantages(rewards: torch.Tensor, G: int):
     """REF:787-793: group mean, UNBIASED std, eps 1e-4."""
     r = rewards.view(-1, G)
@@ -381,10 +393,16 @@ class SCGRPOEngine:
             if c.is_llava and a.llava_rotate_right_padded_rows:
                 sel = sel.reshape(n, C).copy()
                 for r in range(r0, r1):
-                    ln = int(cmask[r].sum())
-                    if ln == C or (ids[r, : P + ln] == c.pad_token_id).any():
+                    pl = right_padding_shift(ids[r], c.pad_token_id)
+                    if pl == 0:
                         continue                       # no right padding / left padding present: the reference leaves the row alone
-                    pl = C - ln                        # the row is shifted right by pl columns: window column t holds original token P - pl + t
+                    ln = int(cmask[r].sum())           # the loss mask stays the un-rotated completion mask (REF:722-728)
+                    if P - pl - 1 < 0:
+                        # the window would start inside the rotated row's padding: the reference then scores pad tokens predicted from masked positions
+                        # (its values depend on how the attention backend treats fully masked queries) -- not a defined target
+                        raise ValueError(f"llava left-padding fix-up: row {r} ends in {pl} pad columns but its prompt has only {P} positions; "
+                                         "the reference's rotated window would read masked positions (prompt shorter than the padding of an early-ended completion)")
+                    # the row is shifted right by pl columns: window column t holds original token P - pl + t
                     for t_ in range(ln):
                         qi = P - pl + t_               # predicted token (original column), read from the hidden state of column qi - 1
                         hi = qi - 1

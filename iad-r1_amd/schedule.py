@@ -65,7 +65,12 @@ def shard(order: np.ndarray, rank: int, world: int) -> np.ndarray:
 
 class RankSampler:
     """Row indices for (rank, world), epoch after epoch; position `k` (0-based count of rows this rank has consumed since step 0) maps to a
-    dataset index deterministically, so a resumed run continues exactly where the stopped one would have gone."""
+    dataset index deterministically, so a resumed run continues exactly where the stopped one would have gone.
+    Deviation from transformers.Trainer, stated: rows are consumed as ONE continuous stream with always-full batches (epoch = k // rows_per_rank), while
+    `total_steps` uses HF's per-epoch formula.  When the batch size divides rows_per_rank and the accumulation count divides the batches of an epoch -- true
+    for every reference launch script (batch 1; 2 accumulation steps over an even shard) -- the two coincide.  Otherwise HF ends an epoch with a short batch
+    (and, in 4.51, a remainder update) where this sampler lets a batch straddle the epoch boundary: the run sees a few rows more or fewer per "epoch" and
+    the logged epoch fraction drifts accordingly.  Step counts and the collective sequence are identical across ranks either way."""
 
     def __init__(self, n_rows: int, rank: int, world: int, seed: int = 42, shuffle: bool = True):
         if n_rows <= 0:

@@ -48,7 +48,8 @@ class GRPOConfig:
     max_grad_norm: float = 1.0
     lr_scheduler_type: str = "linear"
     warmup_steps: int = 0
-    num_train_epochs: float = 3.0       # (transformers TrainingArguments; the launch scripts do not override it)
+    num_train_epochs: float = 3.0       # transformers TrainingArguments' default, like logging_steps / save_steps = 500 below; every SC_GRPO_*.sh passes
+                                        # --num_train_epochs 1 --logging_steps 1 --save_steps 100 --per_device_train_batch_size 1 (tests/golden/launch_flags.json)
     max_steps: int = -1
     logging_steps: int = 500
     save_steps: int = 500

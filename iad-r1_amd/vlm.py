@@ -780,20 +780,6 @@ class Engine:
         ops.embed_fwd(plan.ids, None, P.w("embed"), None, out=carry["x0"][r0:r1])
         B = self._text_buffers(T, True)
         ctx = {"layers": [], "plan": carry["full_plan"]}
-        f1, f2 = carry.get("trace_folded") or (False, False)
-        if f1 or f2:
-            # a decode step with folded norms (Rollout._decode_step_folded) leaves only the residual rows of those norms: their normalised rows and per-row
-            # statistics, which the backward pass reads, are one RMSNorm launch per norm over the whole completion block (the reference's own rounding: TF:65-79)
-            eps, H = float(c.rms_norm_eps), c.hidden_size
-            norm = lambda x, w, y, rstd: ops.hip.call("rmsnorm_fwd", x, None, 0, None, None, None, w, y, rstd, r1 - r0, H, x.stride(0), x.stride(0), y.stride(0), eps, None)
-            for i in range(c.num_hidden_layers):
-                b = f"layers.{i}."
-                if f1:
-                    norm((carry["x0"] if i == 0 else B["x_in"][i, :T])[r0:r1], P.w(b + "ln1"), B["h1"][i, r0:r1], B["rstd1"][i, r0:r1])
-                if f2:
-                    norm(B["x_mid"][i, r0:r1], P.w(b + "ln2"), B["h2"][i, r0:r1], B["rstd2"][i, r0:r1])
-            if f1:
-                norm(carry["x_last"][r0:r1], P.w("norm"), carry["hf"][r0:r1], carry["rstdf"][r0:r1])
         for i in range(c.num_hidden_layers):
             full = lambda name: B[name][i, :T]
             lse = B["lse"][i].view(-1)[: Hq * T].view(Hq, T)

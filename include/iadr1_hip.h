@@ -43,26 +43,6 @@ typedef struct iadr1_side_out {
     long long base, seq_stride;
 } iadr1_side_out_t;
 
-/* Norm folding of the decode step (iadr1_gemm_skinny_bf16 / iadr1_gemm_qkv_rope_kv_bf16): the pre-norm RMSNorm of a decoder layer (TF:65-79)
- * followed by a Linear is  (g * x / rms(x)) W^T = (x (W diag g)^T) / rms(x),  so the GEMM can read the UN-normalised residual stream when the gain is
- * folded into its packed weights (the `colscale` argument of the iadr1_pack_* functions) and every output row is scaled by 1/rms(x) in the epilogue --
- * the separate RMSNorm launch (7 us of a 72 us layer at 64 sequences, two per layer) disappears from the decode step.  1/rms needs the row sums of
- * squares; they are produced, as per-16-column-tile partial sums in a fixed order (no atomics on values: bit-reproducible), by whatever wrote the
- * residual stream: iadr1_embed_decode or a GEMM in out_mode 5.  `fold` is a HOST pointer read during the call (NULL: plain GEMM); it holds DEVICE pointers.
- *   consumer (any out_mode but 5):  y[m][n] = acc[m][n] * rsqrt(sum_t ssq_in[t][m] / K + eps) (+ bias ...)          -- ssq_in != NULL
- *   producer (out_mode 5):  Y is the residual stream itself, updated in place:  Y[m][n] = bf16(Y[m][n] + bf16(X W^T)[m][n])  (the reference's rounding
- *     points: bf16 branch output, bf16 residual sum), and ssq_out[n/16][m] = sum over the 16 columns of that tile of Y[m][n]^2 (of the ROUNDED values,
- *     what the next norm would see).  With ksplit > 1 the K slices exchange fp32 partial tiles through `slabs` and the LAST block to arrive at a tile
- *     (`counters`, zero before the first call, left zero) adds them in slice order.
- * Mpad = roundup(M, 64).  Rows of the padding carry zeros. */
-typedef struct iadr1_norm_fold {
-    const float* ssq_in;  int ssq_in_tiles;  float eps;     /* consumer */
-    float* ssq_out;                                         /* producer: [N/16][Mpad] */
-    void* y_packed;                                         /* producer, optional: the new rows ALSO in the decode-packed layout (when Y itself is row-major) */
-    float* slabs;                                           /* producer, ksplit > 1: [ksplit][Mpad][N] fp32 workspace */
-    unsigned* counters;                                     /* producer, ksplit > 1: [Mpad/64][N/16] */
-} iadr1_norm_fold_t;
-
 /* ---- dense contractions ----------------------------------------------------------------------------
  * C[M,N] (+)= act(A[M,K] . B[N,K]^T + bias[N]).  out_mode: 0 = bf16 store, 1 = fp32 store, 2 = fp32
  * accumulate (C += ...).  act: 0 none, 1 exact GELU.  K, lda, ldb multiples of 8; A/B 16-byte aligned.
@@ -84,42 +64,35 @@ int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, void* Aout, i
  * ldx == 0: X is DECODE-PACKED (MFMA B-fragment order, rows padded to 64: Xp[m/64][k/32][(m%64)/16][m%16 + 16*((k%32)/8)][k%8],
  * see iadr1_pack_act_bf16) -- every X fragment load is then 1 KiB contiguous like the weights; iadr1_rmsnorm_fwd (ldy == 0),
  * iadr1_attn_decode (ldo == 0) and out_mode 3 here (ldy == 0) emit that layout directly, so the decode step never repacks.
- * 5: residual-stream producer (iadr1_norm_fold_t above; Y row-major or, ldy == 0, decode-packed; side output p0 = the new residual rows).
  * Replaces the same Linears inside vLLM's decode step (REF:train/stage_rl/trainer/sc_grpo_trainer.py:667). */
 int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,
-                           long long ldw, long long ldy, int out_mode, int ksplit, const iadr1_side_out_t* side, const iadr1_norm_fold_t* fold,
-                           iadr1_stream_t stream);
+                           long long ldw, long long ldy, int out_mode, int ksplit, const iadr1_side_out_t* side, iadr1_stream_t stream);
 /* W[N,K] row-major -> decode-packed MFMA-fragment order Wp[N/16][K/32][64 lanes][8] (what iadr1_gemm_skinny_bf16 reads:
- * every wave-level load of the weight stream is then 1 KiB contiguous).  N % 16 == 0, K % 32 == 0.
- * colscale (bf16 [K], may be NULL): Wp holds bf16(W[n][k] * colscale[k]) -- the norm gain folded into the weights (iadr1_norm_fold_t). */
-int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, const void* colscale, iadr1_stream_t stream);
+ * every wave-level load of the weight stream is then 1 KiB contiguous).  N % 16 == 0, K % 32 == 0. */
+int iadr1_pack_weight_bf16(const void* W, long long ldw, void* Wp, int N, int K, iadr1_stream_t stream);
 /* gate|up matrix W[2I,K] -> decode-packed with gate/up 16-row tiles interleaved, for out_mode 3 (fused SwiGLU) of
  * iadr1_gemm_skinny_bf16: Y[M, I] = silu(X.Wgate^T) * (X.Wup^T).  I % 64 == 0. */
-int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, const void* colscale, iadr1_stream_t stream);
+int iadr1_pack_gateup_bf16(const void* W, long long ldw, void* Wp, int I, int K, iadr1_stream_t stream);
 /* Decode-step fusion of the q|k|v projection with iadr1_rope_kv_store: Y = X.Wqkv^T + b, rotary on the q and k heads (fp32 on the
  * bf16-rounded projections, TF:153-171), q heads -> q_out[M, >= Hq*D] (row stride ldq), new K / V rows -> the paged cache at slot[m]
  * (< 0: skipped).  Wp / bias_p come from iadr1_pack_qkv_rope_bf16: decode-packed with the rotary partners (d, d+64) of every q / k
  * head dealt into the same 16-column tile.  ldx == 0: X decode-packed.  One launch instead of two per layer of the rollout. */
 int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const void* bias_p, void* q_out, const float* rope_cos,
                                 const float* rope_sin, const long long* slot, void* kcache, void* vcache, int M, int Hq, int Hkv,
-                                int D, int K, long long ldx, long long ldq, const iadr1_side_out_t* side, const iadr1_norm_fold_t* fold,
-                                iadr1_stream_t stream);
+                                int D, int K, long long ldx, long long ldq, const iadr1_side_out_t* side, iadr1_stream_t stream);
 int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, void* Wp, void* bias_p, int Hq, int Hkv, int D, int K,
-                             const void* colscale, iadr1_stream_t stream);
-/* First kernel of a folded decode step: x[m] = E[ids[m]] (row-major, or decode-packed when ldx == 0; pad rows untouched) and ssq_out[0][m] = sum x[m]^2
- * (ONE tile: the consumer is called with ssq_in_tiles = 1). */
-int iadr1_embed_decode(const long long* ids, const void* E, void* x, long long ldx, float* ssq_out, int M, int H, iadr1_stream_t stream);
+                             iadr1_stream_t stream);
 /* FP8 weights for the decode stream (BASELINE config 5: "fp8 weights"; opt-in, the rollout only -- the training passes and the log-probs of the loss stay
  * bf16).  iadr1_pack_weight_fp8: W[N,K] bf16 -> OCP e4m3 with ONE fp32 scale per output row (scale[n] = max_k |w[n][k]| / 448, round to nearest even),
  * decode-packed so that a lane's 16-byte load holds its 8 weights of TWO consecutive 32-deep k-steps: Wp8[N/16][K/64][64 lanes][16 B].  gateup_I > 0:
- * W is a gate|up matrix [2I, K], tiles interleaved as by iadr1_pack_gateup_bf16.  colscale as for the bf16 packs.  K % 64 == 0.
+ * W is a gate|up matrix [2I, K], tiles interleaved as by iadr1_pack_gateup_bf16.  K % 64 == 0.
  * iadr1_gemm_skinny_fp8w: Y = (X . dequant(Wp8)^T) with the out_modes 0-3 of iadr1_gemm_skinny_bf16 (the fragments are widened to bf16 in registers --
  * exact, every e4m3 value is a bf16 value -- and fed to the bf16 MFMA; columns are multiplied by wscale in the epilogue).  N % 64 == 0.
  * Stated tolerance of the format: |w - dequant(quant(w))| <= 2^-4 |w| + scale * 2^-10 per weight (3 mantissa bits); the kernel adds nothing to it
  * (tests/test_hip_kernels.py::test_fp8_weight_gemm compares against the dequantised weights at the bf16 GEMM's own tolerance). */
-int iadr1_pack_weight_fp8(const void* W, long long ldw, void* Wp8, float* scale, int N, int K, int gateup_I, const void* colscale, iadr1_stream_t stream);
+int iadr1_pack_weight_fp8(const void* W, long long ldw, void* Wp8, float* scale, int N, int K, int gateup_I, iadr1_stream_t stream);
 int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const float* wscale, void* Y, const void* bias, int M, int N, int K, long long ldx,
-                           long long ldy, int out_mode, int ksplit, const iadr1_norm_fold_t* fold, iadr1_stream_t stream);
+                           long long ldy, int out_mode, int ksplit, iadr1_stream_t stream);
 /* X[M,K] row-major -> decode-packed activations Xp (buffer of roundup(M,64)*K elements; pad rows zeroed).  K % 32 == 0. */
 int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);

@@ -291,9 +291,9 @@ def test_weight_decay_group_is_the_hf_trainers():
 
 
 def test_entry_point_defaults_are_the_references():
-    """Flags a launch script does not pass take the reference's defaults: transformers TrainingArguments (SC-GRPO inherits them through trl's GRPOConfig; its
-    scripts pass no --num_train_epochs, so the reference trains THREE epochs with the linear schedule laid over all of them) and LLaMA-Factory's
-    DataArguments / ModelArguments (hparams/data_args.py:41-57, model_args.py:62)."""
+    """Flags a launch script does not pass take the reference's defaults: transformers TrainingArguments (SC-GRPO inherits them through trl's GRPOConfig) and
+    LLaMA-Factory's DataArguments / ModelArguments (hparams/data_args.py:41-57, model_args.py:62).  The SC-GRPO scripts themselves override four of them --
+    checked below against the argv extracted from the reference's scripts (tests/golden/launch_flags.json)."""
     import iadr1_amd  # noqa: F401
     from iadr1_amd.trainer import GRPOConfig
     rl = _load("train/stage_rl/grpo_ad.py").build_parser().parse_args(["--model_name_or_path", "/m", "--output_dir", "o", "--dataset_name", "d.json"])
@@ -303,12 +303,45 @@ def test_entry_point_defaults_are_the_references():
     for k, v in want_rl.items():
         assert getattr(rl, k) == v, (k, getattr(rl, k))
         assert getattr(GRPOConfig(), k) == v, (k, getattr(GRPOConfig(), k))
+    flags = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "launch_flags.json")))["scripts"]
+    grpo_scripts = [f for f in flags if "SC_GRPO" in f["script"]]
+    assert len(grpo_scripts) == 7
+    for f in grpo_scripts:      # what every scripts/train/SC_GRPO/*.sh passes (the comments in trainer.py / grpo_ad.py say so)
+        got = {f["argv"][i]: f["argv"][i + 1] for i in range(len(f["argv"]) - 1) if f["argv"][i].startswith("--")}
+        assert (got["--num_train_epochs"], got["--logging_steps"], got["--save_steps"], got["--per_device_train_batch_size"]) == ("1", "1", "100", "1"), f["script"]
     sft = _load("train/stage_sft/train.py").build_parser().parse_args(["--model_name_or_path", "/m", "--dataset", "d", "--output_dir", "o"])
     want_sft = dict(num_train_epochs=3.0, per_device_train_batch_size=8, gradient_accumulation_steps=1, learning_rate=5e-5, weight_decay=0.0, max_grad_norm=1.0,
                     lr_scheduler_type="linear", warmup_steps=0, logging_steps=500, save_steps=500, seed=42, max_steps=-1, cutoff_len=2048, dataset_dir="data",
                     image_resolution=512 * 512, train_on_prompt=False, mask_history=False, freeze_vision_tower=True, freeze_multi_modal_projector=True)
     for k, v in want_sft.items():
         assert getattr(sft, k) == v, (k, getattr(sft, k))
+
+
+def test_llava_rotation_trigger_follows_the_reference_on_the_ids():
+    """the llava left-padding fix-up (REF:516-567) decides from the IDS -- first pad token with an all-pad suffix -- not from the EOS mask.
+    `right_padding_shift` against the oracle's restatement of the reference function on: early EOS + pads, full-length rows, left-padded rows, a pad inside
+    the text, a completion shorter than C WITHOUT an EOS (rotated by the reference), and pad == EOS (the EOS itself moves into the padding)."""
+    import numpy as np
+    import torch
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.sc_grpo import right_padding_shift
+    from oracle.llava_ov import ensure_left_padding
+    pad, eos = 2, 1
+    rows = {
+        "early_eos": [5, 6, 7, 8, 9, eos, pad, pad], "full": [5, 6, 7, 8, 9, 10, 11, 12], "left_padded": [pad, pad, 5, 6, 7, eos, pad, pad],
+        "pad_inside": [5, pad, 7, 8, 9, eos, pad, pad], "short_no_eos": [5, 6, 7, 8, 9, 10, pad, pad], "all_but_one": [5, pad, pad, pad, pad, pad, pad, pad],
+    }
+    for name, r in rows.items():
+        ids = torch.tensor([r])
+        rot, _ = ensure_left_padding(ids, torch.ones_like(ids), pad)
+        pl = right_padding_shift(np.asarray(r), pad)
+        want = [pad] * pl + r[: len(r) - pl]
+        assert rot[0].tolist() == want, (name, pl, rot[0].tolist())
+    assert right_padding_shift(np.asarray(rows["early_eos"]), pad) == 2 and right_padding_shift(np.asarray(rows["short_no_eos"]), pad) == 2
+    assert right_padding_shift(np.asarray(rows["left_padded"]), pad) == 0 and right_padding_shift(np.asarray(rows["pad_inside"]), pad) == 0
+    # pad == EOS: the first EOS starts the all-pad suffix
+    r = [5, 6, 7, 1, 1, 1]
+    assert right_padding_shift(np.asarray(r), 1) == 3 and ensure_left_padding(torch.tensor([r]), torch.ones(1, 6, dtype=torch.long), 1)[0][0].tolist() == [1, 1, 1, 5, 6, 7]
 
 
 def test_product_never_imports_the_oracle():

@@ -689,115 +689,11 @@ def test_decode_side_outputs_equal_the_main_outputs():
     assert torch.equal(ops.swiglu_fwd(sg[rows].contiguous()), sa[rows])              # the activation is the SwiGLU of exactly the stored pre-activations
 
 
-# ------------------------------------------------------------------------------------------------ norm folding of the decode step
-def _tile_ssq(x, tiles_rows=None):
-    """[H/16, Mpad] fp32 partial sums of squares of x's rows per 16-column tile (what a producer leaves for the next GEMM)."""
-    M, H = x.shape
-    Mp = (M + 63) // 64 * 64
-    out = torch.zeros(H // 16, Mp, dtype=F32, device=DEV)
-    out[:, :M] = (x.float() ** 2).view(M, H // 16, 16).sum(-1).t()
-    return out
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K,packed", [(64, 2560, 2048, True), (64, 640, 256, False), (8, 256, 512, True), (100, 1008, 1056, False), (64, 22016, 2048, True),
-                                          (64, 151936, 2048, True), (64, 9216, 3584, True), (33, 18944, 1536, True)])
-def test_norm_fold_consumer_equals_rmsnorm_then_gemm(M, N, K, packed):
-    """GEMM on the UN-normalised rows with the gain folded into the packed weights and rows scaled by 1/rms in the epilogue (include/iadr1_hip.h
-    iadr1_norm_fold_t) vs RMSNorm launch + plain GEMM, both against fp32 torch: the folded form is at least as close (it skips the two bf16 roundings
-    of the normalised activations).  Shapes reach the narrow, wide and persistent kernels, bf16+bias and fp32 outputs, packed and row-major X."""
-    x, w, bias, g = rnd(M, K, seed=1, scale=2.0), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3), (1 + 0.2 * rnd(K, seed=4).float()).to(BF)
-    eps = 1e-6
-    rinv = torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + eps)
-    ref = (x.float() * rinv * g.float()) @ w.float().t()
-    h, _ = ops.rmsnorm_fwd(x, g, eps)
-    wp, wpg = ops.pack_weight(w), ops.pack_weight(w, colscale=g)
-    ssq = _tile_ssq(x)
-    xin = ops.pack_act(x) if packed else x
-    nf = ops.NormFold.consumer(ssq, eps)
-    y_old, y_new = ops.gemm_skinny(h, wp, N, out_dtype=F32), ops.gemm_skinny(xin, wpg, N, out_dtype=F32, fold=nf)
-    e_old, e_new = (y_old - ref).abs().max().item(), (y_new - ref).abs().max().item()
-    scale = ref.abs().max().item()
-    assert e_new <= max(1.2 * e_old, 2e-3 * scale), (e_old, e_new, scale)
-    yb = ops.gemm_skinny(xin, wpg, N, bias=bias, fold=nf)
-    close(yb, ref + bias.float(), 1e-2, 1e-2 * scale, f"folded bf16+bias {M}x{N}x{K}")
-    one = ops.NormFold.consumer(ssq.sum(0, keepdim=True).contiguous(), eps)        # the embedding's single-tile form
-    close(ops.gemm_skinny(xin, wpg, N, out_dtype=F32, fold=one), y_new, 1e-5, 1e-5 * scale, "one-tile partials")
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 96), (64, 18944, 3584)])
-def test_norm_fold_consumer_fused_swiglu(M, I, K):
-    x, w, g = rnd(M, K, seed=1, scale=2.0), rnd(2 * I, K, seed=2, scale=0.3), (1 + 0.2 * rnd(K, seed=4).float()).to(BF)
-    eps = 1e-6
-    rinv = torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + eps)
-    gu = ((x.float() * rinv * g.float()) @ w.float().t())
-    ref = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
-    h, _ = ops.rmsnorm_fwd(x, g, eps)
-    a_old = ops.gemm_skinny(h, ops.pack_gateup(w), 2 * I, swiglu=True)
-    a_new = ops.gemm_skinny(ops.pack_act(x), ops.pack_gateup(w, colscale=g), 2 * I, swiglu=True, fold=ops.NormFold.consumer(_tile_ssq(x), eps), out=ops.PackedAct(M, I, DEV)).unpack()
-    e_old, e_new, scale = (a_old.float() - ref).abs().max().item(), (a_new.float() - ref).abs().max().item(), ref.abs().max().item()
-    assert e_new <= max(1.2 * e_old, 1e-2 * scale), (e_old, e_new, scale)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K,ks,packed,same_kernel", [(64, 2048, 2048, 1, True, True), (64, 2048, 2048, 2, True, True), (64, 2048, 11008, 8, True, True),
-                                                         (64, 3584, 18944, 8, True, False), (64, 256, 512, 1, False, True), (100, 1024, 1056, 2, False, True),
-                                                         (8, 256, 512, 8, True, True), (64, 1536, 8960, 8, True, False)])
-def test_norm_fold_producer_equals_slabs_then_residual_norm(M, N, K, ks, packed, same_kernel):
-    """out_mode 5 (the projection adds itself INTO the residual stream, K slices exchanged through the last-arriving block) is BIT-identical to the
-    split-K slabs + fused residual-RMSNorm launch it replaces -- same partial products, same summation order, same rounding points -- and leaves the
-    per-tile sums of squares of the new rows.  Repeated 100 times on the same inputs: every repetition gives the same bits (the cross-block exchange
-    has no order dependence) and the tile counters are left at zero."""
-    a, w, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, N, seed=3)
-    wp = ops.pack_weight(w)
-    Mp = (M + 63) // 64 * 64
-    part = ops.gemm_skinny(a, wp, N, out=torch.zeros((ks, M, N), dtype=F32, device=DEV), ksplit=ks)
-    x_want = torch.empty_like(res)
-    ops.rmsnorm_fwd(None, torch.ones(N, dtype=BF, device=DEV), 1e-6, res=res, res_out=x_want, x32=part)
-    slabs = torch.full((ks, Mp, N), float("nan"), dtype=F32, device=DEV)
-    cnt = torch.zeros(Mp // 64 * (N // 16), dtype=torch.int32, device=DEV)
-    first = None
-    for rep in range(100):
-        x = ops.pack_act(res) if packed else res.clone()
-        ssq = torch.full((N // 16, Mp), -1.0, dtype=F32, device=DEV)
-        ops.gemm_skinny(a, wp, N, resid=x, ksplit=ks, fold=ops.NormFold.producer(ssq, slabs if ks > 1 else None, cnt if ks > 1 else None))
-        got = x.unpack() if packed else x
-        if first is None:
-            first = (got.clone(), ssq.clone())
-            if same_kernel:      # the slab form of this shape runs the same kernel with the same K split over waves: bit-identical
-                assert torch.equal(got, x_want), f"max diff {(got.float() - x_want.float()).abs().max().item()}"
-            else:                # (the wide slab kernel splits K differently: fp32 summation order differs -> at most one bf16 ulp at each of the two roundings)
-                close(got, x_want, 2e-2, 1e-2, "producer vs slabs + residual norm")
-            close(ssq[:, :M], _tile_ssq(got)[:, :M], 1e-5, 1e-6, "tile sums of squares")
-        else:
-            assert torch.equal(got, first[0]) and torch.equal(ssq[:, :M], first[1][:, :M]), f"repetition {rep} differs"
-    assert int(cnt.abs().sum()) == 0
-    if packed:
-        full = x.buf.view(Mp // 64, N // 32, 4, 4, 16, 8).permute(0, 2, 4, 1, 3, 5).reshape(Mp, N)
-        assert float(full[M:].float().abs().sum()) == 0.0      # pad rows of the packed residual stream stay zero
-
-
-@pytest.mark.gpu
-def test_embed_decode_rows_and_sums_of_squares():
-    E = rnd(1000, 256, seed=1)
-    ids = torch.tensor([5, 999, 0, 17, 5], dtype=torch.int64, device=DEV)
-    for packed in (True, False):
-        x = ops.PackedAct(5, 256, DEV) if packed else torch.zeros(5, 256, dtype=BF, device=DEV)
-        ssq = torch.zeros(16, 64, dtype=F32, device=DEV)
-        ops.embed_decode(ids, E, x, ssq)
-        got = x.unpack() if packed else x
-        assert torch.equal(got, E[ids])
-        close(ssq[0, :5], (E[ids].float() ** 2).sum(-1), 1e-6, 1e-6, "embed ssq")
-
-
 # ------------------------------------------------------------------------------------------------ FP8 weight stream of the rollout (opt-in)
-def _fp8_reference(w, colscale=None, scale=None):
+def _fp8_reference(w, scale=None):
     """torch restatement of iadr1_pack_weight_fp8: per-row scale amax / 448, round-to-nearest-even to OCP e4m3; returns (fp8 values [N,K], scales, dequantised fp32).
     `scale`: quantise with these scales (the device's: its amax / 448 may differ from torch's in the last bit, which moves exact ties like 84 -> 80 | 88)."""
-    wf = w.float() * (colscale.float()[None, :] if colscale is not None else 1.0)
-    if colscale is not None:
-        wf = wf.to(BF).float()                                  # the gain is folded in with one bf16 rounding, as in the bf16 packs
+    wf = w.float()
     own = wf.abs().amax(1).clamp_min(1e-30) / 448.0
     scale = own if scale is None else scale
     q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
@@ -838,15 +734,14 @@ def test_fp8_weight_gemm(M, N, K, packed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 128), (64, 18944, 3584)])
 def test_fp8_weight_gemm_fused_swiglu(M, I, K):
-    x, w, g = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.3), (1 + 0.2 * rnd(K, seed=4).float()).to(BF)
-    for colscale in (None, g):
-        w8, sc = ops.pack_weight_fp8(w, gateup=True, colscale=colscale)
-        q, scale, deq = _fp8_reference(w, colscale, scale=sc)
-        assert torch.equal(_unpack_fp8(w8, 2 * I, K, gateup=True), q.view(torch.uint8))
-        gu = (x.float() @ deq.t()).to(BF)
-        ref = torch.nn.functional.silu(gu[:, :I].float()).to(BF).float() * gu[:, I:].float()
-        a = ops.gemm_skinny(ops.pack_act(x), (w8, sc), 2 * I, swiglu=True, out=ops.PackedAct(M, I, DEV)).unpack()
-        close(a, ref, 2e-2, 2e-2 * math.sqrt(K) * 0.3, f"fp8w swiglu {M}x{I}x{K}")
+    x, w = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.3)
+    w8, sc = ops.pack_weight_fp8(w, gateup=True)
+    q, scale, deq = _fp8_reference(w, scale=sc)
+    assert torch.equal(_unpack_fp8(w8, 2 * I, K, gateup=True), q.view(torch.uint8))
+    gu = (x.float() @ deq.t()).to(BF)
+    ref = torch.nn.functional.silu(gu[:, :I].float()).to(BF).float() * gu[:, I:].float()
+    a = ops.gemm_skinny(ops.pack_act(x), (w8, sc), 2 * I, swiglu=True, out=ops.PackedAct(M, I, DEV)).unpack()
+    close(a, ref, 2e-2, 2e-2 * math.sqrt(K) * 0.3, f"fp8w swiglu {M}x{I}x{K}")
 
 
 @pytest.mark.gpu

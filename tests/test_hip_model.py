@@ -584,11 +584,13 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
 def test_full_depth_3b_sc_grpo_step_vs_oracle():
     """The UNREDUCED Qwen2.5-VL-3B (36 decoder layers, 32 ViT blocks, 151 936-token vocabulary; BASELINE configs 2 / 3) against the fp32 CPU oracle on
     the same weights: what bf16 storage costs over the real depth (every other oracle comparison runs <= 4 layers).  1 prompt x G = 2, one 8 x 8-patch
-    image (16 image tokens) + 64 text tokens, C = 8, policy = reference x (1 + 5 % element-wise noise), EOS inside one completion.  Checked: per-token
+    image (16 image tokens) + 64 text tokens, C = 8, policy = reference x (1 + 2 % element-wise noise), EOS inside one completion.  Checked: per-token
     log-probs of both models, KL and loss relative, gradients of five named tensors (two of them at the bottom of the decoder stack / in the ViT).
     REF sc_grpo_trainer.py:116-137 (model), :384-514 (log-probs), :746-798 (loss).
     The yardstick for the log-probs is the reference's OWN precision: the same oracle run in bf16 (what `--bf16` makes the reference compute, torch CPU kernels)
-    against the fp32 oracle.  The HIP path must not be further from fp32 than 1.5x that (two bf16 implementations with different summation orders)."""
+    against the fp32 oracle.  The HIP path must not be further from fp32 than 1.5x that (two bf16 implementations with different summation orders).
+    Measured on MI355X at 5 % noise (KL 1.14): HIP |dlogp| max 0.263 / mean 0.104, bf16 oracle max 0.247 / mean 0.124 -- bf16 storage over 36 + 32 layers
+    costs the HIP path what it costs the reference; KL within 3.0 %, gradient cosines 0.994-0.998, gradient norms within 0.4 %."""
     import time
     from oracle import qwen25vl as oq
     from oracle import sc_grpo as og
@@ -608,7 +610,7 @@ def test_full_depth_3b_sc_grpo_step_vs_oracle():
     gen = torch.Generator(device=DEV).manual_seed(7)
     for lo in range(0, pol.flat.numel(), 1 << 28):
         v = pol.flat[lo: lo + (1 << 28)]
-        v.copy_((v.float() * (1.0 + 0.05 * torch.randn(v.shape, generator=gen, device=DEV))).to(torch.bfloat16))     # zero padding / zero biases stay zero
+        v.copy_((v.float() * (1.0 + 0.02 * torch.randn(v.shape, generator=gen, device=DEV))).to(torch.bfloat16))     # zero padding / zero biases stay zero
     pol.finalize()
     G, C = 2, 8
     grid = (1, 8, 8)

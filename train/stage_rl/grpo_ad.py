@@ -69,7 +69,8 @@ def build_parser():
     p.add_argument("--attn_implementation", default="flash_attention_2")
     p.add_argument("--torch_dtype", default=None)
     # GRPOConfig / TrainingArguments subset; defaults = theirs (trl/trl/trainer/grpo_config.py, transformers TrainingArguments: 3 epochs, batch 8, logging / saving every 500
-    # steps, linear schedule without warm-up) -- the launch scripts do NOT pass --num_train_epochs, so the reference runs three epochs
+    # steps, linear schedule without warm-up).  These are only the fall-backs: all seven scripts/train/SC_GRPO/*.sh pass --num_train_epochs 1
+    # --logging_steps 1 --save_steps 100 --per_device_train_batch_size 1 (checked against tests/golden/launch_flags.json in tests/test_entrypoints.py)
     p.add_argument("--output_dir", required=True)
     p.add_argument("--per_device_train_batch_size", type=int, default=8)
     p.add_argument("--gradient_accumulation_steps", type=int, default=1)
