@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--workload", default="sc_grpo", choices=["sc_grpo", "pa_sft"], help="sc_grpo = the north-star SC-GRPO step (default); pa_sft = BASELINE config 2 (PA-SFT, bs 16, 448^2 image, 512 prompt + 256 supervised tokens)")
     ap.add_argument("--sft-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-real-processor-legs", action="store_true", help="skip the two extra (untimed for `value`) loops that feed uint8 images through the HF image processor inside the step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-full-step", action="store_true", help="run the oracle's REAL B = 1 x G SC-GRPO step once at full 3B size on the host cores (about 6 minutes, "
@@ -519,6 +520,75 @@ class SynthProcessor:
         return [self.texts[i % len(self.texts)] for i in range(len(ids))]
 
 
+class RealImageProcessor(SynthProcessor):
+    """The `real_processor` legs: the processor call does the reference's real host work on real pixels -- uint8 [448, 448, 3] images
+    (numpy RandomState(1234 + i)) read back from PNG files (PIL decode, REF:610) through the HF `Qwen2VLImageProcessor` (smart_resize,
+    rescale, normalise, patchify -> fp32 [1024, 1176] per image, REF:612-622) -- on the host, per step, as `compute_loss` does.  The prompt token ids stay the
+    synthetic ones of the step the text names (no tokenizer exists offline)."""
+
+    def __init__(self, batches, texts):
+        super().__init__(batches, texts)
+        from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+        self.ip = Qwen2VLImageProcessorPil()
+        self.ip.max_pixels, self.ip.min_pixels = 480000, 3136          # the launch scripts' --max_pixels (REF:192-193); 448 x 448 = 200 704 pixels pass unresized
+
+    def apply_chat_template(self, conv, add_generation_prompt=True, tokenize=False):
+        raise AssertionError("rows of the real-processor legs carry plain-string prompts")
+
+    def __call__(self, text=None, images=None, **kw):
+        step = int(text[0].rsplit(" ", 1)[1])
+        enc = self.ip(images=images, return_tensors="pt")
+        b = self.batches[step]
+        assert enc["pixel_values"].shape == b["pixel_values"].shape, (enc["pixel_values"].shape, b["pixel_values"].shape)
+        return {"input_ids": b["input_ids"], "attention_mask": b["attention_mask"], "pixel_values": enc["pixel_values"], "image_grid_thw": enc["image_grid_thw"]}
+
+
+def real_processor_legs(tr, batches, n_prompts, steps, first_step, N):
+    """Same step, host work included: (1) the reference's form -- `prepare_batch` inside compute_loss, synchronously; (2) with the trainer's prefetch
+    (micro-batch k+1 prepared on a worker thread + pinned upload on a copy stream while the GPU runs k), as SCGRPOTrainer.train() drives it."""
+    import tempfile
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="iadr1_bench_img_")
+    n_steps = 2 * (steps + 1)
+    assert first_step + n_steps <= len(batches)
+    paths = {}
+    for s in range(first_step, first_step + n_steps):
+        for j in range(n_prompts):
+            i = s * n_prompts + j
+            paths[s, j] = os.path.join(tmp, f"img_{i}.png")
+            Image.fromarray(np.random.RandomState(1234 + i).randint(0, 256, (448, 448, 3)).astype(np.uint8)).save(paths[s, j], compress_level=1)
+    rows = lambda s: [{"prompt": f"SYNTHETIC PROMPT {s}", "image": [paths[s, j]], "solution": SOLUTION} for j in range(n_prompts)]
+    saved = tr.processing_class
+    tr.processing_class = RealImageProcessor(batches, CANNED)
+    res = {}
+    try:
+        t_host = time.perf_counter()
+        tr._prepare(rows(first_step))
+        res["host_prepare_seconds_per_step"] = time.perf_counter() - t_host
+        s = first_step
+        for mode in ("inline", "prefetch"):
+            tr.training_step([rows(s)])           # one untimed step of the leg
+            s += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nxt = tr.prefetch([rows(s)]) if mode == "prefetch" else None
+            for k in range(steps):
+                prepared = nxt
+                nxt = tr.prefetch([rows(s + 1)]) if (mode == "prefetch" and k + 1 < steps) else None
+                tr.training_step([rows(s)], prepared)
+                s += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[mode] = {"samples_per_s": N * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
+    finally:
+        tr.processing_class = saved
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    res["note"] = ("the headline `value` runs on pixel patches already resident in HBM; these legs add the per-step host work of a real run -- PNG decode + HF Qwen2VLImageProcessor "
+                   f"on {n_prompts} uint8 448x448 images -- inline (the reference's form, REF:600-625) and through the trainer's prefetch thread (the default of SCGRPOTrainer.train())")
+    return res
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` without a torchrun environment: run the same command line as N ranks of one node (one rank per GPU over RCCL)."""
     import socket
@@ -595,7 +665,8 @@ def main():
     N = a.prompts * a.group
     # inputs are generated and made resident in HBM BEFORE the timed region (the processor's fp32 patches stay fp32: the bf16 cast is part of the step)
     batches = []
-    for step_id in range(a.warmup + a.steps + 1):
+    real_legs = world == 1 and not llava and not a.no_real_processor_legs and a.prompt_len >= 261
+    for step_id in range(a.warmup + a.steps + 1 + (2 * (a.steps + 1) + 1 if real_legs else 0)):
         if llava:
             b = synth_batch_llava(cfg, a.prompts, 253, seed=1234 + 7919 * rank + step_id)
             bb = {"input_ids": torch.from_numpy(b["input_ids"]), "attention_mask": torch.from_numpy(b["attention_mask"]), "pixel_values": b["pixel_values"].to(dev)}
@@ -645,6 +716,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    ms1 = torch.cuda.memory_stats()      # read HERE: the extra legs below (other layout, real processor) are not the timed region
+    hbm = {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30, "peak_reserved_GB": torch.cuda.max_memory_reserved() / 2**30,
+           "alloc_retries": ms1.get("num_alloc_retries", 0),
+           "device_allocs_in_timed_region": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+           "device_frees_in_timed_region": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)}
     if alloc_trace:
         snap = torch.cuda.memory._snapshot()
         torch.cuda.memory._record_memory_history(enabled=None)
@@ -681,6 +757,13 @@ def main():
             repeated = {"error": repr(exc)[:200]}
         finally:
             eng.args.share_prefix, eng.args.micro_batch_seqs = True, a.micro_batch
+    real = None
+    if real_legs:
+        try:
+            real = real_processor_legs(tr, batches, a.prompts, a.steps, step_id + 1, N)
+            real["prefetch_vs_headline"] = real["prefetch"]["samples_per_s"] / (world * N * a.steps / dt)
+        except Exception as exc:
+            real = {"error": repr(exc)[:300]}
     if rank == 0:
         n_launch, t_sum, fl_gemm = timer.summary()
         t_gemm = timer.busy_seconds()            # union of the launch intervals (wgrad GEMMs overlap dgrad GEMMs on a second stream)
@@ -727,6 +810,7 @@ def main():
                                     "tests/test_hip_model.py::test_api_step_with_rollout_handover_matches_the_oracle)" if traced else ""))
                        if eng.args.share_prefix else "ViT once per image"},
             "repeated_rows_layout": repeated,
+            "real_processor": real,
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
@@ -742,10 +826,7 @@ def main():
             "roofline_decode": decode_roofline(cfg, pol, dec_ev, N, a.gen_len),
             "last_step_metrics": metrics,
             "gemm_by_shape": timer.by_shape(),
-            "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30, "peak_reserved_GB": torch.cuda.max_memory_reserved() / 2**30,
-                    "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0),
-                    "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
-                    "device_frees_in_timed_region": torch.cuda.memory_stats().get("num_device_free", 0) - ms0.get("num_device_free", 0)},
+            "hbm": hbm,
         }
         if not a.no_cpu_baseline and a.model == "3b" and world == 1:     # rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in the closing barrier
             out["cpu_baseline"] = cpu_baseline(D3, a.cpu_seconds, P=a.prompt_len, C=a.gen_len, G=a.group)

@@ -59,6 +59,7 @@ class GRPOConfig:
     model_init_kwargs: Optional[dict] = None
     micro_batch_seqs: int = 64      # sequences per reference / policy pass; >= batch x group lets the rollout double as the policy's training forward
     shuffle: bool = True            # seeded per-epoch permutation (HF Trainer's RandomSampler / DistributedSampler)
+    prefetch_batches: bool = os.environ.get("IADR1_PREFETCH", "1") != "0"    # prepare micro-batch k+1 on a worker thread while the GPU runs k (iadr1_amd.prefetch)
     run_name: Optional[str] = None
     report_to: Any = None
     push_to_hub: bool = False
@@ -348,10 +349,18 @@ class SCGRPOTrainer:
         self.state = type("State", (), {"global_step": 0})()
         self._metrics = defaultdict(list)
         self.log_history = []
+        self._prefetcher = None
 
     # ---- batch construction (host) -------------------------------------------------------------------------------
     def _prepare(self, inputs: list[dict]):
         return prepare_batch(self.processing_class, inputs)
+
+    def prefetch(self, micro_batches: list[list[dict]]) -> list:
+        """Start the host preparation (REF:600-625) of the given micro-batches on the worker thread; hand the result to training_step(prepared=...)."""
+        if self._prefetcher is None:
+            from .prefetch import BatchPrefetcher
+            self._prefetcher = BatchPrefetcher(self._prepare, self.device)
+        return [self._prefetcher.submit(inputs) for inputs in micro_batches]
 
     def _rewards(self, inputs, completion_ids: np.ndarray):
         G = self.args.num_generations
@@ -369,14 +378,19 @@ class SCGRPOTrainer:
         return np.stack(cols, 1)
 
     # ---- reference API ---------------------------------------------------------------------------------------------
-    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, last_micro_step=True, _defer=False):
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, last_micro_step=True, _defer=False, _prepared=None):
         """One SC-GRPO micro-step on `inputs` (list of dataset rows).  Returns the loss value; gradients are
         accumulated inside the engine (there is no autograd graph to hand back).
         _defer (training_step, last micro-batch): returns a callable that yields the loss once called -- the two device-side means (loss, KL) are then read
-        AFTER the optimizer has been enqueued, so the GPU does not idle while the host returns from the read."""
+        AFTER the optimizer has been enqueued, so the GPU does not idle while the host returns from the read.
+        _prepared: a Future from `prefetch` for these same rows (the batch was built while the previous micro-batch ran); None: built here, as the reference does."""
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")  # REF:587-588
-        batch = self._prepare(inputs)
+        if _prepared is not None:
+            from .prefetch import BatchPrefetcher
+            batch = BatchPrefetcher.ready(_prepared.result())
+        else:
+            batch = self._prepare(inputs)
         # the engine's whole micro-step (SCGRPOEngine.step): vision tower once per image, rollout whose prefill / decode steps double as the policy's
         # training forward when the micro-batch holds whole groups, rewards evaluated on the host while the reference pass is in the GPU queue
         out = self.engine.step(batch, lambda comp: self._rewards(inputs, comp), do_optimizer_step=False, last_micro_step=last_micro_step, return_outputs=True, defer_metrics=_defer)
@@ -410,12 +424,13 @@ class SCGRPOTrainer:
         a = self.args
         return schedule.lr_at(step, total, a.learning_rate, a.warmup_steps, a.lr_scheduler_type)
 
-    def training_step(self, micro_batches: list[list[dict]]) -> list[float]:
+    def training_step(self, micro_batches: list[list[dict]], prepared: Optional[list] = None) -> list[float]:
         """One optimizer step = gradient_accumulation_steps micro-batches through compute_loss (the data-parallel gradient buckets leave during the
         last one's backward) + clip / AdamW / weight-copy refresh.  What transformers.Trainer.training_step + the optimizer block of its inner loop do
         around the reference's compute_loss (TF:trainer.py:1892-1961, :1785); train() and bench.py both go through here."""
         last = len(micro_batches) - 1
-        losses = [self.compute_loss(None, inputs, last_micro_step=(k == last), _defer=(k == last)) for k, inputs in enumerate(micro_batches)]
+        losses = [self.compute_loss(None, inputs, last_micro_step=(k == last), _defer=(k == last), _prepared=None if prepared is None else prepared[k])
+                  for k, inputs in enumerate(micro_batches)]
         self.engine.optimizer_step()
         losses[last] = losses[last]()       # the last micro-batch's loss / KL means are read after the optimizer launches are in the queue
         self.state.global_step += 1
@@ -440,16 +455,20 @@ class SCGRPOTrainer:
         total = schedule.total_steps(len(rows), world, bs, ga, a.num_train_epochs, a.max_steps)
         sampler = schedule.RankSampler(len(rows), rank, world, seed=a.seed, shuffle=a.shuffle)
         t0 = time.time()
-        i = start * bs * ga
         steps_per_epoch = max(1, schedule.total_steps(len(rows), world, bs, ga, 1.0, -1))
         window_loss, window_from = 0.0, start
+
+        def micro_rows(step):      # the rows of optimizer step `step`: a function of the step number alone (the sampler order is fixed up front)
+            base = step * bs * ga
+            return [[rows[sampler.index(base + k * bs + j)] for j in range(bs)] for k in range(ga)]
+
+        nxt = self.prefetch(micro_rows(start)) if (a.prefetch_batches and start < total) else None
         for step in range(start, total):
             self.engine.args.learning_rate = self._lr(step, total)
-            micro = []
-            for k in range(ga):
-                micro.append([rows[sampler.index(i + j)] for j in range(bs)])
-                i += bs
-            losses = self.training_step(micro)
+            micro, prepared = micro_rows(step), nxt
+            # step + 1's batches are built on the worker thread while this step runs on the GPU
+            nxt = self.prefetch(micro_rows(step + 1)) if (a.prefetch_batches and step + 1 < total) else None
+            losses = self.training_step(micro, prepared)
             window_loss += float(np.mean(losses))
             if self.state.global_step % a.logging_steps == 0:
                 # transformers.Trainer._maybe_log_save_evaluate: the mean step loss since the last log line, rounded to 4 places; the scheduler has already stepped,

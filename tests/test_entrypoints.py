@@ -344,6 +344,29 @@ def test_llava_rotation_trigger_follows_the_reference_on_the_ids():
     assert right_padding_shift(np.asarray(r), 1) == 3 and ensure_left_padding(torch.tensor([r]), torch.ones(1, 6, dtype=torch.long), 1)[0][0].tolist() == [1, 1, 1, 5, 6, 7]
 
 
+def test_batch_prefetcher_keeps_order_and_propagates_errors():
+    """iadr1_amd.prefetch.BatchPrefetcher on the host alone (device None: no upload): results come back per submission, in order; an exception of the
+    preparation surfaces at `.result()` (the step that would have consumed the batch), not silently on the worker thread."""
+    import threading
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd.prefetch import BatchPrefetcher
+    seen = []
+
+    def prepare(inputs):
+        seen.append((threading.current_thread().name, inputs[0]))
+        if inputs[0] == "bad":
+            raise ValueError("processor failed")
+        return {"input_ids": [len(x) for x in inputs], "tag": inputs[0]}
+    pf = BatchPrefetcher(prepare, None)
+    futs = [pf.submit([f"row{i}", "x" * i]) for i in range(5)] + [pf.submit(["bad"])]
+    got = [BatchPrefetcher.ready(f.result()) for f in futs[:5]]
+    assert [g["tag"] for g in got] == [f"row{i}" for i in range(5)] and got[3]["input_ids"] == [4, 3]
+    assert all(name.startswith("iadr1-prefetch") for name, _ in seen) and [t for _, t in seen] == [f"row{i}" for i in range(5)] + ["bad"]
+    with pytest.raises(ValueError, match="processor failed"):
+        futs[5].result()
+    pf.shutdown()
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch it."""
     import re

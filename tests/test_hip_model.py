@@ -274,6 +274,30 @@ def test_trainer_api_runs_two_optimizer_steps():
         assert "model.layers.0.self_attn.q_proj.weight" in sf.keys() and "visual.blocks.0.attn.qkv.weight" in sf.keys()
 
 
+def test_trainer_prefetch_is_bit_identical_to_inline_preparation():
+    """The host input pipeline (iadr1_amd.prefetch: micro-batch k+1 prepared on a worker thread -- the REAL offline Qwen2-VL processor on uint8 images here --
+    and uploaded through pinned memory on a copy stream while the GPU runs k) against the reference's form, the processor call inside compute_loss
+    (REF:600-625): same sampler order, same batches -> every logged metric and the trained parameters are bit-identical."""
+    from iadr1_amd import rewards
+    from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
+    proc = fx.local_qwen2vl_processor(max_pixels=480000, min_pixels=3136)
+    cfg_d = dict(fx.TINY, image_token_id=5, vision_start_token_id=3, vision_end_token_id=4, eos_token_id=2, pad_token_id=0)      # the local tokenizer's ids
+    cfg = VLMConfig.from_dict(cfg_d)
+    img = lambda: {"type": "image"}
+    rows = [{"prompt": [{"role": "user", "content": [img(), {"type": "text", "text": f"Is there any defect {i}?"}]}], "image": [fx.synth_pil_image(224 + 28 * (i % 3), 196, 10 + i)],
+             "solution": "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"} for i in range(6)]
+    out = {}
+    for prefetch in (False, True):
+        cfgT = GRPOConfig(output_dir="/tmp/iadr1_prefetch_test", num_generations=4, max_completion_length=6, max_prompt_length=4096, learning_rate=1e-3,
+                          per_device_train_batch_size=1, gradient_accumulation_steps=2, max_steps=3, logging_steps=1, save_steps=0, prefetch_batches=prefetch)
+        tr = SCGRPOTrainer((cfg, fx.make_weights(cfg_d, 0)), [rewards.accuracy_reward, rewards.consistency_reward], args=cfgT, train_dataset=rows, processing_class=proc)
+        hist = tr.train()
+        assert (tr._prefetcher is not None) == prefetch
+        out[prefetch] = ([{k: v for k, v in h.items() if k != "elapsed_s"} for h in hist], tr.policy.flat.clone())
+    assert out[False][0] == out[True][0], (out[False][0], out[True][0])
+    assert torch.equal(out[False][1], out[True][1])
+
+
 def _ddp_worker(rank, world, port, q, hook, wire="fp32"):
     import os as _os
     _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), IADR1_REDUCE_DTYPE=wire)
@@ -584,13 +608,14 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
 def test_full_depth_3b_sc_grpo_step_vs_oracle():
     """The UNREDUCED Qwen2.5-VL-3B (36 decoder layers, 32 ViT blocks, 151 936-token vocabulary; BASELINE configs 2 / 3) against the fp32 CPU oracle on
     the same weights: what bf16 storage costs over the real depth (every other oracle comparison runs <= 4 layers).  1 prompt x G = 2, one 8 x 8-patch
-    image (16 image tokens) + 64 text tokens, C = 8, policy = reference x (1 + 2 % element-wise noise), EOS inside one completion.  Checked: per-token
+    image (16 image tokens) + 64 text tokens, C = 8, policy = reference x (1 + 1 % element-wise noise), EOS inside one completion.  Checked: per-token
     log-probs of both models, KL and loss relative, gradients of five named tensors (two of them at the bottom of the decoder stack / in the ViT).
     REF sc_grpo_trainer.py:116-137 (model), :384-514 (log-probs), :746-798 (loss).
     The yardstick for the log-probs is the reference's OWN precision: the same oracle run in bf16 (what `--bf16` makes the reference compute, torch CPU kernels)
     against the fp32 oracle.  The HIP path must not be further from fp32 than 1.5x that (two bf16 implementations with different summation orders).
-    Measured on MI355X at 5 % noise (KL 1.14): HIP |dlogp| max 0.263 / mean 0.104, bf16 oracle max 0.247 / mean 0.124 -- bf16 storage over 36 + 32 layers
-    costs the HIP path what it costs the reference; KL within 3.0 %, gradient cosines 0.994-0.998, gradient norms within 0.4 %."""
+    Measured on MI355X: at 5 % noise (KL 1.14) HIP |dlogp| max 0.263 / mean 0.104, bf16 oracle max 0.247 / mean 0.124, KL within 3.0 %; at 2 % noise
+    (KL 0.38) HIP 0.252 / 0.109, bf16 oracle 0.339 / 0.151, KL within 6.7 % -- bf16 storage over 36 + 32 layers costs the HIP path what it costs the
+    reference; gradient cosines 0.994-0.998, gradient norms within 1.2 %."""
     import time
     from oracle import qwen25vl as oq
     from oracle import sc_grpo as og
@@ -610,7 +635,7 @@ def test_full_depth_3b_sc_grpo_step_vs_oracle():
     gen = torch.Generator(device=DEV).manual_seed(7)
     for lo in range(0, pol.flat.numel(), 1 << 28):
         v = pol.flat[lo: lo + (1 << 28)]
-        v.copy_((v.float() * (1.0 + 0.02 * torch.randn(v.shape, generator=gen, device=DEV))).to(torch.bfloat16))     # zero padding / zero biases stay zero
+        v.copy_((v.float() * (1.0 + 0.01 * torch.randn(v.shape, generator=gen, device=DEV))).to(torch.bfloat16))     # zero padding / zero biases stay zero
     pol.finalize()
     G, C = 2, 8
     grid = (1, 8, 8)
@@ -644,6 +669,11 @@ def test_full_depth_3b_sc_grpo_step_vs_oracle():
         o16 = oq.Qwen25VLOracle(d3, {k: t.detach() for k, t in o_pol.w.items() if not (k == "lm_head.weight")}, dtype=torch.bfloat16)
         lp16 = o16.per_token_logps(ids_t, mask_t, torch.from_numpy(px).repeat(G, 1), [grid] * G)[:, ids.shape[1] - 1:].float().numpy()
         del o16
+        o16 = oq.Qwen25VLOracle(d3, {k: t.detach() for k, t in o_ref.w.items() if not (k == "lm_head.weight")}, dtype=torch.bfloat16)
+        lr16 = o16.per_token_logps(ids_t, mask_t, torch.from_numpy(px).repeat(G, 1), [grid] * G)[:, ids.shape[1] - 1:].float().numpy()
+        del o16
+    cm = want["completion_mask"].float()
+    kl16 = float(og.grpo_loss(torch.from_numpy(lp16), torch.from_numpy(lr16), want["advantages"], cm, 0.04)[2])      # the k3 estimate the bf16 reference would log
     t4 = time.time()
     m = want["completion_mask"].bool().numpy()
     assert np.array_equal(out["completion_mask"], want["completion_mask"].numpy()) and int(m.sum()) == C + 6
@@ -654,17 +684,18 @@ def test_full_depth_3b_sc_grpo_step_vs_oracle():
     d16mean = np.abs(lp16[m] - want["logps"].detach().numpy()[m]).mean()
     wl, wk = float(want["loss"].detach()), float(want["metrics"]["kl"])
     mt = out["metrics"]
-    dk, dl = abs(mt["kl"] - wk), abs(mt["loss"] - wl)
+    dk, dl, dk16 = abs(mt["kl"] - wk), abs(mt["loss"] - wl), abs(kl16 - wk)
     cos = {}
     for n in names:
         a, b = grads[n], o_pol.w[n].grad.numpy().reshape(-1).astype(np.float64)
         cos[n] = (float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)), float(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30)))
     print(f"[full depth 3B] |dlogp|max policy={dlp:.4f} (mean {dmean:.4f}) ref={dlr:.4f}; the bf16 ORACLE vs fp32: max {d16:.4f} mean {d16mean:.4f}  logp range [{want['logps'].min().item():.2f}, {want['logps'].max().item():.2f}]  "
-          f"kl hip={mt['kl']:.5e} oracle={wk:.5e} ({100 * dk / wk:.2f}%)  loss hip={mt['loss']:.6e} oracle={wl:.6e} (d={dl:.2e})  "
+          f"kl hip={mt['kl']:.5e} oracle={wk:.5e} ({100 * dk / wk:.2f}%; the bf16 oracle: {kl16:.5e}, {100 * dk16 / wk:.2f}%)  loss hip={mt['loss']:.6e} oracle={wl:.6e} (d={dl:.2e})  "
           f"grad (cos, norm ratio)={ {k: (round(c, 4), round(r, 3)) for k, (c, r) in cos.items()} }  "
           f"seconds: hip {t1 - t0:.0f}, export {t2 - t1:.0f}, oracle fp32 {t3 - t2:.0f}, bf16 {t4 - t3:.0f}", flush=True)
     assert dlp <= 1.5 * d16 + 0.02 and dlr <= 1.5 * d16 + 0.02 and dmean <= 1.5 * d16mean + 0.005, (dlp, dlr, d16, dmean, d16mean)
-    assert dk <= 0.10 * wk and dl <= 0.04 * 0.10 * wk + 2e-6 and dl < 1e-3, (mt, wk, wl)
+    tol_k = max(0.10 * wk, 1.5 * dk16)          # relative 10 %, or what the reference's own bf16 arithmetic does to the k3 estimate
+    assert dk <= tol_k and dl <= 0.04 * tol_k + 2e-6 and dl < 1e-3, (mt, wk, wl, kl16)
     for n, (c, r) in cos.items():
         assert c > 0.97 and 0.85 < r < 1.15, (n, c, r)
 
