@@ -76,6 +76,27 @@ class TextPlan:
     tail: "TextPlan" = None      # completion rows only (two-phase forward), set by text_plan_shared
 
 
+class _Ring:
+    """Round-robin static buffers shared between the main stream (writer, reader) and a side stream (reader): `take` hands out the next slot after making
+    the current stream wait for the side-stream reader that last used it; `busy(slot, stream)` records that reader."""
+
+    def __init__(self, bufs):
+        self.bufs, self.ev, self.k = bufs, [None] * len(bufs), 0
+
+    def take(self, rows):
+        k = self.k
+        self.k = (k + 1) % len(self.bufs)
+        if self.ev[k] is not None:
+            torch.cuda.current_stream().wait_event(self.ev[k])
+            self.ev[k] = None
+        return self.bufs[k][:rows], (self, k)
+
+    def busy(self, k, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.ev[k] = ev
+
+
 class Engine:
     def __init__(self, params: ParamStore):
         self.p = params
@@ -599,8 +620,28 @@ class Engine:
         self._wgrad("visual.patch_embed", dres, ctx["px"])
         self.join_wgrads()
 
-    def _wgrad(self, name, dy, x):
+    def _bw_scratch(self, T):
+        """Static scratch of the decoder backward pass: every temporary of a layer lives in buffers allocated once (grow-only in T) -- main-stream-only
+        tensors in one buffer each, tensors a weight-gradient GEMM reads on the side stream in small RINGS whose slots are guarded by events.  Before this,
+        those tensors came from the caching allocator with `record_stream` marks: a block freed by the main stream could not be reused until the side
+        stream had passed it, the host runs a whole backward ahead, so every layer asked for fresh 430 / 860 MiB blocks, and once the card was full the
+        allocator answered with hipFree / hipMalloc pairs inside the step (BENCH_r02: 84 device allocations + 153 frees in the timed region)."""
+        s = self.__dict__.get("_bw")
+        if s is not None and s["cap"] >= T:
+            return s
+        self.join_wgrads()
+        self.__dict__["_bw"] = None
+        c = self.cfg
+        H, I, qw = c.hidden_size, c.intermediate_size, c.qkv_width
+        mk = lambda w: torch.empty(T, w, dtype=BF16, device=self.dev)
+        s = {"cap": T, "da": mk(I), "dh": mk(H), "do": mk(c.num_attention_heads * c.head_dim),
+             "res": _Ring([mk(H) for _ in range(6)]), "dgu": _Ring([mk(2 * I) for _ in range(3)]), "dqkv": _Ring([mk(qw) for _ in range(3)])}
+        self.__dict__["_bw"] = s
+        return s
+
+    def _wgrad(self, name, dy, x, slot=None):
         """grad[name] ([N,K] fp32) += dy[T,N]^T . x[T,K]   (NT kernel on transposed copies).
+        slot: dy lives in a `_Ring` slot (static scratch): the slot is marked busy until the side stream has read it, instead of a record_stream mark.
         Weight gradients are leaves of the backward graph: by default they (transposes + GEMM) are issued on a side stream, so the dgrad chain
         on the main stream never waits for them and the two queues fill each other's tile-quantisation tails and launch bubbles (a 640-tile
         GEMM leaves half the CUs idle in its third round): -35 ms per step.  Measured alternative: only the transposes on the side stream --
@@ -612,7 +653,10 @@ class Engine:
         ws.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ws):
             ops.gemm_nt(ops.transpose(dy, pad_rows_to=8), ops.transpose(x, pad_rows_to=8), out=self.p.g(name), accumulate=True)
-        dy.record_stream(ws)     # the caching allocator must not hand these blocks to the main stream before the side stream is done with them
+        if slot is not None:
+            slot[0].busy(slot[1], ws)
+        else:
+            dy.record_stream(ws)     # the caching allocator must not hand these blocks to the main stream before the side stream is done with them
         x.record_stream(ws)
 
     def join_wgrads(self):
@@ -795,30 +839,41 @@ class Engine:
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         qw, kw = Hq * D, Hkv * D
         plan: TextPlan = ctx["plan"]
-        dres = ops.rmsnorm_bwd(dhf, ctx["x_last"], P.w("norm"), ctx["rstdf"], dw=P.g("norm"))
+        T = dhf.shape[0]
+        S = self._bw_scratch(T)          # static scratch: no allocator traffic in the loop (see _bw_scratch)
+        side = self.wgrad_stream is not None
+        take = lambda ring: ring.take(T)
+        dres, sl_res = take(S["res"])
+        ops.rmsnorm_bwd(dhf, ctx["x_last"], P.w("norm"), ctx["rstdf"], dw=P.g("norm"), out=dres)
         for i in reversed(range(c.num_hidden_layers)):
             b = f"layers.{i}."
             x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a = ctx["layers"][i]
-            self._wgrad(b + "down.w", dres, a)          # side stream; the dgrad chain below does not wait for it
-            da = ops.gemm_nt(dres, P.wT(b + "down.w"))
-            dgu = ops.swiglu_bwd(da, gu)
-            self._wgrad(b + "gu.w", dgu, h2)
-            dh2 = ops.gemm_nt(dgu, P.wT(b + "gu.w"))
-            dx_mid = ops.rmsnorm_bwd(dh2, x_mid, P.w(b + "ln2"), rstd2, dres=dres, dw=P.g(b + "ln2"))
-            self._wgrad(b + "o.w", dx_mid, o)
-            do = ops.gemm_nt(dx_mid, P.wT(b + "o.w"))
+            self._wgrad(b + "down.w", dres, a, slot=sl_res if side else None)          # side stream; the dgrad chain below does not wait for it
+            da = ops.gemm_nt(dres, P.wT(b + "down.w"), out=S["da"][:T])
+            dgu, sl_gu = take(S["dgu"])
+            ops.swiglu_bwd(da, gu, out=dgu)
+            self._wgrad(b + "gu.w", dgu, h2, slot=sl_gu if side else None)
+            dh2 = ops.gemm_nt(dgu, P.wT(b + "gu.w"), out=S["dh"][:T])
+            dx_mid, sl_mid = take(S["res"])
+            ops.rmsnorm_bwd(dh2, x_mid, P.w(b + "ln2"), rstd2, dres=dres, dw=P.g(b + "ln2"), out=dx_mid)
+            self._wgrad(b + "o.w", dx_mid, o, slot=sl_mid if side else None)
+            do = ops.gemm_nt(dx_mid, P.wT(b + "o.w"), out=S["do"][:T])
+            dqkv, sl_qkv = take(S["dqkv"])
             # rows of left padding belong to no segment: their gradient is exactly 0 (attn_bwd writes every row that is in a segment)
-            dqkv = torch.empty_like(qkv) if plan.seg.covers(0, qkv.shape[0]) else torch.zeros_like(qkv)
-            if _POISON and plan.seg.covers(0, qkv.shape[0]):
+            if not plan.seg.covers(0, qkv.shape[0]):
+                dqkv.zero_()
+            elif _POISON:
                 dqkv.fill_(float("nan"))
             ops.attn_bwd(qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, do, lse, plan.seg, Hq, Hkv, D, True, c.attn_scale,
                          dqkv[:, :qw], dqkv[:, qw: qw + kw], dqkv[:, qw + kw:])
             ops.rope_(dqkv, plan.cos, plan.sin, Hq + Hkv, D, backward=True)
             if c.qkv_bias:           # (LLaMA / Mistral: no q/k/v biases -- the fused bias row stays zero and receives no gradient)
                 ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
-            self._wgrad(b + "qkv.w", dqkv, h1)
-            dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"))
-            dres = ops.rmsnorm_bwd(dh1, x_in, P.w(b + "ln1"), rstd1, dres=dx_mid, dw=P.g(b + "ln1"))
+            self._wgrad(b + "qkv.w", dqkv, h1, slot=sl_qkv if side else None)
+            dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"), out=S["dh"][:T])
+            dres_new, sl_new = take(S["res"])
+            ops.rmsnorm_bwd(dh1, x_in, P.w(b + "ln1"), rstd1, dres=dx_mid, dw=P.g(b + "ln1"), out=dres_new)
+            dres, sl_res = dres_new, sl_new
             ctx["layers"][i] = None  # release this layer's activations
             if layer_done is not None:   # this layer's weight gradients are final: the DDP bucket can leave -- ordered after the side stream
                 if self.wgrad_stream is not None:

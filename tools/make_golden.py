@@ -629,6 +629,9 @@ def hf_param_groups(model):
     return decay, no_decay
 
 
+LR20 = 5e-5
+
+
 def gen_sft():
     """PA-SFT numeric oracle: HF forward(labels) loss + 3 AdamW steps (lr 1e-3 for visible motion,
     wd 0.1 as PA_SFT_*.sh:38-44, betas/eps = torch defaults = HF Trainer defaults)."""
@@ -651,12 +654,24 @@ def gen_sft():
         loss.backward()
         opt.step()
         losses.append(loss.item())
+    # the north star's "loss curve": 20 AdamW steps from the same start at lr 5e-5 (each step moves a weight by <= 5e-5 against |w| ~ 0.05; the reference script uses 1e-5 / 2e-5: the loss falls
+    # visibly without the trajectory turning chaotic), same groups / weight decay
+    model = build_hf_model(cfg, fx.make_weights(cfg, seed=0)).train()
+    decay, no_decay = hf_param_groups(model)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}], lr=LR20, betas=(0.9, 0.999), eps=1e-8)
+    losses20 = []
+    for _ in range(20):
+        opt.zero_grad()
+        loss = model(**inputs).loss
+        loss.backward()
+        opt.step()
+        losses20.append(loss.item())
     np.savez_compressed(
-        os.path.join(OUT, "sft.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 11, "lr": 1e-3, "wd": 0.1, "no_decay": "transformers.Trainer.get_decay_parameter_names (tests/golden/sft_freeze.json: decay_parameters)"}),
+        os.path.join(OUT, "sft.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 11, "lr": 1e-3, "wd": 0.1, "lr20": LR20, "no_decay": "transformers.Trainer.get_decay_parameter_names (tests/golden/sft_freeze.json: decay_parameters)"}),
         input_ids=ids.numpy(), attention_mask=mask.numpy(), labels=labels.numpy(), pixel_values=b["pixel_values"].numpy(),
-        image_grid_thw=b["image_grid_thw"].numpy(), losses=np.array(losses, dtype=np.float64),
+        image_grid_thw=b["image_grid_thw"].numpy(), losses=np.array(losses, dtype=np.float64), losses20=np.array(losses20, dtype=np.float64),
     )
-    print("sft.npz: losses", losses)
+    print("sft.npz: losses", losses, "\n  20 steps at lr", LR20, [round(x, 4) for x in losses20])
 
 
 def gen_qwen2vl(SCGRPOTrainer):

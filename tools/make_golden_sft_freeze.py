@@ -126,10 +126,27 @@ def main():
     assert all(moved[n] == 0.0 for n in frozen) and all(v > 0 for n, v in moved.items() if n not in frozen)
     inv = {mg.hf_name(k): k for k in fx.param_shapes(cfg)}
     after = {inv[n]: p.detach().numpy() for n, p in model.named_parameters() if n in inv and inv[n] in ("model.norm.weight", "model.layers.1.self_attn.k_proj.bias", "visual.merger.mlp.2.bias", "visual.blocks.0.attn.qkv.bias")}
+    # 20-step curve with the same trainable set from the same start (lr as tools/make_golden.py LR20)
+    model = mg.build_hf_model_qwen2vl(cfg, fx.make_weights(cfg, seed=0)).train()
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        if n in frozen:
+            p.requires_grad_(False)
+        else:
+            (decay if n in dnames else no_decay).append(p)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}], lr=mg.LR20, betas=(0.9, 0.999), eps=1e-8)
+    losses20 = []
+    for _ in range(20):
+        opt.zero_grad()
+        loss = model(**inputs).loss
+        loss.backward()
+        opt.step()
+        losses20.append(loss.item())
     np.savez_compressed(os.path.join(OUT, "qwen2vl_sft_frozen.npz"),
-                        meta=json.dumps({**mg.meta(), "batch": "qwen2vl_sft.npz", "lr": 1e-3, "wd": 0.1, "flags": FLAGS[0], "frozen_hf_names": frozen}),
-                        losses=np.array(losses, dtype=np.float64), grad_norms=np.array(gnorms, dtype=np.float64), **{"after::" + k: v for k, v in after.items()})
-    print("qwen2vl_sft_frozen.npz: losses", losses, "grad norms", gnorms, "frozen", len(frozen), "tensors; kept", sorted(after))
+                        meta=json.dumps({**mg.meta(), "batch": "qwen2vl_sft.npz", "lr": 1e-3, "wd": 0.1, "lr20": mg.LR20, "flags": FLAGS[0], "frozen_hf_names": frozen}),
+                        losses=np.array(losses, dtype=np.float64), grad_norms=np.array(gnorms, dtype=np.float64), losses20=np.array(losses20, dtype=np.float64),
+                        **{"after::" + k: v for k, v in after.items()})
+    print("qwen2vl_sft_frozen.npz: losses", losses, "grad norms", gnorms, "frozen", len(frozen), "tensors; kept", sorted(after), "\n  20 steps", [round(x, 4) for x in losses20])
 
 
 if __name__ == "__main__":
