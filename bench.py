@@ -533,7 +533,7 @@ class RealImageProcessor(SynthProcessor):
         self.ip.max_pixels, self.ip.min_pixels = 480000, 3136          # the launch scripts' --max_pixels (REF:192-193); 448 x 448 = 200 704 pixels pass unresized
 
     def apply_chat_template(self, conv, add_generation_prompt=True, tokenize=False):
-        raise AssertionError("rows of the real-processor legs carry plain-string prompts")
+        return conv[0]["content"][-1]["text"]          # "SYNTHETIC PROMPT <step>": names the synthetic token ids of the step
 
     def __call__(self, text=None, images=None, **kw):
         step = int(text[0].rsplit(" ", 1)[1])
@@ -557,7 +557,8 @@ def real_processor_legs(tr, batches, n_prompts, steps, first_step, N):
             i = s * n_prompts + j
             paths[s, j] = os.path.join(tmp, f"img_{i}.png")
             Image.fromarray(np.random.RandomState(1234 + i).randint(0, 256, (448, 448, 3)).astype(np.uint8)).save(paths[s, j], compress_level=1)
-    rows = lambda s: [{"prompt": f"SYNTHETIC PROMPT {s}", "image": [paths[s, j]], "solution": SOLUTION} for j in range(n_prompts)]
+    rows = lambda s: [{"prompt": [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": f"SYNTHETIC PROMPT {s}"}]}], "image": [paths[s, j]], "solution": SOLUTION}
+                      for j in range(n_prompts)]
     saved = tr.processing_class
     tr.processing_class = RealImageProcessor(batches, CANNED)
     res = {}

@@ -60,16 +60,32 @@ def get_ans(response_text, options=None):
     return "E"
 
 
-def build_messages(n_few_shot: int = 0) -> list:
-    """The reference's fixed detection prompt (vLLM_Qwen_detect_format.py:85-121): optional normal templates, the test image, one question."""
+FAMILIES = ("qwen", "llava", "llava_1_5")
+
+
+def build_messages(n_few_shot: int = 0, family: str = "qwen") -> list:
+    """The reference's fixed detection prompt: optional normal templates, the test image, one question.  Three scripts, three wordings (pinned by
+    tests/golden/eval.json `prompts`, captured from the reference's own `build_prompt` methods):
+      qwen       vLLM_Qwen_detect_format.py:88-128       "Following is image of test sample:" only with templates; "... in the test image?"
+      llava      vLLM_LLaVA_detect_format.py:90-127      (LLaVA-OneVision, LLaVA-1.6) the same structure; "... in the query image?"
+      llava_1_5  vLLM_LLaVA_1_5_detect_format.py:90-126  "Following is image of test sample:" ALWAYS (also zero-shot); "... in the test image?" """
+    if family not in FAMILIES:
+        raise ValueError(f"family must be one of {FAMILIES}")
     parts = []
     if n_few_shot:
         parts.append({"type": "text", "text": f"Following is {n_few_shot} image of normal sample, which can be used as a template to compare the image being queried."})
         parts += [{"type": "image"}] * n_few_shot
+    if n_few_shot or family == "llava_1_5":
         parts.append({"type": "text", "text": "Following is image of test sample:"})
     parts.append({"type": "image"})
-    parts.append({"type": "text", "text": "Are there any defects in the test image?"})
+    parts.append({"type": "text", "text": "Are there any defects in the query image?" if family == "llava" else "Are there any defects in the test image?"})
     return [{"role": "user", "content": parts}]
+
+
+def template_kwargs(family: str = "qwen") -> dict:
+    """Keyword arguments of the reference's apply_chat_template call: the Qwen script renders through the TOKENIZER with tokenize=False
+    (vLLM_Qwen_detect_format.py:122-126), the LLaVA scripts through the PROCESSOR with its defaults (vLLM_LLaVA_detect_format.py:122-125)."""
+    return {"tokenize": False, "add_generation_prompt": True} if family == "qwen" else {"add_generation_prompt": True}
 
 
 def accuracy_table(all_answers: list, normal_flag: str = "good", show_overkill_miss: bool = False):
@@ -148,16 +164,12 @@ class GreedyGenerator:
     def generate(self, batch: dict) -> np.ndarray:
         """batch: input_ids / attention_mask [B, P] (left padded), pixel_values, image_grid_thw, images_per_prompt.
         Returns completion ids [B, <= max_new] (pad after EOS)."""
-        import torch
-        from . import ops
         from .rollout import Rollout
         e, c = self.engine, self.cfg
         ids, mask = np.asarray(batch["input_ids"]), np.asarray(batch["attention_mask"])
-        grids = [tuple(int(z) for z in g) for g in batch["image_grid_thw"]]
-        px = torch.as_tensor(batch["pixel_values"]).to(e.dev)
-        px = px if px.dtype == torch.bfloat16 else ops.cast_f32_to_bf16(px.float().contiguous())
-        img, _ = e.vision_forward(px, e.vision_plan(grids), save=False)
-        rows = np.cumsum([0] + [g[0] * g[1] * g[2] // c.v_merge**2 for g in grids])
+        # Qwen-VL: image_grid_thw + patch rows; LLaVA families: image_sizes (+ crops) -- Engine.vision_inputs reads either (the trainer's own path)
+        grids, plan_v, px, rows = e.vision_inputs(batch)
+        img, _ = e.vision_forward(px, plan_v, save=False)
         gpr, off, k = [], [], 0
         for n in batch.get("images_per_prompt") or [1] * len(ids):
             gpr.append(grids[k: k + n])
@@ -174,10 +186,13 @@ class GreedyGenerator:
 
 
 def evaluate_dataset(generator: GreedyGenerator, processor, data_root: str, chat_ad: dict, few_shot_model: int = 0, batch_size: int = 4,
-                     similar_template: bool = False, answers_json_path: str | None = None, existing: list | None = None) -> list:
-    """The reference's evaluation loop (vLLM_Qwen_detect_format.py:283-380): first question of every image, greedy answer, letter by
-    `get_ans`, one entry per question; writes the answers json after every batch when a path is given."""
+                     similar_template: bool = False, answers_json_path: str | None = None, existing: list | None = None, family: str = "qwen") -> list:
+    """The reference's evaluation loop (vLLM_Qwen_detect_format.py:283-380, vLLM_LLaVA_detect_format.py:300-367, vLLM_LLaVA_1_5_detect_format.py): first
+    question of every image, greedy answer, letter by `get_ans`, one entry per question; writes the answers json after every batch when a path is given.
+    family: which script's prompt wording / template call / image mode (the LLaVA scripts convert every image to RGB, :85-87)."""
     from PIL import Image
+    opener = (lambda p: Image.open(p)) if family == "qwen" else (lambda p: Image.open(p).convert("RGB"))
+    render = processor.tokenizer if (family == "qwen" and hasattr(processor, "tokenizer") and getattr(processor.tokenizer, "chat_template", None)) else processor
     all_answers = list(existing or [])
     done = {a["image"] for a in all_answers}
     todo = [k for k in chat_ad if k not in done]
@@ -189,16 +204,20 @@ def evaluate_dataset(generator: GreedyGenerator, processor, data_root: str, chat
             if not qs or not ans:
                 continue
             shots = (text_gt["similar_templates"] if similar_template else text_gt["random_templates"])[:few_shot_model] if few_shot_model else []
-            prompts.append(processor.apply_chat_template(build_messages(len(shots)), tokenize=False, add_generation_prompt=True))
-            ims = [Image.open(os.path.join(data_root, p)) for p in shots] + [Image.open(os.path.join(data_root, key))]
+            prompts.append(render.apply_chat_template(build_messages(len(shots), family), **template_kwargs(family)))
+            ims = [opener(os.path.join(data_root, p)) for p in shots] + [opener(os.path.join(data_root, key))]
             images += ims
             per.append(len(ims))
             metas.append((key, qs[0:1], ans[0:1], text_gt))
         if not prompts:
             continue
         enc = processor(text=prompts, images=images, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
-        comp = generator.generate({"input_ids": enc["input_ids"].numpy(), "attention_mask": enc["attention_mask"].numpy(), "pixel_values": enc["pixel_values"],
-                                   "image_grid_thw": enc["image_grid_thw"].numpy().tolist(), "images_per_prompt": per})
+        batch = {"input_ids": enc["input_ids"].numpy(), "attention_mask": enc["attention_mask"].numpy(), "pixel_values": enc["pixel_values"], "images_per_prompt": per}
+        if "image_sizes" in enc:            # LLaVA-OneVision / LLaVA-NeXT processors (trainer.prepare_batch reads the same keys)
+            batch["image_sizes"] = np.asarray(enc["image_sizes"]).reshape(-1, 2).tolist()
+        elif "image_grid_thw" in enc:       # Qwen2-VL / Qwen2.5-VL processors
+            batch["image_grid_thw"] = np.asarray(enc["image_grid_thw"]).tolist()
+        comp = generator.generate(batch)
         texts = processor.batch_decode(comp, skip_special_tokens=True)
         for (key, qs, ans, text_gt), response in zip(metas, texts):
             letter = get_ans(response, qs[0]["options"]) or response
@@ -209,3 +228,50 @@ def evaluate_dataset(generator: GreedyGenerator, processor, data_root: str, chat
             with open(answers_json_path, "w") as f:
                 json.dump(all_answers, f, indent=4)
     return all_answers
+
+
+def detect_main(family: str, argv=None):
+    """Shared body of scripts/Inference/IAD-R1-Inference/hip_{qwen,llava,llava_1_5}_detect_format.py: the reference script's flags (defaults per script:
+    vLLM_Qwen_detect_format.py:254-266 -- 0-shot, name "Qwen"; vLLM_LLaVA*_detect_format.py:240-253 -- 1-shot, name "LlaVA", `--temperature` on the
+    OneVision / 1.6 script only) and result files (`result/<name>/<test_dataset>/answers_<k>_shot_<model>_vllm.json` + `..._accuracy.csv`); decoding on the
+    rollout engine instead of a vLLM process.  The checkpoint directory must hold the HF processor / tokenizer files, as for the reference."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model-path", type=str, default="model_path")
+    ap.add_argument("--few_shot_model", type=int, default=0 if family == "qwen" else 1)
+    ap.add_argument("--reproduce", action="store_true")
+    ap.add_argument("--similar_template", action="store_true")
+    ap.add_argument("--record_history", action="store_true")
+    ap.add_argument("--batch_size", type=int, default=4)
+    ap.add_argument("--tensor_parallel_size", type=int, default=1, help="accepted for compatibility; one MI355X holds the model")
+    ap.add_argument("--gpu_memory_utilization", type=float, default=0.9, help="accepted for compatibility")
+    ap.add_argument("--step", type=int, default=500)
+    ap.add_argument("--test_dataset", type=str, default="test_data")
+    ap.add_argument("--name", type=str, default="Qwen" if family == "qwen" else "LlaVA")
+    if family == "llava":
+        ap.add_argument("--temperature", type=float, default=0.0)
+    ap.add_argument("--data_path", type=str, default=os.environ.get("IADR1_TEST_DATA", "Industrial_test"))
+    ap.add_argument("--json_path", type=str, default=None, help="default: data/Test/<test_dataset>_format.json")
+    a = ap.parse_args(argv)
+    if getattr(a, "temperature", 0.0) != 0.0:
+        raise SystemExit("--temperature: only 0 (greedy -- what every reference Inference.sh runs) is built; vLLM's temperature > 0 with top_p = 1.0 samples the whole "
+                         "vocabulary, the rollout's sampler keeps at most 64 candidates (top-k 50 is the training setting)")
+    from transformers import AutoProcessor
+    from .trainer import load_checkpoint
+    cfg, store = load_checkpoint(a.model_path, "cuda", trainable=False, with_decode_pack=True)
+    if (family == "qwen") == bool(cfg.is_llava) or (family == "llava_1_5") != (cfg.is_llava and cfg.llava_family == "llava"):
+        raise SystemExit(f"{a.model_path}: this script evaluates the {family} checkpoints (config.json says otherwise)")
+    processor = AutoProcessor.from_pretrained(a.model_path)
+    if cfg.is_llava and hasattr(processor, "tokenizer"):
+        processor.tokenizer.padding_side = "left"
+    gen = GreedyGenerator(cfg, store, max_new_tokens=512)
+    model_name = os.path.split(a.model_path.rstrip("/"))[-1] + ("_Similar_template" if a.similar_template else "")
+    out_dir = f"result/{a.name}/{a.test_dataset}/"
+    os.makedirs(out_dir, exist_ok=True)
+    answers_path = f"{out_dir}answers_{a.few_shot_model}_shot_{model_name}_vllm.json"
+    existing = json.load(open(answers_path)) if (os.path.exists(answers_path) and not a.reproduce) else []
+    chat_ad = json.load(open(a.json_path or f"data/Test/{a.test_dataset}_format.json"))
+    evaluate_dataset(gen, processor, a.data_path, chat_ad, a.few_shot_model, a.batch_size, a.similar_template, answers_path, existing, family=family)
+    df, _ = write_accuracy(answers_path)
+    print(df)
+    return df

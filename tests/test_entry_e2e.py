@@ -324,6 +324,76 @@ def test_evaluation_script_end_to_end(tmp_path, offline_processor, monkeypatch):
     assert json.load(open(ans_path)) == answers
 
 
+@pytest.mark.parametrize("script,family", [("hip_llava_detect_format.py", "llava_ov"), ("hip_llava_detect_format.py", "llava_next"), ("hip_llava_1_5_detect_format.py", "llava")])
+def test_llava_evaluation_scripts_end_to_end(tmp_path, monkeypatch, script, family):
+    """scripts/Inference/IAD-R1-Inference/hip_llava_detect_format.py (= the reference's vLLM_LLaVA_detect_format.py: LLaVA-OneVision and LLaVA-1.6) and
+    hip_llava_1_5_detect_format.py (= vLLM_LLaVA_1_5_detect_format.py) on the rollout engine: checkpoint directory + MMAD-format question file + image files
+    (one of them greyscale: the LLaVA scripts convert to RGB) -> 1-shot prompts (two images) through the offline transformers processor of the family ->
+    greedy answers -> answers json + accuracy csv in the reference's layout; resume; the wrong script for a checkpoint is refused."""
+    import transformers
+    from PIL import Image
+    if family == "llava_ov":
+        proc = fx.local_llava_ov_processor()
+        tok = proc.tokenizer
+        d = dict(fx.TINY_OV, image_token_id=tok.convert_tokens_to_ids("<image>"), eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id)
+        t, v = d["text"], d["vision"]
+        hf = {"model_type": "llava_onevision", "architectures": ["LlavaOnevisionForConditionalGeneration"], "image_token_index": d["image_token_id"],
+              "image_grid_pinpoints": [list(p) for p in d["image_grid_pinpoints"]], "vision_aspect_ratio": "anyres_max_9", "vision_feature_layer": -1,
+              "vision_feature_select_strategy": "full", "tie_word_embeddings": False,
+              "text_config": {"model_type": "qwen2", "vocab_size": t["vocab_size"], "hidden_size": t["hidden_size"], "intermediate_size": t["intermediate_size"],
+                              "num_hidden_layers": t["num_hidden_layers"], "num_attention_heads": t["num_attention_heads"], "num_key_value_heads": t["num_key_value_heads"],
+                              "rms_norm_eps": t["rms_norm_eps"], "rope_theta": t["rope_theta"], "eos_token_id": d["eos_token_id"], "pad_token_id": d["pad_token_id"]},
+              "vision_config": {"model_type": "siglip_vision_model", "num_hidden_layers": v["depth"], "hidden_size": v["hidden_size"], "intermediate_size": v["intermediate_size"],
+                                "num_attention_heads": v["num_heads"], "num_channels": v["in_channels"], "patch_size": v["patch_size"], "image_size": v["image_size"], "layer_norm_eps": 1e-6}}
+        weights, name = fx.make_weights_ov(d, 0), "llava-onevision-tiny-si"
+    else:
+        cfg0 = fx.TINY_LLAVA15 if family == "llava" else fx.TINY_LLAVA_NEXT
+        proc = fx.local_llava_processor(cfg0)
+        tok = proc.tokenizer
+        d = dict(cfg0, image_token_id=tok.convert_tokens_to_ids("<image>"), eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id, vision_start_token_id=-1, vision_end_token_id=-1)
+        hf, weights, name = _llava_config_json(d), fx.make_weights_llava(d, 0), ("llava_1_5-tiny-hf" if family == "llava" else "llava_next-mistral-tiny-hf")
+    proc.save_pretrained = lambda *a, **k: None
+    monkeypatch.setattr(transformers.AutoProcessor, "from_pretrained", classmethod(lambda cls, *a, **k: proc))
+    src = str(tmp_path / name)
+    s0 = ParamStore(VLMConfig.from_dict(d), DEV, trainable=False)
+    s0.load_named(weights)
+    save_checkpoint(s0, src, hf)
+    data = tmp_path / "Industrial_test"
+    (data / "MVTec" / "bottle").mkdir(parents=True)
+    fx.synth_pil_image(100, 80, 5).save(str(data / "MVTec" / "bottle" / "template.png"))
+    chat = {}
+    for i in range(3):
+        rel = f"MVTec/bottle/{'good' if i == 0 else 'broken'}_{i}.png"
+        im = fx.synth_pil_image(100 + 20 * i, 80, 90 + i)
+        (im.convert("L") if i == 1 else im).save(str(data / rel))          # a greyscale file: Image.open(...).convert("RGB") of the LLaVA scripts
+        chat[rel] = {"conversation": [{"Question": "Is there any defect in the object?", "Answer": "B" if i == 0 else "A", "Options": {"A": "Yes.", "B": "No."}, "type": "Anomaly Detection"}],
+                     "similar_templates": ["MVTec/bottle/template.png"], "random_templates": ["MVTec/bottle/template.png"]}
+    qfile = tmp_path / "test_data_format.json"
+    qfile.write_text(json.dumps(chat))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr("iadr1_amd.evaluate.GreedyGenerator.__init__", _short_generator_init(), raising=True)
+    seen = []
+    from iadr1_amd import evaluate
+    orig_gen = evaluate.GreedyGenerator.generate
+    monkeypatch.setattr(evaluate.GreedyGenerator, "generate", lambda self, batch: (seen.append((batch["images_per_prompt"], np.asarray(batch["input_ids"]).shape)), orig_gen(self, batch))[1])
+    m = _load("scripts/Inference/IAD-R1-Inference/" + script)
+    argv = ["x", "--model-path", src, "--test_dataset", "test_data", "--json_path", str(qfile), "--data_path", str(data), "--batch_size", "2"]      # defaults: 1-shot, name "LlaVA"
+    monkeypatch.setattr(sys, "argv", argv)
+    m.main()
+    ans_path = tmp_path / "result" / "LlaVA" / "test_data" / f"answers_1_shot_{name}_vllm.json"
+    answers = json.load(open(ans_path))
+    assert [a["image"] for a in answers] == list(chat) and all(a["gpt_answer"] for a in answers) and all(a["question_type"] == "Anomaly Detection" for a in answers)
+    assert [ipp for ipp, _ in seen] == [[2, 2], [2]]                                    # template + query image per prompt, batches of 2 and 1
+    assert os.path.exists(str(ans_path).replace(".json", "_accuracy.csv"))
+    m.main()                                                                             # resume: nothing left
+    assert json.load(open(ans_path)) == answers and len(seen) == 2
+    other = "hip_llava_1_5_detect_format.py" if script == "hip_llava_detect_format.py" else "hip_llava_detect_format.py"
+    with pytest.raises(SystemExit, match="config.json says otherwise"):
+        _load("scripts/Inference/IAD-R1-Inference/" + other).main()
+    with pytest.raises(SystemExit, match="config.json says otherwise"):
+        _load("scripts/Inference/IAD-R1-Inference/hip_qwen_detect_format.py").main()
+
+
 def _short_generator_init():
     """The script decodes up to 512 tokens per answer; a random-weight model never stops early, so the test caps the length (same code path)."""
     from iadr1_amd import evaluate

@@ -34,6 +34,16 @@ def test_accuracy_table_csv_is_bit_exact(golden_dir):
         assert stats == acc["question_stats"]
 
 
+def test_prompts_of_the_three_scripts_match_the_reference(golden_dir):
+    """`build_messages` / `template_kwargs` per family against what the reference's own `build_prompt` methods hand to apply_chat_template
+    (vLLM_Qwen_detect_format.py, vLLM_LLaVA_detect_format.py, vLLM_LLaVA_1_5_detect_format.py; captured by tools/make_golden_eval.py): 0-, 1- and 2-shot."""
+    cases = _g(golden_dir)["prompts"]
+    assert {(c["family"], c["n_few_shot"]) for c in cases} == {(f, n) for f in evaluate.FAMILIES for n in (0, 1, 2)}
+    for c in cases:
+        assert evaluate.build_messages(c["n_few_shot"], c["family"]) == c["messages"], c
+        assert evaluate.template_kwargs(c["family"]) == c["kwargs"], c
+
+
 def test_prompt_structure():
     m = evaluate.build_messages(2)
     kinds = [p["type"] for p in m[0]["content"]]

@@ -160,6 +160,36 @@ def test_sft_loss_curve(golden_dir):
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-4)
 
 
+def test_sft_20_step_loss_curves(golden_dir):
+    """The north star's "loss curve": 20 AdamW steps at lr 5e-5 (tests/golden/sft.npz `losses20`: Qwen2.5-VL structure, everything trained;
+    qwen2vl_sft_frozen.npz `losses20`: Qwen2-VL with the reference's PA-SFT trainable set) -- the fp32 oracle follows the HF model to 1e-3 over all 20 steps."""
+    for name, cfg, mt, batch_file in (("sft.npz", fx.TINY, "qwen2_5_vl", "sft.npz"), ("qwen2vl_sft_frozen.npz", fx.TINY_Q2, "qwen2_vl", "qwen2vl_sft.npz")):
+        g, g0 = _load(golden_dir, name), _load(golden_dir, batch_file)
+        meta = json.loads(str(g["meta"]))
+        m = oq.Qwen25VLOracle(cfg, fx.make_weights(cfg, 0), requires_grad=True)
+        params = dict(m.parameters())
+        frozen = {n[len("model."):] if n.startswith("model.visual.") else n for n in meta.get("frozen_hf_names", [])}
+        for k in frozen:
+            params[k].requires_grad_(False)
+        decay, no_decay = _hf_groups(golden_dir, mt, params)
+        keep = {id(p) for k, p in params.items() if k not in frozen}
+        opt = torch.optim.AdamW([{"params": [p for p in decay if id(p) in keep], "weight_decay": meta["wd"]},
+                                 {"params": [p for p in no_decay if id(p) in keep], "weight_decay": 0.0}], lr=meta["lr20"])
+        grids = [tuple(int(z) for z in r) for r in g0["image_grid_thw"]]
+        ids, mask, labels = (torch.from_numpy(g0[k]) for k in ("input_ids", "attention_mask", "labels"))
+        pv = torch.from_numpy(g0["pixel_values"])
+        losses = []
+        for _ in range(len(g["losses20"])):
+            opt.zero_grad()
+            loss = m.sft_loss(ids, mask, labels, pv, grids)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        dev = np.abs(np.array(losses) - g["losses20"]).max()
+        print(f"[sft curve, oracle] {name}: max |dloss| over 20 steps = {dev:.2e} (loss {g['losses20'][0]:.3f} -> {g['losses20'][-1]:.3f})")
+        assert len(losses) == 20 and dev < 1e-3, (name, dev)
+
+
 def test_forward_7b_like_config(golden_dir):
     """Untied lm_head + GQA group of 7 (the structural deltas of Qwen2.5-VL-7B, BASELINE config 4)."""
     g = _load(golden_dir, "logps_7b_like.npz")

@@ -69,7 +69,33 @@ with tempfile.TemporaryDirectory() as d:
     csv = open(pth.replace(".json", "_accuracy.csv")).read()
     stats2 = caculate_accuracy_mmad(pth, show_overkill_miss=True)
     csv2 = open(pth.replace(".json", "_accuracy.csv")).read()
+# ---- prompt construction of the three evaluation scripts: their own `build_prompt` methods, with a recording stand-in for the tokenizer / processor ----
+class _Recorder:
+    def apply_chat_template(self, messages, **kw):
+        self.last = {"messages": messages, "kwargs": kw}
+        return "PROMPT"
+
+
+prompt_cases = []
+for fam, fname, cls in (("qwen", "vLLM_Qwen_detect_format.py", "QwenVLLMQuery"), ("llava", "vLLM_LLaVA_detect_format.py", "LLaVAVLLMQuery"),
+                        ("llava_1_5", "vLLM_LLaVA_1_5_detect_format.py", "LLaVAVLLMQuery")):
+    sp = importlib.util.spec_from_file_location("ref_" + fam, os.path.join(REF, "scripts/Inference/IAD-R1-Inference", fname))
+    m = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(m)
+    for n_shot in (0, 1, 2):
+        qy = getattr(m, cls).__new__(getattr(m, cls))
+        rec = _Recorder()
+        qy.few_shot = [f"t{i}.png" for i in range(n_shot)]
+        qy.tokenizer = qy.processor = rec
+        out = qy.build_prompt([{"type": "text", "text": "Question 1: ...", "options": OPT}])
+        assert out == "PROMPT"
+        prompt_cases.append({"family": fam, "script": fname, "n_few_shot": n_shot, **rec.last})
+    # get_ans of the LLaVA scripts is the same function restated: run the same cases through it
+    for c in get_ans_cases:
+        assert m.get_ans(c["response"], c["options"]) == c["expected"], (fname, c)
+
 json.dump({"meta": {"generator": "tools/make_golden_eval.py", "reference": "Yanhui-Lee/IAD-R1 @ /root/reference"}, "get_ans": get_ans_cases, "parse_conversation": parse_cases,
+           "prompts": prompt_cases,
            "accuracy": {"answers": answers, "csv": csv, "csv_overkill_miss": csv2, "question_stats": stats}}, open(os.path.join(ROOT, "tests", "golden", "eval.json"), "w"))
 print("eval.json:", len(get_ans_cases), "get_ans cases,", len(parse_cases), "parse cases,", len(answers), "answers")
 print(csv)
