@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-repeated-rows-leg", action="store_true", help="skip the extra (untimed) step in the reference's repeated-prompt-rows layout")
     ap.add_argument("--workload", default="sc_grpo", choices=["sc_grpo", "pa_sft"], help="sc_grpo = the north-star SC-GRPO step (default); pa_sft = BASELINE config 2 (PA-SFT, bs 16, 448^2 image, 512 prompt + 256 supervised tokens)")
     ap.add_argument("--sft-batch", type=int, default=16)
+    ap.add_argument("--gradient-checkpointing", default="off", choices=["off", "auto", "on"], help="decoder activation recompute policy of the step (the reference scripts' "
+                    "--gradient_checkpointing true = auto): lets e.g. --model 7b run one 64-sequence micro-batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-processor-legs", action="store_true", help="skip the two extra (untimed for `value`) loops that feed uint8 images through the HF image processor inside the step")
     ap.add_argument("--no-graph", action="store_true")
@@ -300,16 +302,20 @@ def cpu_baseline(cfg_dict_3b, seconds_budget, P=512, C=256, G=8):
             m.text_model(x, mask, pos).sum().backward()
         lay[nl, "fb"] = timed(fb)
         lay[nl, "prefill"] = timed(lambda: m.text_model(x[:1, :P], mask[:1, :P], pos[:, :1, :P]).detach())
-        if nl == 1:     # KV-cached decode step of the G sequences at mid context (P + C/2 keys)
-            st = {"cache": [[torch.randn(G, d["text"]["num_key_value_heads"], P + C // 2, 128, generator=gen)] * 2], "mask": torch.ones(G, P + C // 2, dtype=torch.long),
-                  "deltas": torch.zeros(G, dtype=torch.long)}
-            tok = torch.randint(3, vocab_small - 16, (G,), generator=gen)
-            def dec():
-                st["cache"][0] = [st["cache"][0][0][:, :, : P + C // 2], st["cache"][0][1][:, :, : P + C // 2]]
-                st["mask"] = st["mask"][:, : P + C // 2]
-                m.decode_step_cached(tok, st)
-            lay["dec_layer_plus_small_head"] = timed(dec, reps=4)
-            d0, m0 = d, m
+    # KV-cached decode step of the G sequences at mid context (P + C/2 keys) over NDEC distinct layers: a decode step is a WEIGHT STREAM (G rows against every matrix),
+    # and one layer's 344 MB of fp32 weights would be served from the host's last-level cache -- the full-size run (profiles/r03_cpu_full_step.json: 1.29 s per decode
+    # step, 36 layers = 12.4 GB) showed the single-layer timing of rounds 1-2 to be 4.7x too fast
+    NDEC = 6
+    d, m = model(NDEC, 0, vocab_small, False)
+    st = {"cache": [[torch.randn(G, d["text"]["num_key_value_heads"], P + C // 2, 128, generator=gen)] * 2 for _ in range(NDEC)], "mask": torch.ones(G, P + C // 2, dtype=torch.long),
+          "deltas": torch.zeros(G, dtype=torch.long)}
+    tok = torch.randint(3, vocab_small - 16, (G,), generator=gen)
+    def dec():
+        st["cache"] = [[kv[0][:, :, : P + C // 2], kv[1][:, :, : P + C // 2]] for kv in st["cache"]]
+        st["mask"] = st["mask"][:, : P + C // 2]
+        m.decode_step_cached(tok, st)
+    lay["dec_layers_plus_small_head"] = timed(dec, reps=2)
+    del m, st
     t_layer = {k: pos0(lay[1, k] - lay[0, k]) for k in ("f", "fb", "prefill")}
     # ---- lm_head + log-softmax + gather at the full vocabulary: the reference projects ALL S positions of every row (REF:505); timed on R rows --
     V = cfg_dict_3b["text"]["vocab_size"]
@@ -328,7 +334,7 @@ def cpu_baseline(cfg_dict_3b, seconds_budget, P=512, C=256, G=8):
         head_dec = timed(lambda: (hd @ Wh.t()).argmax(-1), reps=4)           # decode: G rows against the whole matrix (weight-read bound)
         small = (torch.randn(vocab_small, H, generator=gen) * 0.02)
         head_dec_small = timed(lambda: (hd @ small.t()).argmax(-1), reps=4)
-    t_dec_layer = pos0(lay["dec_layer_plus_small_head"] - head_dec_small)
+    t_dec_layer = pos0(lay["dec_layers_plus_small_head"] - head_dec_small) / NDEC
     rows_all = G * S
     parts = {
         "rollout_vision_1_image_fwd": vit["f"],
@@ -342,7 +348,7 @@ def cpu_baseline(cfg_dict_3b, seconds_budget, P=512, C=256, G=8):
     return {"value": G / step_s, "unit": "samples/s", "cores": cores, "kind": "port", "seconds_per_step_B1_G8": step_s,
             "parts_seconds": {k: round(v, 3) for k, v in parts.items()},
             "sample": (f"oracle (fp32 torch CPU restatement) components of ONE B=1 x G={G} SC-GRPO step at full Qwen2.5-VL-3B width, P={P}, C={C}: ViT block fwd / fwd+bwd "
-                       f"(1 image), decoder layer fwd / fwd+bwd on the [{G}, {S}] training rows, prefill layer on [1, {P}], KV-cached greedy decode step of {G} sequences "
+                       f"(1 image), decoder layer fwd / fwd+bwd on the [{G}, {S}] training rows, prefill layer on [1, {P}], KV-cached greedy decode step of {G} sequences over {NDEC} distinct layers (a weight stream: one layer alone runs from the host's cache) "
                        f"at {P + C // 2} cached keys, lm_head + log-softmax + gather on {R} rows of the {V}-token vocabulary (all S positions per row as REF:505), "
                        f"decode head on {G} rows; each the median of 3 timings after a first-touch run (differences of medians clamped at 0), multiplied by its count in the step (layers x {L_full}, ViT blocks x {V_full}, "
                        f"decode steps x {C - 1}); ViT recomputed per sequence in the training passes as the reference does")}
@@ -688,6 +694,7 @@ def main():
                        train_dataset=None, processing_class=SynthProcessor(batches, CANNED))
     eng = tr.engine
     eng.args.suppress_eos = True            # fixed-length completions, every sequence generates gen_len tokens
+    eng.args.recompute = a.gradient_checkpointing
     eng.args.use_hip_graph = not a.no_graph
     timer = GemmTimer()
     timer.install()
@@ -801,7 +808,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{model_name} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {image_note}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
-                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "grad_exchange": ({"wire": eng.reducer.wire, "bytes_per_step": getattr(eng.reducer, "last_bytes_on_wire", 0), "buckets_per_step": getattr(eng.reducer, "last_n_buckets", 0)}
                                          if eng.reducer.active else None),
                        "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "

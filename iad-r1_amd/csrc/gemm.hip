@@ -47,6 +47,10 @@ struct GemmArgs {
     const float* lse;           // OUT_DLOGITS: [M] log-sum-exp of the row
     const float* g;             // OUT_DLOGITS: [M] dLoss/dlogp of the row
     int nparts;
+    // split-K (gemm_nt_256<OUT_F32>, iadr1_gemm_nt_splitk_acc_bf16): grid = ksplit x tiles; slice z = blockIdx.x / tiles contracts columns
+    // [z * kslice, min(K, (z + 1) * kslice)) of A and B and stores its fp32 partial tile at C + z * zstride (a workspace the reduce kernel sums)
+    int ksplit, kslice;
+    long long zstride;
 };
 
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_SWIGLU = 3, OUT_LSE = 4, OUT_DLOGITS = 5 };
@@ -288,7 +292,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 
     const int tiles_m = (p.M + T2 - 1) / T2, tiles_n = (p.N + T2 - 1) / T2;
     const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    if constexpr (OUT == OUT_F32) {
+        if (p.ksplit > 1) {      // block-uniform: this block's K slice and its slab of the partial-sum workspace
+            const int z = bid / nwg;
+            bid -= z * nwg;
+            p.A += (long long)z * p.kslice;
+            p.B += (long long)z * p.kslice;
+            p.K = min(p.kslice, p.K - z * p.kslice);
+            p.C = (float*)p.C + (long long)z * p.zstride;
+        }
+    }
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int BR = p.band;
@@ -1029,9 +1043,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_wide_kernel(SkinnyArgs
 // streams, then every block reduces).  tools/decode_stream.py on weights that really come from HBM: 19.8 vs 24.9 us on the 90 MB
 // gate|up stream (4.55 TB/s; a plain read of the same bytes runs at 5.4).  grid.x = nz * bps blocks: slice z = blockIdx.x / bps of K
 // (split-K partial slabs, out_mode 2), block b = blockIdx.x % bps takes tile groups b, b + bps, ...
-template <int WAVES, int KSW>
+// FP8 = true: the weights are the FP8 decode pack (see gemm_skinny_wide_kernel): a lane's 16-byte load holds its fragments of k-steps 2s and 2s + 1, so a
+// wave owns the DOUBLE steps w + j * WAVES (j < KSW / 2) and keeps the X fragments of both halves; the fragments are widened to bf16 in registers and the
+// output columns multiplied by the per-row scale in the epilogue.  Half the weight bytes per tile, the same MFMA count.
+template <int WAVES, int KSW, bool FP8 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs p) {
     constexpr int TPI = 2, RLD = 16 * TPI + 1;
+    static_assert(!FP8 || KSW % 2 == 0, "FP8 packs pair the k-steps");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [WAVES][64][RLD]
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
@@ -1039,21 +1057,31 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     const int m_base = blockIdx.y * 64;
     const long long sb = p.out_mode == 3 ? side_base(p.so) : -1;
     STAMP(4);
-    const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks)
-    // X fragments of this wave's k-steps w + j*WAVES: loaded once, resident for the whole launch
+    const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks); elements of a bf16 tile = BYTES of an FP8 tile
+    // X fragments of this wave's k-steps w + j*WAVES (FP8: 2 (w + (j/2) WAVES) + (j & 1)): loaded once, resident for the whole launch
     const bool xpk = p.ldx == 0;
     const bf16_t* xbase = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + l * 8 : p.X + (long long)min(m_base + lm, p.M - 1) * p.ldx + lq * 8;
     const long long xgroup = xpk ? 512 : 16 * p.ldx, xstep = xpk ? 2048 : 32;
     const int xgroups_ok = xpk ? 4 : (p.M - m_base - lm + 15) / 16;
     const bf16_t* wlane = p.W + (long long)w * 512 + l * 8;
+    const char* wlane8 = (const char*)p.W + (long long)w * 1024 + l * 16;
     const int ngroups = p.N / (16 * TPI);
-    bf16x8_t wf[KSW][TPI];
+    bf16x8_t wf[FP8 ? 1 : KSW][TPI];
+    u32x4_t wq[FP8 ? KSW / 2 : 1][TPI];
     auto loadw = [&](int g) {
-        const bf16_t* wb = wlane + (long long)g * TPI * tile_stride;
+        if constexpr (FP8) {
+            const char* wb = wlane8 + (long long)g * TPI * tile_stride;
 #pragma unroll
-        for (int j = 0; j < KSW; ++j)
+            for (int j = 0; j < KSW / 2; ++j)
 #pragma unroll
-            for (int tt = 0; tt < TPI; ++tt) wf[j][tt] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + tt * tile_stride + j * (WAVES * 512))));
+                for (int tt = 0; tt < TPI; ++tt) wq[j][tt] = __builtin_nontemporal_load((const u32x4_t*)(wb + tt * tile_stride + j * (WAVES * 1024)));
+        } else {
+            const bf16_t* wb = wlane + (long long)g * TPI * tile_stride;
+#pragma unroll
+            for (int j = 0; j < KSW; ++j)
+#pragma unroll
+                for (int tt = 0; tt < TPI; ++tt) wf[j][tt] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + tt * tile_stride + j * (WAVES * 512))));
+        }
     };
     // Order of the tile groups.  Plain: block b takes b, b + bps, ...  With side outputs (rows of the row-major training arena: 32 bytes of a row per
     // group and array) the four groups that share a 128-byte line of a row go, in the SAME iteration, to four blocks of ONE XCD (blockIdx.x % 8 is
@@ -1075,7 +1103,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     for (int j = 0; j < KSW; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            xf[j][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)(w + j * WAVES) * xstep));
+            xf[j][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)(FP8 ? 2 * (w + (j >> 1) * WAVES) + (j & 1) : w + j * WAVES) * xstep));
 #ifdef IADR1_PERS_XFIRST
     if (g < ngroups) loadw(g);
 #endif
@@ -1087,12 +1115,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if constexpr (FP8) {
 #pragma unroll
-        for (int j = 0; j < KSW; ++j)
+            for (int j = 0; j < KSW; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int tt = 0; tt < TPI; ++tt) {
+                    const bf16x8_t wfr = fp8x8_to_bf16(wq[j >> 1][tt][2 * (j & 1)], wq[j >> 1][tt][2 * (j & 1) + 1]);
 #pragma unroll
-                for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][tt], xf[j][i], acc[i][tt], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[j][i], acc[i][tt], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KSW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int tt = 0; tt < TPI; ++tt) acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][tt], xf[j][i], acc[i][tt], 0, 0, 0);
+        }
         if (gq == gq0) STAMP(5);
         if (g_next < ngroups) loadw(g_next);     // in flight during the reduction below
 #pragma unroll
@@ -1114,6 +1153,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
                     gsum += red[((size_t)ww * 64 + m) * RLD + n];
                     usum += red[((size_t)ww * 64 + m) * RLD + 16 + n];
                 }
+                if constexpr (FP8) { gsum *= p.wscale[gn]; usum *= p.wscale[(p.N >> 1) + gn]; }
                 gsum = bf2f(f2bf(gsum));
                 usum = bf2f(f2bf(usum));
                 const float sg = bf2f(f2bf(gsum / (1.f + __expf(-gsum))));
@@ -1133,6 +1173,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
                 float v = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+                if constexpr (FP8) v *= p.wscale[gn];
                 if (p.out_mode == 0) {
                     if (p.bias) v += bf2f(p.bias[gn]);
                     ((bf16_t*)p.Y)[(long long)gm * p.ldy + gn] = f2bf(v);
@@ -1152,32 +1193,39 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
 // slice z = blockIdx.x / bps owns k-steps [z*per_z, ...), its bps blocks walk 16-column tiles b, b + bps, ... (one tile per iteration so
 // that a block has >= 4 iterations to pipeline: with two-tile groups it had 2 and ran slower than the one-shot kernel).  A wave's steps
 // past the end of the slice get a zero X fragment and a clamped (valid, redundant) W address: no predicated loads in the loop.
-template <int WAVES, int KSW>
+// FP8 = true: K is walked in 64-deep DOUBLE steps of the FP8 decode pack (KSW of them per wave), see gemm_skinny_pers_kernel.
+template <int WAVES, int KSW, bool FP8 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(SkinnyArgs p, int nz, int bps) {
-    constexpr int RLD = 16 + 1;
+    constexpr int RLD = 16 + 1, XS = FP8 ? 2 : 1;      // X fragments per step of the weight walk
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [WAVES][64][RLD]
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lm = l & 15, lq = l >> 4;
     const int z = blockIdx.x / bps, b = blockIdx.x - z * bps;
     const int m_base = blockIdx.y * 64;
-    const int ksteps = p.K >> 5;
+    const int ksteps = FP8 ? p.K >> 6 : p.K >> 5;        // steps of the weight walk: 32 deep (bf16), 64 deep (FP8: one 16-byte load = two MFMA k-steps)
     const int per_z = (ksteps + nz - 1) / nz;
     const int st_begin = z * per_z, st_end = min(ksteps, st_begin + per_z);
-    const long long tile_stride = (long long)ksteps * 512;
+    const long long tile_stride = (long long)ksteps * (FP8 ? 1024 : 512);      // elements of a bf16 tile / bytes of an FP8 tile
     const bool xpk = p.ldx == 0;
     const bf16_t* xbase = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + l * 8 : p.X + (long long)min(m_base + lm, p.M - 1) * p.ldx + lq * 8;
     const long long xgroup = xpk ? 512 : 16 * p.ldx, xstep = xpk ? 2048 : 32;
     const int xgroups_ok = xpk ? 4 : (p.M - m_base - lm + 15) / 16;
-    bf16x8_t xf[KSW][4];
+    bf16x8_t xf[KSW * XS][4];
     int woff[KSW];
 #pragma unroll
-    for (int j = 0; j < KSW; ++j) woff[j] = min(st_begin + w + j * WAVES, st_end - 1) * 512 + l * 8;
+    for (int j = 0; j < KSW; ++j) woff[j] = min(st_begin + w + j * WAVES, st_end - 1) * (FP8 ? 1024 : 512) + l * (FP8 ? 16 : 8);
     const int ntiles = p.N >> 4;
-    bf16x8_t wf[KSW];
+    u32x4_t wf[KSW];
     auto loadw = [&](int g) {
-        const bf16_t* wb = p.W + (long long)g * tile_stride;
+        if constexpr (FP8) {
+            const char* wb = (const char*)p.W + (long long)g * tile_stride;
 #pragma unroll
-        for (int j = 0; j < KSW; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wb + woff[j])));
+            for (int j = 0; j < KSW; ++j) wf[j] = __builtin_nontemporal_load((const u32x4_t*)(wb + woff[j]));
+        } else {
+            const bf16_t* wb = p.W + (long long)g * tile_stride;
+#pragma unroll
+            for (int j = 0; j < KSW; ++j) wf[j] = __builtin_nontemporal_load((const u32x4_t*)(wb + woff[j]));
+        }
     };
     int g = b;
 #ifdef IADR1_SPLIT_WFIRST
@@ -1188,11 +1236,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
         const int st = st_begin + w + j * WAVES;
         const bool ok = st < st_end;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x4_t v = {0, 0, 0, 0};
-            if (ok) v = *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)st * xstep);
-            xf[j][i] = __builtin_bit_cast(bf16x8_t, v);
-        }
+        for (int h = 0; h < XS; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4_t v = {0, 0, 0, 0};
+                if (ok) v = *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)(st * XS + h) * xstep);
+                xf[j * XS + h][i] = __builtin_bit_cast(bf16x8_t, v);
+            }
     }
 #ifndef IADR1_SPLIT_WFIRST
     if (g < ntiles) loadw(g);          // after the X fragments here: measured 12.2 vs 12.8 us with the weights first (the opposite of the un-split kernel)
@@ -1203,9 +1253,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < KSW; ++j)
+        for (int j = 0; j < KSW; ++j) {
+            if constexpr (FP8) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[j][i], acc[i], 0, 0, 0);
+                for (int h = 0; h < 2; ++h) {
+                    const bf16x8_t wfr = fp8x8_to_bf16(wf[j][2 * h], wf[j][2 * h + 1]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[j * 2 + h][i], acc[i], 0, 0, 0);
+                }
+            } else {
+                const bf16x8_t wfr = __builtin_bit_cast(bf16x8_t, wf[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[j][i], acc[i], 0, 0, 0);
+            }
+        }
         if (g + bps < ntiles) loadw(g + bps);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1218,6 +1279,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
             float v = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WAVES; ++ww) v += red[((size_t)ww * 64 + m) * RLD + n];
+            if constexpr (FP8) v *= p.wscale[g * 16 + n];          // the per-row dequantisation scale distributes over the K slices
             ((float*)p.Y)[((long long)z * p.M + gm) * p.ldy + g * 16 + n] = v;
         }
         __syncthreads();
@@ -1328,6 +1390,20 @@ __global__ __launch_bounds__(256) void pack_act_kernel(const bf16_t* X, long lon
     }
 }
 
+// C[m][n] += sum_z ws[z][m][n], z in slice order (fixed: the sum does not depend on which block finished first); 4 floats per thread
+__global__ __launch_bounds__(256) void splitk_reduce_acc_kernel(const float* ws, float* C, long long ldc, int M, int N, int ks, long long zstride) {
+    const int nq = N >> 2;
+    const long long total = (long long)M * nq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / nq), c = (int)(i - (long long)m * nq) * 4;
+        const float* src = ws + (long long)m * N + c;
+        f32x4_t a = *(const f32x4_t*)src;
+        for (int z = 1; z < ks; ++z) a += *(const f32x4_t*)(src + z * zstride);
+        float* dst = C + (long long)m * ldc + c;
+        *(f32x4_t*)dst = *(const f32x4_t*)dst + a;
+    }
+}
+
 __device__ char g_zero16[64] __attribute__((aligned(64)));
 
 }  // namespace
@@ -1372,6 +1448,36 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     else if (out_mode == 1) hipLaunchKernelGGL(gemm_nt_128<OUT_F32>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     else hipLaunchKernelGGL(gemm_nt_128<OUT_F32_ACC>, dim3(grid), dim3(NTHREADS), SMEM_BYTES, stream, p);
     return iadr1_check_launch("gemm_nt_bf16");
+}
+
+// Split-K form of the accumulate mode for contractions with FEW output tiles and a long K -- the weight gradients of the narrow projections
+// (dW_o [2048 x 2048], dW_qkv [2560 x 2048] over K = 20480 token rows: 64 / 80 tiles of 256^2 on 256 CUs ran at 310 / 612 TFLOP/s), the down projection's
+// (344 tiles: 1.3 rounds) and the vision tower's: ksplit K slices per tile fill the chip, fp32 partial tiles go to a workspace, a second launch adds them
+// to C in slice order (no atomics: bit-reproducible, and equal to the un-split kernel up to fp32 summation order).
+extern "C" long long iadr1_gemm_nt_splitk_workspace_bytes(int M, int N, int ksplit) {
+    return (M <= 0 || N <= 0 || ksplit <= 1) ? 0 : (long long)ksplit * M * N * 4;
+}
+
+extern "C" int iadr1_gemm_nt_splitk_acc_bf16(const void* A, const void* B, float* C, void* workspace, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                                             int ksplit, hipStream_t stream) {
+    IADR1_REQUIRE(M > 0 && N > 0 && K > 0 && ksplit >= 2, "gemm_nt_splitk: empty problem / ksplit < 2 (M=%d N=%d K=%d ksplit=%d)", M, N, K, ksplit);
+    IADR1_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (N % 4) == 0 && (ldc % 4) == 0, "gemm_nt_splitk: K, lda, ldb multiples of 8, N, ldc multiples of 4");
+    IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 && (((uintptr_t)C) & 15) == 0 && workspace && (((uintptr_t)workspace) & 15) == 0,
+                  "gemm_nt_splitk: A, B, C and the workspace must be 16-byte aligned");
+    const int kslice = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;      // whole 64-deep K tiles per slice
+    IADR1_REQUIRE((long long)(ksplit - 1) * kslice < K, "gemm_nt_splitk: ksplit %d leaves an empty slice for K = %d", ksplit, K);
+    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, workspace, nullptr, zeros_ptr(), M, N, K, lda, ldb, (long long)N, 0, band_rows, nullptr, 0};
+    p.ksplit = ksplit; p.kslice = kslice; p.zstride = (long long)M * N;
+    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
+    (void)attr_done;
+    const int tiles = ((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
+    hipLaunchKernelGGL(gemm_nt_256<OUT_F32>, dim3(tiles * ksplit), dim3(NT2), SMEM2_BYTES, stream, p);
+    if (int rc = iadr1_check_launch("gemm_nt_splitk (partials)")) return rc;
+    long long blocks = ((long long)M * (N / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_acc_kernel, dim3((int)blocks), dim3(256), 0, stream, (const float*)workspace, C, ldc, M, N, ksplit, (long long)M * N);
+    return iadr1_check_launch("gemm_nt_splitk (reduce)");
 }
 
 // linear_logprob: logp[r] = log_softmax(H[r] . W^T)[targets[r]] and lse[r] without the [M, V] logits ever reaching HBM (gemm_nt_256 with the OUT_LSE
@@ -1569,10 +1675,39 @@ extern "C" int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const floa
     SkinnyArgs p{};
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)Wp8; p.wscale = wscale; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
     p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.out_mode = out_mode;
-    constexpr int SMW = 8 * 64 * 33 * 4;
-    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW); return true; }();
-    (void)attr_done;
-    hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8, true>), dim3(N / 64, (M + 63) / 64, ksplit), dim3(512), SMW, stream, p);
+    constexpr int SMW = 8 * 64 * 33 * 4, SMS = 8 * 64 * 17 * 4;
+    static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1) && iadr1_env_int("IADR1_SKINNY_PERS_FP8", 1);
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS);
+        return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }();
+    const int mz = (M + 63) / 64;
+    // the persistent X-resident forms (same shape rules as the bf16 launcher): split-K slabs for the long-K down projection, one block per CU for the
+    // big un-split streams (gate|up, lm_head).  The one-shot wide kernel takes everything else (K = 3584 of the 7B widths: the X fragments of a wave's
+    // k-steps no longer fit in registers).
+    {
+        const int dst = K >> 6, per_z = (dst + ksplit - 1) / ksplit, bps = ncu / ksplit;
+        if (pers && ksplit > 1 && out_mode == 2 && per_z <= 24 && bps >= 1 && (N >> 4) >= 4 * bps && (dst % ksplit == 0 || (ksplit - 1) * per_z < dst)) {
+            hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 3, true>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
+            return iadr1_check_launch("gemm_skinny_fp8w");
+        }
+        const int ksw = K / 256;
+        if (pers && ksplit == 1 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu) {
+            const dim3 grid(ncu, mz, 1), block(512);
+            if (ksw == 8) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 8, true>), grid, block, SMW, stream, p);
+            else if (ksw == 6) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 6, true>), grid, block, SMW, stream, p);
+            else hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 4, true>), grid, block, SMW, stream, p);
+            return iadr1_check_launch("gemm_skinny_fp8w");
+        }
+    }
+    hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8, true>), dim3(N / 64, mz, ksplit), dim3(512), SMW, stream, p);
     return iadr1_check_launch("gemm_skinny_fp8w");
 }
 

@@ -42,8 +42,40 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     mode = 0 if out.dtype == BF16 else (2 if accumulate else 1)
     assert not (accumulate and out.dtype != F32)
+    ks = splitk_slices(M, N, K) if (accumulate and bias is None and act == 0) else 1
+    if ks > 1:
+        ws = _splitk_workspace(ks * M * N, a.device)
+        hip.call("gemm_nt_splitk_acc_bf16", a, b, out, ws, M, N, K, _ld(a), _ld(b), _ld(out), ks)
+        return out
     hip.call("gemm_nt_bf16", a, b, out, bias, M, N, K, _ld(a), _ld(b), _ld(out), mode, act)
     return out
+
+
+_SPLITK = os.environ.get("IADR1_GEMM_SPLITK", "1") != "0"
+_splitk_ws = {}
+
+
+def splitk_slices(M, N, K) -> int:
+    """K slices for an accumulate-mode GEMM (weight gradient) whose 256 x 256 output tiles do not fill 256 CUs twice over: enough slices for >= 512 blocks, each
+    at least 1024 deep (16 K tiles: the prologue / epilogue of a tile stay below ~10 %); 1 = the plain kernel.  IADR1_GEMM_SPLITK=0 switches it off (A/B)."""
+    if not _SPLITK or M < 512 or N < 512 or N % 4 or K < 4096:
+        return 1
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles >= 448:
+        return 1
+    ks = min((512 + tiles - 1) // tiles, K // 1024)
+    while ks > 1 and (ks - 1) * (((K + ks - 1) // ks + 63) // 64 * 64) >= K:      # no empty last slice
+        ks -= 1
+    return max(ks, 1)
+
+
+def _splitk_workspace(n_floats, device):
+    """fp32 partial tiles of the split-K weight-gradient GEMMs: one grow-only buffer per (device, stream) -- launches on a stream are ordered, so are its users."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    w = _splitk_ws.get(key)
+    if w is None or w.numel() < n_floats:
+        w = _splitk_ws[key] = torch.empty(n_floats, dtype=F32, device=device)
+    return w
 
 
 def pack_weight(w, out=None):

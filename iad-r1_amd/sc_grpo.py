@@ -62,6 +62,9 @@ class GRPOArgs:
     # loss terms are the log-probs of the tokens `C - len` positions EARLIER (the end of the prompt, then the start of the completion).  False
     # scores the completion tokens themselves, as the Qwen branches do.
     llava_rotate_right_padded_rows: bool = True
+    # `--gradient_checkpointing` (REF scripts/train/SC_GRPO/*.sh:56): "off" | "auto" | "on" -- vlm.Engine.recompute_wanted.  With recomputation the policy's
+    # forward is run after the rollout (the rollout's own activations are not kept either)
+    recompute: str = "off"
 
 
 def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.ndarray:
@@ -426,7 +429,7 @@ class SCGRPOEngine:
                 else:
                     hf, ctx = self.pol.text_forward(plan.tail, None, save=True, rows=((b1 - b0) * P, T_all, T_all), carry=train_carry)
             else:
-                hf, ctx = self.pol.text_forward(plan, img_pol, save=backward)
+                hf, ctx = self.pol.text_forward(plan, img_pol, save=backward, recompute=backward and self.pol.recompute_wanted(plan.ids.numel(), a.recompute))
             lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel)
             adv_d = advantages()["adv_d"]
             dlogp, kl, rloss, rkl = ops.grpo_loss(lp.view(n, C), rl.view(n, C), adv_d[r0:r1].contiguous(), cmask_d[r0:r1].contiguous(), a.beta, n_total_rows=N)
@@ -499,6 +502,10 @@ class SCGRPOEngine:
         a = self.args
         N = len(batch["input_ids"]) * a.num_generations
         carry = {} if (a.share_prefix and a.reuse_prefill and a.num_generations > 1 and a.micro_batch_seqs >= N and N % a.num_generations == 0) else None
+        if carry is not None and a.recompute != "off":
+            P_ = np.asarray(batch["input_ids"]).shape[1] if a.max_prompt_length is None else min(np.asarray(batch["input_ids"]).shape[1], a.max_prompt_length)
+            if self.pol.recompute_wanted(len(batch["input_ids"]) * P_ + N * a.max_completion_length, a.recompute):
+                carry = None       # gradient checkpointing: nothing of the rollout is kept, the policy forward runs (checkpointed) before backward
         comp = self.rollout(batch, vis=vis, train_carry=carry)
         t2 = mark()
         # rewards are computed on the host inside loss_and_grads, after the first forward passes are in the GPU queue (in the

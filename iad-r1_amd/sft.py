@@ -29,6 +29,7 @@ class SFTArgs:
     gradient_accumulation_steps: int = 1
     micro_batch_seqs: int = 16
     frozen: Optional[Callable[[str], bool]] = None      # parameter-store names that do not train (frozen_parameter_rule); None: everything trains
+    recompute: str = "off"                              # `--gradient_checkpointing`: "off" | "auto" | "on" (vlm.Engine.recompute_wanted)
 
 
 # Families the reference's LLaMA-Factory registers as composite models (model/model_utils/visual.py:236-288), by HF `model_type`.  For these -- and only
@@ -104,7 +105,7 @@ class SFTEngine:
                 continue
             rows_d = ops.h2d(sel.astype(np.int64), self.dev)
             tgt_d = ops.h2d(tgt[r0:r1].reshape(-1)[sel], self.dev)
-            hf, ctx = e.text_forward(plan, img, save=backward)
+            hf, ctx = e.text_forward(plan, img, save=backward, recompute=backward and e.recompute_wanted(plan.ids.numel(), self.args.recompute))
             lp, lctx = e.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel)
             total += -lp.sum()
             if backward:

@@ -55,7 +55,8 @@ class GRPOConfig:
     save_steps: int = 500
     seed: int = 42
     bf16: bool = True
-    gradient_checkpointing: bool = False   # accepted; 288 GB HBM holds the activations of a micro-batch, nothing is recomputed
+    gradient_checkpointing: bool = False   # True (every reference script): decoder activations are recomputed in backward WHEN they would not fit comfortably
+                                           # in HBM (vlm.Engine.recompute_wanted: "auto"); 3B at the bench shape keeps them, 7B at 20 480 token rows recomputes
     model_init_kwargs: Optional[dict] = None
     micro_batch_seqs: int = 64      # sequences per reference / policy pass; >= batch x group lets the rollout double as the policy's training forward
     shuffle: bool = True            # seeded per-epoch permutation (HF Trainer's RandomSampler / DistributedSampler)
@@ -345,7 +346,8 @@ class SCGRPOTrainer:
             num_generations=args.num_generations, max_prompt_length=args.max_prompt_length, max_completion_length=args.max_completion_length,
             beta=args.beta, temperature=args.temperature, learning_rate=args.learning_rate, weight_decay=args.weight_decay,
             adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
-            gradient_accumulation_steps=args.gradient_accumulation_steps, micro_batch_seqs=args.micro_batch_seqs, seed=args.seed), group=group)
+            gradient_accumulation_steps=args.gradient_accumulation_steps, micro_batch_seqs=args.micro_batch_seqs, seed=args.seed,
+            recompute="auto" if args.gradient_checkpointing else "off"), group=group)
         self.state = type("State", (), {"global_step": 0})()
         self._metrics = defaultdict(list)
         self.log_history = []

@@ -733,8 +733,76 @@ class Engine:
             self._ws[key] = cur
         return cur
 
-    def text_forward(self, plan: TextPlan, img_embeds, save: bool, kv_sink=None, rows=None, carry=None):
+    def saved_activation_bytes(self, T: int) -> int:
+        """Bytes of the per-layer activation arena text_forward(save=True) keeps for T token rows (what gradient checkpointing avoids)."""
+        c = self.cfg
+        per_tok = (5 * c.hidden_size + c.qkv_width + c.num_attention_heads * c.head_dim + 3 * c.intermediate_size) * 2 + (2 + c.num_attention_heads) * 4
+        return c.num_hidden_layers * T * per_tok
+
+    def recompute_wanted(self, T: int, mode: str) -> bool:
+        """`--gradient_checkpointing` (every reference launch script passes it, REF scripts/train/SC_GRPO/*.sh:56) as a POLICY on a 288 GB part: "off" never
+        recomputes; "on" always; "auto" (what the flag selects) recomputes only when the saved activations of the micro-batch would not fit comfortably --
+        more than 60 % of the HBM that is free once the parameters / optimizer state are resident (3B at 20 480 token rows: 71 GB of 190 free -> kept, and
+        the rollout goes on doubling as the policy forward; 7B at 20 480 rows: 91 GB of ~110 free -> one decoder layer is recomputed at a time in backward)."""
+        if mode == "on" or os.environ.get("IADR1_RECOMPUTE") == "1":
+            return True
+        if mode != "auto" or os.environ.get("IADR1_RECOMPUTE") == "0":
+            return False
+        cur = self._ws.get("act_save")
+        if cur is not None and cur["T"] >= T:
+            return False                       # the arena exists already: nothing to save by recomputing
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        reusable = torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)      # cached by the allocator, available to a new request
+        return self.saved_activation_bytes(T) > 0.6 * (free + reusable)
+
+    def _recompute_layer(self, i, ctx):
+        """Gradient checkpointing: the activations of decoder layer i, rebuilt from its checkpointed input rows with the forward's own kernels (bit-identical to
+        what save=True would have kept), into one of two single-layer slabs -- two, because the weight-gradient GEMMs of layer i still read this slab on the
+        side stream while the main stream rebuilds layer i - 1; the slab is handed out again only after those have finished (event)."""
+        c, P = self.cfg, self.p
+        H, D, Hq, Hkv = c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        qw, kw = Hq * D, Hkv * D
+        plan = ctx["plan"]
+        x_in = ctx["recompute"]["x_in"][i]
+        T = x_in.shape[0]
+        rc = self.__dict__.get("_rc")
+        if rc is None or rc["T"] < T:
+            self.join_wgrads()
+            self.__dict__["_rc"] = None
+            I = c.intermediate_size
+            mk = lambda w: torch.empty(T, w, dtype=BF16, device=self.dev)
+            slab = lambda: {"h1": mk(H), "qkv": mk(c.qkv_width), "o": mk(Hq * D), "x_mid": mk(H), "h2": mk(H), "gu": mk(2 * I), "a": mk(I),
+                            "rstd1": torch.empty(T, dtype=F32, device=self.dev), "rstd2": torch.empty(T, dtype=F32, device=self.dev),
+                            "lse": torch.empty(Hq, T, dtype=F32, device=self.dev)}
+            rc = self.__dict__["_rc"] = {"T": T, "ring": _Ring([slab(), slab()])}
+        ring = rc["ring"]
+        k = ring.k
+        ring.k = (k + 1) % 2
+        if ring.ev[k] is not None:
+            torch.cuda.current_stream().wait_event(ring.ev[k])
+            ring.ev[k] = None
+        S = ring.bufs[k]
+        b = f"layers.{i}."
+        eps = float(c.rms_norm_eps)
+        h1, rstd1, qkv, o, x_mid, h2, rstd2 = S["h1"][:T], S["rstd1"][:T], S["qkv"][:T], S["o"][:T], S["x_mid"][:T], S["h2"][:T], S["rstd2"][:T]
+        lse = S["lse"].view(-1)[: Hq * T].view(Hq, T)
+        ops.hip.call("rmsnorm_fwd", x_in, None, 0, None, None, None, P.w(b + "ln1"), h1, rstd1, T, H, H, H, H, eps, None)
+        ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=qkv)
+        ops.rope_(qkv, plan.cos, plan.sin, Hq + Hkv, D)
+        if not plan.seg.covers(0, T):
+            o.zero_()
+        ops.hip.call("attn_fwd", qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
+                     plan.seg.n_head, plan.seg.max_tail, T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, c.attn_scale)
+        ab = ops.gemm_nt(o, P.w(b + "o.w"), out=self._workspace("rc_ab", (T, H), BF16))
+        ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, T, H, H, H, H, eps, None)
+        gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=S["gu"][:T], a_out=S["a"][:T], keep_gu=True)
+        return (x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a), (ring, k)
+
+    def text_forward(self, plan: TextPlan, img_embeds, save: bool, kv_sink=None, rows=None, carry=None, recompute: bool = False):
         """Decoder forward over the flat token rows of `plan`.
+
+        recompute (with save=True, single-phase calls): gradient checkpointing -- only the residual-stream rows ENTERING every layer are kept ([L, T, H]);
+        text_backward rebuilds one layer's activations at a time (`_recompute_layer`).  The per-layer arena of save=True is not touched.
 
         rows = (r0, r1, T_total), carry = dict: TWO-PHASE use (save=True only).  This call covers rows [r0, r1) of a T_total-row batch whose
         other rows are produced by another call sharing `carry` and the same activation arena: the rollout's prefill runs the prompt rows
@@ -749,6 +817,9 @@ class Engine:
         r0, r1, T = (0, Tl, Tl) if rows is None else rows
         assert r1 - r0 == Tl and (rows is None or (save and carry is not None))
         part = rows is not None
+        recompute = bool(recompute and save and not part)
+        keep = save and not recompute          # per-layer arena slabs; otherwise one scratch slab reused by every layer
+        CK = self._workspace("ckpt_x_in", (c.num_hidden_layers, Tl, H), BF16) if recompute else None
         if part and "x0" not in carry:
             # persistent like the activation arena: the decode graph may hold these pointers (rollout side outputs)
             cb = self._ws.get("carry")
@@ -757,23 +828,27 @@ class Engine:
                                           "x_last": torch.empty(T, H, dtype=BF16, device=self.dev), "rstdf": torch.empty(T, dtype=F32, device=self.dev)}
             carry.update(x0=cb["x0"], hf=cb["hf"], x_last=cb["x_last"], rstdf=cb["rstdf"])
         x = ops.embed_fwd(plan.ids, plan.img_index if img_embeds is not None else None, P.w("embed"), img_embeds, out=carry["x0"][r0:r1] if part else None)
-        B = self._text_buffers(T, save)
+        B = self._text_buffers(T, keep)
         ctx = {"layers": [], "plan": carry.get("full_plan", plan) if part else plan} if save else None
+        if recompute:
+            ctx["recompute"] = {"x_in": []}
         res, branch = x, None
         eps = c.rms_norm_eps
         for i in range(c.num_hidden_layers):
             b = f"layers.{i}."
-            li = i if save else 0
+            li = i if keep else 0
             buf = lambda name: B[name][li, r0:r1]
             full = lambda name: B[name][li, :T]
             h1 = buf("h1")
-            rstd1 = B["rstd1"][li, r0:r1] if save else None
+            rstd1 = B["rstd1"][li, r0:r1] if keep else None
             if branch is None:
                 x_in = res
                 ops.hip.call("rmsnorm_fwd", res, None, 0, None, None, None, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps), None)
             else:
-                x_in = buf("x_in") if save else res
+                x_in = CK[i] if recompute else (buf("x_in") if keep else res)
                 ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps), None)
+            if recompute:
+                ctx["recompute"]["x_in"].append(x_in)
             qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=buf("qkv"))
             ops.rope_(qkv, plan.cos, plan.sin, Hq + Hkv, D)
             if kv_sink is not None:
@@ -783,21 +858,23 @@ class Engine:
                 o.fill_(float("nan"))
             if not plan.seg.covers(r0, r1):
                 o.zero_()  # rows outside every segment (left / post-EOS padding) must read as zeros downstream (0 x stale NaN in wgrad otherwise)
-            lse = B["lse"][li].view(-1)[: Hq * T].view(Hq, T) if save else None
+            lse = B["lse"][li].view(-1)[: Hq * T].view(Hq, T) if keep else None
             # attention addresses rows absolutely: the keys of a completion segment live in the prompt rows written by the other phase
             qkv_all, o_all = full("qkv"), full("o")
             ops.hip.call("attn_fwd", qkv_all[:, :qw], qkv_all[:, qw: qw + kw], qkv_all[:, qw + kw:], o_all, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
                          plan.seg.n_head, plan.seg.max_tail, T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, c.attn_scale)
             ab = ops.gemm_nt(o, P.w(b + "o.w"))
-            x_mid = buf("x_mid") if save else x_in
+            x_mid = buf("x_mid") if (keep or recompute) else x_in          # (recompute: x_in is a checkpoint, it must not be overwritten)
             h2 = buf("h2")
-            rstd2 = B["rstd2"][li, r0:r1] if save else None
+            rstd2 = B["rstd2"][li, r0:r1] if keep else None
             ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, Tl, H, H, H, H, float(eps), None)
             # gate|up projection with the activation in its epilogue; the gate|up matrix itself is written only when backward will read it
-            gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=buf("gu"), a_out=buf("a"), keep_gu=save)
+            gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=buf("gu"), a_out=buf("a"), keep_gu=keep)
             branch = ops.gemm_nt(a, P.w(b + "down.w"))
             res = x_mid
-            if save:
+            if recompute:
+                ctx["layers"].append(None)      # (the scratch slab's x_mid rows are consumed by the next layer's ln1 before its ln2 overwrites them: stream order)
+            elif save:
                 if not part:
                     ctx["layers"].append((x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a))
                 else:   # views over ALL rows of the batch (the other phase fills / has filled the rest)
@@ -845,8 +922,12 @@ class Engine:
         take = lambda ring: ring.take(T)
         dres, sl_res = take(S["res"])
         ops.rmsnorm_bwd(dhf, ctx["x_last"], P.w("norm"), ctx["rstdf"], dw=P.g("norm"), out=dres)
+        rcomp = ctx.get("recompute")
         for i in reversed(range(c.num_hidden_layers)):
             b = f"layers.{i}."
+            rc_slot = None
+            if rcomp is not None:
+                ctx["layers"][i], rc_slot = self._recompute_layer(i, ctx)
             x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a = ctx["layers"][i]
             self._wgrad(b + "down.w", dres, a, slot=sl_res if side else None)          # side stream; the dgrad chain below does not wait for it
             da = ops.gemm_nt(dres, P.wT(b + "down.w"), out=S["da"][:T])
@@ -870,6 +951,8 @@ class Engine:
             if c.qkv_bias:           # (LLaMA / Mistral: no q/k/v biases -- the fused bias row stays zero and receives no gradient)
                 ops.colsum_acc(dqkv, P.g(b + "qkv.b"))
             self._wgrad(b + "qkv.w", dqkv, h1, slot=sl_qkv if side else None)
+            if rc_slot is not None and side:
+                rc_slot[0].busy(rc_slot[1], self.wgrad_stream)          # the recompute slab is free again once this layer's weight gradients have read it
             dh1 = ops.gemm_nt(dqkv, P.wT(b + "qkv.w"), out=S["dh"][:T])
             dres_new, sl_new = take(S["res"])
             ops.rmsnorm_bwd(dh1, x_in, P.w(b + "ln1"), rstd1, dres=dx_mid, dw=P.g(b + "ln1"), out=dres_new)

@@ -51,6 +51,13 @@ typedef struct iadr1_side_out {
  * :1386-1387 (lm_head), and their autograd backward (dgrad / wgrad run on transposed operands). */
 int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, int M, int N, int K, long long lda,
                        long long ldb, long long ldc, int out_mode, int act, iadr1_stream_t stream);
+/* C[M,N] (fp32) += A[M,K] . B[N,K]^T for contractions with few output tiles and a long K (the weight gradients dW = dY^T . X of the narrow projections: 64-80 tiles
+ * of 256 x 256 on 256 CUs): `ksplit` K slices per tile, fp32 partial tiles in `workspace` (iadr1_gemm_nt_splitk_workspace_bytes, 16-byte aligned), summed into C
+ * in slice order by a second launch -- bit-reproducible, no atomics.  Same operand rules as iadr1_gemm_nt_bf16; N, ldc multiples of 4.  Replaces the autograd
+ * weight-gradient GEMMs of TF:634-637 (q/k/v/o), :552-554 (MLP), :85-96,218-219 (ViT). */
+long long iadr1_gemm_nt_splitk_workspace_bytes(int M, int N, int ksplit);
+int iadr1_gemm_nt_splitk_acc_bf16(const void* A, const void* B, float* C, void* workspace, int M, int N, int K, long long lda, long long ldb,
+                                  long long ldc, int ksplit, iadr1_stream_t stream);
 /* gate|up projection + SwiGLU in one launch (training / prefill shapes): GU[M, 2I] = A[M,K] . W[2I,K]^T is stored when GU != NULL (the backward
  * pass reads it), Aout[M, I] = bf16(silu(gate)) * up with gate = GU[:, :I], up = GU[:, I:], computed in the GEMM epilogue from the rounded gate|up
  * values: bit-identical to iadr1_gemm_nt_bf16 followed by iadr1_swiglu_fwd.  M %% 256 == 0, I %% 128 == 0.  Replaces TF:552-554

@@ -85,6 +85,30 @@ def test_linear_logprob_matches_gemm_then_logprob_rows(R, V, K):
         assert torch.equal(dl, dl0), f"dlogits {R}x{V}x{K}: {(dl.float() - dl0.float()).abs().max().item()}"
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 20480), (2560, 2048, 20480), (2048, 11008, 20480), (6912, 1280, 8192), (1280, 1280, 8192), (1300, 516, 4096), (3840, 1280, 8200)])
+def test_gemm_nt_splitk_accumulate(M, N, K):
+    """Weight-gradient shapes with few 256 x 256 output tiles run as split-K (iadr1_gemm_nt_splitk_acc_bf16: K slices -> fp32 partial tiles -> reduce launch).
+    Against fp32 torch, against the un-split kernel (fp32 summation order differs, nothing else), run-to-run bit-stable; ragged tiles, a K that is not a
+    multiple of the slice (2560 x 2048 x 20480 -> 7 slices of 2944), strided C."""
+    ks = ops.splitk_slices(M, N, K)
+    assert ks >= 2, (M, N, K, ks)
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.5)
+    ref = a.float() @ b.float().t()
+    base = rnd(M, N + 8, seed=4, dtype=F32)
+    out = base.clone()
+    ops.gemm_nt(a, b, out=out[:, 4: 4 + N], accumulate=True)
+    tol = 1e-3 * math.sqrt(K) * 0.1
+    close(out[:, 4: 4 + N], ref + base[:, 4: 4 + N], 1e-4, tol, f"gemm split-K {ks} acc {M}x{N}x{K}")
+    assert torch.equal(out[:, :4], base[:, :4]) and torch.equal(out[:, 4 + N:], base[:, 4 + N:])
+    out2 = base.clone()
+    ops.gemm_nt(a, b, out=out2[:, 4: 4 + N], accumulate=True)
+    assert torch.equal(out, out2)                                           # no atomics: bit-reproducible
+    plain = base.clone()
+    ops.hip.call("gemm_nt_bf16", a, b, plain[:, 4: 4 + N], None, M, N, K, K, K, N + 8, 2, 0)
+    close(out[:, 4: 4 + N], plain[:, 4: 4 + N], 1e-5, 1e-4 * math.sqrt(K) * 0.1, "split-K vs plain kernel")
+    assert ops.splitk_slices(22016, 2048, 20480) == 1 and ops.splitk_slices(2048, 2048, 2048) == 1 and ops.splitk_slices(256, 2048, 20480) == 1
+
+
 def test_gemm_nt_strided_views():
     # operands / outputs that are column slices of wider buffers (the fused qkv / gate|up layouts)
     big_a, big_b = rnd(300, 512, seed=5), rnd(260, 512, seed=6)
@@ -710,10 +734,12 @@ def _unpack_fp8(buf, N, K, gateup=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K,packed", [(64, 2048, 11008, True), (64, 151936, 2048, True), (8, 256, 512, False), (33, 3584, 18944, True), (100, 640, 256, False)])
+@pytest.mark.parametrize("M,N,K,packed", [(64, 2048, 11008, True), (64, 151936, 2048, True), (8, 256, 512, False), (33, 3584, 18944, True), (100, 640, 256, False),
+                                          (40, 16384, 1024, True), (64, 17920, 1536, True), (64, 16384, 2048, False)])
 def test_fp8_weight_gemm(M, N, K, packed):
     """FP8 (e4m3, per-row scale) decode weights: the pack holds exactly torch's round-to-nearest e4m3 of w / scale, and the GEMM on it equals the GEMM on the
-    dequantised weights at the bf16 kernels' own tolerance -- the kernel adds no error to the format's.  fp32 / bf16+bias / split-K slab outputs."""
+    dequantised weights at the bf16 kernels' own tolerance -- the kernel adds no error to the format's.  fp32 / bf16+bias / split-K slab outputs.  Shapes of
+    every kernel form: persistent X-resident (K = 1024 / 1536 / 2048, N >= 16384), persistent split-K (2048 x 11008, 8 slices), one-shot wide (the rest)."""
     x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
     w8, sc = ops.pack_weight_fp8(w)
     q, scale, deq = _fp8_reference(w, scale=sc)

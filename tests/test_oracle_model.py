@@ -188,6 +188,32 @@ def test_sft_20_step_loss_curves(golden_dir):
         dev = np.abs(np.array(losses) - g["losses20"]).max()
         print(f"[sft curve, oracle] {name}: max |dloss| over 20 steps = {dev:.2e} (loss {g['losses20'][0]:.3f} -> {g['losses20'][-1]:.3f})")
         assert len(losses) == 20 and dev < 1e-3, (name, dev)
+        # the reference's mixed precision (bf16 parameters in the forward, fp32 master under AdamW: tools/make_golden.py::curve_bf16_weights), same oracle
+        m = oq.Qwen25VLOracle(cfg, fx.make_weights(cfg, 0), requires_grad=True)
+        params = dict(m.parameters())
+        for k in frozen:
+            params[k].requires_grad_(False)
+        train = {k: p for k, p in params.items() if k not in frozen}
+        master = {k: p.detach().clone().requires_grad_(True) for k, p in train.items()}
+        decay, no_decay = _hf_groups(golden_dir, mt, params)
+        dec_ids = {id(p) for p in decay}
+        opt = torch.optim.AdamW([{"params": [master[k] for k, p in train.items() if id(p) in dec_ids], "weight_decay": meta["wd"]},
+                                 {"params": [master[k] for k, p in train.items() if id(p) not in dec_ids], "weight_decay": 0.0}], lr=meta["lr20"])
+        losses = []
+        for _ in range(20):
+            with torch.no_grad():
+                for k, p in train.items():
+                    p.copy_(master[k].to(torch.bfloat16).float())
+                    p.grad = None
+            loss = m.sft_loss(ids, mask, labels, pv, grids)
+            loss.backward()
+            for k, p in train.items():
+                master[k].grad = p.grad.detach().clone()
+            opt.step()
+            losses.append(loss.item())
+        dev = np.abs(np.array(losses) - g["losses20_bf16w"]).max()
+        print(f"[sft curve, oracle, bf16 weights + fp32 master] {name}: max |dloss| = {dev:.2e}; vs the fp32 curve {np.abs(g['losses20_bf16w'] - g['losses20']).max():.2e}")
+        assert dev < 1e-3, (name, dev)
 
 
 def test_forward_7b_like_config(golden_dir):

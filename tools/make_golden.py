@@ -632,6 +632,32 @@ def hf_param_groups(model):
 LR20 = 5e-5
 
 
+def curve_bf16_weights(model, inputs, groups_fn, steps=20, lr=LR20, trainable=None):
+    """The reference's mixed precision (`--bf16` + DeepSpeed: bf16 parameters in the forward / backward, fp32 master copy under AdamW) on the fp32 HF model: before
+    every step the model's parameters are set to bf16(master); the gradients go to the master copy.  At this learning rate an Adam step (5e-5) is smaller than
+    half a bf16 spacing of a typical weight (|w| ~ 0.05: 1.2e-4), so the bf16 copy moves in stair steps -- the curve differs from the pure-fp32 one by far more than any
+    kernel error, and it is THIS curve a bf16 run of the reference follows.  Activations stay fp32 here (their bf16 rounding is the small part: a few 1e-3 of the loss)."""
+    params = [(n, p) for n, p in model.named_parameters() if (trainable is None or trainable(n))]
+    master = [p.detach().clone().requires_grad_(True) for _, p in params]
+    dec, nod = groups_fn(model)
+    ids_dec = {id(p) for p in dec}
+    opt = torch.optim.AdamW([{"params": [m for m, (_, p) in zip(master, params) if id(p) in ids_dec], "weight_decay": 0.1},
+                             {"params": [m for m, (_, p) in zip(master, params) if id(p) not in ids_dec], "weight_decay": 0.0}], lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    losses = []
+    for _ in range(steps):
+        with torch.no_grad():
+            for m, (_, p) in zip(master, params):
+                p.copy_(m.to(torch.bfloat16).float())
+        model.zero_grad()
+        loss = model(**inputs).loss
+        loss.backward()
+        for m, (_, p) in zip(master, params):
+            m.grad = p.grad.detach().clone()
+        opt.step()
+        losses.append(loss.item())
+    return losses
+
+
 def gen_sft():
     """PA-SFT numeric oracle: HF forward(labels) loss + 3 AdamW steps (lr 1e-3 for visible motion,
     wd 0.1 as PA_SFT_*.sh:38-44, betas/eps = torch defaults = HF Trainer defaults)."""
@@ -666,12 +692,14 @@ def gen_sft():
         loss.backward()
         opt.step()
         losses20.append(loss.item())
+    losses20_bf16w = curve_bf16_weights(build_hf_model(cfg, fx.make_weights(cfg, seed=0)).train(), inputs, hf_param_groups)
     np.savez_compressed(
         os.path.join(OUT, "sft.npz"), meta=json.dumps({**meta(), "grids": grids, "n_text": [5, 17], "seed": 11, "lr": 1e-3, "wd": 0.1, "lr20": LR20, "no_decay": "transformers.Trainer.get_decay_parameter_names (tests/golden/sft_freeze.json: decay_parameters)"}),
         input_ids=ids.numpy(), attention_mask=mask.numpy(), labels=labels.numpy(), pixel_values=b["pixel_values"].numpy(),
         image_grid_thw=b["image_grid_thw"].numpy(), losses=np.array(losses, dtype=np.float64), losses20=np.array(losses20, dtype=np.float64),
+        losses20_bf16w=np.array(losses20_bf16w, dtype=np.float64),
     )
-    print("sft.npz: losses", losses, "\n  20 steps at lr", LR20, [round(x, 4) for x in losses20])
+    print("sft.npz: losses", losses, "\n  20 steps at lr", LR20, [round(x, 4) for x in losses20], "\n  bf16 weights + fp32 master", [round(x, 4) for x in losses20_bf16w])
 
 
 def gen_qwen2vl(SCGRPOTrainer):

@@ -142,10 +142,15 @@ def main():
         loss.backward()
         opt.step()
         losses20.append(loss.item())
+    def groups(mdl):
+        dn = set(Trainer.get_decay_parameter_names(Trainer.__new__(Trainer), mdl))
+        return [p for n, p in mdl.named_parameters() if n in dn], [p for n, p in mdl.named_parameters() if n not in dn]
+    losses20_bf16w = mg.curve_bf16_weights(mg.build_hf_model_qwen2vl(cfg, fx.make_weights(cfg, seed=0)).train(), inputs, groups, trainable=lambda n: n not in frozen)
     np.savez_compressed(os.path.join(OUT, "qwen2vl_sft_frozen.npz"),
                         meta=json.dumps({**mg.meta(), "batch": "qwen2vl_sft.npz", "lr": 1e-3, "wd": 0.1, "lr20": mg.LR20, "flags": FLAGS[0], "frozen_hf_names": frozen}),
                         losses=np.array(losses, dtype=np.float64), grad_norms=np.array(gnorms, dtype=np.float64), losses20=np.array(losses20, dtype=np.float64),
-                        **{"after::" + k: v for k, v in after.items()})
+                        losses20_bf16w=np.array(losses20_bf16w, dtype=np.float64), **{"after::" + k: v for k, v in after.items()})
+    print("  bf16 weights + fp32 master", [round(x, 4) for x in losses20_bf16w])
     print("qwen2vl_sft_frozen.npz: losses", losses, "grad norms", gnorms, "frozen", len(frozen), "tensors; kept", sorted(after), "\n  20 steps", [round(x, 4) for x in losses20])
 
 

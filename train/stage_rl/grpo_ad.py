@@ -96,7 +96,9 @@ def build_parser():
     # ModelConfig's LoRA switch: refused with the reason (the trainer's peft_config error), not silently ignored
     p.add_argument("--use_peft", nargs="?", default=False, const=True)
     # accepted for script compatibility, no effect here
-    for flag in ("--deepspeed", "--report_to", "--gradient_checkpointing", "--bf16", "--ddp_timeout", "--push_to_hub"):
+    # decoder activations recomputed in backward when they would not fit comfortably in HBM (iadr1_amd.vlm.Engine.recompute_wanted); every reference script passes true
+    p.add_argument("--gradient_checkpointing", nargs="?", default=False, const=True, type=lambda v: str(v).lower() in ("1", "true", "yes"))
+    for flag in ("--deepspeed", "--report_to", "--bf16", "--ddp_timeout", "--push_to_hub"):
         p.add_argument(flag, nargs="?", default=None, const=True)
     return p
 
@@ -186,7 +188,7 @@ def main(argv=None):
     from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
 
     rows = [make_conversation(r, a.image_path, str2bool(a.use_system_prompt), a.single_img) for r in load_rows(a.dataset_name)]
-    cfg = GRPOConfig(**{k: getattr(a, k) for k in GRPOConfig.__dataclass_fields__ if hasattr(a, k) and getattr(a, k) is not None and k not in ("report_to", "gradient_checkpointing", "bf16", "push_to_hub")})
+    cfg = GRPOConfig(**{k: getattr(a, k) for k in GRPOConfig.__dataclass_fields__ if hasattr(a, k) and getattr(a, k) is not None and k not in ("report_to", "bf16", "push_to_hub")})
     trainer = SCGRPOTrainer(model=a.model_name_or_path, reward_funcs=[REWARD_FUNCS[n] for n in a.reward_funcs], args=cfg, train_dataset=rows,
                             attn_implementation=a.attn_implementation, max_pixels=a.max_pixels, min_pixels=a.min_pixels, use_vllm_for_gen=str2bool(a.use_vllm_for_gen))
     trainer.train()

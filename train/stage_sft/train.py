@@ -57,8 +57,10 @@ def build_parser():
     p.add_argument("--train_on_prompt", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     p.add_argument("--mask_history", nargs="?", const=True, default=False, type=lambda v: str(v).lower() in ("1", "true", "yes"))
     for flag in ("--deepspeed", "--bf16", "--plot_loss", "--overwrite_cache", "--overwrite_output_dir", "--ddp_timeout", "--preprocessing_num_workers",
-                 "--report_to", "--gradient_checkpointing", "--flash_attn", "--image_max_pixels", "--image_min_pixels"):
+                 "--report_to", "--flash_attn", "--image_max_pixels", "--image_min_pixels"):
         p.add_argument(flag, nargs="?", default=None, const=True)
+    # decoder activations recomputed in backward when they would not fit comfortably in HBM (iadr1_amd.vlm.Engine.recompute_wanted); the PA_SFT scripts do not pass it
+    p.add_argument("--gradient_checkpointing", nargs="?", default=False, const=True, type=tf)
     return p
 
 
@@ -162,7 +164,8 @@ def main(argv=None):
         n_fz = sum(1 for n in store.slots if frozen(n))
         print(f"[pa-sft] model_type {model_type}: {n_fz} of {len(store.slots)} parameter tensors frozen (vision tower: {a.freeze_vision_tower}, projector: {a.freeze_multi_modal_projector})", flush=True)
     eng = SFTEngine(cfg, store, SFTArgs(learning_rate=a.learning_rate, weight_decay=a.weight_decay, max_grad_norm=a.max_grad_norm,
-                                        gradient_accumulation_steps=a.gradient_accumulation_steps, micro_batch_seqs=a.micro_batch_seqs, frozen=frozen), group=group)
+                                        gradient_accumulation_steps=a.gradient_accumulation_steps, micro_batch_seqs=a.micro_batch_seqs, frozen=frozen,
+                                        recompute="auto" if a.gradient_checkpointing else "off"), group=group)
     from iadr1_amd import schedule
     if a.lr_scheduler_type not in schedule.SCHEDULES:
         raise ValueError(f"--lr_scheduler_type {a.lr_scheduler_type}: supported {schedule.SCHEDULES}")
