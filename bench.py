@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--sft-batch", type=int, default=16)
     ap.add_argument("--gradient-checkpointing", default="off", choices=["off", "auto", "on"], help="decoder activation recompute policy of the step (the reference scripts' "
                     "--gradient_checkpointing true = auto): lets e.g. --model 7b run one 64-sequence micro-batch")
+    ap.add_argument("--ref-fp8", action="store_true", help="opt-in: the frozen reference's decoder Linears on the FP8 matrix instruction (BASELINE config 5 'fp8 MFMA weights'); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-processor-legs", action="store_true", help="skip the two extra (untimed for `value`) loops that feed uint8 images through the HF image processor inside the step")
     ap.add_argument("--no-graph", action="store_true")
@@ -695,6 +696,9 @@ def main():
     eng = tr.engine
     eng.args.suppress_eos = True            # fixed-length completions, every sequence generates gen_len tokens
     eng.args.recompute = a.gradient_checkpointing
+    if a.ref_fp8:
+        eng.args.ref_fp8 = True
+        eng.ref.enable_fp8_linears()
     eng.args.use_hip_graph = not a.no_graph
     timer = GemmTimer()
     timer.install()
@@ -808,7 +812,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{model_name} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {image_note}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
-                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "reference_forward": "fp8 mfma linears" if a.ref_fp8 else "bf16", "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "grad_exchange": ({"wire": eng.reducer.wire, "bytes_per_step": getattr(eng.reducer, "last_bytes_on_wire", 0), "buckets_per_step": getattr(eng.reducer, "last_n_buckets", 0)}
                                          if eng.reducer.active else None),
                        "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "

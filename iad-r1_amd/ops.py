@@ -51,6 +51,27 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
+def quant_rows_fp8(x, out=None, out_scale=None):
+    """x [M,K] bf16 -> (OCP e4m3 [M,K] as uint8, fp32 scale per row): scale = amax / 448, round to nearest even of x / scale (include/iadr1_hip.h iadr1_quant_rows_fp8)."""
+    M, K = x.shape
+    q = out if out is not None else torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    s = out_scale if out_scale is not None else torch.empty(M, dtype=F32, device=x.device)
+    assert x.dtype == BF16 and q.dtype == torch.uint8 and q.shape == (M, K) and s.numel() >= M
+    hip.call("quant_rows_fp8", x, _ld(x), q, _ld(q), s, M, K)
+    return q, s
+
+
+def gemm_nt_fp8(aq, sa, bq, sb, bias=None, out=None):
+    """out[M,N] (bf16) = (aq . bq^T) * sa[:, None] * sb[None, :] + bias on the FP8 matrix instruction (include/iadr1_hip.h iadr1_gemm_nt_fp8)."""
+    M, K = aq.shape
+    N, K2 = bq.shape
+    assert K == K2 and aq.dtype == torch.uint8 and bq.dtype == torch.uint8
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=aq.device)
+    hip.call("gemm_nt_fp8", aq, sa, bq, sb, out, bias, M, N, K, _ld(aq), _ld(bq), _ld(out))
+    return out
+
+
 _SPLITK = os.environ.get("IADR1_GEMM_SPLITK", "1") != "0"
 _splitk_ws = {}
 
