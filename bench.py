@@ -39,16 +39,17 @@ def _skinny_pmc():
     """HBM-side bytes of the decode step from the PMC passes recorded under profiles/ (3B shapes): every kernel of the step (r02_decode_pmc.json: FETCH / WRITE per
     kernel, summed over the launches of one step), else the heaviest kernel alone (r01_skinny_pmc.json)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_decode_pmc.json")))
+        rec = next(f for f in ("r03_decode_pmc.json", "r02_decode_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        d = json.load(open(os.path.join(ROOT, "profiles", rec)))
         attn = next(k for k in d["kernels"] if "attn_decode" in k["kernel"])
         steps = attn["launches"] / 36.0
         total = sum((k["read_bytes_corrected"] + k["write_bytes"]) * k["launches"] for k in d["kernels"]) / steps
         return {"kernel": "all kernels of one decode step (Qwen2.5-VL-3B shapes, 64 sequences, context ~520)", "bytes_per_launch": total, "algorithmic_bytes_per_launch": None,
-                "source": "profiles/r02_decode_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"}
+                "source": f"profiles/{rec} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"}
     except Exception:
         pass
     try:
-        k = json.load(open(os.path.join(ROOT, "profiles", "r01_skinny_pmc.json")))
+        k = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r03_skinny_pmc.json", "r01_skinny_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f))))))
         return {"kernel": k["kernel"], "bytes_per_launch": k["traffic_bytes"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"], "MNK": k["MNK"], "source": "profiles/r01_skinny_pmc.json"}
     except Exception:
         return None
@@ -746,9 +747,13 @@ def main():
     metrics = {k: (sum(v) / len(v) if v else None) for k, v in tr._metrics.items()}
     traced = bool(getattr(eng, "last_step_traced", False))      # read now: the extra (untimed) leg below runs the other layout
     dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
+    per_rank_ms = [dt / a.steps * 1e3]
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                       # each rank's own wall time between the two barriers (they differ by the skew of the closing barrier only)
+        per_rank_ms = [float(x) / a.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     # one extra step OUTSIDE the timed region in the reference's own layout (every prompt repeated in all G rows of its group,
@@ -783,7 +788,7 @@ def main():
         # HBM-side traffic of the heaviest GEMM shape and the MFMA-pipe busy fraction from the PMC passes recorded under profiles/ (separate rocprofv3
         # --pmc runs, gfx950 FETCH_SIZE correction applied there); null when the record is absent
         traffic = None
-        pmc_file = next((f for f in ("r02_gemm_pmc.json", "r01_gemm_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+        pmc_file = next((f for f in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             k0 = pmc["kernels"][0]
@@ -792,10 +797,11 @@ def main():
             pass
         mfma_busy = None
         try:
-            mb = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_busy.json")))
+            mb_file = next(f for f in ("r03_mfma_busy.json", "r02_mfma_busy.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            mb = json.load(open(os.path.join(ROOT, "profiles", mb_file)))
             g0 = next(k for k in mb["kernels"] if "gemm_nt_256<0>" in k.get("kernel", "") and k.get("grid") == 3522560)
             mfma_busy = {"kernel": "gemm_nt_256 [20480 x 22016 x 2048]", "mfma_busy_frac": g0["mfma_busy_frac"], "lds_conflict_frac": g0.get("lds_conflict_frac"),
-                         "source": "profiles/r02_mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, separate profiled pass)"}
+                         "source": f"profiles/{mb_file} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, separate profiled pass)"}
         except Exception:
             pass
         model_name = ({"llava_ov_7b": "LLaVA-OneVision-SI-7B", "llava15_7b": "LLaVA-1.5-7B", "llava_next_7b": "LLaVA-NeXT-Mistral-7B"}[a.model] if llava
@@ -821,6 +827,7 @@ def main():
                                     "policy's forward over the completions is the decode itself and is not run a second time before backward (pinned to the oracle by "
                                     "tests/test_hip_model.py::test_api_step_with_rollout_handover_matches_the_oracle)" if traced else ""))
                        if eng.args.share_prefix else "ViT once per image"},
+            "per_rank_ms_per_step": [round(x, 2) for x in per_rank_ms],
             "repeated_rows_layout": repeated,
             "real_processor": real,
             "samples_per_sec_per_gpu": N * a.steps / dt,

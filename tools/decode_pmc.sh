@@ -1,8 +1,9 @@
 #!/bin/bash
 # HBM-side traffic of every kernel of the decode step ("record the decode kernels' FETCH_SIZE too"): rocprofv3 --kernel-trace --pmc, one
-# counter per pass (FETCH_SIZE, WRITE_SIZE), on tools/decode_step_time.py (64 sequences, 3B shapes, hipGraph replay).  Output: gpurun_out/decode_pmc.json
+# counter per pass (FETCH_SIZE, WRITE_SIZE), on tools/decode_step_time.py (64 sequences, 3B shapes, hipGraph replay).  Output: gpurun_out/<TAG>_decode_pmc.json (TAG = $1, default r03)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r03}
 mkdir -p $R/gpurun_out
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_dec_$ctr
@@ -24,7 +25,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
 for (name, grid), c in sorted(agg.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0))[0]):
     f, w = c.get("FETCH_SIZE", (0, 0)), c.get("WRITE_SIZE", (0, 0))
     out["kernels"].append({"kernel": name, "grid": grid, "launches": f[1], "FETCH_SIZE_KiB_raw": f[0], "WRITE_SIZE_KiB": w[0], "read_bytes_corrected": 2 * f[0] * 1024, "write_bytes": w[0] * 1024})
-json.dump(out, open("$R/gpurun_out/decode_pmc.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/${TAG}_decode_pmc.json", "w"), indent=1)
 for k in out["kernels"][:12]:
     print(f'{k["kernel"][:70]:70s} grid {k["grid"]:8d} n {k["launches"]:5d} read {k["read_bytes_corrected"]/1e6:8.2f} MB  write {k["write_bytes"]/1e6:7.2f} MB')
 PY

@@ -1,6 +1,7 @@
 # MFMA-pipe busy fraction and LDS bank-conflict fraction of the training GEMMs and attention kernels (north star: "choices evidenced by
 # rocprof HBM GB/s and MFMA-busy counters").  Counters only: rocprofv3 --pmc with --kernel-trace, one pass per probe.
-# usage (GPU box): bash tools/mfma_pmc.sh  ->  gpurun_out/r02_mfma_busy.json   (copy to profiles/)
+# usage (GPU box): bash tools/mfma_pmc.sh [TAG]  ->  gpurun_out/<TAG>_mfma_busy.json   (copy to profiles/; TAG defaults to r03)
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -35,7 +36,7 @@ for probe in ("gemm_pmc", "attn_probe"):
             if c.get("SQ_LDS_IDX_ACTIVE"):
                 rec["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
             out["kernels"].append(rec)
-json.dump(out, open(os.path.join("$R", "gpurun_out", "r02_mfma_busy.json"), "w"), indent=1)
+json.dump(out, open(os.path.join("$R", "gpurun_out", "${TAG}_mfma_busy.json"), "w"), indent=1)
 for k in out["kernels"]:
     print(k.get("kernel", k)[:70], k.get("grid"), "mfma_busy", round(k.get("mfma_busy_frac", -1), 3), "lds_conflict", round(k.get("lds_conflict_frac", -1), 4))
 PY
