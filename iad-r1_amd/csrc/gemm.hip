@@ -755,6 +755,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
     const float bias_pre = ((p.out_mode == 0 || p.out_mode == 4) && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
     const long long side0 = (NB == 1 && p.out_mode == 4) ? side_base(p.so) : -1;
+    if (NB == 1 && p.out_mode == 4) side_mark(p.so);
     // out_mode 4 (one output per thread when WAVES*64 == 64*16): rotary factors and the cache slot are fetched up front as well
     float pre_cos = 1.f, pre_sin = 0.f;
     long long pre_slot = -1;
@@ -1056,6 +1057,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     const int b = blockIdx.x, bps = gridDim.x;
     const int m_base = blockIdx.y * 64;
     const long long sb = p.out_mode == 3 ? side_base(p.so) : -1;
+    if (p.out_mode == 3) side_mark(p.so);
     STAMP(4);
     const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks); elements of a bf16 tile = BYTES of an FP8 tile
     // X fragments of this wave's k-steps w + j*WAVES (FP8: 2 (w + (j/2) WAVES) + (j & 1)): loaded once, resident for the whole launch
@@ -1590,7 +1592,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         const int ksw = K / 256;
         const bool pers_ok = pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu;
         if (int e = iadr1_side_arg(side, &p.so)) return e;
-        IADR1_REQUIRE(!p.so.step || (out_mode == 3 && pers_ok),
+        IADR1_REQUIRE((!p.so.step && !p.so.mark) || (out_mode == 3 && pers_ok),
                       "gemm_skinny: side outputs exist for the fused-SwiGLU projection in the persistent kernel only (mode %d N=%d K=%d)", out_mode, N, K);
         if (pers_ok) {
             const dim3 grid(ncu, mz, 1), block(512);
