@@ -426,7 +426,11 @@ extern "C" int iadr1_embed_fwd(const long long* ids, const int* img_index, const
 // Weight prefetcher of the decode step (include/iadr1_hip.h iadr1_decode_weight_prefetch)
 namespace {
 struct PfSeg { const char* ptr; long long bytes; unsigned need; unsigned pad; };
-__global__ __launch_bounds__(256) void decode_weight_prefetch_kernel(const PfSeg* segs, int nseg, const unsigned* mark, const unsigned* epoch, unsigned* sink) {
+// Few, fat blocks: the decode kernels fill whole register files (attention: 16 waves x 126 VGPRs; the persistent gate|up GEMM: 8 waves x 252 VGPRs = one block per CU
+// and nothing beside it), so a prefetch block on EVERY CU keeps those kernels from being placed at all.  PF_BLOCKS (32) blocks of 512 threads own their CUs for the
+// step; the marked gate|up launches run on the remaining CUs (launcher: grid = CUs - PF_BLOCKS); everything else co-resides (<= 288 VGPRs per SIMD) or has spare CUs.
+constexpr int PF_THREADS = 512, PF_INFLIGHT = 16, PF_ITER = PF_THREADS * 16 * PF_INFLIGHT;      // 128 KB per block iteration
+__global__ __launch_bounds__(PF_THREADS) void decode_weight_prefetch_kernel(const PfSeg* segs, int nseg, const unsigned* mark, const unsigned* epoch, unsigned* sink) {
     const unsigned e = *epoch * 256u;
     u32x4_t acc = {0, 0, 0, 0};
     const long long t0 = wall_clock64();
@@ -441,13 +445,15 @@ __global__ __launch_bounds__(256) void decode_weight_prefetch_kernel(const PfSeg
             }
             __syncthreads();
         }
-        // this block's slice, 16 KB per iteration (4 loads of 16 bytes per thread in flight); a clamped tail re-reads the last lines instead of predicating the loads
-        const long long per = ((sg.bytes + gridDim.x - 1) / gridDim.x + 16383) & ~16383LL;
-        const long long lo = (long long)blockIdx.x * per, hi = min(sg.bytes, lo + per);
+        // Blocks take 128 KB pieces round-robin, in address order (the order the consumers walk their column tiles): PF_INFLIGHT loads of 16 bytes per thread in
+        // flight; a clamped tail re-reads the last lines instead of predicating the loads
         const long long last = sg.bytes - 16;
-        for (long long o = lo; o < hi; o += 16384) {
+        for (long long o = (long long)blockIdx.x * PF_ITER; o < sg.bytes; o += (long long)gridDim.x * PF_ITER) {
+            u32x4_t v[PF_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc ^= __builtin_nontemporal_load((const u32x4_t*)(sg.ptr + min(o + u * 4096 + threadIdx.x * 16, last)));
+            for (int u = 0; u < PF_INFLIGHT; ++u) v[u] = __builtin_nontemporal_load((const u32x4_t*)(sg.ptr + min(o + u * (PF_THREADS * 16) + threadIdx.x * 16, last)));
+#pragma unroll
+            for (int u = 0; u < PF_INFLIGHT; ++u) acc ^= v[u];
         }
     }
     if (acc[0] == 0x9E3779B9u && acc[1] == 0x7F4A7C15u && acc[2] == 0xDEADBEEFu) *sink = acc[3];     // (never: the loads must not be optimised away)
@@ -455,14 +461,8 @@ __global__ __launch_bounds__(256) void decode_weight_prefetch_kernel(const PfSeg
 }  // namespace
 extern "C" int iadr1_decode_weight_prefetch(const void* segs, int nseg, const unsigned* mark, const unsigned* epoch, void* sink, hipStream_t stream) {
     IADR1_REQUIRE(segs && nseg > 0 && mark && epoch && sink, "decode_weight_prefetch: segments, mark, epoch and sink are required");
-    static const int ncu = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
-        return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }();
-    static const int blocks = iadr1_env_int("IADR1_PREFETCH_BLOCKS", 0) > 0 ? iadr1_env_int("IADR1_PREFETCH_BLOCKS", 0) : ncu;
-    hipLaunchKernelGGL(decode_weight_prefetch_kernel, dim3(blocks), dim3(256), 0, stream, (const PfSeg*)segs, nseg, mark, epoch, (unsigned*)sink);
+    static const int blocks = iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) > 0 ? iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) : 32;
+    hipLaunchKernelGGL(decode_weight_prefetch_kernel, dim3(blocks), dim3(PF_THREADS), 0, stream, (const PfSeg*)segs, nseg, mark, epoch, (unsigned*)sink);
     return iadr1_check_launch("decode_weight_prefetch");
 }
 extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,

@@ -1595,7 +1595,11 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         IADR1_REQUIRE((!p.so.step && !p.so.mark) || (out_mode == 3 && pers_ok),
                       "gemm_skinny: side outputs exist for the fused-SwiGLU projection in the persistent kernel only (mode %d N=%d K=%d)", out_mode, N, K);
         if (pers_ok) {
-            const dim3 grid(ncu, mz, 1), block(512);
+            // a marked launch runs beside the weight prefetcher, whose blocks own IADR1_PREFETCH_BLOCKS CUs for the step (iadr1_decode_weight_prefetch): this kernel's
+            // blocks fill a CU's register file, so it takes the others (a multiple of 8 keeps the XCD-aware group order)
+            static const int pf_blocks = iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) > 0 ? iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) : 32;
+            const int gx = p.so.mark && ncu - pf_blocks >= 64 ? ((ncu - pf_blocks) & ~7) : ncu;
+            const dim3 grid(gx, mz, 1), block(512);
             if (ksw == 8) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 8>), grid, block, SMP, stream, p);
             else if (ksw == 6) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 6>), grid, block, SMP, stream, p);
             else hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 4>), grid, block, SMP, stream, p);
