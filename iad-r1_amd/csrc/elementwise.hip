@@ -447,13 +447,35 @@ __global__ __launch_bounds__(PF_THREADS) void decode_weight_prefetch_kernel(cons
         }
         // Blocks take 128 KB pieces round-robin, in address order (the order the consumers walk their column tiles): PF_INFLIGHT loads of 16 bytes per thread in
         // flight; a clamped tail re-reads the last lines instead of predicating the loads
+        // Two register sets: the loads of piece k + 1 are issued before the loads of piece k are consumed, so ~2 x 128 KB per block stay in flight.
+        // Best effort: a segment whose consumers have already run (the mark is two stages past its trigger) is dropped, at its start and every 4 pieces.
         const long long last = sg.bytes - 16;
-        for (long long o = (long long)blockIdx.x * PF_ITER; o < sg.bytes; o += (long long)gridDim.x * PF_ITER) {
-            u32x4_t v[PF_INFLIGHT];
+        const unsigned stale = e + sg.need + 2;
+        const long long stride = (long long)gridDim.x * PF_ITER;
+        auto issue = [&](u32x4_t (&v)[PF_INFLIGHT], long long o) {
 #pragma unroll
             for (int u = 0; u < PF_INFLIGHT; ++u) v[u] = __builtin_nontemporal_load((const u32x4_t*)(sg.ptr + min(o + u * (PF_THREADS * 16) + threadIdx.x * 16, last)));
+        };
+        auto eat = [&](const u32x4_t (&v)[PF_INFLIGHT]) {
 #pragma unroll
             for (int u = 0; u < PF_INFLIGHT; ++u) acc ^= v[u];
+        };
+        long long o = (long long)blockIdx.x * PF_ITER;
+        if (o < sg.bytes && (int)(__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - stale) < 0) {
+            u32x4_t va[PF_INFLIGHT], vb[PF_INFLIGHT];
+            issue(va, o);
+            for (int it = 0;; ++it) {
+                const long long o1 = o + stride;
+                if (o1 >= sg.bytes) { eat(va); break; }
+                issue(vb, o1);
+                eat(va);
+                const long long o2 = o1 + stride;
+                if (o2 >= sg.bytes) { eat(vb); break; }
+                issue(va, o2);
+                eat(vb);
+                o = o2;
+                if ((it & 1) == 1 && (int)(__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - stale) >= 0) { eat(va); break; }
+            }
         }
     }
     if (acc[0] == 0x9E3779B9u && acc[1] == 0x7F4A7C15u && acc[2] == 0xDEADBEEFu) *sink = acc[3];     // (never: the loads must not be optimised away)
