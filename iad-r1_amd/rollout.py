@@ -98,6 +98,8 @@ class Rollout:
                 if i + 1 < L:
                     assert pk(i + 1, "qkv.w").data_ptr() == pk(i, "down.w").data_ptr() + nb(pk(i, "down.w"))
                 rows.append((pk(i, "down.w").data_ptr(), tail, 2 * i + 2))
+            frac = float(os.environ.get("IADR1_PREFETCH_FRAC", "1"))          # (diagnosis: prefetch only the head of every segment)
+            rows = [(p_, int(b_ * frac) // 16 * 16, n_) for p_, b_, n_ in rows]
             self.pf_segs = torch.tensor(rows, dtype=torch.int64, device=dev)
             self.pf_mark = torch.zeros(1, dtype=torch.int32, device=dev)
             self.pf_sink = torch.zeros(1, dtype=torch.int32, device=dev)
