@@ -109,16 +109,7 @@ struct SideOut {                   // same layout as iadr1_side_out_t
     void* p2; long long ld2;
     const unsigned* step;          // device-resident decode step counter; nullptr = side outputs off
     long long base, seq_stride;
-    // progress mark for the decode weight prefetcher (iadr1_decode_weight_prefetch): block 0 of the launch stores *mark_epoch * 256 + mark_value to *mark at kernel
-    // entry (agent scope).  Independent of the row outputs above (step may be null).  mark == nullptr: none.
-    unsigned* mark;
-    const unsigned* mark_epoch;
-    unsigned mark_value;
 };
-__device__ __forceinline__ void side_mark(const SideOut& so) {
-    if (so.mark && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        __hip_atomic_store(so.mark, *so.mark_epoch * 256u + so.mark_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // the caller's struct (host memory, may be null) -> the by-value kernel argument; argument checks in runtime.hip
 int iadr1_side_arg(const void* side, SideOut* out);
 // IADR1_* A/B switches of the launchers: read ONCE (`static const int x = iadr1_env_int(...)`, thread-safe static initialisation), constant afterwards

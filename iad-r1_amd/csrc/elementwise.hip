@@ -423,70 +423,6 @@ extern "C" int iadr1_embed_fwd(const long long* ids, const int* img_index, const
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)E, (const bf16_t*)img, (bf16_t*)out, T, H);
     return iadr1_check_launch("embed_fwd");
 }
-// Weight prefetcher of the decode step (include/iadr1_hip.h iadr1_decode_weight_prefetch)
-namespace {
-struct PfSeg { const char* ptr; long long bytes; unsigned need; unsigned pad; };
-// Few, fat blocks: the decode kernels fill whole register files (attention: 16 waves x 126 VGPRs; the persistent gate|up GEMM: 8 waves x 252 VGPRs = one block per CU
-// and nothing beside it), so a prefetch block on EVERY CU keeps those kernels from being placed at all.  PF_BLOCKS (32) blocks of 512 threads own their CUs for the
-// step; the marked gate|up launches run on the remaining CUs (launcher: grid = CUs - PF_BLOCKS); everything else co-resides (<= 288 VGPRs per SIMD) or has spare CUs.
-constexpr int PF_THREADS = 512, PF_INFLIGHT = 16, PF_ITER = PF_THREADS * 16 * PF_INFLIGHT;      // 128 KB per block iteration
-__global__ __launch_bounds__(PF_THREADS) void decode_weight_prefetch_kernel(const PfSeg* segs, int nseg, const unsigned* mark, const unsigned* epoch, unsigned* sink) {
-    const unsigned e = *epoch * 256u;
-    u32x4_t acc = {0, 0, 0, 0};
-    const long long t0 = wall_clock64();
-    for (int s = 0; s < nseg; ++s) {
-        const PfSeg sg = segs[s];
-        if (sg.need) {
-            if (threadIdx.x == 0) {      // one poller per block, sleeping between polls (a polling wave costs its CU's streams issue slots)
-                while ((int)(__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (e + sg.need)) < 0) {
-                    __builtin_amdgcn_s_sleep(64);
-                    if (wall_clock64() - t0 > 5000000) break;          // 50 ms at 100 MHz: never hang a stream on a mark that does not come
-                }
-            }
-            __syncthreads();
-        }
-        // Blocks take 128 KB pieces round-robin, in address order (the order the consumers walk their column tiles): PF_INFLIGHT loads of 16 bytes per thread in
-        // flight; a clamped tail re-reads the last lines instead of predicating the loads
-        // Two register sets: the loads of piece k + 1 are issued before the loads of piece k are consumed, so ~2 x 128 KB per block stay in flight.
-        // Best effort: a segment whose consumers have already run (the mark is two stages past its trigger) is dropped, at its start and every 4 pieces.
-        const long long last = sg.bytes - 16;
-        const unsigned stale = e + sg.need + 2;
-        const long long stride = (long long)gridDim.x * PF_ITER;
-        auto issue = [&](u32x4_t (&v)[PF_INFLIGHT], long long o) {
-#pragma unroll
-            for (int u = 0; u < PF_INFLIGHT; ++u) v[u] = __builtin_nontemporal_load((const u32x4_t*)(sg.ptr + min(o + u * (PF_THREADS * 16) + threadIdx.x * 16, last)));
-        };
-        auto eat = [&](const u32x4_t (&v)[PF_INFLIGHT]) {
-#pragma unroll
-            for (int u = 0; u < PF_INFLIGHT; ++u) acc ^= v[u];
-        };
-        long long o = (long long)blockIdx.x * PF_ITER;
-        if (o < sg.bytes && (int)(__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - stale) < 0) {
-            u32x4_t va[PF_INFLIGHT], vb[PF_INFLIGHT];
-            issue(va, o);
-            for (int it = 0;; ++it) {
-                const long long o1 = o + stride;
-                if (o1 >= sg.bytes) { eat(va); break; }
-                issue(vb, o1);
-                eat(va);
-                const long long o2 = o1 + stride;
-                if (o2 >= sg.bytes) { eat(vb); break; }
-                issue(va, o2);
-                eat(vb);
-                o = o2;
-                if ((it & 1) == 1 && (int)(__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - stale) >= 0) { eat(va); break; }
-            }
-        }
-    }
-    if (acc[0] == 0x9E3779B9u && acc[1] == 0x7F4A7C15u && acc[2] == 0xDEADBEEFu) *sink = acc[3];     // (never: the loads must not be optimised away)
-}
-}  // namespace
-extern "C" int iadr1_decode_weight_prefetch(const void* segs, int nseg, const unsigned* mark, const unsigned* epoch, void* sink, hipStream_t stream) {
-    IADR1_REQUIRE(segs && nseg > 0 && mark && epoch && sink, "decode_weight_prefetch: segments, mark, epoch and sink are required");
-    static const int blocks = iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) > 0 ? iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) : 32;
-    hipLaunchKernelGGL(decode_weight_prefetch_kernel, dim3(blocks), dim3(PF_THREADS), 0, stream, (const PfSeg*)segs, nseg, mark, epoch, (unsigned*)sink);
-    return iadr1_check_launch("decode_weight_prefetch");
-}
 extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
                                hipStream_t stream) {
     IADR1_REQUIRE(T > 0 && (H % 8) == 0, "embed_bwd: H must be a multiple of 8");

@@ -755,7 +755,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
     const float bias_pre = ((p.out_mode == 0 || p.out_mode == 4) && p.bias) ? bf2f(p.bias[min(n0 + (t % BNC), p.N - 1)]) : 0.f;
     const long long side0 = (NB == 1 && p.out_mode == 4) ? side_base(p.so) : -1;
-    if (NB == 1 && p.out_mode == 4) side_mark(p.so);
     // out_mode 4 (one output per thread when WAVES*64 == 64*16): rotary factors and the cache slot are fetched up front as well
     float pre_cos = 1.f, pre_sin = 0.f;
     long long pre_slot = -1;
@@ -1057,7 +1056,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     const int b = blockIdx.x, bps = gridDim.x;
     const int m_base = blockIdx.y * 64;
     const long long sb = p.out_mode == 3 ? side_base(p.so) : -1;
-    if (p.out_mode == 3) side_mark(p.so);
     STAMP(4);
     const long long tile_stride = (long long)WAVES * KSW * 512;   // K == 32 * WAVES * KSW exactly (host checks); elements of a bf16 tile = BYTES of an FP8 tile
     // X fragments of this wave's k-steps w + j*WAVES (FP8: 2 (w + (j/2) WAVES) + (j & 1)): loaded once, resident for the whole launch
@@ -1592,14 +1590,10 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         const int ksw = K / 256;
         const bool pers_ok = pers && ksplit == 1 && out_mode <= 3 && (N % 32) == 0 && (K % 256) == 0 && (ksw == 8 || ksw == 6 || ksw == 4) && (N / 32) >= 2 * ncu;
         if (int e = iadr1_side_arg(side, &p.so)) return e;
-        IADR1_REQUIRE((!p.so.step && !p.so.mark) || (out_mode == 3 && pers_ok),
+        IADR1_REQUIRE(!p.so.step || (out_mode == 3 && pers_ok),
                       "gemm_skinny: side outputs exist for the fused-SwiGLU projection in the persistent kernel only (mode %d N=%d K=%d)", out_mode, N, K);
         if (pers_ok) {
-            // a marked launch runs beside the weight prefetcher, whose blocks own IADR1_PREFETCH_BLOCKS CUs for the step (iadr1_decode_weight_prefetch): this kernel's
-            // blocks fill a CU's register file, so it takes the others (a multiple of 8 keeps the XCD-aware group order)
-            static const int pf_blocks = iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) > 0 ? iadr1_env_int("IADR1_PREFETCH_BLOCKS", 32) : 32;
-            const int gx = p.so.mark && ncu - pf_blocks >= 64 ? ((ncu - pf_blocks) & ~7) : ncu;
-            const dim3 grid(gx, mz, 1), block(512);
+            const dim3 grid(ncu, mz, 1), block(512);
             if (ksw == 8) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 8>), grid, block, SMP, stream, p);
             else if (ksw == 6) hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 6>), grid, block, SMP, stream, p);
             else hipLaunchKernelGGL((gemm_skinny_pers_kernel<8, 4>), grid, block, SMP, stream, p);

@@ -26,8 +26,7 @@ int iadr1_side_arg(const void* side, SideOut* out) {
     *out = SideOut{};
     if (!side) return IADR1_OK;
     const SideOut s = *(const SideOut*)side;
-    IADR1_REQUIRE((s.step != nullptr || s.mark != nullptr) && s.base >= 0 && s.seq_stride >= 0, "side outputs: a device step counter (or a progress mark) and non-negative row arithmetic are required");
-    IADR1_REQUIRE(s.mark == nullptr || s.mark_epoch != nullptr, "side outputs: a progress mark needs its epoch counter");
+    IADR1_REQUIRE(s.step != nullptr && s.base >= 0 && s.seq_stride >= 0, "side outputs: a device step counter and non-negative row arithmetic are required");
     IADR1_REQUIRE((s.ld0 % 8) == 0 && (((uintptr_t)s.p0 | (uintptr_t)s.p1 | (uintptr_t)s.p2) & 15) == 0, "side outputs: 16-byte aligned rows");
     *out = s;
     return IADR1_OK;

@@ -130,29 +130,20 @@ class SideOut(ctypes.Structure):
     """include/iadr1_hip.h iadr1_side_out_t: where a decode-step kernel also writes its rows of the training arena.  Built once per (kernel, layer)
     by the rollout (the pointers are static) and handed to the four entry points that take `side`."""
     _fields_ = [("p0", ctypes.c_void_p), ("ld0", ctypes.c_longlong), ("p1", ctypes.c_void_p), ("ld1", ctypes.c_longlong), ("p2", ctypes.c_void_p),
-                ("ld2", ctypes.c_longlong), ("step", ctypes.c_void_p), ("base", ctypes.c_longlong), ("seq_stride", ctypes.c_longlong),
-                ("mark", ctypes.c_void_p), ("mark_epoch", ctypes.c_void_p), ("mark_value", ctypes.c_uint)]
+                ("ld2", ctypes.c_longlong), ("step", ctypes.c_void_p), ("base", ctypes.c_longlong), ("seq_stride", ctypes.c_longlong)]
 
     @staticmethod
-    def make(step, base, seq_stride, p0=None, p1=None, p2=None, ld1=None, rows=True, mark=None, mark_value=0):
-        """p0 / p1 are [rows, width] tensors (ld = row stride) except where the header says otherwise (ld1 overrides, e.g. the [Hq][T] log-sum-exp).
-        rows=False: no row outputs (the struct then only carries the progress mark).  mark: device word the launch stores step * 256 + mark_value to."""
+    def make(step, base, seq_stride, p0=None, p1=None, p2=None, ld1=None):
+        """p0 / p1 are [rows, width] tensors (ld = row stride) except where the header says otherwise (ld1 overrides, e.g. the [Hq][T] log-sum-exp)."""
         ld = lambda t: 0 if t is None else (t.stride(0) if t.dim() > 1 else 1)
         ptr = lambda t: None if t is None else t.data_ptr()
-        so = SideOut(ptr(p0), ld(p0), ptr(p1), ld(p1) if ld1 is None else ld1, ptr(p2), ld(p2), step.data_ptr() if rows else None, int(base), int(seq_stride),
-                     ptr(mark), step.data_ptr() if mark is not None else None, int(mark_value))
-        so._keep = (step, p0, p1, p2, mark)      # the struct holds raw device pointers: keep their owners alive with it
+        so = SideOut(ptr(p0), ld(p0), ptr(p1), ld(p1) if ld1 is None else ld1, ptr(p2), ld(p2), step.data_ptr(), int(base), int(seq_stride))
+        so._keep = (step, p0, p1, p2)      # the struct holds raw device pointers: keep their owners alive with it
         return so
 
 
 def _side(so):
     return None if so is None else ctypes.addressof(so)
-
-
-def decode_weight_prefetch(segs, mark, epoch, sink):
-    """include/iadr1_hip.h iadr1_decode_weight_prefetch.  segs: int64 [n, 3] device tensor of (pointer, bytes, need) rows."""
-    assert segs.dtype == torch.int64 and segs.dim() == 2 and segs.shape[1] == 3 and segs.is_contiguous()
-    hip.call("decode_weight_prefetch", segs, int(segs.shape[0]), mark, epoch, sink)
 
 
 class PackedAct:

@@ -78,32 +78,6 @@ class Rollout:
         self.trace = None           # training arena filled by the decode steps (generate(train_trace=...)); part of the captured graph
         self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-        # weight prefetcher of the decode step (include/iadr1_hip.h iadr1_decode_weight_prefetch): one launch per step on a second stream pulls the layer weights into
-        # the memory-side cache just ahead of their consumers, paced by progress marks the q|k|v and gate|up launches store.  Segments in consumption order: at once
-        # q|k|v(0) + o(0); after q|k|v(i) started: gate|up(i); after gate|up(i) started: down(i) + q|k|v(i+1) + o(i+1) (contiguous in the decode pack)
-        # (only where the gate|up projection runs on the persistent kernel, the launch that carries the second mark: include/iadr1_hip.h)
-        ncu = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 0
-        pers_gu = (os.environ.get("IADR1_SKINNY_PERS", "1") != "0" and H % 256 == 0 and H // 256 in (4, 6, 8) and (2 * I) % 128 == 0 and (2 * I) // 32 >= 2 * ncu and N <= 64)
-        self.prefetch = (os.environ.get("IADR1_DECODE_PREFETCH", "1") != "0" and engine.p.qkv_rope_packed and self.fuse_swiglu and not engine.p.decode_fp8
-                         and dev.type == "cuda" and pers_gu and self.packed)
-        if self.prefetch:
-            P_ = engine.p
-            nb = lambda t: t.numel() * t.element_size()
-            pk = lambda i, k: P_.wpk(f"layers.{i}.{k}")
-            rows = [(pk(0, "qkv.w").data_ptr(), nb(pk(0, "qkv.w")) + nb(pk(0, "o.w")), 0)]
-            assert pk(0, "o.w").data_ptr() == pk(0, "qkv.w").data_ptr() + nb(pk(0, "qkv.w"))
-            for i in range(L):
-                rows.append((pk(i, "gu.w").data_ptr(), nb(pk(i, "gu.w")), 2 * i + 1))
-                tail = nb(pk(i, "down.w")) + ((nb(pk(i + 1, "qkv.w")) + nb(pk(i + 1, "o.w"))) if i + 1 < L else 0)
-                if i + 1 < L:
-                    assert pk(i + 1, "qkv.w").data_ptr() == pk(i, "down.w").data_ptr() + nb(pk(i, "down.w"))
-                rows.append((pk(i, "down.w").data_ptr(), tail, 2 * i + 2))
-            frac = float(os.environ.get("IADR1_PREFETCH_FRAC", "1"))          # (diagnosis: prefetch only the head of every segment)
-            rows = [(p_, int(b_ * frac) // 16 * 16, n_) for p_, b_, n_ in rows]
-            self.pf_segs = torch.tensor(rows, dtype=torch.int64, device=dev)
-            self.pf_mark = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.pf_sink = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.pf_stream = torch.cuda.Stream(dev)
         self.sampling = dict(temperature=0.9, top_k=50, top_p=0.9, suppress=-1, eos=c.eos_token_id, pad=c.pad_token_id)
 
     # ---- one decode step (graph body) -------------------------------------------------------------------------
@@ -111,22 +85,16 @@ class Rollout:
         e, c, P = self.e, self.e.cfg, self.e.p
         tr = self.trace      # None, or the training arena the step also fills (Rollout.generate(train_trace=...))
 
-        def side(mark=0, **kw):
-            """iadr1_side_out_t for one launch of this step: rows base + s * stride + *step of the given arena tensors (None without a trace), and / or the progress
-            mark of the weight prefetcher.  The structs are host memory read at launch time; they are kept in self._sides so that a re-capture builds them anew."""
-            mk = self.pf_mark if (self.prefetch and mark) else None
-            if tr is None and mk is None:
+        def side(**kw):
+            """iadr1_side_out_t for one launch of this step: rows base + s * stride + *step of the given arena tensors (None without a trace).
+            The structs are host memory read at launch time; they are kept in self._sides so that a re-capture builds them anew."""
+            if tr is None:
                 return None
-            so = (ops.SideOut.make(self.step, tr["base"], tr["stride"], mark=mk, mark_value=mark, **kw) if tr is not None
-                  else ops.SideOut.make(self.step, 0, 0, rows=False, mark=mk, mark_value=mark))
+            so = ops.SideOut.make(self.step, tr["base"], tr["stride"], **kw)
             self._sides.append(so)
             return so
 
         self._sides = []
-        if self.prefetch:      # fork: the prefetcher runs beside the whole step on its own stream (inside a captured graph: a second branch)
-            self.pf_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.pf_stream):
-                ops.decode_weight_prefetch(self.pf_segs, self.pf_mark, self.step, self.pf_sink)
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         qw, kw = Hq * D, Hkv * D
         s = self.sampling
@@ -143,7 +111,7 @@ class Rollout:
                                 side=side(p0=T_("x_in", i), p1=T_("h1", i), p2=T_("rstd1", i)))
             if P.qkv_rope_packed:   # q|k|v projection + rotary + K/V cache append in one launch
                 ops.gemm_qkv_rope_kv(self.h, P.wpk(b + "qkv.w"), P.wpk_bias(b + "qkv.w"), self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D,
-                                     side=side(mark=2 * i + 1, p0=T_("qkv", i)))
+                                     side=side(p0=T_("qkv", i)))
             else:
                 assert tr is None
                 ops.gemm_skinny(self.h, P.wpk(b + "qkv.w"), c.qkv_width, bias=P.w(b + "qkv.b"), out=self.qkv)
@@ -153,7 +121,7 @@ class Rollout:
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h,
                             side=side(p0=T_("x_mid", i), p1=T_("h2", i), p2=T_("rstd2", i)))
             if self.fuse_swiglu:
-                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True, side=side(mark=2 * i + 2, p0=T_("gu", i), p1=T_("a", i)))
+                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True, side=side(p0=T_("gu", i), p1=T_("a", i)))
             else:
                 assert tr is None
                 ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.gu)
@@ -163,8 +131,6 @@ class Rollout:
         ops.rmsnorm_fwd(None, P.w("norm"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h,
                         side=side(p0=None if tr is None else tr["x_last"], p1=None if tr is None else tr["hf"], p2=None if tr is None else tr["rstdf"]))
         ops.gemm_skinny(self.h, P.wpk(P.lm_head_name()), c.vocab_size, out=self.logits)
-        if self.prefetch:      # join before the step counter advances (the prefetcher reads it as its epoch)
-            torch.cuda.current_stream().wait_stream(self.pf_stream)
         self._sample_and_advance()
 
     def _attention(self, i, side):

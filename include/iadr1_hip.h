@@ -41,11 +41,6 @@ typedef struct iadr1_side_out {
     void* p2; long long ld2;
     const unsigned* step;
     long long base, seq_stride;
-    /* progress mark (iadr1_gemm_qkv_rope_kv_bf16 and the fused-SwiGLU iadr1_gemm_skinny_bf16 only): the launch stores *mark_epoch * 256 + mark_value to *mark when
-     * it starts -- what iadr1_decode_weight_prefetch paces itself by.  NULL: none; independent of the row outputs (step may then be NULL). */
-    unsigned* mark;
-    const unsigned* mark_epoch;
-    unsigned mark_value;
 } iadr1_side_out_t;
 
 /* ---- dense contractions ----------------------------------------------------------------------------
@@ -113,13 +108,6 @@ int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const float* wscale, 
 int iadr1_quant_rows_fp8(const void* X, long long ldx, void* Q, long long ldq, float* scale, int M, int K, iadr1_stream_t stream);
 int iadr1_gemm_nt_fp8(const void* A8, const float* sa, const void* B8, const float* sb, void* C, const void* bias, int M, int N, int K, long long lda,
                       long long ldb, long long ldc, iadr1_stream_t stream);
-/* Weight prefetcher of the decode step.  A decode step streams every weight once (6.2 GB at 3B) through ~250 short kernels, of which only the two big GEMMs of a
- * layer pull anything near the HBM rate; in between (norms, q|k|v, attention, o: latency-bound) the memory system idles.  This kernel -- launched ONCE per step on a
- * second stream, one small block per CU beside the step's own blocks -- reads the weight segments `segs[i] = {ptr, bytes, need}` in consumption order into the 256 MB
- * memory-side cache just ahead of their consumers: segment i is started when the progress mark (iadr1_side_out_t.mark, stored by the q|k|v and gate|up launches)
- * has reached *epoch * 256 + need (need 0: at once).  Best effort: no kernel waits for it, a late prefetch only means the consumer reads HBM as before; it gives up
- * after 50 ms.  `sink`: 4 bytes never written in practice (keeps the loads alive). */
-int iadr1_decode_weight_prefetch(const void* segs, int nseg, const unsigned* mark, const unsigned* epoch, void* sink, iadr1_stream_t stream);
 /* X[M,K] row-major -> decode-packed activations Xp (buffer of roundup(M,64)*K elements; pad rows zeroed).  K % 32 == 0. */
 int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
