@@ -301,6 +301,10 @@ TINY_OV = {
 TINY_OV64 = dict(TINY_OV, text=dict(TINY_OV["text"], num_attention_heads=4, num_key_value_heads=2))
 
 
+# ... and with the decoder geometry of LLaVA-OneVision-7B (Qwen2-7B: 28 query heads on 4 kv heads = a GQA group of 7; BASELINE config 5): 7 query heads, 1 kv head, width 896
+TINY_OV7 = dict(TINY_OV, text=dict(TINY_OV["text"], hidden_size=896, intermediate_size=1152, num_attention_heads=7, num_key_value_heads=1))
+
+
 def param_shapes_ov(cfg: dict) -> dict[str, tuple[int, ...]]:
     t, v = cfg["text"], cfg["vision"]
     h, inter = t["hidden_size"], t["intermediate_size"]

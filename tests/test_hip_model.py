@@ -1155,21 +1155,30 @@ def test_llava_onevision_forward_matches_hf_golden(golden_dir, cfg_name, golden)
     assert err < 0.08, err
 
 
-@pytest.mark.parametrize("share", [True, False])
-def test_llava_onevision_sc_grpo_matches_reference_golden(golden_dir, share):
+@pytest.mark.parametrize("share,golden", [(True, "sc_grpo_llava_ov.npz"), (False, "sc_grpo_llava_ov.npz"), (True, "sc_grpo_llava_ov_g7.npz"), (False, "sc_grpo_llava_ov_g7.npz")])
+def test_llava_onevision_sc_grpo_matches_reference_golden(golden_dir, share, golden):
     """The reference's compute_loss on its llava branch (tests/golden/sc_grpo_llava_ov.npz, model id containing "llava_ov"): two of the four rows end
     early, so `_ensure_left_padding_data` (REF:516-567) rotates them and their loss terms are the log-probs of EARLIER tokens; the engine reproduces
-    that by index arithmetic on the host (GRPOArgs.llava_rotate_right_padded_rows), in the shared-prefix and in the repeated-rows layout."""
-    g = load(golden_dir, "sc_grpo_llava_ov.npz")
+    that by index arithmetic on the host (GRPOArgs.llava_rotate_right_padded_rows), in the shared-prefix and in the repeated-rows layout.
+    sc_grpo_llava_ov_g7.npz: the same through the reference on TINY_OV7 -- 7 query heads per kv head, the decoder geometry of LLaVA-OneVision-7B (BASELINE config 5):
+    forward AND backward of the SC-GRPO step at GQA group 7 on the SigLIP / any-resolution path."""
+    g = load(golden_dir, golden)
     meta = json.loads(str(g["meta"]))
     G, C, seed = meta["G"], meta["C"], meta["seed"]
-    w_ref = fx.make_weights_ov(fx.TINY_OV, 0)
+    cfg_d = getattr(fx, (meta.get("config") or "fixture_util.TINY_OV").split(".")[-1] or "TINY_OV")
+    CFG_OV = VLMConfig.from_dict(cfg_d)
+
+    def _ov_store(weights, trainable):
+        s_ = ParamStore(CFG_OV, DEV, trainable=trainable)
+        s_.load_named(weights)
+        return s_
+    w_ref = fx.make_weights_ov(cfg_d, 0)
     pol, ref = _ov_store(fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"]), True), _ov_store(w_ref, False)
     eng = SCGRPOEngine(CFG_OV, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=16, share_prefix=share))
     P = g["prompt_completion_ids"].shape[1] - C
-    batch = {"input_ids": g["prompt_completion_ids"][:1, :P], "attention_mask": g["attention_mask"][:1, :P], "pixel_values": fx.synth_crops(meta["crops"], fx.TINY_OV, seed),
+    batch = {"input_ids": g["prompt_completion_ids"][:1, :P], "attention_mask": g["attention_mask"][:1, :P], "pixel_values": fx.synth_crops(meta["crops"], cfg_d, seed),
              "image_sizes": [tuple(x) for x in meta["sizes"]]}
-    comps = fx.synth_completions(G, C, fx.TINY_OV, seed + 100, {int(k): v for k, v in meta["eos_rows"].items()})
+    comps = fx.synth_completions(G, C, cfg_d, seed + 100, {int(k): v for k, v in meta["eos_rows"].items()})
     out = eng.loss_and_grads(batch, comps, g["rewards_per_func"])
     assert np.array_equal(out["ids"], g["prompt_completion_ids"]) and np.array_equal(out["completion_mask"], g["completion_mask"])
     m = g["completion_mask"].astype(bool)
@@ -1177,8 +1186,9 @@ def test_llava_onevision_sc_grpo_matches_reference_golden(golden_dir, share):
     dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - g["ref_per_token_logps"][m]).max()
     gl, gk = float(g["loss"]), float(g["metric_kl"])
     mt = out["metrics"]
-    print(f"[parity] llava-ov share={share}: loss hip={mt['loss']:.6e} ref={gl:.6e}  kl hip={mt['kl']:.6e} ref={gk:.6e} ({100 * abs(mt['kl'] - gk) / gk:.1f}%)  |dlogp|max={dlp:.4f}/{dlr:.4f}")
-    assert dlp < 0.08 and dlr < 0.08, (dlp, dlr)
+    print(f"[parity] llava-ov {golden} share={share}: loss hip={mt['loss']:.6e} ref={gl:.6e}  kl hip={mt['kl']:.6e} ref={gk:.6e} ({100 * abs(mt['kl'] - gk) / gk:.1f}%)  |dlogp|max={dlp:.4f}/{dlr:.4f}")
+    tol_lp = 0.08 if CFG_OV.hidden_size <= 256 else 0.12           # hidden 896: log-probs down to -13 (1 % of the range, as for TINY7)
+    assert dlp < tol_lp and dlr < tol_lp, (dlp, dlr)
     np.testing.assert_allclose(out["advantages"].numpy(), g["advantages"], rtol=1e-5, atol=1e-6)
     assert abs(mt["kl"] - gk) <= 0.10 * gk and abs(mt["loss"] - gl) <= 0.04 * 0.10 * gk + 2e-6
     grads = pol.export_named(source="grad")

@@ -332,13 +332,15 @@ def test_llava_onevision_forward(golden_dir, cfg_name, golden):
     assert np.array_equal(dense.T, dense_t)
 
 
-def test_llava_onevision_sc_grpo_compute_loss(golden_dir):
+@pytest.mark.parametrize("golden", ["sc_grpo_llava_ov.npz", "sc_grpo_llava_ov_g7.npz"])
+def test_llava_onevision_sc_grpo_compute_loss(golden_dir, golden):
     """The reference's compute_loss on its llava branch (model id containing "llava_ov": `_ensure_left_padding_data` rotates the rows whose completion
-    ended early, REF:502-504,516-567) vs oracle.sc_grpo.sc_grpo_step(rotate_right_padded_rows=True)."""
+    ended early, REF:502-504,516-567) vs oracle.sc_grpo.sc_grpo_step(rotate_right_padded_rows=True).  _g7: the 7:1 head geometry of LLaVA-OneVision-7B's
+    decoder (BASELINE config 5), fixture TINY_OV7."""
     from oracle import llava_ov as oo
-    g = _load(golden_dir, "sc_grpo_llava_ov.npz")
+    g = _load(golden_dir, golden)
     meta = json.loads(str(g["meta"]))
-    cfg = fx.TINY_OV
+    cfg = getattr(fx, (meta.get("config") or "fixture_util.TINY_OV").split(".")[-1] or "TINY_OV")
     G, C, seed = meta["G"], meta["C"], meta["seed"]
     w_ref = fx.make_weights_ov(cfg, 0)
     pol = oo.LlavaOVOracle(cfg, fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"]), requires_grad=True)

@@ -176,15 +176,16 @@ class OVProcessor(mg.FakeProcessor):
         self.chat_template = "x"
 
 
-def gen_sc_grpo(SCGRPOTrainer, reward, family="llava_ov"):
-    """family "llava_ov": LLaVA-OneVision; "llava" / "llava_next": LLaVA-1.5 / NeXT under the model ids the reference's switch routes to them."""
+def gen_sc_grpo(SCGRPOTrainer, reward, family="llava_ov", cfg_name="TINY_OV", fname=None, perturb=0.25):
+    """family "llava_ov": LLaVA-OneVision; "llava" / "llava_next": LLaVA-1.5 / NeXT under the model ids the reference's switch routes to them.
+    cfg_name: the llava_ov fixture (TINY_OV; TINY_OV7 = the 7:1 head geometry of LLaVA-OneVision-7B's decoder, BASELINE config 5)."""
     if family == "llava_ov":
-        cfg = fx.TINY_OV
+        cfg = getattr(fx, cfg_name)
         w_ref = fx.make_weights_ov(cfg, 0)
     else:
         cfg = fx.TINY_LLAVA15 if family == "llava" else fx.TINY_LLAVA_NEXT
         w_ref = fx.make_weights_llava(cfg, 0)
-    w_pol = fx.perturb_weights(w_ref, seed=1, scale=0.25)
+    w_pol = fx.perturb_weights(w_ref, seed=1, scale=perturb)
     bh = build_hf if family == "llava_ov" else build_hf_llava
     ref, pol = bh(cfg, w_ref).eval(), bh(cfg, w_pol).train()
     for p in ref.parameters():
@@ -218,8 +219,8 @@ def gen_sc_grpo(SCGRPOTrainer, reward, family="llava_ov"):
                 "vision_tower.vision_model.encoder.layers.1.layer_norm2.weight", "vision_tower.vision_model.embeddings.class_embedding",
                 "vision_tower.vision_model.pre_layrnorm.bias"] + (["image_newline"] if family == "llava_next" else [])
     grads = {inv[k]: p.grad for k, p in pol.named_parameters() if p.grad is not None and k in inv}
-    out = {"meta": json.dumps({**mg.meta(), "G": G, "C": C, "sizes": sizes, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows, "perturb_scale": 0.25, "crops": ncrops,
-                               "model_id": t.model_id}),
+    out = {"meta": json.dumps({**mg.meta(), "G": G, "C": C, "sizes": sizes, "n_text": 9, "seed": seed, "beta": 0.04, "eos_rows": eos_rows, "perturb_scale": perturb, "crops": ncrops,
+                               "model_id": t.model_id, "config": "fixture_util." + (cfg_name if family == "llava_ov" else "")}),
            "prompt_completion_ids": loc["prompt_completion_ids"].numpy(), "attention_mask": loc["attention_mask"].numpy(), "completion_mask": loc["completion_mask"].numpy(),
            "per_token_logps": loc["per_token_logps"].detach().numpy(), "ref_per_token_logps": loc["ref_per_token_logps"].numpy(), "rewards_per_func": loc["rewards_per_func"].numpy(),
            "advantages": loc["advantages"].numpy(), "loss": np.float64(loss.item()), "metric_kl": np.float64(t._metrics["kl"][0]),
@@ -227,7 +228,7 @@ def gen_sc_grpo(SCGRPOTrainer, reward, family="llava_ov"):
            "grad_norm_names": np.array(sorted(grads)), "grad_norms": np.array([float(grads[k].norm()) for k in sorted(grads)], dtype=np.float64)}
     for k in keep:
         out["grad::" + k] = grads[k].numpy()
-    fname = {"llava_ov": "sc_grpo_llava_ov.npz", "llava": "sc_grpo_llava15.npz", "llava_next": "sc_grpo_llava_next.npz"}[family]
+    fname = fname or {"llava_ov": "sc_grpo_llava_ov.npz", "llava": "sc_grpo_llava15.npz", "llava_next": "sc_grpo_llava_next.npz"}[family]
     np.savez_compressed(os.path.join(OUT, fname), **out)
     print(f"{fname}: loss={loss.item():.8f} kl={t._metrics['kl'][0]:.6f} len={t._metrics['completion_length'][0]}")
 
@@ -235,6 +236,10 @@ def gen_sc_grpo(SCGRPOTrainer, reward, family="llava_ov"):
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["ov7"]:       # only the config-5 head-geometry golden
+        reward, _, _, SCGRPOTrainer, _ = mg.import_reference()
+        gen_sc_grpo(SCGRPOTrainer, reward, "llava_ov", cfg_name="TINY_OV7", fname="sc_grpo_llava_ov_g7.npz", perturb=0.08)
+        sys.exit(0)
     gen_forward()
     gen_forward(fx.TINY_OV64, "llava_ov_hd64.npz")        # 64-wide decoder heads (LLaVA-OneVision-0.5B's Qwen2-0.5B structure)
     gen_forward_llava(fx.TINY_LLAVA15, "llava15.npz", [(56, 56), (56, 56)])
@@ -243,3 +248,4 @@ if __name__ == "__main__":
     gen_sc_grpo(SCGRPOTrainer, reward)
     gen_sc_grpo(SCGRPOTrainer, reward, "llava")
     gen_sc_grpo(SCGRPOTrainer, reward, "llava_next")
+    gen_sc_grpo(SCGRPOTrainer, reward, "llava_ov", cfg_name="TINY_OV7", fname="sc_grpo_llava_ov_g7.npz", perturb=0.08)
