@@ -1193,7 +1193,9 @@ def test_llava_onevision_sc_grpo_matches_reference_golden(golden_dir, share, gol
     assert abs(mt["kl"] - gk) <= 0.10 * gk and abs(mt["loss"] - gl) <= 0.04 * 0.10 * gk + 2e-6
     grads = pol.export_named(source="grad")
     for n, ref_norm in zip([str(n) for n in g["grad_norm_names"]], g["grad_norms"]):
-        if n == "language_model.lm_head.weight" or ref_norm < 1e-9:
+        # (a key bias shifts every score of a query by the same amount: its exact gradient is 0, the reference's value is fp32 rounding noise ~1e-9 and the bf16
+        # path's ~1e-4 -- norms below 1e-6 of the largest are not compared)
+        if n == "language_model.lm_head.weight" or ref_norm < 1e-6 * float(np.max(g["grad_norms"])):
             continue
         got = float(grads[n].norm())
         assert abs(got - ref_norm) <= 0.10 * ref_norm + 1e-7, (n, got, ref_norm)
