@@ -771,9 +771,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(DecodeArgs p, S
         b = gi * p.gseq + (mem - kvh * p.gseq);
     }
     const int group = p.Hq / p.Hkv;
-    // wave index as a scalar: the page loop and the block-table reads are then wave-uniform (s_load through the scalar cache instead of a vector load + vmcnt(0)
-    // in front of every page's K / V loads)
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, li = l & 15, g = l >> 4;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
     const long long sb = side_base(so);
     STAMP(0);
     const int n = p.ctx_len[b];
