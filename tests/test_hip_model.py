@@ -69,13 +69,14 @@ def test_forward_matches_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("name,mb", [("sc_grpo_g4.npz", 16), ("sc_grpo_g8.npz", 16), ("sc_grpo_g8.npz", 3), ("sc_grpo_g8_far.npz", 16), ("sc_grpo_trunc.npz", 16),
-                                     ("sc_grpo_7b_like.npz", 16), ("sc_grpo_7b_like.npz", 3)])
+                                     ("sc_grpo_7b_like.npz", 16), ("sc_grpo_7b_like.npz", 3), ("sc_grpo_qwen2vl.npz", 16), ("sc_grpo_qwen2vl.npz", 3)])
 def test_sc_grpo_step_matches_reference_golden(golden_dir, name, mb):
     """HIP engine vs the reference's own compute_loss (tests/golden/sc_grpo_*.npz).  g4 / g8: policy close to the frozen reference (KL ~ 3e-3,
     loss ~ 1e-4); g8_far: policy far from it (KL ~ 0.2, loss ~ 8e-3), where loss and KL tolerances are RELATIVE; trunc: the reference's left
     truncation of the prompt (max_prompt_length = P - 2, REF:630-634); 7b_like: the reference's compute_loss on TINY7 -- untied lm_head and 7 query heads
     per kv head, the structure of BASELINE config 4 (Qwen2.5-VL-7B, 28:4) and of config 5's decoder -- forward AND backward, in both layouts
-    (mb = 16: shared prefix, mb = 3: repeated rows, micro-batches cutting the group)."""
+    (mb = 16: shared prefix, mb = 3: repeated rows, micro-batches cutting the group); qwen2vl: the reference's compute_loss on TINY_Q2 (Qwen2-VL: LayerNorm /
+    QuickGELU vision tower without windows, the reference's SC_GRPO_Qwen_Instruct_2_VL.sh), incl. the gradients of its LayerNorm biases."""
     g = load(golden_dir, name)
     meta = json.loads(str(g["meta"]))
     G, C, seed = meta["G"], meta["C"], meta["seed"]

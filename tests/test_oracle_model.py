@@ -59,7 +59,7 @@ def test_forward_left_padded_batch(golden_dir):
     np.testing.assert_allclose(lp.numpy()[valid], g["per_token_logps"][valid], rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("name", ["sc_grpo_g4.npz", "sc_grpo_g8.npz", "sc_grpo_g8_far.npz", "sc_grpo_trunc.npz", "sc_grpo_7b_like.npz"])
+@pytest.mark.parametrize("name", ["sc_grpo_g4.npz", "sc_grpo_g8.npz", "sc_grpo_g8_far.npz", "sc_grpo_trunc.npz", "sc_grpo_7b_like.npz", "sc_grpo_qwen2vl.npz"])
 def test_sc_grpo_compute_loss(golden_dir, name):
     g = _load(golden_dir, name)
     meta = json.loads(str(g["meta"]))

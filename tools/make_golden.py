@@ -790,6 +790,11 @@ def main():
         gen_sc_grpo(SCGRPOTrainer, reward, G=8, C=12, eos_rows={1: 9, 4: 2, 6: 5}, name="sc_grpo_7b_like.npz", seed=25, perturb_scale=0.08, cfg=fx.TINY7, cfg_name="fixture_util.TINY7",
                     grad_full=["model.norm.weight", "model.layers.1.self_attn.k_proj.bias", "model.layers.1.self_attn.q_proj.bias", "model.layers.0.input_layernorm.weight",
                                "model.layers.0.self_attn.v_proj.weight", "visual.merger.ln_q.weight", "visual.blocks.1.norm2.weight", "visual.merger.mlp.2.bias"])
+    if not only or "grpo_q2" in only:
+        # the Qwen2-VL structure (LayerNorm / QuickGELU ViT without windows; the reference's SC_GRPO_Qwen_Instruct_2_VL.sh) through the reference's compute_loss
+        gen_sc_grpo(SCGRPOTrainer, reward, G=4, C=10, eos_rows={0: 7, 2: 3}, name="sc_grpo_qwen2vl.npz", seed=26, perturb_scale=0.25, cfg=fx.TINY_Q2, cfg_name="fixture_util.TINY_Q2",
+                    grad_full=["model.norm.weight", "model.layers.1.self_attn.k_proj.bias", "model.layers.0.input_layernorm.weight", "visual.merger.ln_q.weight",
+                               "visual.blocks.0.attn.qkv.bias", "visual.blocks.2.norm2.weight", "visual.blocks.1.norm1.bias", "visual.merger.mlp.2.bias"])
     if not only or "reward_model" in only:
         gen_reward_model(SCGRPOTrainer, reward)
     if not only or "logps" in only:
