@@ -612,8 +612,10 @@ def test_eval_harness_greedy_generator_matches_hf_generate(golden_dir):
     assert toks.tolist() == g["sequences"][:, P:].tolist()
 
 
-def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
-    """BASELINE-size widths (Qwen2.5-VL-3B hidden 2048 / 16:2 heads / MLP 11008 / vocab 151936 / ViT 1280, 448x448 image, P = 512) on a
+@pytest.mark.parametrize("model", ["3b", "7b"])
+def test_full_width_3b_shapes_shared_prefix_and_rollout_properties(model):
+    """BASELINE-size widths (Qwen2.5-VL-3B hidden 2048 / 16:2 heads / MLP 11008 / vocab 151936 / ViT 1280, 448x448 image, P = 512; "7b": Qwen2.5-VL-7B --
+    BASELINE config 4 -- hidden 3584 / 28:4 heads / MLP 18944 / untied 152064-token head, whose decode step runs the one-shot skinny kernels) on a
     depth-reduced model (2 decoder layers, 2 ViT blocks), random-init weights -- size-independent properties of the SC-GRPO step:
     (1) policy == reference  =>  KL is exactly 0 and the two log-prob tensors are bit-identical (same kernels, same inputs);
     (2) the shared-prefix layout and the reference's repeated-row layout give the same log-probs and gradients;
@@ -623,7 +625,7 @@ def test_full_width_3b_shapes_shared_prefix_and_rollout_properties():
     import sys
     sys.path.insert(0, sys_path_bench)
     import bench
-    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
+    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b() if model == "3b" else VLMConfig.qwen25vl_7b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
     pol = ParamStore(cfg, DEV, trainable=True)
     pol.init_random(seed=0)
     ref = ParamStore(cfg, DEV, trainable=False)
