@@ -834,6 +834,9 @@ def main():
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+                         "traffic_note": ("FETCH_SIZE / WRITE_SIZE are counted at the L2's fabric side: the 3.4x over the algorithmic bytes are operand-panel re-reads that miss the 4 MB L2 of an XCD "
+                                          "(64 resident 256x256 tiles arranged 4 x 16 reuse a panel 6.4x) and are served by the 256 MB memory-side cache -- A + B of this launch are 174 MB; "
+                                          "the kernel is MFMA / power bound (mfma_busy, power_limit), not traffic bound"),
                          "mfma_busy": mfma_busy,
                          "power_limit": {"source": "profiles/r02_gemm_power.txt (tools/gemm_power.py: rocm-smi during a 6 s back-to-back gemm_nt stream, separate run)",
                                          "sclk_mhz_under_gemm_stream": 1900, "sclk_mhz_idle": 2400, "socket_power_w": 1388,
