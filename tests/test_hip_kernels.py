@@ -645,6 +645,32 @@ def test_sampler_greedy_and_topk_topp(V):
     assert torch.equal(ops.sample(lg, 0.9, 50, 0.9, seed=0, step=3, seed_ptr=sd), ops.sample(lg, 0.9, 50, 0.9, seed=1234567890123, step=3))
 
 
+def test_sampler_against_transformers_warpers():
+    """sample.hip against the THIRD-PARTY golden of tools/make_golden_sampler.py (transformers' Temperature -> TopK -> TopP warpers on fixed logits;
+    the reference's vLLM SamplingParams(temperature, top_p=0.9, top_k=50), REF sc_grpo_trainer.py:353-358): every draw lies in the kept set, every
+    kept token with expected count >= 5 is drawn, and the empirical frequencies of 10 240 draws per row are within 3 sigma of the renormalised
+    probabilities (+ a chi-square bound on the whole row).  A wrong candidate set or a sampler drawing from the un-renormalised distribution fails."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_hf.npz"))
+    B, STEPS = 64, 160
+    N = B * STEPS
+    for i in range(len(g["vocab"])):
+        t, k, p = (float(z) for z in g["settings"][i])
+        V = int(g["vocab"][i])
+        lg = torch.from_numpy(g["logits"][i, :V]).to(DEV).repeat(B, 1).contiguous()
+        n = int(g["count"][i])
+        ids, pr = g["ids"][i, :n], g["probs"][i, :n].astype(np.float64)
+        draws = torch.stack([ops.sample(lg, t, int(k), p, seed=977 + i, step=s) for s in range(STEPS)]).flatten().cpu().numpy()
+        assert set(np.unique(draws).tolist()) <= set(ids.tolist()), f"row {i}: a draw outside transformers' kept set"
+        cnt = np.array([(draws == a).sum() for a in ids], dtype=np.float64)
+        sig = np.sqrt(N * pr * (1 - pr))
+        z = np.abs(cnt - N * pr) / np.maximum(sig, 1.0)
+        assert z.max() < 3.0 + 1.0 * (n > 20), f"row {i}: frequency off by {z.max():.2f} sigma (token {int(ids[int(z.argmax())])})"   # 3 sigma; 4 when > 20 tokens are tested at once
+        assert (cnt[N * pr >= 5] > 0).all(), f"row {i}: a kept token is never drawn"
+        if n > 1:
+            chi2 = float((((cnt - N * pr) ** 2) / (N * pr)).sum())
+            assert chi2 < (n - 1) + 4.5 * math.sqrt(2 * (n - 1)) + 4, f"row {i}: chi2 {chi2:.1f} for {n - 1} dof"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,I,K,keep", [(2048, 3072, 256, True), (2048, 3072, 256, False), (4096, 1664, 512, True), (768, 11008, 2048, True)])
 def test_gemm_swiglu_is_bit_identical_to_gemm_then_swiglu(M, I, K, keep):

@@ -428,3 +428,20 @@ def test_llava15_and_next_sc_grpo_compute_loss(golden_dir, family):
     for n, ref_norm in zip([str(n) for n in g["grad_norm_names"]], g["grad_norms"]):
         if ref_norm > 1e-9:
             assert abs(float(grads[n].grad.norm()) - ref_norm) <= 3e-3 * ref_norm + 1e-7, n
+
+
+def test_sampler_candidates_match_transformers_warpers(golden_dir):
+    """Third-party pin of the rollout sampler's filter (REF sc_grpo_trainer.py:353-358: temperature, top_k=50, top_p=0.9): the kept index set and
+    the renormalised probabilities of oracle.sampler.candidates against transformers' TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper
+    on fixed logits (tools/make_golden_sampler.py).  Sets bit-exact, probabilities to 2e-6 (fp32 softmax)."""
+    from oracle import sampler as osamp
+    g = np.load(os.path.join(golden_dir, "sampler_hf.npz"))
+    for i in range(len(g["vocab"])):
+        t, k, p = g["settings"][i]
+        lg = g["logits"][i, : int(g["vocab"][i])]
+        ids, w = osamp.candidates(lg, float(t), int(k), float(p))
+        n = int(g["count"][i])
+        want_ids, want_p = g["ids"][i, :n], g["probs"][i, :n]
+        assert set(ids.tolist()) == set(want_ids.tolist()), f"row {i}: candidate set differs from transformers'"
+        pr = dict(zip(ids.tolist(), (w / w.sum(dtype=np.float32)).tolist()))
+        assert max(abs(pr[int(a)] - float(b)) for a, b in zip(want_ids, want_p)) < 2e-6, f"row {i}"
