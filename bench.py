@@ -90,7 +90,7 @@ def parse():
     ap.add_argument("--no-repeated-rows-leg", action="store_true", help="skip the extra (untimed) step in the reference's repeated-prompt-rows layout")
     ap.add_argument("--workload", default="sc_grpo", choices=["sc_grpo", "pa_sft"], help="sc_grpo = the north-star SC-GRPO step (default); pa_sft = BASELINE config 2 (PA-SFT, bs 16, 448^2 image, 512 prompt + 256 supervised tokens)")
     ap.add_argument("--sft-batch", type=int, default=16)
-    ap.add_argument("--gradient-checkpointing", default="off", choices=["off", "auto", "on"], help="decoder activation recompute policy of the step (the reference scripts' "
+    ap.add_argument("--gradient-checkpointing", default=None, choices=["off", "auto", "on"], help="decoder activation recompute policy of the step (the reference scripts' "
                     "--gradient_checkpointing true = auto): lets e.g. --model 7b run one 64-sequence micro-batch")
     ap.add_argument("--ref-fp8", action="store_true", help="opt-in: the frozen reference's decoder Linears on the FP8 matrix instruction (BASELINE config 5 'fp8 MFMA weights'); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,6 +100,13 @@ def parse():
     ap.add_argument("--cpu-full-step", action="store_true", help="run the oracle's REAL B = 1 x G SC-GRPO step once at full 3B size on the host cores (about 6 minutes, "
                     "~130 GB of host memory; no GPU work) and print its JSON record -- the committed record is profiles/r03_cpu_full_step.json; the default run's cpu_baseline "
                     "stays the bounded component sample")
+    ap.add_argument("--launch-check", action="store_true", help="only the N-rank launch contract, no GPU work: respawn under torch.distributed.run when needed, assert WORLD_SIZE == --gpus, "
+                    "rendezvous over gloo on 127.0.0.1, max-reduce a per-rank value, ONE JSON line from rank 0 (what tests/test_ddp_gloo.py runs on CPU)")
+    ap.add_argument("--check", action="store_true", help="with --cpu-full-step: the full-size PARITY record instead of the timing record -- the same weights, prompt and completion "
+                    "tokens through SCGRPOEngine.loss_and_grads on cuda:0 and through the fp32 oracle on the host (plus the oracle in bf16 as the yardstick), at P / C / G of the "
+                    "headline, full depth; prints one JSON object (committed: profiles/r04_full_size_parity.json)")
+    ap.add_argument("--check-noise", type=float, default=0.02, help="--check: element-wise relative noise policy = reference x (1 + noise)")
+    ap.add_argument("--check-greedy-tokens", type=int, default=24, help="--check: greedy tokens compared between the hipGraph rollout and the oracle's KV-cached decode")
     return ap.parse_args()
 
 
@@ -434,6 +441,137 @@ def cpu_full_step(cfg_dict_3b, P=512, C=256, G=8):
                        f"reference + policy forward on [{G}, {P + C}] rows (all-position logits, ViT per row as REF:505,625-628), backward, AdamW; {cores} threads")}
 
 
+def full_size_parity(a):
+    """`--cpu-full-step --check`: parity AT THE HEADLINE'S SHAPE (VERDICT r3 "missing" #2).  One prompt (448 x 448 image = 256 image tokens, P positions) x G
+    completions of C tokens through the UNREDUCED Qwen2.5-VL-3B (36 + 32 layers, 151 936-token head): `SCGRPOEngine.loss_and_grads` on cuda:0 (shared-prefix layout,
+    the kernels of the measured step) against `oracle.sc_grpo.sc_grpo_step` in fp32 on the host on the SAME weights / prompt / completion tokens / rewards
+    (REF sc_grpo_trainer.py:586-819), and against the same oracle in bf16 -- the precision `--bf16` gives the reference -- as the yardstick.
+    Weights: ParamStore.init_random(seed 0) with the embedding x 2 (logit std ~ 1.8), policy = reference x (1 + noise) element-wise.  Completions: the engine's own
+    SAMPLED rollout (temperature 0.9 / top-k 50 / top-p 0.9: eight different rows; a greedy rollout of one prompt gives G identical rows), one row cut by an EOS.
+    Also recorded: greedy token ids of the hipGraph rollout against the oracle's KV-cached greedy decode for the first tokens, with the oracle's top-2 logit gap at
+    the first disagreement (random-init logits are nearly flat; the bit-exact greedy check against HF lives in tests/ on fixtures with real structure)."""
+    import resource
+    from oracle import qwen25vl as oq
+    from oracle import sc_grpo as og
+    from iadr1_amd.params import ParamStore, VLMConfig
+    from iadr1_amd.sc_grpo import GRPOArgs, SCGRPOEngine
+    P, C, G = a.prompt_len, a.gen_len, a.group
+    dev = "cuda:0"
+    cores = int(os.environ.get("IADR1_CPU_THREADS", min(os.cpu_count() or 1, 32)))
+    torch.set_num_threads(cores)
+    cfg = VLMConfig.qwen25vl_3b()
+    d3 = json.loads(json.dumps(D3))
+    d3.update(image_token_id=cfg.image_token_id, video_token_id=151656, vision_start_token_id=cfg.vision_start_token_id, vision_end_token_id=cfg.vision_end_token_id,
+              eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id, tie_word_embeddings=True)
+    T = {"t0": time.time()}
+    pol, ref = ParamStore(cfg, dev, trainable=True), ParamStore(cfg, dev, trainable=False)
+    ref.init_random(seed=0)
+    ref.w("embed").mul_(2.0)
+    ref.finalize()
+    pol.flat.copy_(ref.flat)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    for lo in range(0, pol.flat.numel(), 1 << 28):
+        v = pol.flat[lo: lo + (1 << 28)]
+        v.copy_((v.float() * (1.0 + a.check_noise * torch.randn(v.shape, generator=gen, device=dev))).to(torch.bfloat16))
+    pol.finalize()
+    grid = (1, 32, 32)
+    rs = np.random.RandomState(1234)
+    n_text = P - (3 + 1 + 256 + 1)
+    row = rs.randint(1000, 150000, 3).tolist() + [cfg.vision_start_token_id] + [cfg.image_token_id] * 256 + [cfg.vision_end_token_id] + rs.randint(1000, 150000, n_text).tolist()
+    ids, mask = np.array([row], dtype=np.int64), np.ones((1, P), dtype=np.int64)
+    px = rs.standard_normal((1024, cfg.patch_dim)).astype(np.float32)
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": torch.from_numpy(px), "image_grid_thw": [grid]}
+    eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=G, seed=11))
+    n_greedy = max(0, min(a.check_greedy_tokens, C))
+    toks_greedy = eng.rollout(batch, greedy=True)[0, :n_greedy].tolist() if n_greedy else []
+    comps = eng.rollout(batch, greedy=False)
+    comps = [r.tolist() for r in comps]
+    comps[3] = comps[3][: C // 3] + [cfg.eos_token_id]                       # one completion ends early: the EOS mask and the ragged rows are part of the check
+    wrapped = [[{"role": "assistant", "content": CANNED[i % len(CANNED)]}] for i in range(G)]
+    from iadr1_amd import rewards as rw
+    rew = np.stack([rw.accuracy_reward(wrapped, [SOLUTION] * G), rw.consistency_reward(wrapped, [SOLUTION] * G)], 1).astype(np.float32)
+    out = eng.loss_and_grads(batch, comps, rew)
+    torch.cuda.synchronize()
+    T["hip"] = time.time()
+    names = ["model.norm.weight", "model.layers.35.post_attention_layernorm.weight", "model.layers.17.self_attn.k_proj.bias", "model.layers.0.input_layernorm.weight",
+             "visual.merger.ln_q.weight", "visual.blocks.0.norm1.weight"]
+    grads = pol.export_named(source="grad")
+    grads = {n: grads[n].numpy().reshape(-1).astype(np.float64) for n in names}
+    hip_lp, hip_lr, hip_cm, mt = out["logps"].cpu().numpy(), out["ref_logps"].cpu().numpy(), np.asarray(out["completion_mask"]), dict(out["metrics"])
+    w_pol, w_ref = pol.export_named(), ref.export_named()
+    del eng, out, pol, ref
+    torch.cuda.empty_cache()
+    T["export"] = time.time()
+    o_pol = oq.Qwen25VLOracle(d3, w_pol, requires_grad=set(names), copy=False)
+    o_ref = oq.Qwen25VLOracle(d3, w_ref, copy=False)
+    # greedy ids: the oracle's KV-cached decode on the policy weights
+    greedy = {"tokens_compared": 0}
+    if n_greedy:
+        with torch.no_grad():
+            lg, st = o_pol.prefill_cached(torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(px), [grid])
+            want_tok, gaps = [], []
+            for it in range(n_greedy):
+                top2 = torch.topk(lg[0], 2)
+                want_tok.append(int(top2.indices[0]))
+                gaps.append(float(top2.values[0] - top2.values[1]))
+                if it + 1 < n_greedy:
+                    lg = o_pol.decode_step_cached(torch.tensor([toks_greedy[it]]), st)     # teacher-forced with the HIP token: every position is compared on the same prefix
+            del st
+        agree = [int(x == y) for x, y in zip(toks_greedy, want_tok)]
+        first_bad = agree.index(0) if 0 in agree else -1
+        greedy = {"tokens_compared": n_greedy, "agree": int(sum(agree)), "first_disagreement": first_bad,
+                  "oracle_top2_logit_gap_at_disagreements": [round(g_, 5) for g_, ok in zip(gaps, agree) if not ok], "median_top2_gap": float(np.median(gaps)),
+                  "note": "teacher-forced on the HIP tokens; a disagreement with a top-2 gap below the bf16 logit error (~0.05 at logit std 1.8) is a near-tie, not an error"}
+    T["greedy"] = time.time()
+    want = og.sc_grpo_step(o_pol, o_ref, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(px), [grid], comps, torch.from_numpy(rew), G, 0.04,
+                           cfg.eos_token_id, cfg.pad_token_id)
+    T["oracle_fwd"] = time.time()
+    want["loss"].backward()
+    T["oracle_bwd"] = time.time()
+    m = want["completion_mask"].bool().numpy()
+    assert np.array_equal(hip_cm.astype(bool), m), "completion masks differ"
+    w_lp, w_lr = want["logps"].detach().numpy(), want["ref_logps"].numpy()
+    # the reference's precision: the same oracle in bf16 (log-softmax in fp32 as REF:509)
+    bf = None
+    try:
+        ids_t = torch.cat([torch.from_numpy(ids).repeat(G, 1), og.right_pad(comps, cfg.pad_token_id)], 1)
+        mask_t = torch.cat([torch.from_numpy(mask).repeat(G, 1), want["completion_mask"].long()], 1)
+        with torch.no_grad():
+            lps = []
+            for o in (o_pol, o_ref):
+                o16 = oq.Qwen25VLOracle(d3, {k: t.detach() for k, t in o.w.items() if k != "lm_head.weight"}, dtype=torch.bfloat16)
+                lps.append(o16.per_token_logps(ids_t, mask_t, torch.from_numpy(px).repeat(G, 1), [grid] * G)[:, P - 1:].float().numpy())
+                del o16
+        kl16 = float(og.grpo_loss(torch.from_numpy(lps[0]), torch.from_numpy(lps[1]), want["advantages"], want["completion_mask"].float(), 0.04)[2])
+        bf = {"dlogp_policy_max": float(np.abs(lps[0][m] - w_lp[m]).max()), "dlogp_policy_mean": float(np.abs(lps[0][m] - w_lp[m]).mean()),
+              "dlogp_ref_max": float(np.abs(lps[1][m] - w_lr[m]).max()), "dlogp_ref_mean": float(np.abs(lps[1][m] - w_lr[m]).mean()), "kl": kl16}
+    except Exception as ex:      # the yardstick is optional: a host without a usable bf16 GEMM must not lose the record
+        bf = {"error": repr(ex)}
+    T["bf16"] = time.time()
+    wl, wk = float(want["loss"].detach()), float(want["metrics"]["kl"])
+    cos = {}
+    for n in names:
+        x, y = grads[n], o_pol.w[n].grad.numpy().reshape(-1).astype(np.float64)
+        cos[n] = {"cosine": float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30)), "norm_ratio": float(np.linalg.norm(x) / (np.linalg.norm(y) + 1e-30))}
+    e_p, e_r = hip_lp[m] - w_lp[m], hip_lr[m] - w_lr[m]
+    rec = {"shape": {"model": "Qwen2.5-VL-3B, unreduced (36 decoder layers, 32 ViT blocks, vocab 151936)", "prompts": 1, "G": G, "P": P, "C": C, "scored_tokens": int(m.sum()),
+                     "policy": f"reference x (1 + {a.check_noise} N(0,1)) element-wise", "completions": "sampled by the engine's hipGraph rollout (T 0.9, top-k 50, top-p 0.9), row 3 cut by EOS"},
+           "hip_vs_fp32_oracle": {"dlogp_policy_max": float(np.abs(e_p).max()), "dlogp_policy_mean": float(np.abs(e_p).mean()), "dlogp_ref_max": float(np.abs(e_r).max()),
+                                  "dlogp_ref_mean": float(np.abs(e_r).mean()), "err_of_ref_minus_policy_std": float(np.std(e_r - e_p)),
+                                  "logp_range": [float(w_lp[m].min()), float(w_lp[m].max())],
+                                  "kl_hip": mt["kl"], "kl_oracle": wk, "kl_rel_err": abs(mt["kl"] - wk) / max(wk, 1e-30), "loss_hip": mt["loss"], "loss_oracle": wl, "loss_abs_err": abs(mt["loss"] - wl),
+                                  "metrics_hip": {k: float(v) for k, v in mt.items() if isinstance(v, (int, float))},
+                                  "metrics_oracle": {k: float(v) for k, v in want["metrics"].items() if isinstance(v, (int, float))},
+                                  "gradients": cos},
+           "bf16_oracle_vs_fp32_oracle": bf, "greedy_ids": greedy,
+           "seconds": {"hip_rollouts_and_step": round(T["hip"] - T["t0"], 1), "export": round(T["export"] - T["hip"], 1), "oracle_greedy": round(T["greedy"] - T["export"], 1),
+                       "oracle_fp32_forward": round(T["oracle_fwd"] - T["greedy"], 1), "oracle_fp32_backward": round(T["oracle_bwd"] - T["oracle_fwd"], 1), "oracle_bf16": round(T["bf16"] - T["oracle_bwd"], 1)},
+           "host": {"threads": cores, "peak_rss_GB": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20}, "device": torch.cuda.get_device_name(0)}
+    if bf and "kl" in bf:
+        rec["bf16_oracle_vs_fp32_oracle"]["kl_rel_err"] = abs(bf["kl"] - wk) / max(wk, 1e-30)
+    return rec
+
+
 def run_pa_sft(a, cfg, dev, rank, world):
     """BASELINE.json config 2: one PA-SFT optimizer step = forward(labels) + backward + AdamW on `--sft-batch` sequences of
     [448^2 image + prompt (512 positions) | 256 supervised response tokens] (llamafactory supervised masking: prompt labels -100)."""
@@ -621,6 +759,11 @@ D3 = {"text": {"vocab_size": 151936, "hidden_size": 2048, "intermediate_size": 1
 
 def main():
     a = parse()
+    if a.cpu_full_step and a.check:      # the full-size parity record: HIP engine on cuda:0 against the oracle on the host cores
+        import iadr1_amd  # noqa: F401
+        rec = full_size_parity(a)
+        print(json.dumps({"full_size_parity": rec}), flush=True)
+        return
     if a.cpu_full_step:      # host cores only: the oracle's real step, once
         import iadr1_amd  # noqa: F401
         print(json.dumps({"cpu_full_step": cpu_full_step(D3, P=a.prompt_len, C=a.gen_len, G=a.group)}), flush=True)
@@ -632,12 +775,35 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus} launched with WORLD_SIZE={world}: the two must agree (one rank per GPU)")
+    if a.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == world == a.gpus and dist.get_rank() == rank
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the max-over-ranks step of the timing contract
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local))
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": a.gpus, "world_size": world, "max_over_ranks": float(t), "ranks_seen": sorted(r for r, _ in seen),
+                              "local_ranks": sorted(l for _, l in seen), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+        return
+    # IADR1_BENCH_SHARE_GPU=1 + IADR1_BENCH_BACKEND=gloo: every rank on cuda:0 with the exchange over gloo -- how the N > 1 path of this file runs end to end on a
+    # ONE-GPU box (tests/test_hip_model.py); RCCL refuses two ranks on one device.  Never the measured configuration.
+    share_gpu = os.environ.get("IADR1_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("IADR1_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rccl_ranks = 1
     if world > 1 or os.environ.get("IADR1_FORCE_REDUCE"):   # IADR1_FORCE_REDUCE=1 under torchrun --nproc-per-node 1: the RCCL exchange path on one GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         rccl_ranks = dist.get_world_size()
         assert rccl_ranks == world
     if a.decode_weights == "fp8":
@@ -697,6 +863,10 @@ def main():
                        train_dataset=None, processing_class=SynthProcessor(batches, CANNED))
     eng = tr.engine
     eng.args.suppress_eos = True            # fixed-length completions, every sequence generates gen_len tokens
+    if a.gradient_checkpointing is None:
+        # one GPU, no process group: "off" (the headline keeps its activations).  Under a process group: "auto" -- the static budget of
+        # Engine.recompute_wanted then reserves RCCL's buffers, so the 7B-class configurations recompute instead of sitting at 255 of 288 GB
+        a.gradient_checkpointing = "auto" if rccl_ranks > 1 or os.environ.get("IADR1_FORCE_REDUCE") else "off"
     eng.args.recompute = a.gradient_checkpointing
     if a.ref_fp8:
         eng.args.ref_fp8 = True
@@ -749,6 +919,7 @@ def main():
     traced = bool(getattr(eng, "last_step_traced", False))      # read now: the extra (untimed) leg below runs the other layout
     dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
     per_rank_ms = [dt / a.steps * 1e3]
+    exposed_ms = eng.reducer.exposed_ms() if eng.reducer.active else None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -819,8 +990,10 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{model_name} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {image_note}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
-                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "reference_forward": "fp8 mfma linears" if a.ref_fp8 else "bf16", "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
-                       "grad_exchange": ({"wire": eng.reducer.wire, "bytes_per_step": getattr(eng.reducer, "last_bytes_on_wire", 0), "buckets_per_step": getattr(eng.reducer, "last_n_buckets", 0)}
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "reference_forward": "fp8 mfma linears" if a.ref_fp8 else "bf16", "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks, "collective_backend": backend if (world > 1 or os.environ.get("IADR1_FORCE_REDUCE")) else None,
+                       "grad_exchange": ({"wire": eng.reducer.wire, "bytes_on_wire": getattr(eng.reducer, "last_bytes_on_wire", 0), "n_buckets": getattr(eng.reducer, "last_n_buckets", 0),
+                                          "exposed_ms": exposed_ms, "exposed_note": "GPU time the compute stream waited in GradReducer.finish() for the exchange after backward ended (last timed step, this rank): what did not hide under backward",
+                                          "staging_bytes": eng.reducer.staging_bytes()}
                                          if eng.reducer.active else None),
                        "dedup": ("ViT once per image; prompt tokens once per group in the ref / policy passes (shared-prefix attention: identical math to the "
                                  "reference's G repeated rows, parity-tested); the rollout's prefill is the prompt part of the policy's training forward"

@@ -185,6 +185,15 @@ class GreedyGenerator:
         return r.generate(plan, img, 1, self.max_new, temperature=0.0, top_k=1, top_p=1.0, seed=0).cpu().numpy()
 
 
+def encode_prompts(processor, prompts, images, family: str):
+    """Prompt TEXT -> ids the way the reference's evaluation scripts get them: they hand the rendered prompt string to vLLM's `llm.generate`
+    (vLLM_LLaVA_detect_format.py:330-340, vLLM_LLaVA_1_5_detect_format.py, vLLM_Qwen_detect_format.py:340-352), whose tokenizer call is `encode(prompt)` with
+    the tokenizer's DEFAULT `add_special_tokens=True`.  For the Llama / Vicuna / Mistral tokenizers of LLaVA-1.5 / 1.6 that prepends `<s>` (the llava-hf chat
+    templates emit no BOS themselves); the Qwen2 tokenizers of Qwen2(.5)-VL and LLaVA-OneVision define no BOS, so the flag changes nothing there.
+    (The TRAINING path is different on purpose: REF sc_grpo_trainer.py:615 passes `add_special_tokens=False`; trainer.prepare_batch keeps that.)"""
+    return processor(text=prompts, images=images, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=(family != "qwen"))
+
+
 def evaluate_dataset(generator: GreedyGenerator, processor, data_root: str, chat_ad: dict, few_shot_model: int = 0, batch_size: int = 4,
                      similar_template: bool = False, answers_json_path: str | None = None, existing: list | None = None, family: str = "qwen") -> list:
     """The reference's evaluation loop (vLLM_Qwen_detect_format.py:283-380, vLLM_LLaVA_detect_format.py:300-367, vLLM_LLaVA_1_5_detect_format.py): first
@@ -211,7 +220,7 @@ def evaluate_dataset(generator: GreedyGenerator, processor, data_root: str, chat
             metas.append((key, qs[0:1], ans[0:1], text_gt))
         if not prompts:
             continue
-        enc = processor(text=prompts, images=images, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
+        enc = encode_prompts(processor, prompts, images, family)
         batch = {"input_ids": enc["input_ids"].numpy(), "attention_mask": enc["attention_mask"].numpy(), "pixel_values": enc["pixel_values"], "images_per_prompt": per}
         if "image_sizes" in enc:            # LLaVA-OneVision / LLaVA-NeXT processors (trainer.prepare_batch reads the same keys)
             batch["image_sizes"] = np.asarray(enc["image_sizes"]).reshape(-1, 2).tolist()

@@ -484,6 +484,15 @@ class ParamStore:
                 o += _rup(k, 64)
             self._pkb = {f"layers.{i}.qkv.w": torch.zeros(c.qkv_width, dtype=BF16, device=self.device) for i in range(c.num_hidden_layers)}
 
+    def resident_bytes(self) -> int:
+        """Bytes this store keeps in HBM for its whole life: bf16 parameters, transposed and decode-packed shadows, fp32 master / Adam moments / gradient."""
+        n = 0
+        for name in ("flat", "flat_t", "master", "m", "v", "grad", "flat_pk", "flat_pk8"):
+            t = getattr(self, name, None)
+            if t is not None:
+                n += t.numel() * t.element_size()
+        return n
+
     # ---- views -------------------------------------------------------------------------------------------
     def w(self, name: str) -> torch.Tensor:
         v = self._views.get(name)

@@ -47,4 +47,4 @@ class BatchPrefetcher:
         return batch
 
     def shutdown(self):
-        self._pool.shutdown(wait=True)
+        self._pool.shutdown(wait=True, cancel_futures=True)

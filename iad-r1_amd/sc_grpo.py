@@ -170,6 +170,14 @@ class GradReducer:
         self.first_layer_off = s["layers.0.qkv.w"].offset
         self.reset()
 
+    def exposed_ms(self) -> float | None:
+        """Milliseconds of the LAST finish() that the compute stream waited for the exchange (synchronises on the second event); None without an exchange."""
+        ev = self.__dict__.get("_exposed_events")
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return float(ev[0].elapsed_time(ev[1]))
+
     def staging_bytes(self) -> int:
         """Device memory the exchange adds to the training state."""
         return 0 if self.ring is None else sum(r.numel() * r.element_size() for r in self.ring)
@@ -239,7 +247,13 @@ class GradReducer:
                 self.layer_ready(i)
 
     def finish(self):
-        """Reduce whatever has not been sent yet (vision tower, embedding, lm_head, norm gains / biases) and join."""
+        """Reduce whatever has not been sent yet (vision tower, embedding, lm_head, norm gains / biases) and join.
+        `exposed_ms()` afterwards: GPU time the compute stream spent waiting here for the exchange -- the part of the collective that did NOT hide under backward
+        (two events on the compute stream: at entry = end of backward in stream order, and behind the join)."""
+        ev = None
+        if self.stream is not None and self.active:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self.all_layers_ready()
         covered = sorted(self.done)
         cur = 0
@@ -250,6 +264,9 @@ class GradReducer:
         self._reduce(0, 0, drain=True)      # the buckets still in the ring: wait + cast back
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        if ev is not None:
+            ev[1].record()
+            self._exposed_events = ev
         self.last_bytes_on_wire, self.last_n_buckets = self.bytes_on_wire, self.n_buckets
         self.bytes_on_wire = self.n_buckets = 0
         self.reset()
@@ -271,6 +288,7 @@ class SCGRPOEngine:
             self.ref.enable_fp8_linears()
         self.dev = policy.device
         self.reducer = GradReducer(policy, group)
+        self.pol.resident_extra = ref.resident_bytes() + self.reducer.staging_bytes()       # static inputs of Engine.recompute_wanted("auto")
         self.opt_step = 0
         self.accum = 0
         self._rollout = None

@@ -14,6 +14,7 @@ from __future__ import annotations
 import json
 import math
 import os
+import threading
 import time
 from collections import defaultdict
 from dataclasses import dataclass, field
@@ -348,7 +349,8 @@ class SCGRPOTrainer:
             beta=args.beta, temperature=args.temperature, learning_rate=args.learning_rate, weight_decay=args.weight_decay,
             adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
             gradient_accumulation_steps=args.gradient_accumulation_steps, micro_batch_seqs=args.micro_batch_seqs, seed=args.seed,
-            recompute="auto" if args.gradient_checkpointing else "off", ref_fp8=args.ref_fp8), group=group)
+            # under data parallelism the policy is "auto" even without the flag: it recomputes only where the static budget (which then reserves RCCL's buffers) is tight
+            recompute="auto" if (args.gradient_checkpointing or group is not None) else "off", ref_fp8=args.ref_fp8), group=group)
         self.state = type("State", (), {"global_step": 0})()
         self._metrics = defaultdict(list)
         self.log_history = []
@@ -361,13 +363,35 @@ class SCGRPOTrainer:
     def prefetch(self, micro_batches: list[list[dict]]) -> list:
         """Start the host preparation (REF:600-625) of the given micro-batches on the worker thread; hand the result to training_step(prepared=...)."""
         if self._prefetcher is None:
+            import copy
             from .prefetch import BatchPrefetcher
-            self._prefetcher = BatchPrefetcher(self._prepare, self.device)
+            # the worker thread gets its OWN copy of the processor: HF fast tokenizers are not thread-safe (a padding=True call on one thread while the main
+            # thread runs batch_decode can raise "Already borrowed"); a processor that cannot be copied is shared behind a lock the decode side takes too
+            try:
+                pc = copy.deepcopy(self.processing_class)
+                prep = lambda inputs: prepare_batch(pc, inputs)
+            except Exception:
+                prep = lambda inputs: self._locked(self._prepare, inputs)
+                self._pc_lock = threading.Lock()
+            self._prefetcher = BatchPrefetcher(prep, self.device)
         return [self._prefetcher.submit(inputs) for inputs in micro_batches]
+
+    def _locked(self, fn, *a):
+        lock = self.__dict__.get("_pc_lock")
+        if lock is None:
+            return fn(*a)
+        with lock:
+            return fn(*a)
+
+    def close(self):
+        """Stop the prefetch worker (queued preparations are dropped)."""
+        if self._prefetcher is not None:
+            self._prefetcher.shutdown()
+            self._prefetcher = None
 
     def _rewards(self, inputs, completion_ids: np.ndarray):
         G = self.args.num_generations
-        texts = self.processing_class.batch_decode(completion_ids, skip_special_tokens=True)
+        texts = self._locked(self.processing_class.batch_decode, completion_ids, True) if self.__dict__.get("_pc_lock") else self.processing_class.batch_decode(completion_ids, skip_special_tokens=True)
         conversational = isinstance(inputs[0]["prompt"], list)
         completions = [[{"role": "assistant", "content": t}] for t in texts] if conversational else texts
         prompts = [ex["prompt"] for ex in inputs for _ in range(G)]
@@ -459,12 +483,19 @@ class SCGRPOTrainer:
         sampler = schedule.RankSampler(len(rows), rank, world, seed=a.seed, shuffle=a.shuffle)
         t0 = time.time()
         steps_per_epoch = max(1, schedule.total_steps(len(rows), world, bs, ga, 1.0, -1))
-        window_loss, window_from = 0.0, start
 
         def micro_rows(step):      # the rows of optimizer step `step`: a function of the step number alone (the sampler order is fixed up front)
             base = step * bs * ga
             return [[rows[sampler.index(base + k * bs + j)] for j in range(bs)] for k in range(ga)]
 
+        try:
+            return self._train_loop(start, total, micro_rows, steps_per_epoch, rank, t0)
+        finally:
+            self.close()        # also after an exception: no queued preparation keeps running behind a dead training loop
+
+    def _train_loop(self, start, total, micro_rows, steps_per_epoch, rank, t0):
+        a = self.args
+        window_loss, window_from = 0.0, start
         nxt = self.prefetch(micro_rows(start)) if (a.prefetch_batches and start < total) else None
         for step in range(start, total):
             self.engine.args.learning_rate = self._lr(step, total)

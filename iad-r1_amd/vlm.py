@@ -131,6 +131,16 @@ class Engine:
             self._ws[key] = t
         return t
 
+    def _workspace_rows(self, key, lead, T, width, dtype):
+        """Grow-only scratch [*lead, cap >= T, width] sliced to T rows: token counts vary from micro-batch to micro-batch (image sizes, prompt lengths), and
+        `_workspace` would free + re-malloc a multi-GB block on every change of shape (ckpt_x_in is ~4 GB at 7B)."""
+        t = self._ws.get(key)
+        if t is None or t.shape[:-2] != tuple(lead) or t.shape[-2] < T or t.shape[-1] != width or t.dtype != dtype:
+            self._ws[key] = t = None        # release before growing
+            t = torch.empty((*lead, T, width), dtype=dtype, device=self.dev)
+            self._ws[key] = t
+        return t[..., :T, :]
+
     # ========================================================================================================
     # plans
     # ========================================================================================================
@@ -763,19 +773,39 @@ class Engine:
 
     def recompute_wanted(self, T: int, mode: str) -> bool:
         """`--gradient_checkpointing` (every reference launch script passes it, REF scripts/train/SC_GRPO/*.sh:56) as a POLICY on a 288 GB part: "off" never
-        recomputes; "on" always; "auto" (what the flag selects) recomputes only when the saved activations of the micro-batch would not fit comfortably --
-        more than 60 % of the HBM that is free once the parameters / optimizer state are resident (3B at 20 480 token rows: 71 GB of 190 free -> kept, and
-        the rollout goes on doubling as the policy forward; 7B at 20 480 rows: 91 GB of ~110 free -> one decoder layer is recomputed at a time in backward)."""
+        recomputes; "on" always; "auto" (what the flag selects) recomputes only when the saved activations of the micro-batch would not fit comfortably.
+        The decision is STATIC (it used to read the allocator's free memory at call time, so kernels and numerics could differ between ranks, steps
+        and runs): the arena of the token-row bucket (T rounded up to 2048 rows) against 60 % of
+            total HBM - resident parameter / optimizer bytes of this store - `resident_extra` (the frozen reference, the gradient-exchange staging ring:
+            set by the owner of the engine) - a fixed reserve (12 GB: KV pool, workspaces, allocator slack; + 40 GB when a process group exists: RCCL's
+            channel buffers and the headroom the first multi-rank run should not have to discover),
+        cached per (bucket, mode) and logged once.  3B at 20 480 rows: 71 GB against 0.6 x 186 -> kept, the rollout goes on doubling as the policy forward;
+        7B at 20 480 rows: 91 GB against 0.6 x 96 -> one decoder layer is recomputed at a time in backward; 7B under DDP at 10 240 rows: 45 GB against
+        0.6 x 56 -> recomputed (<= 235 GB reserved instead of 255).  Every rank computes the same answer from the same sizes."""
         if mode == "on" or os.environ.get("IADR1_RECOMPUTE") == "1":
             return True
         if mode != "auto" or os.environ.get("IADR1_RECOMPUTE") == "0":
             return False
-        cur = self._ws.get("act_save")
-        if cur is not None and cur["T"] >= T:
-            return False                       # the arena exists already: nothing to save by recomputing
-        free, _ = torch.cuda.mem_get_info(self.dev)
-        reusable = torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)      # cached by the allocator, available to a new request
-        return self.saved_activation_bytes(T) > 0.6 * (free + reusable)
+        bucket = (int(T) + 2047) // 2048 * 2048
+        cache = self.__dict__.setdefault("_recompute_decisions", {})
+        if bucket not in cache:
+            total = torch.cuda.get_device_properties(self.dev).total_memory
+            ddp = False
+            try:
+                import torch.distributed as dist
+                ddp = dist.is_available() and dist.is_initialized()
+            except Exception:
+                pass
+            reserve = (12 << 30) + ((40 << 30) if ddp else 0)
+            budget = total - self.p.resident_bytes() - int(self.__dict__.get("resident_extra", 0)) - reserve
+            need = self.saved_activation_bytes(bucket)
+            cache[bucket] = need > 0.6 * budget
+            if os.environ.get("IADR1_QUIET") != "1":
+                print(f"[iadr1] gradient checkpointing (auto): {bucket} token rows need {need / 2**30:.1f} GiB of saved activations, budget 0.6 x {budget / 2**30:.1f} GiB "
+                      f"-> {'recompute one decoder layer at a time' if cache[bucket] else 'keep'}", flush=True)
+        if cache[bucket]:
+            self._ws.pop("act_save", None)          # a stale arena of an earlier (smaller) bucket must not sit next to the checkpoint buffers
+        return cache[bucket]
 
     def _recompute_layer(self, i, ctx):
         """Gradient checkpointing: the activations of decoder layer i, rebuilt from its checkpointed input rows with the forward's own kernels (bit-identical to
@@ -815,7 +845,7 @@ class Engine:
             o.zero_()
         ops.hip.call("attn_fwd", qkv[:, :qw], qkv[:, qw: qw + kw], qkv[:, qw + kw:], o, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
                      plan.seg.n_head, plan.seg.max_tail, T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, c.attn_scale)
-        ab = ops.gemm_nt(o, P.w(b + "o.w"), out=self._workspace("rc_ab", (T, H), BF16))
+        ab = ops.gemm_nt(o, P.w(b + "o.w"), out=self._workspace_rows("rc_ab", (), T, H, BF16))
         ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, T, H, H, H, H, eps, None)
         gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=S["gu"][:T], a_out=S["a"][:T], keep_gu=True)
         return (x_in, rstd1, h1, qkv, o, lse, x_mid, rstd2, h2, gu, a), (ring, k)
@@ -841,7 +871,7 @@ class Engine:
         part = rows is not None
         recompute = bool(recompute and save and not part)
         keep = save and not recompute          # per-layer arena slabs; otherwise one scratch slab reused by every layer
-        CK = self._workspace("ckpt_x_in", (c.num_hidden_layers, Tl, H), BF16) if recompute else None
+        CK = self._workspace_rows("ckpt_x_in", (c.num_hidden_layers,), Tl, H, BF16) if recompute else None
         if part and "x0" not in carry:
             # persistent like the activation arena: the decode graph may hold these pointers (rollout side outputs)
             cb = self._ws.get("carry")

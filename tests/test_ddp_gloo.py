@@ -173,3 +173,24 @@ def test_lr_schedules_follow_the_hf_lambdas():
     assert schedule.lr_at(3, 10, 2.0, 4, "constant_with_warmup") == 1.5 and schedule.lr_at(7, 10, 2.0, 4, "constant") == 2.0
     with pytest.raises(ValueError):
         schedule.lr_at(0, 10, 1.0, 0, "polynomial")
+
+
+def test_bench_multi_rank_launch_contract():
+    """`python bench.py --gpus 2` without a torchrun environment re-executes itself as two ranks (127.0.0.1 rendezvous), every rank asserts WORLD_SIZE == --gpus,
+    the per-rank values are max-reduced and ONLY rank 0 prints ONE JSON line -- the launch half of the bench contract, on CPU over gloo (`--launch-check`: no GPU
+    work; the full N > 1 step runs in tests/test_hip_model.py::test_bench_two_ranks_on_one_gpu).  A WORLD_SIZE that disagrees with --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == rec["world_size"] == 2 and rec["ranks_seen"] == [0, 1] and rec["local_ranks"] == [0, 1] and rec["max_over_ranks"] == 2.0
+    assert rec["master"].startswith("127.0.0.1:")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)

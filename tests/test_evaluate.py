@@ -3,6 +3,9 @@ import io
 import json
 import os
 
+import numpy as np
+import pytest
+
 import iadr1_amd  # noqa: F401
 from iadr1_amd import evaluate
 
@@ -49,3 +52,27 @@ def test_prompt_structure():
     kinds = [p["type"] for p in m[0]["content"]]
     assert kinds == ["text", "image", "image", "text", "image", "text"] and m[0]["content"][-1]["text"] == "Are there any defects in the test image?"
     assert [p["type"] for p in evaluate.build_messages(0)[0]["content"]] == ["image", "text"]
+
+
+@pytest.mark.parametrize("family", ["llava_1_5", "llava"])
+def test_llava_eval_prompts_are_tokenized_as_vllm_does(family):
+    """The reference's LLaVA evaluation scripts hand the prompt TEXT to vLLM, whose tokenizer call keeps the default add_special_tokens=True: a Llama / Vicuna /
+    Mistral tokenizer then prepends <s> (the port tokenized with add_special_tokens=False and its prompts were one token short).  Fixture: the offline
+    LLaVA processor with the post-processor a Llama tokenizer carries (`<s> $A`).  `encode_prompts` must equal the tokenizer's default call on the same text."""
+    import fixture_util as fx
+    from tokenizers import processors
+    cfg = fx.TINY_LLAVA15 if family == "llava_1_5" else fx.TINY_LLAVA_NEXT
+    proc = fx.local_llava_processor(cfg)
+    tok = proc.tokenizer
+    tok._tokenizer.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", tok.bos_token_id)])
+    tok.padding_side = "left"
+    prompts = [proc.apply_chat_template(evaluate.build_messages(n, family), **evaluate.template_kwargs(family)) for n in (0, 1)]
+    images = [fx.synth_pil_image(40, 32, 1), fx.synth_pil_image(36, 36, 2), fx.synth_pil_image(32, 40, 3)]
+    enc = evaluate.encode_prompts(proc, prompts, images, family)
+    ids, mask = enc["input_ids"].numpy(), enc["attention_mask"].numpy()
+    for r in range(2):
+        row = ids[r][mask[r] == 1]
+        assert row[0] == tok.bos_token_id and (row[1:] != tok.bos_token_id).all(), "exactly one BOS, in front"
+    # the qwen family keeps add_special_tokens=False (Qwen2 tokenizers define no BOS: same ids either way)
+    want = proc(text=prompts, images=images, return_tensors="pt", padding=True, padding_side="left")["input_ids"].numpy()
+    assert np.array_equal(ids, want)

@@ -390,6 +390,30 @@ def test_ddp_two_ranks_match_single_process_average():
     assert np.abs(b0 - w0).max() <= 4e-3
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --steps 1 --model tiny`: the N > 1 path of the bench END TO END on this one-GPU box -- respawn under torch.distributed.run, one
+    process per rank, WORLD_SIZE asserted, sharded prompts, the bucketed gradient exchange launched from the backward hook, barrier + max-over-ranks timing, ONE JSON
+    line from rank 0 with `grad_exchange.{bytes_on_wire, n_buckets, exposed_ms}`.  Both ranks share cuda:0 and the exchange runs over gloo (RCCL refuses two ranks
+    on one device: IADR1_BENCH_SHARE_GPU / IADR1_BENCH_BACKEND, test-only switches); the RCCL leg itself runs in test_rccl_exchange_path_on_one_rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IADR1_BENCH_SHARE_GPU="1", IADR1_BENCH_BACKEND="gloo", IADR1_QUIET="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--model", "tiny", "--prompts", "2", "--group", "4",
+                        "--prompt-len", "300", "--gen-len", "8", "--no-cpu-baseline", "--no-repeated-rows-leg"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["rccl_ranks"] == 2 and len(rec["per_rank_ms_per_step"]) == 2
+    assert rec["config"]["gradient_checkpointing"] == "auto"            # the data-parallel default (static budget, Engine.recompute_wanted)
+    ge = rec["config"]["grad_exchange"]
+    assert ge["n_buckets"] >= 1 and ge["bytes_on_wire"] > 0 and ge["exposed_ms"] is not None and ge["exposed_ms"] >= 0.0
+    assert abs(rec["value"] - 2 * 8 * 1 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]       # whole-job samples / max-over-ranks time
+
+
 def _rccl_one_rank_worker(port, q):
     import os as _os
     _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", IADR1_FORCE_REDUCE="1")

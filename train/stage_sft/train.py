@@ -165,7 +165,7 @@ def main(argv=None):
         print(f"[pa-sft] model_type {model_type}: {n_fz} of {len(store.slots)} parameter tensors frozen (vision tower: {a.freeze_vision_tower}, projector: {a.freeze_multi_modal_projector})", flush=True)
     eng = SFTEngine(cfg, store, SFTArgs(learning_rate=a.learning_rate, weight_decay=a.weight_decay, max_grad_norm=a.max_grad_norm,
                                         gradient_accumulation_steps=a.gradient_accumulation_steps, micro_batch_seqs=a.micro_batch_seqs, frozen=frozen,
-                                        recompute="auto" if a.gradient_checkpointing else "off"), group=group)
+                                        recompute="auto" if (a.gradient_checkpointing or group is not None) else "off"), group=group)
     from iadr1_amd import schedule
     if a.lr_scheduler_type not in schedule.SCHEDULES:
         raise ValueError(f"--lr_scheduler_type {a.lr_scheduler_type}: supported {schedule.SCHEDULES}")
