@@ -92,9 +92,10 @@ def parse():
     ap.add_argument("--sft-batch", type=int, default=16)
     ap.add_argument("--gradient-checkpointing", default=None, choices=["off", "auto", "on"], help="decoder activation recompute policy of the step (the reference scripts' "
                     "--gradient_checkpointing true = auto): lets e.g. --model 7b run one 64-sequence micro-batch")
-    ap.add_argument("--ref-fp8", action="store_true", help="opt-in: the frozen reference's decoder Linears on the FP8 matrix instruction (BASELINE config 5 'fp8 MFMA weights'); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-processor-legs", action="store_true", help="skip the two extra (untimed for `value`) loops that feed uint8 images through the HF image processor inside the step")
+    ap.add_argument("--no-real-shapes-leg", action="store_true", help="skip the (untimed for `value`) leg at the reference scripts' shapes: B=1 x G=4, accum 2, ragged prompts, EOS live, 512 tokens")
+    ap.add_argument("--real-shapes-steps", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-full-step", action="store_true", help="run the oracle's REAL B = 1 x G SC-GRPO step once at full 3B size on the host cores (about 6 minutes, "
@@ -736,6 +737,80 @@ def real_processor_legs(tr, batches, n_prompts, steps, first_step, N):
     return res
 
 
+def synth_prompt_batch(cfg, grid_hw, n_text, seed, dev):
+    """One prompt: 3 prefix ids + <|vision_start|> + (h/2 * w/2) x <|image_pad|> + <|vision_end|> + n_text text ids; pixel patches of an h x w patch grid."""
+    rs = np.random.RandomState(seed)
+    h, w = grid_hw
+    n_img = (h // 2) * (w // 2)
+    hi = min(150000, cfg.vocab_size - 8, cfg.vision_start_token_id)
+    lo = min(1000, hi - 1)
+    row = rs.randint(lo, hi, 3).tolist() + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_token_id] + rs.randint(lo, hi, n_text).tolist()
+    ids = np.array([row], dtype=np.int64)
+    px = torch.from_numpy(rs.standard_normal((h * w, cfg.patch_dim)).astype(np.float32)).to(dev)
+    return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.ones_like(torch.from_numpy(ids)), "pixel_values": px, "image_grid_thw": torch.tensor([[1, h, w]])}
+
+
+def real_shapes_leg(tr, cfg, dev, steps):
+    """The shapes the reference's launch scripts actually run (REF scripts/train/SC_GRPO/SC_GRPO_Qwen_Instruct_2_5_VL_3B.sh:49-59): per_device_train_batch_size 1,
+    num_generations 4, gradient_accumulation_steps 2, max_prompt_length 4096, max_completion_length 512, max_pixels 480000, sampling with EOS LIVE -- on RAGGED
+    prompts: five image sizes <= 480 000 pixels (patch grids 32x32, 46x34, 50x48, 24x40, 34x46: 256 / 391 / 600 / 240 / 391 image tokens) and 100-800 text tokens, a
+    different prompt length in every micro-batch.  Reported beside the headline, never as `value`: samples/s, and the counts of everything a changing shape can
+    cost -- KV-pool rebuilds, hipGraph captures, training-arena re-keys, EOS polls -- plus the completion-length distribution.  Random-init weights never emit EOS
+    (1 token of 151 936), so the EOS row of the (tied) embedding is scaled x 3 for this leg: its logit then reaches the top-k of a sampling step a few per cent
+    of the time and the completions end at ragged lengths (restored afterwards)."""
+    from iadr1_amd import rollout as ro
+    eng, pol = tr.engine, tr.engine.pol.p
+    grids = [(32, 32), (46, 34), (50, 48), (24, 40), (34, 46)]
+    rs = np.random.RandomState(99)
+    n_micro = 2 * (steps + 1)
+    batches = {("rs", k): synth_prompt_batch(cfg, grids[k % len(grids)], int(rs.randint(100, 801)), 4321 + k, dev) for k in range(n_micro)}
+    saved_proc, saved_args = tr.processing_class, dict(vars(eng.args))
+    saved_tr = (tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length)
+    head = pol.w(pol.lm_head_name())
+    eos_row = head[cfg.eos_token_id].clone()
+
+    class P_(SynthProcessor):
+        def __call__(self, text=None, images=None, **kw):
+            return self.batches[images[0][1]]
+    chat = [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "Is there any defect in the image?"}]}]
+    rows = lambda k: [{"prompt": chat, "image": [("synthetic", ("rs", k), 0)], "solution": SOLUTION}]
+    res = {}
+    try:
+        tr.processing_class = P_(batches, CANNED)
+        head[cfg.eos_token_id] = (eos_row.float() * 3.0).to(head.dtype)
+        pol.refresh_shadows()
+        eng.args.num_generations, eng.args.max_completion_length, eng.args.max_prompt_length = 4, 512, 4096
+        eng.args.gradient_accumulation_steps, eng.args.suppress_eos, eng.args.micro_batch_seqs = 2, False, 4
+        tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length = 1, 4, 2, 512
+        tr.training_step([rows(0), rows(1)])        # one untimed optimizer step of the leg: pools, arenas and graph of the new geometry
+        torch.cuda.synchronize()
+        st0 = dict(ro.STATS)
+        tr._metrics.clear()
+        t0 = time.perf_counter()
+        for s_ in range(1, steps + 1):
+            tr.training_step([rows(2 * s_), rows(2 * s_ + 1)])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        d = {k: ro.STATS[k] - st0[k] for k in ro.STATS}
+        lens = tr._metrics.get("completion_length", [])
+        P_lens = [int(batches[("rs", k)]["input_ids"].shape[1]) for k in range(2, n_micro)]
+        res = {"samples_per_s": 8 * steps / dt, "ms_per_optimizer_step": dt / steps * 1e3, "optimizer_steps": steps, "micro_batches": 2 * steps,
+               "prompt_lengths": P_lens, "mean_completion_length_per_micro_batch": [round(float(x), 1) for x in lens],
+               "decode_steps_run": d["decode_steps"], "decode_steps_max": 2 * steps * 511,
+               "kv_pool_rebuilds": d["pool_builds"], "graph_captures": d["graph_captures"], "arena_rekeys": d["trace_rekeys"], "eos_polls_host": d["eos_polls"],
+               "host_drains_for_eos": 0,
+               "note": ("reference launch-script shapes (B=1 x G=4, accum 2, max_completion_length 512, ragged prompts, EOS live); after ONE untimed step of this geometry; "
+                        "the EOS poll waits for a 12-step-old flag copy in pinned memory, never for the newest work (no queue drain); not part of `value`")}
+    finally:
+        head[cfg.eos_token_id] = eos_row
+        pol.refresh_shadows()
+        tr.processing_class = saved_proc
+        for k, v in saved_args.items():
+            setattr(eng.args, k, v)
+        tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length = saved_tr
+    return res
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` without a torchrun environment: run the same command line as N ranks of one node (one rank per GPU over RCCL)."""
     import socket
@@ -868,9 +943,6 @@ def main():
         # Engine.recompute_wanted then reserves RCCL's buffers, so the 7B-class configurations recompute instead of sitting at 255 of 288 GB
         a.gradient_checkpointing = "auto" if rccl_ranks > 1 or os.environ.get("IADR1_FORCE_REDUCE") else "off"
     eng.args.recompute = a.gradient_checkpointing
-    if a.ref_fp8:
-        eng.args.ref_fp8 = True
-        eng.ref.enable_fp8_linears()
     eng.args.use_hip_graph = not a.no_graph
     timer = GemmTimer()
     timer.install()
@@ -953,6 +1025,14 @@ def main():
             real["prefetch_vs_headline"] = real["prefetch"]["samples_per_s"] / (world * N * a.steps / dt)
         except Exception as exc:
             real = {"error": repr(exc)[:300]}
+    shapes = None
+    if world == 1 and a.model in ("3b", "7b", "qwen2vl_2b", "tiny") and not a.no_real_shapes_leg and not llava:
+        timer.enabled = False
+        try:
+            shapes = real_shapes_leg(tr, cfg, dev, a.real_shapes_steps)
+        except Exception as exc:
+            import traceback
+            shapes = {"error": repr(exc)[:300], "where": traceback.format_exc()[-600:]}
     if rank == 0:
         n_launch, t_sum, fl_gemm = timer.summary()
         t_gemm = timer.busy_seconds()            # union of the launch intervals (wgrad GEMMs overlap dgrad GEMMs on a second stream)
@@ -990,7 +1070,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{model_name} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {image_note}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
-                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "reference_forward": "fp8 mfma linears" if a.ref_fp8 else "bf16", "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks, "collective_backend": backend if (world > 1 or os.environ.get("IADR1_FORCE_REDUCE")) else None,
+                       "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "reference_forward": "bf16", "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks, "collective_backend": backend if (world > 1 or os.environ.get("IADR1_FORCE_REDUCE")) else None,
                        "grad_exchange": ({"wire": eng.reducer.wire, "bytes_on_wire": getattr(eng.reducer, "last_bytes_on_wire", 0), "n_buckets": getattr(eng.reducer, "last_n_buckets", 0),
                                           "exposed_ms": exposed_ms, "exposed_note": "GPU time the compute stream waited in GradReducer.finish() for the exchange after backward ended (last timed step, this rank): what did not hide under backward",
                                           "staging_bytes": eng.reducer.staging_bytes()}
@@ -1004,6 +1084,7 @@ def main():
             "per_rank_ms_per_step": [round(x, 2) for x in per_rank_ms],
             "repeated_rows_layout": repeated,
             "real_processor": real,
+            "real_shapes": shapes,
             "samples_per_sec_per_gpu": N * a.steps / dt,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,

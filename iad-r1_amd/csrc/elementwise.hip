@@ -497,13 +497,16 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int* pos, const f
 
 __global__ __launch_bounds__(256) void decode_advance_kernel(const long long* sampled, long long* cur_tok, long long* out_tokens, int C,
                                                              int* pos, int* ctx_len, long long* slot, const int* block_table,
-                                                             int max_pages, int* finished, unsigned* step, int eos, int pad, int B) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+                                                             int max_pages, int* finished, unsigned* step, int eos, int pad, int B,
+                                                             int* all_done, const float* inv_freq, float* cs, float* sn, int half) {
+    const int b = threadIdx.x;
     const unsigned st = *step;
+    int fin = 1;
     if (b < B) {
         long long tok = sampled[b];
-        if (finished[b]) tok = pad;
-        else if (eos >= 0 && tok == eos) finished[b] = 1;
+        fin = finished[b];
+        if (fin) tok = pad;
+        else if (eos >= 0 && tok == eos) finished[b] = fin = 1;
         if ((int)st < C) out_tokens[(long long)b * C + st] = tok;
         cur_tok[b] = tok;
         pos[b] += 1;
@@ -511,8 +514,17 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(const long long* sa
         ctx_len[b] = n + 1;
         slot[b] = (long long)block_table[(long long)b * max_pages + n / 32] * 32 + (n & 31);
     }
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int every = __syncthreads_and(fin);          // also orders the pos[] writes before the table below
+    if (inv_freq != nullptr) {     // the rotary table of the NEXT decode step's positions (what a separate rope_table launch computed at the start of that step)
+        for (int i = threadIdx.x; i < B * half; i += 256) {
+            const int r = i / half, j = i - r * half;
+            const float a = (float)pos[r] * inv_freq[j];
+            cs[i] = cosf(a);
+            sn[i] = sinf(a);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (all_done != nullptr) *all_done = every;
         __threadfence();
         *step = st + 1;
     }
@@ -526,8 +538,10 @@ extern "C" int iadr1_rope_table(const int* pos, const float* inv_freq, float* co
 }
 extern "C" int iadr1_decode_advance(const long long* sampled, long long* cur_tok, long long* out_tokens, int C, int* pos, int* ctx_len,
                                     long long* slot, const int* block_table, int max_pages, int* finished, unsigned* step, int eos,
-                                    int pad, int B, hipStream_t stream) {
+                                    int pad, int B, int* all_done, const float* inv_freq, float* cos_t, float* sin_t, int half, hipStream_t stream) {
     IADR1_REQUIRE(B > 0 && B <= 256, "decode_advance: B must be in [1,256] (single block so the step bump is ordered)");
-    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(256), 0, stream, sampled, cur_tok, out_tokens, C, pos, ctx_len, slot, block_table, max_pages, finished, step, eos, pad, B);
+    IADR1_REQUIRE(inv_freq == nullptr || (cos_t != nullptr && sin_t != nullptr && half > 0), "decode_advance: inv_freq needs cos_t / sin_t / half");
+    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(256), 0, stream, sampled, cur_tok, out_tokens, C, pos, ctx_len, slot, block_table, max_pages, finished, step, eos, pad, B,
+                       all_done, inv_freq, cos_t, sin_t, half);
     return iadr1_check_launch("decode_advance");
 }

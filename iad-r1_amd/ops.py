@@ -51,27 +51,6 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
-def quant_rows_fp8(x, out=None, out_scale=None):
-    """x [M,K] bf16 -> (OCP e4m3 [M,K] as uint8, fp32 scale per row): scale = amax / 448, round to nearest even of x / scale (include/iadr1_hip.h iadr1_quant_rows_fp8)."""
-    M, K = x.shape
-    q = out if out is not None else torch.empty(M, K, dtype=torch.uint8, device=x.device)
-    s = out_scale if out_scale is not None else torch.empty(M, dtype=F32, device=x.device)
-    assert x.dtype == BF16 and q.dtype == torch.uint8 and q.shape == (M, K) and s.numel() >= M
-    hip.call("quant_rows_fp8", x, _ld(x), q, _ld(q), s, M, K)
-    return q, s
-
-
-def gemm_nt_fp8(aq, sa, bq, sb, bias=None, out=None):
-    """out[M,N] (bf16) = (aq . bq^T) * sa[:, None] * sb[None, :] + bias on the FP8 matrix instruction (include/iadr1_hip.h iadr1_gemm_nt_fp8)."""
-    M, K = aq.shape
-    N, K2 = bq.shape
-    assert K == K2 and aq.dtype == torch.uint8 and bq.dtype == torch.uint8
-    if out is None:
-        out = torch.empty(M, N, dtype=BF16, device=aq.device)
-    hip.call("gemm_nt_fp8", aq, sa, bq, sb, out, bias, M, N, K, _ld(aq), _ld(bq), _ld(out))
-    return out
-
-
 _SPLITK = os.environ.get("IADR1_GEMM_SPLITK", "1") != "0"
 _splitk_ws = {}
 
@@ -589,6 +568,8 @@ def rope_table(pos, inv_freq, cos, sin):
     hip.call("rope_table", pos, inv_freq, cos, sin, B, half)
 
 
-def decode_advance(sampled, cur_tok, out_tokens, pos, ctx_len, slot, block_table, finished, step, eos, pad):
+def decode_advance(sampled, cur_tok, out_tokens, pos, ctx_len, slot, block_table, finished, step, eos, pad, all_done=None, inv_freq=None, cos=None, sin=None):
+    """all_done: int32[1] <- every sequence finished; inv_freq + cos / sin [B, half]: also write the rotary table of the bumped positions (the next step's)."""
     B, C = out_tokens.shape
-    hip.call("decode_advance", sampled, cur_tok, out_tokens, C, pos, ctx_len, slot, block_table, block_table.shape[1], finished, step, int(eos), int(pad), B)
+    hip.call("decode_advance", sampled, cur_tok, out_tokens, C, pos, ctx_len, slot, block_table, block_table.shape[1], finished, step, int(eos), int(pad), B,
+             all_done, inv_freq, cos if inv_freq is not None else None, sin if inv_freq is not None else None, cos.shape[1] if inv_freq is not None else 0)

@@ -23,6 +23,9 @@ from .vlm import Engine, TextPlan
 
 BF16, F32 = torch.bfloat16, torch.float32
 PAGE = 32
+# counters of the events that cost host time on ragged real-world batches (bench.py `real_shapes`): KV-pool (re)builds, hipGraph captures, training-arena
+# hand-over re-keys, host reads of the EOS state, decode steps run
+STATS = {"pool_builds": 0, "graph_captures": 0, "trace_rekeys": 0, "eos_polls": 0, "decode_steps": 0, "rollouts": 0}
 
 
 class Rollout:
@@ -30,6 +33,7 @@ class Rollout:
         self.e = engine
         c = engine.cfg
         dev = engine.dev
+        STATS["pool_builds"] += 1
         self.N, self.max_new, self.use_graph, self.max_prompt = max_seqs, max_new, use_graph, max_prompt
         L, H, D, Hq, Hkv, I, V = c.num_hidden_layers, c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads, c.intermediate_size, c.vocab_size
         max_prompts = max_prompts or max_seqs
@@ -48,6 +52,8 @@ class Rollout:
         self.ctx_len = torch.zeros(N, dtype=i32, device=dev)
         self.slot = torch.zeros(N, dtype=i64, device=dev)
         self.finished = torch.zeros(N, dtype=i32, device=dev)
+        self.all_done = torch.zeros(1, dtype=i32, device=dev)                  # written by every decode_advance: 1 when all sequences have finished
+        self.done_host = torch.zeros(8, dtype=i32).pin_memory() if dev.type == "cuda" else torch.zeros(8, dtype=i32)   # ring of host copies (generate's EOS poll)
         self.step = torch.zeros(1, dtype=i32, device=dev)
         self.cur_tok = torch.zeros(N, dtype=i64, device=dev)
         self.sampled = torch.zeros(N, dtype=i64, device=dev)
@@ -99,7 +105,7 @@ class Rollout:
         qw, kw = Hq * D, Hkv * D
         s = self.sampling
         ops.embed_fwd(self.cur_tok, None, P.w("embed"), None, out=self.x)
-        ops.rope_table(self.pos, e.inv_freq, self.cos, self.sin)
+        # (the rotary table of this step's positions was written by the decode_advance that closed the previous step)
         have_branch = False
         T_ = lambda name, i: None if tr is None else tr[name][i]
         for i in range(c.num_hidden_layers):
@@ -148,7 +154,8 @@ class Rollout:
     def _sample_and_advance(self):
         s = self.sampling
         ops.sample(self.logits, s["temperature"], s["top_k"], s["top_p"], 0, 0, suppress_token=s["suppress"], step_ptr=self.step, out=self.sampled, seed_ptr=self.seed_dev)
-        ops.decode_advance(self.sampled, self.cur_tok, self.out_tokens, self.pos, self.ctx_len, self.slot, self.block_table, self.finished, self.step, s["eos"], s["pad"])
+        ops.decode_advance(self.sampled, self.cur_tok, self.out_tokens, self.pos, self.ctx_len, self.slot, self.block_table, self.finished, self.step, s["eos"], s["pad"],
+                           all_done=self.all_done, inv_freq=self.e.inv_freq, cos=self.cos, sin=self.sin)
 
     def _capture(self):
         # warm-up on a side stream (first-call attribute setup must not happen under capture), then capture once
@@ -162,6 +169,7 @@ class Rollout:
         with torch.cuda.graph(g):
             self._decode_step()
         self.graph = g
+        STATS["graph_captures"] += 1
 
     # ---- public ---------------------------------------------------------------------------------------------------
     def generate(self, plan: TextPlan, img_embeds, G: int, max_new: int, temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress_eos=False,
@@ -262,6 +270,7 @@ class Rollout:
                 key = (A["x_in"].data_ptr(), train_carry["hf"].data_ptr(), T_all, max_new)
                 if self.trace is None or self.trace.get("key") != key:
                     self.graph = None       # the arena pointers are kernel arguments frozen in the graph
+                    STATS["trace_rekeys"] += 1
                     # the LAST completion token of a sequence is never a decode input (it is only sampled): its rows are not written by the steps and
                     # nothing in the loss depends on them, but backward reads them -- they must be finite.  Zero the completion block once.
                     for k, v in tr.items():
@@ -287,22 +296,42 @@ class Rollout:
         self._sample_and_advance()                                           # token 0 from the prefill logits
         # ---- decode ----------------------------------------------------------------------------------------------
         if self.use_graph and self.graph is None:
-            saved = [t.clone() for t in (self.pos, self.ctx_len, self.slot, self.finished, self.step, self.cur_tok, self.out_tokens)]
+            state = (self.pos, self.ctx_len, self.slot, self.finished, self.step, self.cur_tok, self.out_tokens, self.cos, self.sin, self.all_done)
+            saved = [t.clone() for t in state]
             self._capture()  # warm-up + capture advance the state twice: restore it (K/V written meanwhile are rewritten by the real steps)
-            for t, s_ in zip((self.pos, self.ctx_len, self.slot, self.finished, self.step, self.cur_tok, self.out_tokens), saved):
+            for t, s_ in zip(state, saved):
                 t.copy_(s_)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.decode_events is not None else None
         if ev:
             ev[0].record()
         nsteps = 0
+        # EOS live: stop once every sequence has finished, WITHOUT draining the queue.  Every POLL steps the device flag decode_advance maintains is copied
+        # to pinned host memory behind the step; the host reads the copy that is LAG polls old (it waits for that copy's event, never for the newest work), so the
+        # GPU always has >= (LAG - 1) * POLL queued steps and at most LAG * POLL steps run past the last EOS.  (Round 3 read `finished.all()` every 32 steps: a full
+        # drain of the queue each time and 16 wasted steps on average.)
+        POLL, LAG = 4, 3
+        polls = []
+        live = sampling["eos"] >= 0
         for it in range(1, max_new):
             if self.graph is not None:
                 self.graph.replay()
             else:
                 self._decode_step()
             nsteps += 1
-            if sampling["eos"] >= 0 and it % 32 == 0 and bool(self.finished.all()):
-                break
+            if live and it % POLL == 0:
+                k = (it // POLL) % self.done_host.numel()
+                self.done_host[k: k + 1].copy_(self.all_done, non_blocking=True)
+                pe = torch.cuda.Event()
+                pe.record()
+                polls.append((pe, k))
+                if len(polls) >= LAG:
+                    ev0, k0 = polls.pop(0)
+                    ev0.synchronize()
+                    STATS["eos_polls"] += 1
+                    if int(self.done_host[k0]):
+                        break
+        STATS["decode_steps"] += nsteps
+        STATS["rollouts"] += 1
         if ev:
             ev[1].record()
             self.decode_events.append((ev[0], ev[1], nsteps, int(np.sum(lengths)) * G))

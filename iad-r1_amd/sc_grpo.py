@@ -65,9 +65,6 @@ class GRPOArgs:
     # `--gradient_checkpointing` (REF scripts/train/SC_GRPO/*.sh:56): "off" | "auto" | "on" -- vlm.Engine.recompute_wanted.  With recomputation the policy's
     # forward is run after the rollout (the rollout's own activations are not kept either)
     recompute: str = "off"
-    # BASELINE config 5 "fp8 MFMA weights", opt-in: the frozen reference's decoder Linears on the FP8 matrix instruction (vlm.Engine.enable_fp8_linears); the policy,
-    # its gradients and the rollout are untouched.  Default off: the headline and every parity golden run bf16
-    ref_fp8: bool = os.environ.get("IADR1_REF_FP8", "0") == "1"
 
 
 def eos_completion_mask(completion_ids: np.ndarray, eos_token_id: int) -> np.ndarray:
@@ -284,8 +281,6 @@ class SCGRPOEngine:
     def __init__(self, cfg: VLMConfig, policy: ParamStore, ref: ParamStore, args: GRPOArgs, group=None):
         self.cfg, self.args = cfg, args
         self.pol, self.ref = Engine(policy), Engine(ref)
-        if args.ref_fp8:
-            self.ref.enable_fp8_linears()
         self.dev = policy.device
         self.reducer = GradReducer(policy, group)
         self.pol.resident_extra = ref.resident_bytes() + self.reducer.staging_bytes()       # static inputs of Engine.recompute_wanted("auto")

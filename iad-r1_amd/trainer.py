@@ -61,7 +61,6 @@ class GRPOConfig:
     model_init_kwargs: Optional[dict] = None
     micro_batch_seqs: int = 64      # sequences per reference / policy pass; >= batch x group lets the rollout double as the policy's training forward
     shuffle: bool = True            # seeded per-epoch permutation (HF Trainer's RandomSampler / DistributedSampler)
-    ref_fp8: bool = os.environ.get("IADR1_REF_FP8", "0") == "1"       # opt-in: frozen-reference decoder Linears on the FP8 matrix instruction (BASELINE config 5)
     prefetch_batches: bool = os.environ.get("IADR1_PREFETCH", "1") != "0"    # prepare micro-batch k+1 on a worker thread while the GPU runs k (iadr1_amd.prefetch)
     run_name: Optional[str] = None
     report_to: Any = None
@@ -350,7 +349,7 @@ class SCGRPOTrainer:
             adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
             gradient_accumulation_steps=args.gradient_accumulation_steps, micro_batch_seqs=args.micro_batch_seqs, seed=args.seed,
             # under data parallelism the policy is "auto" even without the flag: it recomputes only where the static budget (which then reserves RCCL's buffers) is tight
-            recompute="auto" if (args.gradient_checkpointing or group is not None) else "off", ref_fp8=args.ref_fp8), group=group)
+            recompute="auto" if (args.gradient_checkpointing or group is not None) else "off"), group=group)
         self.state = type("State", (), {"global_step": 0})()
         self._metrics = defaultdict(list)
         self.log_history = []

@@ -743,28 +743,6 @@ class Engine:
             self._ws[key] = cur
         return cur
 
-    def enable_fp8_linears(self):
-        """Opt-in (BASELINE config 5 "fp8 MFMA weights"; GRPOArgs.ref_fp8 / IADR1_REF_FP8=1): the four decoder Linears of every layer of THIS engine's no-grad forward
-        (the frozen reference pass, REF:737-743) run on the FP8 matrix instruction -- weights quantised once here (e4m3, one scale per output row), activations per call
-        (one scale per token row), fp32 accumulation, bf16 results (ops.gemm_nt_fp8).  Vision tower, attention, norms and the lm_head stay bf16; nothing with a gradient
-        uses it (text_forward(save=True) ignores the switch).  Cost in accuracy: tests/test_hip_model.py::test_fp8_reference_forward_error_is_stated."""
-        c, P = self.cfg, self.p
-        assert c.hidden_size % 16 == 0 and c.intermediate_size % 16 == 0 and (c.num_attention_heads * c.head_dim) % 16 == 0
-        self._w8 = {}
-        for i in range(c.num_hidden_layers):
-            for nm in ("qkv.w", "o.w", "gu.w", "down.w"):
-                name = f"layers.{i}.{nm}"
-                self._w8[name] = ops.quant_rows_fp8(P.w(name))
-
-    def _lin(self, x, name, bias=None, out=None, fp8=False):
-        """x . W[name]^T (+ bias): bf16 MFMA, or -- fp8 passes of an engine with enable_fp8_linears() -- the FP8 form on row-quantised activations."""
-        w8 = self.__dict__.get("_w8")
-        if fp8 and w8 is not None and name in w8:
-            M, K = x.shape
-            xq, sx = ops.quant_rows_fp8(x, out=self._workspace(("xq8", K), (M, K), torch.uint8), out_scale=self._workspace("xq8_scale", (M,), F32))
-            return ops.gemm_nt_fp8(xq, sx, w8[name][0], w8[name][1], bias=bias, out=out)
-        return ops.gemm_nt(x, self.p.w(name), bias=bias, out=out)
-
     def saved_activation_bytes(self, T: int) -> int:
         """Bytes of the per-layer activation arena text_forward(save=True) keeps for T token rows (what gradient checkpointing avoids)."""
         c = self.cfg
@@ -901,8 +879,7 @@ class Engine:
                 ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, rstd1, Tl, H, H, H, H, float(eps), None)
             if recompute:
                 ctx["recompute"]["x_in"].append(x_in)
-            f8 = not save                  # the FP8 Linears (enable_fp8_linears) serve no-grad passes only
-            qkv = self._lin(h1, b + "qkv.w", bias=P.w(b + "qkv.b"), out=buf("qkv"), fp8=f8)
+            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=buf("qkv"))
             ops.rope_(qkv, plan.cos, plan.sin, Hq + Hkv, D)
             if kv_sink is not None:
                 kv_sink(i, qkv[:, qw: qw + kw], qkv[:, qw + kw:])
@@ -916,18 +893,14 @@ class Engine:
             qkv_all, o_all = full("qkv"), full("o")
             ops.hip.call("attn_fwd", qkv_all[:, :qw], qkv_all[:, qw: qw + kw], qkv_all[:, qw + kw:], o_all, lse, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n, plan.seg.max_len,
                          plan.seg.n_head, plan.seg.max_tail, T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, c.attn_scale)
-            ab = self._lin(o, b + "o.w", fp8=f8)
+            ab = ops.gemm_nt(o, P.w(b + "o.w"))
             x_mid = buf("x_mid") if (keep or recompute) else x_in          # (recompute: x_in is a checkpoint, it must not be overwritten)
             h2 = buf("h2")
             rstd2 = B["rstd2"][li, r0:r1] if keep else None
             ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_mid, P.w(b + "ln2"), h2, rstd2, Tl, H, H, H, H, float(eps), None)
             # gate|up projection with the activation in its epilogue; the gate|up matrix itself is written only when backward will read it
-            if f8 and self.__dict__.get("_w8") is not None:
-                gu = self._lin(h2, b + "gu.w", out=buf("gu"), fp8=True)
-                a = ops.swiglu_fwd(gu, out=buf("a"))
-            else:
-                gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=buf("gu"), a_out=buf("a"), keep_gu=keep)
-            branch = self._lin(a, b + "down.w", fp8=f8)
+            gu, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=buf("gu"), a_out=buf("a"), keep_gu=keep)
+            branch = ops.gemm_nt(a, P.w(b + "down.w"))
             res = x_mid
             if recompute:
                 ctx["layers"].append(None)      # (the scratch slab's x_mid rows are consumed by the next layer's ln1 before its ln2 overwrites them: stream order)

@@ -100,14 +100,6 @@ int iadr1_pack_qkv_rope_bf16(const void* W, long long ldw, const void* bias, voi
 int iadr1_pack_weight_fp8(const void* W, long long ldw, void* Wp8, float* scale, int N, int K, int gateup_I, iadr1_stream_t stream);
 int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const float* wscale, void* Y, const void* bias, int M, int N, int K, long long ldx,
                            long long ldy, int out_mode, int ksplit, iadr1_stream_t stream);
-/* FP8 MFMA form of the dense contraction (BASELINE config 5 "fp8 MFMA weights"; opt-in, the frozen-reference forward only -- nothing differentiated runs through it):
- * iadr1_quant_rows_fp8: X[M,K] bf16 -> OCP e4m3 with one fp32 scale per ROW (scale[m] = max_k |x| / 448, round to nearest even of x / scale) -- weights [N,K] are
- * quantised once (a scale per output row), activations per call (a scale per token row).  iadr1_gemm_nt_fp8: C[M,N] (bf16) = (A8 . B8^T) * sa[m] * sb[n] + bias[n]
- * on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (the row scales carry the range), fp32 accumulation.  K, lda, ldb multiples of 16.
- * Replaces the same nn.Linear sites as iadr1_gemm_nt_bf16 on the no-grad reference pass (REF sc_grpo_trainer.py:737-743). */
-int iadr1_quant_rows_fp8(const void* X, long long ldx, void* Q, long long ldq, float* scale, int M, int K, iadr1_stream_t stream);
-int iadr1_gemm_nt_fp8(const void* A8, const float* sa, const void* B8, const float* sb, void* C, const void* bias, int M, int N, int K, long long lda,
-                      long long ldb, long long ldc, iadr1_stream_t stream);
 /* X[M,K] row-major -> decode-packed activations Xp (buffer of roundup(M,64)*K elements; pad rows zeroed).  K % 32 == 0. */
 int iadr1_pack_act_bf16(const void* X, long long ldx, void* Xp, int M, int K, iadr1_stream_t stream);
 int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo, int R, int C, iadr1_stream_t stream);
@@ -262,12 +254,16 @@ int iadr1_sample_topk_topp(const float* logits, long long ld, long long* out, vo
 /* ---- device-resident rollout bookkeeping (one decode step = a fixed, graph-replayable launch sequence) ------
  * rope_table: cos/sin [B, half] for the current text positions (TF:1165-1176: pos = kv_len + rope_delta).
  * decode_advance: append sampled token (EOS -> finished, then pad; REF:...sc_grpo_trainer.py:680-683,722-726),
- * bump pos / ctx_len / cache slot / step.  B <= 256. */
+ * bump pos / ctx_len / cache slot / step.  B <= 256 (one block). */
 int iadr1_rope_table(const int* pos, const float* inv_freq, float* cos_t, float* sin_t, int B, int half,
                      iadr1_stream_t stream);
 int iadr1_decode_advance(const long long* sampled, long long* cur_tok, long long* out_tokens, int C, int* pos, int* ctx_len,
                          long long* slot, const int* block_table, int max_pages, int* finished, unsigned* step, int eos,
-                         int pad, int B, iadr1_stream_t stream);
+                         int pad, int B, int* all_done, const float* inv_freq, float* cos_t, float* sin_t, int half,
+                         iadr1_stream_t stream);
+/* all_done (optional): 1 when every sequence has finished after this token -- the host polls it through pinned memory without draining the
+ * queue (the reference's vLLM stops a request at EOS, REF:343-358).  inv_freq (optional, with cos_t / sin_t [B, half]): the rotary table
+ * of the NEXT step's positions is written here, bit-identical to iadr1_rope_table on the bumped positions (one launch less per decode step). */
 
 #ifdef __cplusplus
 }

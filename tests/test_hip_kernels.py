@@ -109,32 +109,6 @@ def test_gemm_nt_splitk_accumulate(M, N, K):
     assert ops.splitk_slices(22016, 2048, 20480) == 1 and ops.splitk_slices(2048, 2048, 2048) == 1 and ops.splitk_slices(256, 2048, 20480) == 1
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 260, 512), (2048, 2560, 2048), (1000, 22016, 2048), (640, 2048, 11008), (512, 3584, 3584), (129, 130, 1040), (64, 16, 16)])
-def test_gemm_nt_fp8_mfma(M, N, K):
-    """iadr1_quant_rows_fp8 + iadr1_gemm_nt_fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales, fp32 row scales): the quantiser is torch's own
-    float8_e4m3fn cast of x / scale; the GEMM equals the fp32 product of the DEQUANTISED operands at the bf16 output's tolerance (the kernel adds nothing to the
-    format's error); against the un-quantised product the format costs a few percent of the output scale.  Ragged M / N tiles, K that is not a multiple of the
-    128-deep K tile (1040, 16), bias."""
-    x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
-    xq, sx = ops.quant_rows_fp8(x)
-    wq, sw = ops.quant_rows_fp8(w)
-    for t_, q, s in ((x, xq, sx), (w, wq, sw)):
-        want_s = t_.float().abs().amax(1).clamp_min(1e-30) / 448.0
-        assert torch.allclose(s, want_s, rtol=1e-6, atol=0)
-        assert torch.equal(q, (t_.float() / s[:, None]).to(torch.float8_e4m3fn).view(torch.uint8))
-    dx, dw = xq.view(torch.float8_e4m3fn).float() * sx[:, None], wq.view(torch.float8_e4m3fn).float() * sw[:, None]
-    ref = dx @ dw.t()
-    out = ops.gemm_nt_fp8(xq, sx, wq, sw)
-    close(out, ref, 1e-2, 1e-2 * math.sqrt(K) * 0.3, f"fp8 mfma gemm {M}x{N}x{K}")
-    outb = torch.zeros(M, N + 8, dtype=BF, device=DEV)
-    ops.gemm_nt_fp8(xq, sx, wq, sw, bias=bias, out=outb[:, :N])
-    close(outb[:, :N], ref + bias.float(), 1e-2, 1e-2 * math.sqrt(K) * 0.3, "fp8 mfma gemm + bias, strided out")
-    assert float(outb[:, N:].abs().sum()) == 0
-    full = x.float() @ w.float().t()
-    rel = ((ref - full).norm() / full.norm()).item()
-    assert rel < 0.06, rel
-
-
 def test_gemm_nt_strided_views():
     # operands / outputs that are column slices of wider buffers (the fused qkv / gate|up layouts)
     big_a, big_b = rnd(300, 512, seed=5), rnd(260, 512, seed=6)

@@ -794,65 +794,6 @@ def test_full_depth_3b_sc_grpo_step_vs_oracle():
         assert c > 0.97 and 0.85 < r < 1.15, (n, c, r)
 
 
-def test_fp8_reference_forward_error_is_stated():
-    """BASELINE config 5 "fp8 MFMA weights" (opt-in GRPOArgs.ref_fp8: the frozen reference's decoder Linears on the FP8 matrix instruction, row-wise e4m3 for
-    weights and activations).  What it costs, at the 3B widths (4 layers) and on the TINY golden: the reference log-probs move by the printed amount against the
-    bf16 reference pass; the policy side is bit-identical (nothing with a gradient runs FP8); with policy == reference the k3 KL is no longer exactly 0 but the
-    printed floor.  MEASURED on MI355X (3B widths, 4 layers): |dlogp| max 0.84, mean 0.22, KL floor 4.1e-2 -- e4m3 carries 3 mantissa bits (~2.5 % per element,
-    which a 2048-term dot product of random signs does not average away), so the FP8 reference pass is an order of magnitude noisier than the bf16 one (0.06) and
-    its KL floor is above the KL values SC-GRPO regularises (1e-3 .. 1e-1): stated, not recommended, off by default.  Bounds asserted are those measurements
-    with head-room: |dlogp| max < 1.5, mean < 0.4, KL floor < 0.1."""
-    import dataclasses
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
-    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=4, v_depth=2, v_fullatt=(1,))
-    pol = ParamStore(cfg, DEV, trainable=True)
-    pol.init_random(seed=0)
-    pol.w("embed").mul_(2.0)
-    pol.finalize()
-    ref = ParamStore(cfg, DEV, trainable=False)
-    ref.copy_from(pol)
-    G, C, Bp = 4, 16, 2
-    batch = bench.synth_batch(cfg, Bp, 300, seed=5)
-    comp = np.random.RandomState(3).randint(1000, 100000, (Bp * G, C))
-    rewards = np.random.RandomState(1).rand(Bp * G, 2).astype(np.float32)
-    out = {}
-    for f8 in (False, True):
-        pol.grad.zero_()
-        eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=512, max_completion_length=C, micro_batch_seqs=Bp * G, ref_fp8=f8))
-        o = eng.loss_and_grads(batch, comp, rewards)
-        out[f8] = (o["logps"].clone(), o["ref_logps"].clone(), o["metrics"]["kl"], pol.grad.clone())
-    assert torch.equal(out[True][0], out[False][0])                                     # the policy pass is untouched
-    assert torch.equal(out[False][0], out[False][1]) and out[False][2] == 0.0          # bf16 reference == policy: KL exactly 0
-    d = (out[True][1] - out[False][1]).abs()
-    print(f"[fp8 reference forward, 3B widths x 4 layers] |dlogp| vs the bf16 reference pass: max {float(d.max()):.4f} mean {float(d.mean()):.4f}; "
-          f"k3 KL floor with policy == reference: {out[True][2]:.3e}")
-    assert 0.0 < float(d.max()) < 1.5 and float(d.mean()) < 0.4 and out[True][2] < 0.1
-    # gradients: only the KL term sees the reference; advantage term identical
-    a, b = out[True][3].double(), out[False][3].double()
-    cosg = float((a @ b) / (a.norm() * b.norm()))
-    print(f"[fp8 reference forward] gradient cosine against the bf16-reference step: {cosg:.5f}")
-    assert cosg > 0.98
-    # the TINY golden (reference log-probs of the fp32 HF model)
-    import json as _json
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sc_grpo_g8_far.npz"))
-    meta = _json.loads(str(g["meta"]))
-    w_ref = fx.make_weights(fx.TINY, 0)
-    p2, r2 = store(fx.perturb_weights(w_ref, 1, scale=meta["perturb_scale"]), True), store(w_ref, False)
-    eng = SCGRPOEngine(CFG, p2, r2, GRPOArgs(num_generations=meta["G"], max_prompt_length=4096, max_completion_length=meta["C"], ref_fp8=True))
-    grid = tuple(meta["grid"])
-    ids, mask = fx.left_pad([fx.synth_prompt(grid, meta["n_text"], fx.TINY, meta["seed"])], fx.TINY["pad_token_id"])
-    bt = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=meta["seed"]), "image_grid_thw": [grid]}
-    comps = fx.synth_completions(meta["G"], meta["C"], fx.TINY, meta["seed"] + 100, {int(k): v for k, v in meta["eos_rows"].items()})
-    o = eng.loss_and_grads(bt, comps, g["rewards_per_func"], backward=False)
-    m = g["completion_mask"].astype(bool)
-    dr = np.abs(o["ref_logps"].cpu().numpy()[m] - g["ref_per_token_logps"][m]).max()
-    dk = abs(o["metrics"]["kl"] - float(g["metric_kl"])) / float(g["metric_kl"])
-    print(f"[fp8 reference forward, TINY golden] reference |dlogp| max vs the fp32 HF model {dr:.4f} (bf16 path: < 0.06); KL {o['metrics']['kl']:.4e} vs {float(g['metric_kl']):.4e} ({100 * dk:.1f} %)")
-    assert dr < 0.5 and dk < 1.0
-
-
 def test_two_images_per_prompt_one_shot_template_vs_oracle():
     """The reference's 1-shot prompts carry TWO images (a normal template + the query image, REF:train/stage_rl/grpo_ad.py:92-116,
     `--single_img 0`).  Log-probs of the SC-GRPO passes (shared-prefix layout) vs the fp32 oracle on such prompts, plus greedy rollout

@@ -92,8 +92,6 @@ def build_parser():
     p.add_argument("--micro_batch_seqs", type=int, default=64)
     p.add_argument("--decode_weights", default="bf16", choices=["bf16", "fp8"],
                    help="fp8: the rollout streams the gate|up / down / lm_head weights as e4m3 + per-row scales (BASELINE config 5); the loss and its gradients stay bf16")
-    p.add_argument("--ref_fp8", nargs="?", default=None, const=True, type=lambda v: str(v).lower() in ("1", "true", "yes"),
-                   help="frozen-reference decoder Linears on the FP8 matrix instruction (BASELINE config 5 'fp8 MFMA weights'); the policy, its gradients and the rollout stay bf16")
     p.add_argument("--run_name", default=None)
     # ModelConfig's LoRA switch: refused with the reason (the trainer's peft_config error), not silently ignored
     p.add_argument("--use_peft", nargs="?", default=False, const=True)
