@@ -754,20 +754,19 @@ def real_shapes_leg(tr, cfg, dev, steps):
     """The shapes the reference's launch scripts actually run (REF scripts/train/SC_GRPO/SC_GRPO_Qwen_Instruct_2_5_VL_3B.sh:49-59): per_device_train_batch_size 1,
     num_generations 4, gradient_accumulation_steps 2, max_prompt_length 4096, max_completion_length 512, max_pixels 480000, sampling with EOS LIVE -- on RAGGED
     prompts: five image sizes <= 480 000 pixels (patch grids 32x32, 46x34, 50x48, 24x40, 34x46: 256 / 391 / 600 / 240 / 391 image tokens) and 100-800 text tokens, a
-    different prompt length in every micro-batch.  Reported beside the headline, never as `value`: samples/s, and the counts of everything a changing shape can
-    cost -- KV-pool rebuilds, hipGraph captures, training-arena re-keys, EOS polls -- plus the completion-length distribution.  Random-init weights never emit EOS
-    (1 token of 151 936), so the EOS row of the (tied) embedding is scaled x 3 for this leg: its logit then reaches the top-k of a sampling step a few per cent
-    of the time and the completions end at ragged lengths (restored afterwards)."""
+    different prompt length in every micro-batch.  Reported beside the headline, never as `value`: samples/s with one rollout per optimizer step (the default,
+    GRPOConfig.batch_rollouts) and with one per micro-batch (the reference's order), and the counts of everything a changing shape can cost -- KV-pool rebuilds,
+    hipGraph captures and their seconds, training-arena re-keys, EOS polls -- plus the completion lengths.  Random-init weights never emit the real EOS id
+    (1 token of 151 936), so for this leg the EOS id is set to a token a probe rollout sampled ~0.7 % of the time: completions then end at ragged lengths
+    (geometric, mean ~140).  Everything is restored afterwards."""
     from iadr1_amd import rollout as ro
     eng, pol = tr.engine, tr.engine.pol.p
     grids = [(32, 32), (46, 34), (50, 48), (24, 40), (34, 46)]
     rs = np.random.RandomState(99)
-    n_micro = 2 * (steps + 1)
+    n_micro = 2 + 2 * (2 + 2 * steps)
     batches = {("rs", k): synth_prompt_batch(cfg, grids[k % len(grids)], int(rs.randint(100, 801)), 4321 + k, dev) for k in range(n_micro)}
-    saved_proc, saved_args = tr.processing_class, dict(vars(eng.args))
-    saved_tr = (tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length)
-    head = pol.w(pol.lm_head_name())
-    eos_row = head[cfg.eos_token_id].clone()
+    saved_proc, saved_args, saved_eos = tr.processing_class, dict(vars(eng.args)), cfg.eos_token_id
+    saved_tr = (tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length, tr.args.batch_rollouts)
 
     class P_(SynthProcessor):
         def __call__(self, text=None, images=None, **kw):
@@ -777,37 +776,47 @@ def real_shapes_leg(tr, cfg, dev, steps):
     res = {}
     try:
         tr.processing_class = P_(batches, CANNED)
-        head[cfg.eos_token_id] = (eos_row.float() * 3.0).to(head.dtype)
-        pol.refresh_shadows()
         eng.args.num_generations, eng.args.max_completion_length, eng.args.max_prompt_length = 4, 512, 4096
         eng.args.gradient_accumulation_steps, eng.args.suppress_eos, eng.args.micro_batch_seqs = 2, False, 4
         tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length = 1, 4, 2, 512
-        tr.training_step([rows(0), rows(1)])        # one untimed optimizer step of the leg: pools, arenas and graph of the new geometry
-        torch.cuda.synchronize()
-        st0 = dict(ro.STATS)
-        tr._metrics.clear()
-        t0 = time.perf_counter()
-        for s_ in range(1, steps + 1):
-            tr.training_step([rows(2 * s_), rows(2 * s_ + 1)])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        d = {k: ro.STATS[k] - st0[k] for k in ro.STATS}
-        lens = tr._metrics.get("completion_length", [])
-        P_lens = [int(batches[("rs", k)]["input_ids"].shape[1]) for k in range(2, n_micro)]
-        res = {"samples_per_s": 8 * steps / dt, "ms_per_optimizer_step": dt / steps * 1e3, "optimizer_steps": steps, "micro_batches": 2 * steps,
-               "prompt_lengths": P_lens, "mean_completion_length_per_micro_batch": [round(float(x), 1) for x in lens],
-               "decode_steps_run": d["decode_steps"], "decode_steps_max": 2 * steps * 511,
-               "kv_pool_rebuilds": d["pool_builds"], "graph_captures": d["graph_captures"], "arena_rekeys": d["trace_rekeys"], "eos_polls_host": d["eos_polls"],
-               "host_drains_for_eos": 0,
-               "note": ("reference launch-script shapes (B=1 x G=4, accum 2, max_completion_length 512, ragged prompts, EOS live); after ONE untimed step of this geometry; "
-                        "the EOS poll waits for a 12-step-old flag copy in pinned memory, never for the newest work (no queue drain); not part of `value`")}
+        # probe: which token does this random model sample ~0.7 % of the time?  That token plays EOS for the leg.
+        from iadr1_amd.trainer import combine_batches
+        probe = eng.rollout(combine_batches([batches[("rs", 0)], batches[("rs", 1)]], cfg.pad_token_id))
+        ids_, cnt = np.unique(probe, return_counts=True)
+        freq = cnt / probe.size
+        pick = int(np.argmin(np.abs(freq - 0.007)))
+        cfg.eos_token_id = int(ids_[pick])
+        res["synthetic_eos"] = {"token": cfg.eos_token_id, "probe_frequency": float(freq[pick]), "distinct_tokens_in_probe": int(len(ids_))}
+        k0 = 2
+        for mode, on in (("one_rollout_per_optimizer_step", True), ("one_rollout_per_micro_batch", False)):
+            tr.args.batch_rollouts = on
+            tr.training_step([rows(k0), rows(k0 + 1)])        # one untimed optimizer step of the mode: pools, arenas and graph of its geometry
+            k0 += 2
+            torch.cuda.synchronize()
+            st0 = dict(ro.STATS)
+            tr._metrics.clear()
+            t0 = time.perf_counter()
+            first = k0
+            for s_ in range(steps):
+                tr.training_step([rows(k0), rows(k0 + 1)])
+                k0 += 2
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            d = {k: ro.STATS[k] - st0[k] for k in ro.STATS}
+            res[mode] = {"samples_per_s": 8 * steps / dt, "ms_per_optimizer_step": dt / steps * 1e3, "optimizer_steps": steps, "micro_batches": 2 * steps,
+                         "prompt_lengths": [int(batches[("rs", k)]["input_ids"].shape[1]) for k in range(first, k0)],
+                         "mean_completion_length_per_micro_batch": [round(float(x), 1) for x in tr._metrics.get("completion_length", [])],
+                         "rollouts": d["rollouts"], "decode_steps_run": d["decode_steps"], "decode_steps_if_no_eos": d["rollouts"] * 511,
+                         "kv_pool_rebuilds": d["pool_builds"], "graph_captures": d["graph_captures"], "graph_capture_seconds": round(d["capture_seconds"], 4),
+                         "arena_rekeys": d["trace_rekeys"], "eos_polls_host": d["eos_polls"], "host_drains_for_eos": 0}
+        res["note"] = ("reference launch-script shapes (B=1 x G=4, accum 2, max_completion_length 512, ragged prompts, EOS live); each mode after ONE untimed optimizer step; "
+                       "the EOS poll waits for a 12-step-old flag copy in pinned memory, never for the newest work (no queue drain); not part of `value`")
     finally:
-        head[cfg.eos_token_id] = eos_row
-        pol.refresh_shadows()
+        cfg.eos_token_id = saved_eos
         tr.processing_class = saved_proc
         for k, v in saved_args.items():
             setattr(eng.args, k, v)
-        tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length = saved_tr
+        tr.args.per_device_train_batch_size, tr.args.num_generations, tr.args.gradient_accumulation_steps, tr.args.max_completion_length, tr.args.batch_rollouts = saved_tr
     return res
 
 
@@ -870,6 +879,7 @@ def main():
     backend = os.environ.get("IADR1_BENCH_BACKEND", "nccl")
     if share_gpu:
         local = 0
+        os.environ["LOCAL_RANK"] = "0"          # the trainer places its parameter stores on cuda:LOCAL_RANK
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rccl_ranks = 1

@@ -25,7 +25,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 PAGE = 32
 # counters of the events that cost host time on ragged real-world batches (bench.py `real_shapes`): KV-pool (re)builds, hipGraph captures, training-arena
 # hand-over re-keys, host reads of the EOS state, decode steps run
-STATS = {"pool_builds": 0, "graph_captures": 0, "trace_rekeys": 0, "eos_polls": 0, "decode_steps": 0, "rollouts": 0}
+STATS = {"pool_builds": 0, "graph_captures": 0, "capture_seconds": 0.0, "trace_rekeys": 0, "eos_polls": 0, "decode_steps": 0, "rollouts": 0}
 
 
 class Rollout:
@@ -298,9 +298,13 @@ class Rollout:
         if self.use_graph and self.graph is None:
             state = (self.pos, self.ctx_len, self.slot, self.finished, self.step, self.cur_tok, self.out_tokens, self.cos, self.sin, self.all_done)
             saved = [t.clone() for t in state]
+            import time as _time
+            torch.cuda.synchronize()
+            _t0 = _time.perf_counter()
             self._capture()  # warm-up + capture advance the state twice: restore it (K/V written meanwhile are rewritten by the real steps)
             for t, s_ in zip(state, saved):
                 t.copy_(s_)
+            STATS["capture_seconds"] += _time.perf_counter() - _t0
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.decode_events is not None else None
         if ev:
             ev[0].record()

@@ -498,11 +498,13 @@ class SCGRPOEngine:
         return float(self.norm2.sqrt().item()) * getattr(self, "grad_scale", 1.0)
 
     # ---- the whole micro-step ----------------------------------------------------------------------------------------
-    def step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False, defer_metrics=False):
+    def step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False, defer_metrics=False, completions=None):
         """One SC-GRPO micro-step: vision tower -> group rollout -> rewards -> reference / policy passes + backward (-> optimizer).  This is the path
         `SCGRPOTrainer.compute_loss` (the reference's API, REF:586) runs and the one bench.py times.
         reward_fn(completion_ids: np.ndarray [N,C]) -> [N, n_funcs] rewards (decode + plugin functions live with the caller, which owns the tokenizer).
         last_micro_step (default: do_optimizer_step): the data-parallel gradient buckets leave from this call's backward.
+        completions: [N, C] ids already rolled out for these prompts (SCGRPOTrainer.training_step rolls all micro-batches of an optimizer step out at once): no
+        rollout here, the policy forward runs over the completions.
         return_outputs: the whole loss_and_grads dict (log-probs, advantages, masks, ids, metrics) plus "completion_ids" instead of the metrics alone."""
         import time
         timing = os.environ.get("IADR1_TIMING") == "1"
@@ -519,12 +521,12 @@ class SCGRPOEngine:
         # the training forward (saved in the training arena), so the policy forward after the rollout only runs the completion rows
         a = self.args
         N = len(batch["input_ids"]) * a.num_generations
-        carry = {} if (a.share_prefix and a.reuse_prefill and a.num_generations > 1 and a.micro_batch_seqs >= N and N % a.num_generations == 0) else None
+        carry = {} if (completions is None and a.share_prefix and a.reuse_prefill and a.num_generations > 1 and a.micro_batch_seqs >= N and N % a.num_generations == 0) else None
         if carry is not None and a.recompute != "off":
             P_ = np.asarray(batch["input_ids"]).shape[1] if a.max_prompt_length is None else min(np.asarray(batch["input_ids"]).shape[1], a.max_prompt_length)
             if self.pol.recompute_wanted(len(batch["input_ids"]) * P_ + N * a.max_completion_length, a.recompute):
                 carry = None       # gradient checkpointing: nothing of the rollout is kept, the policy forward runs (checkpointed) before backward
-        comp = self.rollout(batch, vis=vis, train_carry=carry)
+        comp = self.rollout(batch, vis=vis, train_carry=carry) if completions is None else np.asarray(completions)
         t2 = mark()
         # rewards are computed on the host inside loss_and_grads, after the first forward passes are in the GPU queue (in the
         # phase-timing mode they are evaluated here so that they get their own column)

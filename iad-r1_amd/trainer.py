@@ -61,6 +61,10 @@ class GRPOConfig:
     model_init_kwargs: Optional[dict] = None
     micro_batch_seqs: int = 64      # sequences per reference / policy pass; >= batch x group lets the rollout double as the policy's training forward
     shuffle: bool = True            # seeded per-epoch permutation (HF Trainer's RandomSampler / DistributedSampler)
+    # one group rollout for ALL micro-batches of an optimizer step (the policy does not change between them: the reference syncs its vLLM weights once per
+    # optimizer step, REF:637-641): a decode step streams the whole model whatever the number of sequences, so gradient_accumulation_steps rollouts of
+    # B x G sequences cost that many times one rollout of accum x B x G -- the launch scripts' B = 1, G = 4, accum 2 (training_step; IADR1_BATCH_ROLLOUTS=0 = per micro-batch)
+    batch_rollouts: bool = os.environ.get("IADR1_BATCH_ROLLOUTS", "1") != "0"
     prefetch_batches: bool = os.environ.get("IADR1_PREFETCH", "1") != "0"    # prepare micro-batch k+1 on a worker thread while the GPU runs k (iadr1_amd.prefetch)
     run_name: Optional[str] = None
     report_to: Any = None
@@ -204,6 +208,38 @@ def prepare_batch(processing_class, inputs: list[dict]) -> dict:
         grid = enc["image_grid_thw"]
         out["image_grid_thw"] = grid.tolist() if hasattr(grid, "tolist") else [tuple(g) for g in grid]
     # (LLaVA-1.5 processor: one resized crop per image [images, 3, S, S], nothing else)
+    return out
+
+
+def trim_completions(toks: np.ndarray, eos_token_id: int) -> np.ndarray:
+    """[N, C] completion ids (pad after the first EOS) cut to the longest completion of these rows -- what the reference's right-padding of the vLLM outputs
+    yields (REF:680-683: `pad(completion_ids)` to the longest of the micro-batch); the columns dropped are masked for every row."""
+    is_eos = toks == eos_token_id
+    n = np.where(is_eos.any(1), is_eos.argmax(1) + 1, toks.shape[1])
+    return toks[:, : max(1, int(n.max()))]
+
+
+def combine_batches(batches: list[dict], pad_token_id: int) -> Optional[dict]:
+    """The prompts of several micro-batches as ONE batch (for one group rollout over all of them, SCGRPOTrainer.training_step): ids / masks left-padded to the
+    longest prompt, image tensors and their grids / sizes concatenated in prompt order.  None when the pixel tensors cannot be concatenated (the any-resolution
+    LLaVA processors pad the crop dimension per call)."""
+    to_np = lambda x: x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    ids = [to_np(b["input_ids"]) for b in batches]
+    masks = [to_np(b["attention_mask"]) for b in batches]
+    S = max(i.shape[1] for i in ids)
+    padl = lambda a, v: np.concatenate([np.full((a.shape[0], S - a.shape[1]), v, dtype=a.dtype), a], 1)
+    px = [b["pixel_values"] for b in batches]
+    if any(p is None for p in px) or len({tuple(p.shape[1:]) for p in px}) != 1 or len({p.device for p in px if isinstance(p, torch.Tensor)}) > 1:
+        return None
+    out = {"input_ids": np.concatenate([padl(i, pad_token_id) for i in ids], 0), "attention_mask": np.concatenate([padl(m, 0) for m in masks], 0),
+           "pixel_values": torch.cat([p if isinstance(p, torch.Tensor) else torch.as_tensor(p) for p in px], 0),
+           "images_per_prompt": [n for b, i in zip(batches, ids) for n in (b.get("images_per_prompt") or [1] * i.shape[0])]}
+    for key in ("image_grid_thw", "image_sizes"):
+        if any(key in b for b in batches):
+            if not all(key in b for b in batches):
+                return None
+            rows = [to_np(b[key]) for b in batches]
+            out[key] = [tuple(int(z) for z in g) for r in rows for g in r.reshape(-1, r.shape[-1])]
     return out
 
 
@@ -354,6 +390,7 @@ class SCGRPOTrainer:
         self._metrics = defaultdict(list)
         self.log_history = []
         self._prefetcher = None
+        self.prefetch_used = False          # a prefetch worker was started at some point (train() stops it again on the way out)
 
     # ---- batch construction (host) -------------------------------------------------------------------------------
     def _prepare(self, inputs: list[dict]):
@@ -373,6 +410,7 @@ class SCGRPOTrainer:
                 prep = lambda inputs: self._locked(self._prepare, inputs)
                 self._pc_lock = threading.Lock()
             self._prefetcher = BatchPrefetcher(prep, self.device)
+            self.prefetch_used = True
         return [self._prefetcher.submit(inputs) for inputs in micro_batches]
 
     def _locked(self, fn, *a):
@@ -404,7 +442,7 @@ class SCGRPOTrainer:
         return np.stack(cols, 1)
 
     # ---- reference API ---------------------------------------------------------------------------------------------
-    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, last_micro_step=True, _defer=False, _prepared=None):
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, last_micro_step=True, _defer=False, _prepared=None, _batch=None, _completions=None):
         """One SC-GRPO micro-step on `inputs` (list of dataset rows).  Returns the loss value; gradients are
         accumulated inside the engine (there is no autograd graph to hand back).
         _defer (training_step, last micro-batch): returns a callable that yields the loss once called -- the two device-side means (loss, KL) are then read
@@ -412,14 +450,17 @@ class SCGRPOTrainer:
         _prepared: a Future from `prefetch` for these same rows (the batch was built while the previous micro-batch ran); None: built here, as the reference does."""
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")  # REF:587-588
-        if _prepared is not None:
+        if _batch is not None:          # training_step already built it (and rolled the completions out with the other micro-batches of the step: _completions)
+            batch = _batch
+        elif _prepared is not None:
             from .prefetch import BatchPrefetcher
             batch = BatchPrefetcher.ready(_prepared.result())
         else:
             batch = self._prepare(inputs)
         # the engine's whole micro-step (SCGRPOEngine.step): vision tower once per image, rollout whose prefill / decode steps double as the policy's
         # training forward when the micro-batch holds whole groups, rewards evaluated on the host while the reference pass is in the GPU queue
-        out = self.engine.step(batch, lambda comp: self._rewards(inputs, comp), do_optimizer_step=False, last_micro_step=last_micro_step, return_outputs=True, defer_metrics=_defer)
+        out = self.engine.step(batch, lambda comp: self._rewards(inputs, comp), do_optimizer_step=False, last_micro_step=last_micro_step, return_outputs=True, defer_metrics=_defer,
+                               completions=_completions)
         m = out["metrics"]
         self._metrics["completion_length"].append(m["completion_length"])
         rp = out["rewards_per_func"].mean(0)
@@ -455,7 +496,25 @@ class SCGRPOTrainer:
         last one's backward) + clip / AdamW / weight-copy refresh.  What transformers.Trainer.training_step + the optimizer block of its inner loop do
         around the reference's compute_loss (TF:trainer.py:1892-1961, :1785); train() and bench.py both go through here."""
         last = len(micro_batches) - 1
-        losses = [self.compute_loss(None, inputs, last_micro_step=(k == last), _defer=(k == last), _prepared=None if prepared is None else prepared[k])
+        ready = comps = None
+        rows_total = sum(len(mb) for mb in micro_batches) * self.args.num_generations
+        if self.args.batch_rollouts and len(micro_batches) > 1 and rows_total <= 64:
+            # (<= 64 sequences: one 64-row tile of the decode GEMMs -- beyond that a decode step streams the weights once per tile and batching buys nothing, while
+            # a micro-batch of whole groups keeps the rollout -> training hand-over)
+            # ONE rollout for the whole optimizer step (GRPOConfig.batch_rollouts): all prompts left-padded into one batch, completions handed back per micro-batch
+            from .prefetch import BatchPrefetcher
+            ready = [BatchPrefetcher.ready(prepared[k].result()) if prepared is not None else self._prepare(inputs) for k, inputs in enumerate(micro_batches)]
+            both = combine_batches(ready, self.cfg.pad_token_id)
+            if both is not None:
+                G = self.args.num_generations
+                toks = self.engine.rollout(both)
+                comps, r = [], 0
+                for b in ready:
+                    n = len(b["input_ids"]) * G
+                    comps.append(trim_completions(toks[r: r + n], self.cfg.eos_token_id))
+                    r += n
+        losses = [self.compute_loss(None, inputs, last_micro_step=(k == last), _defer=(k == last), _prepared=None if (prepared is None or ready is not None) else prepared[k],
+                                    _batch=None if ready is None else ready[k], _completions=None if comps is None else comps[k])
                   for k, inputs in enumerate(micro_batches)]
         self.engine.optimizer_step()
         losses[last] = losses[last]()       # the last micro-batch's loss / KL means are read after the optimizer launches are in the queue

@@ -230,6 +230,53 @@ def test_greedy_rollout_token_ids_bit_exact(golden_dir, use_graph):
             assert toks[b * 2 + gi, :new].tolist() == want[b].tolist(), (b, gi, toks[b * 2 + gi].tolist(), want[b].tolist())
 
 
+def test_one_rollout_for_all_micro_batches_of_an_optimizer_step():
+    """GRPOConfig.batch_rollouts (default): training_step rolls the prompts of ALL gradient-accumulation micro-batches out in one group rollout -- the policy is the
+    same for all of them (the reference pushes its weights to vLLM once per optimizer step, REF:637-641) and a decode step costs the same for 4 or 8 sequences.
+    (1) `combine_batches` + one greedy rollout gives bit-identical token ids to the per-micro-batch greedy rollouts (ragged prompt lengths, two image sizes: left
+    padding is outside every attention segment).  (2) the trainer runs ONE rollout per optimizer step with the switch on and accum many with it off; the step's
+    logged metrics are finite and the completions of micro-batch k are scored against micro-batch k's solutions."""
+    from iadr1_amd import rewards, rollout as ro
+    from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer, combine_batches, trim_completions
+    w = fx.make_weights(fx.TINY, 0)
+    pol, ref = store(w, True), store(w, False)
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=12, suppress_eos=False))
+    grids = [(1, 16, 12), (1, 8, 8), (1, 12, 12)]
+    parts = []
+    for i, (gr, n) in enumerate(zip(grids, [5, 17, 9])):
+        ids, mask = fx.left_pad([fx.synth_prompt(gr, n, fx.TINY, 177 + i)], fx.TINY["pad_token_id"])
+        parts.append({"input_ids": ids, "attention_mask": mask, "pixel_values": torch.from_numpy(fx.synth_pixel_values([gr], fx.TINY, seed=177 + i)), "image_grid_thw": [gr]})
+    both = combine_batches(parts, CFG.pad_token_id)
+    assert both["input_ids"].shape == (3, max(p["input_ids"].shape[1] for p in parts)) and both["image_grid_thw"] == grids and both["images_per_prompt"] == [1, 1, 1]
+    assert both["pixel_values"].shape[0] == sum(p["pixel_values"].shape[0] for p in parts)
+    together = eng.rollout(both, greedy=True)
+    for k, p in enumerate(parts):
+        alone = eng.rollout(p, greedy=True)
+        assert np.array_equal(together[4 * k: 4 * k + 4], alone), k
+    t = np.array([[7, 8, CFG.eos_token_id, 0, 0, 0], [7, CFG.eos_token_id, 0, 0, 0, 0]])
+    assert trim_completions(t, CFG.eos_token_id).shape == (2, 3) and trim_completions(np.full((2, 6), 9), CFG.eos_token_id).shape == (2, 6)
+
+    class Proc:                      # the processor call returns the prepared prompt of the row it is asked for
+        def apply_chat_template(self, conv, add_generation_prompt=True, tokenize=False):
+            return "P"
+
+        def __call__(self, text=None, images=None, **kw):
+            return parts[images[0][1]]
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return ["<think>a</think><location>top left</location><type>scratch</type><answer>yes</answer>"] * len(ids)
+    chat = [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": "?"}]}]
+    rows = lambda k: [{"prompt": chat, "image": [("synthetic", k)], "solution": "<think>gt</think><location>top left</location><type>scratch</type><answer>yes</answer>"}]
+    for on in (True, False):
+        tr = SCGRPOTrainer((CFG, w), [rewards.accuracy_reward, rewards.consistency_reward], processing_class=Proc(), train_dataset=None,
+                           args=GRPOConfig(output_dir="/tmp/iadr1_batch_rollouts", num_generations=4, max_completion_length=12, max_prompt_length=4096, per_device_train_batch_size=1,
+                                           gradient_accumulation_steps=3, save_steps=0, batch_rollouts=on))
+        n0 = ro.STATS["rollouts"]
+        losses = tr.training_step([rows(0), rows(1), rows(2)])
+        assert ro.STATS["rollouts"] - n0 == (1 if on else 3)
+        assert len(losses) == 3 and all(np.isfinite(l) for l in losses) and len(tr._metrics["reward"]) == 3
+
+
 def test_sampled_rollout_is_reproducible_and_in_vocab():
     w = fx.make_weights(fx.TINY, 0)
     pol, ref = store(w, True), store(w, False)
@@ -323,7 +370,7 @@ def test_trainer_prefetch_is_bit_identical_to_inline_preparation():
                           per_device_train_batch_size=1, gradient_accumulation_steps=2, max_steps=3, logging_steps=1, save_steps=0, prefetch_batches=prefetch)
         tr = SCGRPOTrainer((cfg, fx.make_weights(cfg_d, 0)), [rewards.accuracy_reward, rewards.consistency_reward], args=cfgT, train_dataset=rows, processing_class=proc)
         hist = tr.train()
-        assert (tr._prefetcher is not None) == prefetch
+        assert tr.prefetch_used == prefetch and tr._prefetcher is None      # train() stops its worker on the way out
         out[prefetch] = ([{k: v for k, v in h.items() if k != "elapsed_s"} for h in hist], tr.policy.flat.clone())
     assert out[False][0] == out[True][0], (out[False][0], out[True][0])
     assert torch.equal(out[False][1], out[True][1])
@@ -1560,7 +1607,7 @@ def test_trainer_level_traced_path_with_gradient_accumulation():
         pol.init_random(seed=0)
         tr = SCGRPOTrainer((cfg, pol), [token_reward], args=GRPOConfig(output_dir="/tmp/iadr1_traced_test", num_generations=G, max_completion_length=C, max_prompt_length=None,
                                                                         per_device_train_batch_size=Bp, gradient_accumulation_steps=2, learning_rate=1e-4, max_steps=2, logging_steps=1, save_steps=0,
-                                                                        shuffle=False, micro_batch_seqs=64, seed=7),
+                                                                        shuffle=False, micro_batch_seqs=64, seed=7, batch_rollouts=False),
                            train_dataset=rows, processing_class=Proc(batch, None))
         tr.engine.args.reuse_decode = reuse
         tr.engine.args.suppress_eos = True
