@@ -1572,6 +1572,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMP);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS);
         return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }();
     // wide kernels: NB=8 (128 columns / block) for the big-N streams (gate|up, lm_head); NB=4 with K split over
@@ -1581,9 +1582,12 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     {
         {   // split-K slabs (down projection): <= 6 k-steps per wave in a slice, >= 4 tiles per block
             const int kst = K >> 5, per_z = (kst + ksplit - 1) / ksplit, bps = ksplit > 0 ? ncu / ksplit : 0;
-            if (pers && ksplit > 1 && out_mode == 2 && per_z <= 48 && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
+            static const int ksw10 = iadr1_env_int("IADR1_SPLIT_KSW10", 1);
+            if (pers && ksplit > 1 && out_mode == 2 && per_z <= (ksw10 ? 80 : 48) && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
                 IADR1_REQUIRE(side == nullptr, "gemm_skinny: no side outputs in the split-K slab form");
-                hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 6>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
+                // <= 48 k-steps per slice: 6 resident X steps per wave (3B widths: 344 / 8 = 43); <= 80: 10 (7B widths: 592 / 8 = 74; 160 VGPRs of X fragments)
+                if (per_z <= 48) hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 6>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
+                else hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 10>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
                 return iadr1_check_launch("gemm_skinny_bf16");
             }
         }

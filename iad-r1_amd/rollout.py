@@ -70,7 +70,17 @@ class Rollout:
         self.qkv = torch.empty(N, c.qkv_width, dtype=BF16, device=dev)
         self.o = act(Hq * D)
         self.br = torch.empty(N, H, dtype=BF16, device=dev)
-        self.ks_o, self.ks_down = (2, 8) if H * Hq * D >= 1 << 20 else (1, 1)   # split-K of the two narrow-N projections
+        # split-K of the two narrow-N projections (fp32 partial slabs summed by the fused residual + RMSNorm).  The o projection runs 16-column blocks of 16 waves,
+        # one per CU: K is split until the grid fills the CUs ONCE (3B: 128 tiles x 2; 7B: 224 tiles x 1 -- two slices made 448 blocks = two rounds).  The down
+        # projection: 8 slices where the persistent X-resident split kernel takes it (<= 48 k-steps per slice: 3B), otherwise the one-shot 64-column kernel with
+        # (H / 64) x ks ~ the CU count (7B: 56 x 4).  Measured on the 7B shapes, decode step in ms: (2, 8) 4.83, (1, 8) 4.80, (2, 4) 4.71, (1, 4) 4.64, (1, 6) 4.96,
+        # (1, 2) 5.18 (profiles/r04_decode_ksplit_7b.txt).
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+        if H * Hq * D >= 1 << 20:
+            self.ks_o = max(1, min(2, ncu // max(1, H // 16)))
+            self.ks_down = 8 if (I // 32 + 7) // 8 <= int(os.environ.get("IADR1_SPLIT_MAXSTEPS", "80")) else max(1, min(8, ncu // max(1, H // 64)))
+        else:
+            self.ks_o, self.ks_down = 1, 1
         if os.environ.get("IADR1_DECODE_KS"):
             self.ks_o, self.ks_down = (int(z) for z in os.environ["IADR1_DECODE_KS"].split(","))
         self.part_o = torch.empty(self.ks_o, N, H, dtype=F32, device=dev)

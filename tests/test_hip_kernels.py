@@ -119,7 +119,8 @@ def test_gemm_nt_strided_views():
     assert float(outbuf[:, :256].abs().sum()) == 0 and float(outbuf[:, 516:].abs().sum()) == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (64, 640, 256), (8, 256, 512), (100, 1008, 1056), (64, 22016, 2048), (64, 2048, 11008)])
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (64, 640, 256), (8, 256, 512), (100, 1008, 1056), (64, 22016, 2048), (64, 2048, 11008),
+                                   (64, 3584, 18944), (24, 3584, 18944)])          # the 7B down projection: 8 K slices of 74 steps -> persistent split kernel <8, 10>
 def test_gemm_skinny(M, N, K):
     x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
     wp = ops.pack_weight(w)
@@ -142,7 +143,7 @@ def test_gemm_skinny_fused_swiglu(M, I, K):
     close(a, ref, 2e-2, 2e-2 * math.sqrt(K) * 0.3, f"skinny swiglu {M}x{I}x{K}")
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (8, 256, 512), (100, 1008, 1056), (64, 22016, 2048), (64, 2048, 11008)])
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 2048), (64, 2560, 2048), (8, 256, 512), (100, 1008, 1056), (64, 22016, 2048), (64, 2048, 11008), (64, 3584, 18944)])
 def test_gemm_skinny_decode_packed_x(M, N, K):
     """X in the decode-packed layout (C ABI: ldx == 0) gives the same numbers as row-major X: bit-exact where the K split
     over waves is the same, fp32-rounding-close otherwise."""
