@@ -134,7 +134,8 @@ def test_gemm_skinny(M, N, K):
         close(part.sum(0), ref, 1e-4, 1e-3 * math.sqrt(K) * 0.1, f"skinny split-K {ks} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 96)])
+@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 96),
+                                   (64, 18944, 3584), (24, 18944, 3584), (64, 14336, 4096)])     # 7B / Mistral widths: the one-shot 64-column kernel
 def test_gemm_skinny_fused_swiglu(M, I, K):
     x, w = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.3)
     a = ops.gemm_skinny(x, ops.pack_gateup(w), 2 * I, swiglu=True)
@@ -161,7 +162,7 @@ def test_gemm_skinny_decode_packed_x(M, N, K):
         close(p1.sum(0), p0.sum(0), 1e-5, 1e-4, f"packed X split-K {ks}")
 
 
-@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 96)])
+@pytest.mark.parametrize("M,I,K", [(64, 11008, 2048), (64, 512, 256), (7, 192, 96), (64, 18944, 3584)])
 def test_decode_packed_producers(M, I, K):
     """RMSNorm and the fused-SwiGLU epilogue write the decode-packed layout directly (ldy == 0): same values as row-major."""
     x, w = rnd(M, K, seed=1), rnd(2 * I, K, seed=2, scale=0.3)

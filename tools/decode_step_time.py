@@ -14,19 +14,24 @@ from iadr1_amd.sc_grpo import GRPOArgs, SCGRPOEngine
 import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--layers", type=int, default=36)
+ap.add_argument("--model", default="3b", choices=["3b", "7b"])
+ap.add_argument("--layers", type=int, default=0, help="0 = the model's own depth")
+ap.add_argument("--group", type=int, default=8)
+ap.add_argument("--prompts", type=int, default=8)
 ap.add_argument("--steps", type=int, default=255)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--trace", type=int, default=0, help="1: with the training-arena side outputs (needs memory for the arena)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=a.layers, v_depth=2, v_fullatt=(1,))
+base = VLMConfig.qwen25vl_3b() if a.model == "3b" else VLMConfig.qwen25vl_7b()
+a.layers = a.layers or base.num_hidden_layers
+cfg = dataclasses.replace(base, num_hidden_layers=a.layers, v_depth=2, v_fullatt=(1,))
 pol = ParamStore(cfg, dev, trainable=True)
 pol.init_random(seed=0)
 ref = ParamStore(cfg, dev, trainable=False)
 ref.copy_from(pol)
-eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=8, max_prompt_length=512, max_completion_length=a.steps + 1, micro_batch_seqs=64, suppress_eos=True))
-batch = bench.synth_batch(cfg, 8, 512, seed=5)
+eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=a.group, max_prompt_length=512, max_completion_length=a.steps + 1, micro_batch_seqs=64, suppress_eos=True))
+batch = bench.synth_batch(cfg, a.prompts, 512, seed=5)
 batch["pixel_values"] = batch["pixel_values"].to(dev)
 for rep in range(a.reps + 1):
     carry = {} if a.trace else None
