@@ -460,14 +460,29 @@ def full_size_parity(a):
     dev = "cuda:0"
     cores = int(os.environ.get("IADR1_CPU_THREADS", min(os.cpu_count() or 1, 32)))
     torch.set_num_threads(cores)
-    cfg = VLMConfig.qwen25vl_3b()
+    llava = a.model == "llava_ov_7b"
+    cfg = VLMConfig.llava_ov_7b() if llava else (VLMConfig.qwen25vl_7b() if a.model == "7b" else VLMConfig.qwen25vl_3b())
     d3 = json.loads(json.dumps(D3))
-    d3.update(image_token_id=cfg.image_token_id, video_token_id=151656, vision_start_token_id=cfg.vision_start_token_id, vision_end_token_id=cfg.vision_end_token_id,
-              eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id, tie_word_embeddings=True)
+    if llava:                  # BASELINE config 5: SigLIP-so400m tower + any-resolution packing + Qwen2-7B decoder (params._llava_ov_7b)
+        from oracle import llava_ov as oo
+        d3 = {"text": {"vocab_size": 152064, "hidden_size": 3584, "intermediate_size": 18944, "num_hidden_layers": 28, "num_attention_heads": 28, "num_key_value_heads": 4,
+                       "rms_norm_eps": 1e-6, "rope_theta": 1e6},
+              "vision": {"arch": "siglip", "depth": 26, "hidden_size": 1152, "intermediate_size": 4304, "num_heads": 16, "in_channels": 3, "patch_size": 14, "image_size": 384,
+                         "layer_norm_eps": 1e-6},
+              "image_grid_pinpoints": [[384 * i, 384 * j] for i in range(1, 7) for j in range(1, 7)], "anyres_max": 9, "video_token_id": 151647}
+    if a.model == "7b":       # BASELINE config 4's structure: untied 152 064-token head, 28 layers of 3584, 28:4 heads, MLP 18944; the ViT's merger projects to 3584
+        d3["text"].update(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4)
+        d3["vision"]["out_hidden_size"] = 3584
+    d3.update(image_token_id=cfg.image_token_id, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id, tie_word_embeddings=cfg.tie_word_embeddings)
+    if not llava:
+        d3.update(video_token_id=151656, vision_start_token_id=cfg.vision_start_token_id, vision_end_token_id=cfg.vision_end_token_id)
+    make_oracle = (lambda w, **kw: oo.LlavaOVOracle(d3, w, **{k: v for k, v in kw.items() if k != "copy"})) if llava else (lambda w, **kw: oq.Qwen25VLOracle(d3, w, **kw))
     T = {"t0": time.time()}
     pol, ref = ParamStore(cfg, dev, trainable=True), ParamStore(cfg, dev, trainable=False)
     ref.init_random(seed=0)
     ref.w("embed").mul_(2.0)
+    if not cfg.tie_word_embeddings:
+        ref.w(ref.lm_head_name()).mul_(2.0)          # untied head: the logits' spread comes from lm_head
     ref.finalize()
     pol.flat.copy_(ref.flat)
     gen = torch.Generator(device=dev).manual_seed(7)
@@ -477,25 +492,36 @@ def full_size_parity(a):
     pol.finalize()
     grid = (1, 32, 32)
     rs = np.random.RandomState(1234)
-    n_text = P - (3 + 1 + 256 + 1)
-    row = rs.randint(1000, 150000, 3).tolist() + [cfg.vision_start_token_id] + [cfg.image_token_id] * 256 + [cfg.vision_end_token_id] + rs.randint(1000, 150000, n_text).tolist()
-    ids, mask = np.array([row], dtype=np.int64), np.ones((1, P), dtype=np.int64)
-    px = rs.standard_normal((1024, cfg.patch_dim)).astype(np.float32)
-    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": torch.from_numpy(px), "image_grid_thw": [grid]}
+    if llava:     # one 448 x 448 image through the any-resolution path: 5 crops of 384 x 384 -> 3699 packed image tokens, + 3 prefix ids + 253 text ids (the bench's prompt)
+        sb = synth_batch_llava(cfg, 1, 253, seed=1234)
+        ids, mask, px = sb["input_ids"], sb["attention_mask"], sb["pixel_values"].numpy()
+        P = ids.shape[1]
+        vis_arg = [tuple(z) for z in sb["image_sizes"]]
+        batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": sb["pixel_values"], "image_sizes": sb["image_sizes"]}
+    else:
+        n_text = P - (3 + 1 + 256 + 1)
+        row = rs.randint(1000, 150000, 3).tolist() + [cfg.vision_start_token_id] + [cfg.image_token_id] * 256 + [cfg.vision_end_token_id] + rs.randint(1000, 150000, n_text).tolist()
+        ids, mask = np.array([row], dtype=np.int64), np.ones((1, P), dtype=np.int64)
+        px = rs.standard_normal((1024, cfg.patch_dim)).astype(np.float32)
+        vis_arg = [grid]
+        batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": torch.from_numpy(px), "image_grid_thw": [grid]}
     eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, beta=0.04, micro_batch_seqs=G, seed=11))
-    n_greedy = max(0, min(a.check_greedy_tokens, C))
+    n_greedy = 0 if llava else max(0, min(a.check_greedy_tokens, C))        # (the KV-cached greedy oracle exists for the Qwen structure)
     toks_greedy = eng.rollout(batch, greedy=True)[0, :n_greedy].tolist() if n_greedy else []
     comps = eng.rollout(batch, greedy=False)
     comps = [r.tolist() for r in comps]
-    comps[3] = comps[3][: C // 3] + [cfg.eos_token_id]                       # one completion ends early: the EOS mask and the ragged rows are part of the check
+    comps[min(3, G - 1)] = comps[min(3, G - 1)][: C // 3] + [cfg.eos_token_id]     # one completion ends early: the EOS mask and the ragged rows (llava: the rotation quirk) are part of the check
     wrapped = [[{"role": "assistant", "content": CANNED[i % len(CANNED)]}] for i in range(G)]
     from iadr1_amd import rewards as rw
     rew = np.stack([rw.accuracy_reward(wrapped, [SOLUTION] * G), rw.consistency_reward(wrapped, [SOLUTION] * G)], 1).astype(np.float32)
     out = eng.loss_and_grads(batch, comps, rew)
     torch.cuda.synchronize()
     T["hip"] = time.time()
-    names = ["model.norm.weight", "model.layers.35.post_attention_layernorm.weight", "model.layers.17.self_attn.k_proj.bias", "model.layers.0.input_layernorm.weight",
+    Lm = cfg.num_hidden_layers
+    names = ["model.norm.weight", f"model.layers.{Lm - 1}.post_attention_layernorm.weight", f"model.layers.{Lm // 2 - 1}.self_attn.k_proj.bias", "model.layers.0.input_layernorm.weight",
              "visual.merger.ln_q.weight", "visual.blocks.0.norm1.weight"]
+    if llava:
+        names = ["language_model." + n for n in names[:4]] + ["image_newline", "multi_modal_projector.linear_2.bias", "vision_tower.vision_model.encoder.layers.0.layer_norm1.weight"]
     grads = pol.export_named(source="grad")
     grads = {n: grads[n].numpy().reshape(-1).astype(np.float64) for n in names}
     hip_lp, hip_lr, hip_cm, mt = out["logps"].cpu().numpy(), out["ref_logps"].cpu().numpy(), np.asarray(out["completion_mask"]), dict(out["metrics"])
@@ -503,8 +529,8 @@ def full_size_parity(a):
     del eng, out, pol, ref
     torch.cuda.empty_cache()
     T["export"] = time.time()
-    o_pol = oq.Qwen25VLOracle(d3, w_pol, requires_grad=set(names), copy=False)
-    o_ref = oq.Qwen25VLOracle(d3, w_ref, copy=False)
+    o_pol = make_oracle(w_pol, requires_grad=True if llava else set(names), copy=False)
+    o_ref = make_oracle(w_ref, copy=False)
     # greedy ids: the oracle's KV-cached decode on the policy weights
     greedy = {"tokens_compared": 0}
     if n_greedy:
@@ -524,8 +550,8 @@ def full_size_parity(a):
                   "oracle_top2_logit_gap_at_disagreements": [round(g_, 5) for g_, ok in zip(gaps, agree) if not ok], "median_top2_gap": float(np.median(gaps)),
                   "note": "teacher-forced on the HIP tokens; a disagreement with a top-2 gap below the bf16 logit error (~0.05 at logit std 1.8) is a near-tie, not an error"}
     T["greedy"] = time.time()
-    want = og.sc_grpo_step(o_pol, o_ref, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(px), [grid], comps, torch.from_numpy(rew), G, 0.04,
-                           cfg.eos_token_id, cfg.pad_token_id)
+    want = og.sc_grpo_step(o_pol, o_ref, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(px), vis_arg, comps, torch.from_numpy(rew), G, 0.04,
+                           cfg.eos_token_id, cfg.pad_token_id, rotate_right_padded_rows=llava)
     T["oracle_fwd"] = time.time()
     want["loss"].backward()
     T["oracle_bwd"] = time.time()
@@ -537,11 +563,14 @@ def full_size_parity(a):
     try:
         ids_t = torch.cat([torch.from_numpy(ids).repeat(G, 1), og.right_pad(comps, cfg.pad_token_id)], 1)
         mask_t = torch.cat([torch.from_numpy(mask).repeat(G, 1), want["completion_mask"].long()], 1)
+        if llava:
+            ids_t, mask_t = oo.ensure_left_padding(ids_t, mask_t, cfg.pad_token_id)
+        px_t = torch.from_numpy(px)
         with torch.no_grad():
             lps = []
-            for o in (o_pol, o_ref):
-                o16 = oq.Qwen25VLOracle(d3, {k: t.detach() for k, t in o.w.items() if k != "lm_head.weight"}, dtype=torch.bfloat16)
-                lps.append(o16.per_token_logps(ids_t, mask_t, torch.from_numpy(px).repeat(G, 1), [grid] * G)[:, P - 1:].float().numpy())
+            for wd in (w_pol, w_ref):
+                o16 = make_oracle({k: t for k, t in wd.items() if not (k == "lm_head.weight" and cfg.tie_word_embeddings)}, dtype=torch.bfloat16)
+                lps.append(o16.per_token_logps(ids_t, mask_t, px_t.repeat(G, *[1] * (px_t.dim() - 1)), vis_arg * G)[:, P - 1:].float().numpy())
                 del o16
         kl16 = float(og.grpo_loss(torch.from_numpy(lps[0]), torch.from_numpy(lps[1]), want["advantages"], want["completion_mask"].float(), 0.04)[2])
         bf = {"dlogp_policy_max": float(np.abs(lps[0][m] - w_lp[m]).max()), "dlogp_policy_mean": float(np.abs(lps[0][m] - w_lp[m]).mean()),
@@ -552,10 +581,11 @@ def full_size_parity(a):
     wl, wk = float(want["loss"].detach()), float(want["metrics"]["kl"])
     cos = {}
     for n in names:
-        x, y = grads[n], o_pol.w[n].grad.numpy().reshape(-1).astype(np.float64)
+        x, y = grads[n], dict(o_pol.parameters())[n].grad.numpy().reshape(-1).astype(np.float64)
         cos[n] = {"cosine": float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30)), "norm_ratio": float(np.linalg.norm(x) / (np.linalg.norm(y) + 1e-30))}
     e_p, e_r = hip_lp[m] - w_lp[m], hip_lr[m] - w_lr[m]
-    rec = {"shape": {"model": "Qwen2.5-VL-3B, unreduced (36 decoder layers, 32 ViT blocks, vocab 151936)", "prompts": 1, "G": G, "P": P, "C": C, "scored_tokens": int(m.sum()),
+    rec = {"shape": {"model": "LLaVA-OneVision-SI-7B shapes, unreduced (SigLIP-so400m 26 layers, 5 crops -> 3699 packed image tokens, Qwen2-7B decoder 28 x 3584, vocab 152064, untied head)" if llava else (f"Qwen2.5-VL-{'7B' if a.model == '7b' else '3B'}, unreduced ({cfg.num_hidden_layers} decoder layers of {cfg.hidden_size}, 32 ViT blocks, vocab {cfg.vocab_size}, "
+                               f"{'untied' if not cfg.tie_word_embeddings else 'tied'} head)"), "prompts": 1, "G": G, "P": P, "C": C, "scored_tokens": int(m.sum()),
                      "policy": f"reference x (1 + {a.check_noise} N(0,1)) element-wise", "completions": "sampled by the engine's hipGraph rollout (T 0.9, top-k 50, top-p 0.9), row 3 cut by EOS"},
            "hip_vs_fp32_oracle": {"dlogp_policy_max": float(np.abs(e_p).max()), "dlogp_policy_mean": float(np.abs(e_p).mean()), "dlogp_ref_max": float(np.abs(e_r).max()),
                                   "dlogp_ref_mean": float(np.abs(e_r).mean()), "err_of_ref_minus_policy_std": float(np.std(e_r - e_p)),
