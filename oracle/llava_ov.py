@@ -54,7 +54,7 @@ class LlavaOVOracle(oq.Qwen25VLOracle):
     "image_token_id", "image_grid_pinpoints", "anyres_max", ...}; weights keyed by the checkpoint names of the reference's dependency
     (vision_tower.vision_model.*, multi_modal_projector.*, image_newline, language_model.model.*, language_model.lm_head.weight)."""
 
-    def __init__(self, cfg, weights, requires_grad=False, dtype=torch.float32):
+    def __init__(self, cfg, weights, requires_grad=False, dtype=torch.float32, copy: bool = True):
         w2 = {}
         for k, a in weights.items():
             if k.startswith("language_model.model."):
@@ -65,7 +65,7 @@ class LlavaOVOracle(oq.Qwen25VLOracle):
                 w2[k] = a
         text_cfg = dict(cfg)
         text_cfg["text"] = dict(cfg["text"], mrope_section=[cfg["text"]["hidden_size"] // cfg["text"]["num_attention_heads"] // 2, 0, 0])
-        super().__init__(text_cfg, w2, requires_grad=requires_grad, dtype=dtype)
+        super().__init__(text_cfg, w2, requires_grad=requires_grad, dtype=dtype, copy=copy)
         self.cfg = text_cfg
 
     def parameters(self):

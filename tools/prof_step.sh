@@ -6,9 +6,9 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/${TAG}_bench_3b.json 2> $R/gpurun_out/${TAG}_bench_3b.err
 rm -rf /tmp/prof_a /tmp/prof_b
-rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-repeated-rows-leg --no-real-processor-legs > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o a -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-repeated-rows-leg --no-real-processor-legs --no-real-shapes-leg > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/prof_a -name "*.db" | head -1) > $R/gpurun_out/${TAG}_bench_3b_kernel_stats.txt 2>&1
-IADR1_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-repeated-rows-leg --no-real-processor-legs > /dev/null 2>&1
+IADR1_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-repeated-rows-leg --no-real-processor-legs --no-real-shapes-leg > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/prof_b -name "*.db" | head -1) > $R/gpurun_out/${TAG}_bench_3b_kernel_stats_single_stream.txt 2>&1
 python $R/bench.py --workload pa_sft --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_pa_sft_3b.json 2>/dev/null
 python $R/bench.py --model 7b --no-cpu-baseline --no-repeated-rows-leg > $R/gpurun_out/${TAG}_bench_7b.json 2>/dev/null
