@@ -1560,7 +1560,6 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     // launcher configuration, fixed at first use: A/B switches, the CU count, LDS opt-ins of every kernel this entry point can launch
     static const int wide_nb = iadr1_env_int("IADR1_SKINNY_WIDE_NB", -1);  // -1: 4 with packed X, 8 with row-major X
     static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1);
-    static const int narrow_nb = iadr1_env_int("IADR1_SKINNY_NARROW_NB", 1);   // 2: 32-column blocks of 8 waves for the small projections (A/B probe)
     static const int ncu = [] {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -1612,7 +1611,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     if (big && nb == 4 && (N % 64) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3(N / 64, mz, 1), dim3(512), SMW, stream, p);
     else if (big && (N % 128) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
     else if (ksplit > 1 && (N % 64) == 0 && (N / 64) * ksplit >= 192) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3((N + 63) / 64, mz, ksplit), dim3(512), SMW, stream, p);
-    else if (N >= 8192 || narrow_nb == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
+    else if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
     else hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_skinny_bf16");
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The narrow decode projections (q|k|v-like and o) on weights that really come from HBM (rotating buffers), 64 rows, packed X: us per launch, back-to-back
-(HIP events over 3 x NL launches; includes ~1 us of launch gap).  IADR1_SKINNY_NARROW_NB=2 switches the 16-column / 16-wave blocks to 32-column / 8-wave ones."""
+(HIP events over 3 x NL launches; includes ~1 us of launch gap).  Round 4 measured the 32-column / 8-wave blocks against the shipped 16-column / 16-wave ones with
+it: slower on every shape (profiles/EXPERIMENTS.md); the 7B q|k|v projection (288 tiles on 256 CUs) pays 8 us for its second round of blocks."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import iadr1_amd
@@ -25,5 +26,5 @@ for name, N, K, ks in (("3b qkv-like", 2560, 2048, 1), ("3b o ks2", 2048, 2048, 
     else:
         part = torch.empty(ks, 64, N, dtype=torch.float32, device=dev)
         us = timeit(lambda i: ops.gemm_skinny(x, w[i % NL], N, out=part, ksplit=ks), NL)
-    print(f"NB={os.environ.get('IADR1_SKINNY_NARROW_NB', '1')} {name:12s} N {N} K {K} ks {ks}: {us:6.2f} us  {N * K * 2 / us / 1e6:5.2f} TB/s", flush=True)
+    print(f"{name:12s} N {N} K {K} ks {ks}: {us:6.2f} us  {N * K * 2 / us / 1e6:5.2f} TB/s", flush=True)
     del w
