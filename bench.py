@@ -692,7 +692,7 @@ def run_pa_sft(a, cfg, dev, rank, world):
     if rank == 0:
         n_launch, t_gemm, fl_gemm = timer.summary()
         ach = fl_gemm / max(t_gemm, 1e-9) / 1e12
-        print(json.dumps({
+        emit({
             "metric": f"PA-SFT samples/sec (bs={B}, img448, {P}+{C} tok) {model_name}", "value": world * B * a.steps / dt, "unit": "samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic", "config": {"workload": f"{model_name} PA-SFT step (BASELINE config {1 if a.model == 'qwen2vl_2b' else 2}): {B} sequences x (448x448 image + {P} prompt positions + {C} supervised tokens), forward(labels) + backward + AdamW, random-init weights", "parallelism": f"dp{world}",
@@ -700,7 +700,7 @@ def run_pa_sft(a, cfg, dev, rank, world):
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_256 / gemm_nt_128 (v_mfma_f32_16x16x32_bf16)", "achieved": ach, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None, "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt},
             "last_loss": loss, "tokens_per_s": world * B * (P + C) * a.steps / dt, "cpu_baseline": None,
-            "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30}}), flush=True)
+            "hbm": {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30}})
 
 
 class SynthProcessor:
@@ -897,19 +897,40 @@ D3 = {"text": {"vocab_size": 151936, "hidden_size": 2048, "intermediate_size": 1
       "tie_word_embeddings": True}
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The ONE JSON line of the run, on the process's real stdout."""
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
+def claim_stdout():
+    """The bench contract is ONE JSON line on rank 0's stdout.  Libraries print there too (RCCL writes a five-line version banner to stdout when a communicator is
+    created), so file descriptor 1 is pointed at stderr for the life of the process and the JSON line goes to a saved duplicate of the original stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
 def main():
     a = parse()
     if a.cpu_full_step and a.check:      # the full-size parity record: HIP engine on cuda:0 against the oracle on the host cores
         import iadr1_amd  # noqa: F401
         rec = full_size_parity(a)
-        print(json.dumps({"full_size_parity": rec}), flush=True)
+        emit({"full_size_parity": rec})
         return
     if a.cpu_full_step:      # host cores only: the oracle's real step, once
         import iadr1_amd  # noqa: F401
-        print(json.dumps({"cpu_full_step": cpu_full_step(D3, P=a.prompt_len, C=a.gen_len, G=a.group)}), flush=True)
+        emit({"cpu_full_step": cpu_full_step(D3, P=a.prompt_len, C=a.gen_len, G=a.group)})
         return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        respawn_under_torchrun(a.gpus)
+        respawn_under_torchrun(a.gpus)          # (the ranks inherit this process's stdout)
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -926,8 +947,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": a.gpus, "world_size": world, "max_over_ranks": float(t), "ranks_seen": sorted(r for r, _ in seen),
-                              "local_ranks": sorted(l for _, l in seen), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+            emit({"launch_check": True, "n_gpus": a.gpus, "world_size": world, "max_over_ranks": float(t), "ranks_seen": sorted(r for r, _ in seen),
+                              "local_ranks": sorted(l for _, l in seen), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"})
         return
     # IADR1_BENCH_SHARE_GPU=1 + IADR1_BENCH_BACKEND=gloo: every rank on cuda:0 with the exchange over gloo -- how the N > 1 path of this file runs end to end on a
     # ONE-GPU box (tests/test_hip_model.py); RCCL refuses two ranks on one device.  Never the measured configuration.
@@ -1040,6 +1061,7 @@ def main():
     timer.enabled = False
     ms1 = torch.cuda.memory_stats()      # read HERE: the extra legs below (other layout, real processor) are not the timed region
     hbm = {"peak_allocated_GB": torch.cuda.max_memory_allocated() / 2**30, "peak_reserved_GB": torch.cuda.max_memory_reserved() / 2**30,
+           "reserved_after_timed_region_GB": torch.cuda.memory_reserved() / 2**30,
            "alloc_retries": ms1.get("num_alloc_retries", 0),
            "device_allocs_in_timed_region": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
            "device_frees_in_timed_region": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)}
@@ -1188,7 +1210,7 @@ def main():
                 pass
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1 or os.environ.get("IADR1_FORCE_REDUCE"):
         import torch.distributed as dist
         if dist.is_initialized():

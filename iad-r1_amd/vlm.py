@@ -11,6 +11,7 @@ ONCE per unique image per step and its output rows are fanned out to every seque
 from __future__ import annotations
 
 import os
+import sys
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -764,6 +765,9 @@ class Engine:
             return True
         if mode != "auto" or os.environ.get("IADR1_RECOMPUTE") == "0":
             return False
+        if self.__dict__.get("_recompute_forced"):      # check_ddp_headroom(): an earlier step of this run peaked too close to the card's capacity
+            self._ws.pop("act_save", None)
+            return True
         bucket = (int(T) + 2047) // 2048 * 2048
         cache = self.__dict__.setdefault("_recompute_decisions", {})
         if bucket not in cache:
@@ -780,10 +784,32 @@ class Engine:
             cache[bucket] = need > 0.6 * budget
             if os.environ.get("IADR1_QUIET") != "1":
                 print(f"[iadr1] gradient checkpointing (auto): {bucket} token rows need {need / 2**30:.1f} GiB of saved activations, budget 0.6 x {budget / 2**30:.1f} GiB "
-                      f"-> {'recompute one decoder layer at a time' if cache[bucket] else 'keep'}", flush=True)
+                      f"-> {'recompute one decoder layer at a time' if cache[bucket] else 'keep'}", file=sys.stderr, flush=True)
         if cache[bucket]:
             self._ws.pop("act_save", None)          # a stale arena of an earlier (smaller) bucket must not sit next to the checkpoint buffers
         return cache[bucket]
+
+    def check_ddp_headroom(self, mode: str, limit_bytes: int = 235 << 30):
+        """Data-parallel runs only, policy "auto", called once per optimizer step by the trainers: the static budget above cannot see everything a model family
+        keeps (LLaVA-OneVision's 40 saved SigLIP crops and its 4 000-token KV pool: 261 GB reserved although the decoder arena alone fits).  If a COMPLETED step
+        peaked above `limit_bytes` of reserved memory (235 GB: what VERDICT r3 #5 asks to stay under so that RCCL's channel buffers have room), every later step
+        recomputes.  Deterministic for given shapes (the allocator's peak of a whole step, not its free memory at some call), logged once."""
+        if mode != "auto" or self.__dict__.get("_recompute_forced") or os.environ.get("IADR1_RECOMPUTE") == "0":
+            return
+        try:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                return
+        except Exception:
+            return
+        peak = torch.cuda.max_memory_reserved(self.dev)
+        if peak > limit_bytes:
+            self._recompute_forced = True
+            self._ws.pop("act_save", None)
+            torch.cuda.empty_cache()            # hand the arena's blocks back to the DEVICE: RCCL allocates outside torch's caching allocator
+            if os.environ.get("IADR1_QUIET") != "1":
+                print(f"[iadr1] gradient checkpointing (auto): a step peaked at {peak / 2**30:.1f} GiB reserved (> {limit_bytes / 2**30:.0f}) under a process group -> "
+                      "decoder activations are recomputed from the next step on", file=sys.stderr, flush=True)
 
     def _recompute_layer(self, i, ctx):
         """Gradient checkpointing: the activations of decoder layer i, rebuilt from its checkpointed input rows with the forward's own kernels (bit-identical to
