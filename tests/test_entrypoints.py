@@ -589,3 +589,24 @@ def test_pa_sft_llava_and_llava_next_mistral_templates_match_the_reference(templ
     assert ids.count(image_id) == (16 if template == "llava" else 70) and len(pixels) == 1 and tuple(pixels[0].shape) == ((1, 3, 56, 56) if template == "llava" else (5, 3, 56, 56))
     sup = [t for t in labels if t != -100]
     assert sup[-1] == proc.tokenizer.eos_token_id and len(ids) == len(labels) and (template == "llava" or ids[0] == proc.tokenizer.bos_token_id)
+
+
+def test_combine_batches_and_trim_completions():
+    """Host half of GRPOConfig.batch_rollouts (one group rollout for all micro-batches of an optimizer step): prompts of different lengths are LEFT-padded into one
+    batch with their image tensors / grids concatenated in prompt order; completions are cut to the longest one of a micro-batch, as the reference's right padding
+    of the vLLM outputs does (REF:680-683).  The any-resolution processors pad the crop dimension per call: such batches are not combined (None)."""
+    import numpy as np
+    import torch
+    from iadr1_amd.trainer import combine_batches, trim_completions
+    a = {"input_ids": np.array([[7, 8, 9]]), "attention_mask": np.ones((1, 3), dtype=np.int64), "pixel_values": torch.ones(4, 6), "image_grid_thw": [(1, 2, 2)]}
+    b = {"input_ids": torch.tensor([[0, 5, 6, 7, 8], [1, 2, 3, 4, 5]]), "attention_mask": torch.tensor([[0, 1, 1, 1, 1], [1, 1, 1, 1, 1]]), "pixel_values": torch.zeros(8, 6),
+         "image_grid_thw": torch.tensor([[1, 2, 2], [1, 2, 2]]), "images_per_prompt": [1, 1]}
+    c = combine_batches([a, b], pad_token_id=99)
+    assert c["input_ids"].tolist() == [[99, 99, 7, 8, 9], [0, 5, 6, 7, 8], [1, 2, 3, 4, 5]] and c["attention_mask"].tolist() == [[0, 0, 1, 1, 1], [0, 1, 1, 1, 1], [1, 1, 1, 1, 1]]
+    assert c["pixel_values"].shape == (12, 6) and float(c["pixel_values"][:4].sum()) == 24.0 and c["image_grid_thw"] == [(1, 2, 2)] * 3 and c["images_per_prompt"] == [1, 1, 1]
+    ov1 = {"input_ids": np.array([[1, 2]]), "attention_mask": np.ones((1, 2), dtype=np.int64), "pixel_values": torch.zeros(1, 5, 3, 4, 4), "image_sizes": [(8, 8)]}
+    ov2 = dict(ov1, pixel_values=torch.zeros(1, 3, 3, 4, 4))
+    assert combine_batches([ov1, ov2], 0) is None and combine_batches([ov1, ov1], 0)["image_sizes"] == [(8, 8), (8, 8)]
+    t = np.array([[5, 6, 2, 0, 0, 0], [5, 2, 0, 0, 0, 0]])
+    assert trim_completions(t, eos_token_id=2).tolist() == [[5, 6, 2], [5, 2, 0]]
+    assert trim_completions(np.full((2, 4), 9), eos_token_id=2).shape == (2, 4) and trim_completions(np.array([[2, 0, 0]]), 2).shape == (1, 1)
