@@ -277,6 +277,33 @@ def test_one_rollout_for_all_micro_batches_of_an_optimizer_step():
         assert len(losses) == 3 and all(np.isfinite(l) for l in losses) and len(tr._metrics["reward"]) == 3
 
 
+def test_rollout_stops_soon_after_every_sequence_has_finished():
+    """EOS live: the decode loop ends once all sequences have finished, without draining the queue -- `decode_advance` keeps an all-finished flag, the host reads a copy
+    that is three polls (12 steps) old.  One prompt x G greedy rows are identical, so with the EOS id set to the token greedy decoding emits at step 6 every row ends
+    there: the loop must run far fewer than max_new steps, the tokens up to and including the EOS equal the unstopped run's, everything after is pad (REF:680-683)."""
+    import dataclasses
+    from iadr1_amd import rollout as ro
+    w = fx.make_weights(fx.TINY, 0)
+    pol, ref = store(w, True), store(w, False)
+    grid = (1, 16, 12)
+    ids, mask = fx.left_pad([fx.synth_prompt(grid, 9, fx.TINY, 91)], fx.TINY["pad_token_id"])
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values([grid], fx.TINY, seed=91), "image_grid_thw": [grid]}
+    C = 120
+    eng = SCGRPOEngine(CFG, pol, ref, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=C, suppress_eos=True))
+    free = eng.rollout(batch, greedy=True)
+    k = next(j for j in range(4, 40) if free[0, j] not in free[0, :j].tolist())          # first occurrence of that token: the EOS position is unambiguous
+    cfg2 = dataclasses.replace(CFG, eos_token_id=int(free[0, k]))
+    pol2, ref2 = ParamStore(cfg2, DEV, True), ParamStore(cfg2, DEV, False)
+    pol2.load_named(w)
+    ref2.load_named(w)
+    eng2 = SCGRPOEngine(cfg2, pol2, ref2, GRPOArgs(num_generations=4, max_prompt_length=4096, max_completion_length=C, suppress_eos=False))
+    n0 = ro.STATS["decode_steps"]
+    got = eng2.rollout(batch, greedy=True)
+    ran = ro.STATS["decode_steps"] - n0
+    assert ran <= k + 1 + 4 * 3 + 4 and ran < C - 1, (ran, k)                           # k + 1 steps to reach the EOS, then at most LAG x POLL (+ one poll period) more
+    assert np.array_equal(got[:, : k + 1], free[:, : k + 1]) and (got[:, k + 1:] == cfg2.pad_token_id).all()
+
+
 def test_sampled_rollout_is_reproducible_and_in_vocab():
     w = fx.make_weights(fx.TINY, 0)
     pol, ref = store(w, True), store(w, False)
