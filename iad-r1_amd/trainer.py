@@ -428,7 +428,7 @@ class SCGRPOTrainer:
 
     def _rewards(self, inputs, completion_ids: np.ndarray):
         G = self.args.num_generations
-        texts = self._locked(self.processing_class.batch_decode, completion_ids, True) if self.__dict__.get("_pc_lock") else self.processing_class.batch_decode(completion_ids, skip_special_tokens=True)
+        texts = self._locked(lambda: self.processing_class.batch_decode(completion_ids, skip_special_tokens=True))       # (the lock exists only when the prefetch worker shares this processor)
         conversational = isinstance(inputs[0]["prompt"], list)
         completions = [[{"role": "assistant", "content": t}] for t in texts] if conversational else texts
         prompts = [ex["prompt"] for ex in inputs for _ in range(G)]
