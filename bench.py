@@ -646,8 +646,13 @@ def pa_sft_full_size_parity(a):
     dev = "cuda:0"
     cores = int(os.environ.get("IADR1_CPU_THREADS", min(os.cpu_count() or 1, 32)))
     torch.set_num_threads(cores)
-    cfg = VLMConfig.qwen25vl_3b()
+    q2 = a.model == "qwen2vl_2b"        # BASELINE config 1's model: Qwen2-VL-2B (LayerNorm / QuickGELU ViT without windows), vision tower + projector frozen as in the reference
+    cfg = VLMConfig.qwen2vl_2b() if q2 else VLMConfig.qwen25vl_3b()
     d3 = json.loads(json.dumps(D3))
+    if q2:
+        d3["text"].update(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2)
+        d3["vision"] = {"arch": "qwen2_vl", "depth": 32, "hidden_size": 1280, "intermediate_size": 5120, "num_heads": 16, "in_channels": 3, "patch_size": 14, "spatial_merge_size": 2,
+                        "temporal_patch_size": 2, "window_size": 0, "out_hidden_size": 1536, "fullatt_block_indexes": list(range(32))}
     d3.update(image_token_id=cfg.image_token_id, video_token_id=151656, vision_start_token_id=cfg.vision_start_token_id, vision_end_token_id=cfg.vision_end_token_id,
               eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id, tie_word_embeddings=True)
     B, P, C, STEPS = a.sft_batch, a.prompt_len, a.gen_len, 3
@@ -658,7 +663,10 @@ def pa_sft_full_size_parity(a):
     p.w("embed").mul_(2.0)
     p.finalize()
     w0 = p.export_named()
-    eng = SFTEngine(cfg, p, SFTArgs(learning_rate=1e-5, weight_decay=0.0, micro_batch_seqs=B))
+    from iadr1_amd.sft import frozen_parameter_rule
+    frozen = frozen_parameter_rule("qwen2_vl") if q2 else None
+    eng = SFTEngine(cfg, p, SFTArgs(learning_rate=1e-5, weight_decay=0.0, micro_batch_seqs=B, frozen=frozen))
+    Lm = cfg.num_hidden_layers
 
     def make(seed):
         b = synth_batch(cfg, B, P, seed)
@@ -669,8 +677,8 @@ def pa_sft_full_size_parity(a):
         labels[:, :P] = -100
         return {"input_ids": ids, "attention_mask": np.ones_like(ids), "labels": labels, "pixel_values": b["pixel_values"], "image_grid_thw": b["image_grid_thw"]}
     batches = [make(4321 + i) for i in range(STEPS)]
-    names = ["model.norm.weight", "model.layers.35.post_attention_layernorm.weight", "model.layers.17.self_attn.k_proj.bias", "model.layers.0.input_layernorm.weight",
-             "visual.merger.ln_q.weight", "visual.blocks.0.norm1.weight"]
+    names = ["model.norm.weight", f"model.layers.{Lm - 1}.post_attention_layernorm.weight", f"model.layers.{Lm // 2 - 1}.self_attn.k_proj.bias", "model.layers.0.input_layernorm.weight",
+             "model.layers.0.mlp.down_proj.weight"] + ([] if q2 else ["visual.merger.ln_q.weight", "visual.blocks.0.norm1.weight"])
     hip_loss, grads, hip_gn = [], None, None
     for k, bt in enumerate(batches):
         hip_loss.append(eng.loss_and_grads(dict(bt, pixel_values=bt["pixel_values"].to(dev))))
@@ -686,8 +694,9 @@ def pa_sft_full_size_parity(a):
     del eng, p
     torch.cuda.empty_cache()
     w_init = {k: v.detach().clone() for k, v in w0.items()}        # the first oracle trains w0's tensors in place (copy=False)
-    o = oq.Qwen25VLOracle(d3, w0, requires_grad=True, copy=False)
-    params = [t for _, t in o.parameters()]
+    train_names = {n for n in w0 if not (q2 and n.startswith("visual."))}        # config 1: the vision tower and the merger do not train (LLaMA-Factory's defaults)
+    o = oq.Qwen25VLOracle(d3, w0, requires_grad=train_names, copy=False)
+    params = [t for n, t in o.parameters() if n in train_names]
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8)
     want_loss, cos, want_gn = [], {}, None
     for k, bt in enumerate(batches):
@@ -707,8 +716,8 @@ def pa_sft_full_size_parity(a):
     # the yardstick for steps 2-3: the same fp32 arithmetic with the weights STORED as the reference's --bf16 run stores them -- bf16 in the forward / backward, an
     # fp32 master under AdamW (the HIP path's scheme): what separates the two curves above beyond step 1 is that storage, not the kernels
     del o, opt, params, w0
-    o = oq.Qwen25VLOracle(d3, w_init, requires_grad=True, copy=False)
-    params = [t for _, t in o.parameters()]
+    o = oq.Qwen25VLOracle(d3, w_init, requires_grad=train_names, copy=False)
+    params = [t for n, t in o.parameters() if n in train_names]
     master = [t.detach().clone() for t in params]
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8)
     bf16w_loss = []
@@ -729,8 +738,8 @@ def pa_sft_full_size_parity(a):
             for t_, m_ in zip(params, master):
                 m_.copy_(t_)
     T["oracle_bf16w"] = time.time()
-    return {"shape": {"model": "Qwen2.5-VL-3B, unreduced (36 decoder layers, 32 ViT blocks, vocab 151936)", "sequences": B, "prompt_positions": P, "supervised_tokens": C,
-                      "steps": STEPS, "optimizer": "AdamW lr 1e-5, betas (0.9, 0.999), eps 1e-8, weight decay 0, clip 1.0; everything trains"},
+    return {"shape": {"model": "Qwen2-VL-2B, unreduced (28 decoder layers of 1536, 32 ViT blocks, vocab 151936); vision tower + merger frozen" if q2 else "Qwen2.5-VL-3B, unreduced (36 decoder layers, 32 ViT blocks, vocab 151936)", "sequences": B, "prompt_positions": P, "supervised_tokens": C,
+                      "steps": STEPS, "optimizer": "AdamW lr 1e-5, betas (0.9, 0.999), eps 1e-8, weight decay 0, clip 1.0; " + ("language model trains" if q2 else "everything trains")},
             "loss_hip": hip_loss, "loss_oracle_fp32": want_loss, "loss_abs_diff": [abs(x - y) for x, y in zip(hip_loss, want_loss)],
             "loss_oracle_bf16_stored_weights": bf16w_loss, "loss_abs_diff_vs_bf16_stored_weights": [abs(x - y) for x, y in zip(hip_loss, bf16w_loss)],
             "grad_norm_step1": {"hip": hip_gn, "oracle": want_gn, "ratio": hip_gn / max(want_gn, 1e-30)}, "gradients_step1": cos,
