@@ -731,11 +731,15 @@ struct SkinnyArgs {
     int xcd_order;             // persistent kernel with side outputs: XCD-aware order of the tile groups (IADR1_PERS_XCD_ORDER=0: plain)
 };
 
-template <int NB, int WAVES>
+// FUSEV (out_mode 4, NB == 1 only): the blocks of the K heads also compute the V tile of the same head and 16-dim slice from the X fragments they have already
+// loaded, and the grid holds the q and k tiles only.  For the 7B-class widths (28 q + 4 k + 4 v heads = 288 tiles on 256 CUs) that is ONE round of blocks
+// instead of two: the second round cost 8 us of a 20 us launch (tools/narrow_ab.py), while a second 115 KB weight tile next to 458 KB of X costs a block ~25 %.
+template <int NB, int WAVES, bool FUSEV = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     constexpr int U = 2, BNC = 16 * NB, RLD = BNC + 1;
+    static_assert(!FUSEV || NB == 1, "the fused V tile exists for the 16-column q|k|v kernel");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = (float*)smem_raw;  // [WAVES][64][RLD]
+    float* red = (float*)smem_raw;  // [WAVES][64][RLD] (+ a second one for the fused V tile)
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int lm = l & 15, lq = l >> 4;
     const int n0 = blockIdx.x * BNC;
@@ -750,6 +754,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // fused V tile of a K-head block (block-uniform): tile index of the same (kv head, 16-dim slice) among the V tiles
+    const bool with_v = FUSEV && (int)(blockIdx.x >> 3) >= p.Hq;
+    const int vtile = FUSEV ? (int)blockIdx.x + p.Hkv * 8 : 0;
+    f32x4_t accv[FUSEV ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < (FUSEV ? 4 : 1); ++i) accv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // a thread's epilogue column is the same in every round (WAVES*64 is a multiple of BNC): fetch its bias now, not in the tail
     static_assert((WAVES * 64) % BNC == 0, "epilogue column must be loop invariant");
@@ -768,6 +778,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     const bf16_t* wrow[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) wrow[j] = p.W + ((long long)min(blockIdx.x * NB + j, (p.N >> 4) - 1) * ksteps) * 512 + l * 8;
+    const bf16_t* wrow_v = p.W + ((long long)min(vtile, (p.N >> 4) - 1) * ksteps) * 512 + l * 8;
     const bool xpk = p.ldx == 0;  // decode-packed X (see the wide kernel)
     const long long xstep = xpk ? 2048 : 32;
     const bf16_t* xrow[4];
@@ -776,9 +787,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         xrow[i] = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + i * 512 + l * 8 : p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
 
     // unpredicated loads (see the wide kernel): full trips of U slabs, then single-slab tail trips
-    auto trip = [&](int sb, auto u_tag) {
+    auto trip = [&](int sb, auto u_tag, auto v_tag) {
         constexpr int UU = decltype(u_tag)::value;
-        bf16x8_t wf[UU][2][NB], xf[UU][2][4];
+        constexpr bool WV = decltype(v_tag)::value;      // this block also walks its V tile (block-uniform: chosen once, outside the loops)
+        bf16x8_t wf[UU][2][NB], xf[UU][2][4], wv[FUSEV ? UU : 1][2];
 #pragma unroll
         for (int u = 0; u < UU; ++u)
 #pragma unroll
@@ -787,6 +799,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
                     wf[u][kk][j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + (long long)(k >> 5) * 512)));
+                if constexpr (WV) wv[u][kk] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wrow_v + (long long)(k >> 5) * 512)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xf[u][kk][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + (long long)(k >> 5) * xstep));
             }
@@ -795,14 +808,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][kk][j], xf[u][kk][i], acc[i][j], 0, 0, 0);
+                    if constexpr (WV) accv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[u][kk], xf[u][kk][i], accv[i], 0, 0, 0);
+                }
     };
     int sb = s_begin + w;
-    for (; sb + (U - 1) * WAVES < s_end; sb += WAVES * U) trip(sb, std::integral_constant<int, U>{});
-    for (; sb < s_end; sb += WAVES) trip(sb, std::integral_constant<int, 1>{});
+    if (FUSEV && with_v) {
+        for (; sb + (U - 1) * WAVES < s_end; sb += WAVES * U) trip(sb, std::integral_constant<int, U>{}, std::integral_constant<bool, FUSEV>{});
+        for (; sb < s_end; sb += WAVES) trip(sb, std::integral_constant<int, 1>{}, std::integral_constant<bool, FUSEV>{});
+    } else {
+        for (; sb + (U - 1) * WAVES < s_end; sb += WAVES * U) trip(sb, std::integral_constant<int, U>{}, std::false_type{});
+        for (; sb < s_end; sb += WAVES) trip(sb, std::integral_constant<int, 1>{}, std::false_type{});
+    }
     if ((p.K & 32) && w == 0 && blockIdx.z == gridDim.z - 1) {  // wave-uniform: the odd 32-wide tail of K
         const int k = nslab * 64;
         bf16x8_t wt[NB], xt[4];
@@ -824,6 +844,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) mine[(i * 16 + lm) * RLD + j * 16 + lq * 4 + e] = acc[i][j][e];
+    float* redv = red + (size_t)WAVES * 64 * RLD;
+    if constexpr (FUSEV) {
+        if (with_v) {
+            float* minev = redv + (size_t)w * 64 * RLD;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) minev[(i * 16 + lm) * RLD + lq * 4 + e] = accv[i][e];
+        }
+    }
     __syncthreads();
     STAMP(2);
     if (NB == 1 && p.out_mode == 4) {
@@ -857,6 +887,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             } else {
                 if (sl >= 0) p.vcache[(page * p.Hkv + (head - p.Hq - p.Hkv)) * (long long)D * 32 + (j * 16 + n) * 32 + off] = f2bf(vs);
                 if (side0 >= 0) ((bf16_t*)p.so.p0)[(side0 + (long long)gm * p.so.seq_stride) * p.so.ld0 + head * D + j * 16 + n] = f2bf(vs);
+            }
+            if constexpr (FUSEV) {
+                if (with_v) {      // the V tile of the same kv head and 16-dim slice: bias, cache append, training row -- what the V head's own block does above
+                    float vv = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < WAVES; ++ww) vv += redv[((size_t)ww * 64 + m) * RLD + n];
+                    vv = bf2f(f2bf(vv + (p.bias ? bf2f(p.bias[vtile * 16 + n]) : 0.f)));
+                    const int hv = head + p.Hkv;
+                    if (sl >= 0) p.vcache[(page * p.Hkv + (hv - p.Hq - p.Hkv)) * (long long)D * 32 + (j * 16 + n) * 32 + off] = f2bf(vv);
+                    if (side0 >= 0) ((bf16_t*)p.so.p0)[(side0 + (long long)gm * p.so.seq_stride) * p.so.ld0 + hv * D + j * 16 + n] = f2bf(vv);
+                }
             }
         }
         STAMP(3);
@@ -1636,8 +1677,21 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
     p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.slot = slot; p.kcache = (bf16_t*)kcache; p.vcache = (bf16_t*)vcache; p.Hq = Hq; p.Hkv = Hkv;
     if (int e = iadr1_side_arg(side, &p.so)) return e;
     constexpr int SM1 = 16 * 64 * 17 * 4;
-    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1); return true; }();
-    (void)attr_done;
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SM1);
+        return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }();
+    static const int fuse_v = iadr1_env_int("IADR1_QKV_FUSE_V", 1);
+    // more tiles than CUs, but the q and k tiles alone fit: the K-head blocks take their V tile along (one round of blocks instead of two)
+    const int tiles = p.N / 16, rope_tiles = (Hq + Hkv) * (D / 16);
+    if (fuse_v && tiles > ncu && rope_tiles <= ncu && (K % 64) == 0) {
+        hipLaunchKernelGGL((gemm_skinny_kernel<1, 16, true>), dim3(rope_tiles, (M + 63) / 64, 1), dim3(1024), 2 * SM1, stream, p);
+        return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
+    }
     hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3(p.N / 16, (M + 63) / 64, 1), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
 }

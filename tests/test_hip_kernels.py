@@ -531,6 +531,36 @@ def test_fused_qkv_rope_kv_equals_gemm_then_rope_kv_store(Hq, Hkv, M):
         assert torch.equal(vc2, vc1)                                          # V is a plain copy of the bf16 projection
 
 
+def test_fused_v_tile_side_rows_at_the_7b_head_geometry():
+    """28 q + 4 k + 4 v heads = 288 column tiles on 256 CUs: the K-head blocks of iadr1_gemm_qkv_rope_kv_bf16 take their V tile along (one round of blocks).  The
+    training-arena rows written through `side` (roped q | roped k | v) and both cache pages equal the unfused reference; V is bit-equal."""
+    Hq, Hkv, D, K, M = 28, 4, 128, 3584, 64
+    N = (Hq + 2 * Hkv) * D
+    x, w, bias = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.1), rnd(N, seed=6)
+    ang = torch.rand(M, D // 2, generator=torch.Generator().manual_seed(3)) * 6.28
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    slot = (torch.arange(M) * 32 + 5).to(DEV)
+    kc, vc = torch.zeros(M + 2, Hkv, 32, D, dtype=BF, device=DEV), torch.zeros(M + 2, Hkv, D, 32, dtype=BF, device=DEV)
+    step = torch.tensor([3], dtype=torch.int32, device=DEV)
+    T, base, stride = 40 + M * 8, 20, 8
+    rows = base + torch.arange(M, device=DEV) * stride + 3
+    sq = torch.full((T, N), float("nan"), dtype=BF, device=DEV)
+    wp, bp = ops.pack_qkv_rope(w, bias, Hq, Hkv, D)
+    q_out = torch.zeros(M, N, dtype=BF, device=DEV)
+    ops.gemm_qkv_rope_kv(ops.pack_act(x), wp, bp, q_out, cos, sin, slot, kc, vc, Hq, Hkv, D, side=ops.SideOut.make(step, base, stride, p0=sq))
+    ref = ops.gemm_skinny(x, ops.pack_weight(w), N, bias=bias)
+    kc1, vc1 = torch.zeros_like(kc), torch.zeros_like(vc)
+    ops.rope_kv_store(ref.clone(), cos, sin, slot, kc1, vc1, Hq, Hkv, D)
+    ops.rope_(ref, cos, sin, Hq + Hkv, D)
+    assert torch.equal(sq[rows][:, : Hq * D], q_out[:, : Hq * D])
+    close(sq[rows], ref, 1e-2, 1e-2, "side q|k|v rows")
+    assert torch.equal(sq[rows][:, (Hq + Hkv) * D:], ref[:, (Hq + Hkv) * D:]) and torch.equal(vc, vc1)
+    close(kc, kc1, 1e-2, 1e-2, "K cache")
+    untouched = torch.ones(T, dtype=torch.bool, device=DEV)
+    untouched[rows] = False
+    assert bool(torch.isnan(sq[untouched].float()).all())
+
+
 # ------------------------------------------------------------------------------------------------ losses
 def test_logprob_dlogits_grpo():
     R, V = 37, 1288
