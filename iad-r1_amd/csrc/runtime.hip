@@ -38,5 +38,6 @@ int iadr1_env_int(const char* name, int dflt) {
 }
 
 extern "C" const char* iadr1_last_error(void) { return g_err; }
-extern "C" int iadr1_version(void) { return 104;   // 104: round 4 -- iadr1_decode_advance gained all_done / rotary-table arguments, the FP8-MFMA pair (iadr1_quant_rows_fp8, iadr1_gemm_nt_fp8) is gone }
+// 104: round 4 -- iadr1_decode_advance gained the all_done / rotary-table arguments, the FP8-MFMA pair (iadr1_quant_rows_fp8, iadr1_gemm_nt_fp8) is gone
+extern "C" int iadr1_version(void) { return 104; }
 
