@@ -34,6 +34,11 @@ struct AttnArgs {
     // [prefix_start, +prefix_len) (all visible) followed by its own tokens (causal); segments [child_first, +child_count)
     // are the ones that use THIS segment as their prefix (their queries feed this segment's dK/dV).
     const int* seg_prefix;
+    // Chunked teacher-forced forward (iadr1_attn_fwd_chunk): NULL, or [nseg][4] = {q_first, q_count, blk_log2, blk_stride}.  Only the query rows
+    // [q_first, +q_count) of the segment are computed (its earlier rows were computed by earlier calls; keys are all rows [0, seg_end - seg_start)), and logical
+    // row j of the segment lives at flat row  seg_start + (j >> blk_log2) * blk_stride + (j & (2^blk_log2 - 1))  -- the time-blocked completion layout in which
+    // the rows that ALL sequences produce during the same 2^blk_log2 decode steps are contiguous (blk_log2 = 31: the plain contiguous segment).
+    const int* seg_view;
     long long ldq, ldk, ldv, ldo;  // token row strides (elements); head h lives at column h*D
     int T, Hq, Hkv;
     int causal;
@@ -129,6 +134,18 @@ struct TileRegs {
             if (idx < ROWS * CPR && r < nvalid && c * 8 < D) v[i] = *(const u32x4_t*)(src + (long long)r * ld + c * 8);
         }
     }
+    // rows j0 .. j0 + ROWS of a segment whose logical row j lives at  seg_base + ((j >> blk) * bstride + (j & (2^blk - 1))) * ld  (AttnArgs::seg_view)
+    __device__ __forceinline__ void load_blk(const bf16_t* seg_base, long long ld, int nvalid, int j0, int blk, int bstride) {
+        const int bmask = (int)((1u << blk) - 1u);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = i * NT + threadIdx.x;
+            const int r = idx / CPR, c = idx - r * CPR;
+            const int j = j0 + r;
+            v[i] = (u32x4_t){0, 0, 0, 0};
+            if (idx < ROWS * CPR && r < nvalid && c * 8 < D) v[i] = *(const u32x4_t*)(seg_base + (long long)((j >> blk) * bstride + (j & bmask)) * ld + c * 8);
+        }
+    }
     __device__ __forceinline__ void store(bf16_t* dst) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -183,10 +200,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
     const int seg = blockIdx.y + p.seg_off, head = blockIdx.z, kvh = head / (p.Hq / p.Hkv);
     const int s0 = p.seg_start[seg], slen = p.seg_end[seg] - s0;
-    const int ntile = (slen + BM - 1) / BM;
+    // segment view (chunked forward): query sub-range + blocked row map; the plain call is {0, slen, 31, 0}
+    const int* sv = p.seg_view ? p.seg_view + seg * 4 : nullptr;
+    const int qfirst = sv ? sv[0] : 0, qend = sv ? min(slen, sv[0] + sv[1]) : slen;
+    const int blk = sv ? sv[2] : 31, bstride = sv ? sv[3] : 0, bmask = (int)((1u << blk) - 1u);
+    auto row_of = [&](int j) { return s0 + (j >> blk) * bstride + (j & bmask); };
+    const int ntile = (qend - qfirst + BM - 1) / BM;
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;  // heaviest (last) causal tiles first
     if (qt >= ntile) return;
-    const int q0 = qt * BM;
+    const int q0 = qfirst + qt * BM;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, g = l >> 4;
 
     bf16x8_t qf[R][C::KS];
@@ -194,11 +216,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         qrow[r] = q0 + (w * R + r) * 16 + li;
-        const bf16_t* src = p.q + (long long)(s0 + qrow[r]) * p.ldq + head * D;
+        const bf16_t* src = p.q + (long long)row_of(qrow[r]) * p.ldq + head * D;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
             const int d0 = ks * 32 + g * 8;
-            qf[r][ks] = ld_frag_g(src + d0, qrow[r] < slen && d0 < D);
+            qf[r][ks] = ld_frag_g(src + d0, qrow[r] < qend && d0 < D);
         }
     }
     float m[R], lsum[R];
@@ -223,9 +245,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     auto tile_load = [&](int t) {
         const bool pre = t < np_tiles;
         const int kv0 = (pre ? t : t - np_tiles) * BN;
-        const int row = (pre ? ps0 : s0) + kv0, valid = (pre ? plen : slen) - kv0;
-        kreg.load(p.k + (long long)row * p.ldk + kvh * D, p.ldk, valid);
-        vreg.load(p.v + (long long)row * p.ldv + kvh * D, p.ldv, valid);
+        const int valid = (pre ? plen : slen) - kv0;
+        // (the shared prefix is always a plain contiguous range; own rows go through the segment's row map)
+        kreg.load_blk(p.k + (long long)(pre ? ps0 : s0) * p.ldk + kvh * D, p.ldk, valid, kv0, pre ? 31 : blk, pre ? 0 : bstride);
+        vreg.load_blk(p.v + (long long)(pre ? ps0 : s0) * p.ldv + kvh * D, p.ldv, valid, kv0, pre ? 31 : blk, pre ? 0 : bstride);
     };
     if (nt > 0) tile_load(0);
     for (int t = 0; t < nt; ++t) {
@@ -325,15 +348,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         float lt = lsum[r];
         lt += __shfl_xor(lt, 16, WAVE);
         lt += __shfl_xor(lt, 32, WAVE);
-        if (qrow[r] >= slen) continue;
+        if (qrow[r] >= qend) continue;
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
-        bf16_t* dst = p.o + (long long)(s0 + qrow[r]) * p.ldo + head * D;
+        const int orow = row_of(qrow[r]);
+        bf16_t* dst = p.o + (long long)orow * p.ldo + head * D;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
             const f32x4_t a = acc[dt][r];
             *(u32x2_t*)(dst + dt * 16 + g * 4) = (u32x2_t){pack2bf(a[0] * inv, a[1] * inv), pack2bf(a[2] * inv, a[3] * inv)};
         }
-        if (g == 0 && p.lse) p.lse[(long long)head * p.T + s0 + qrow[r]] = (lt > 0.f) ? (m[r] + log2f(lt)) * LN2 : -INFINITY;
+        if (g == 0 && p.lse) p.lse[(long long)head * p.T + orow] = (lt > 0.f) ? (m[r] + log2f(lt)) * LN2 : -INFINITY;
     }
 }
 
@@ -1252,6 +1276,27 @@ extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void*
 #undef LAUNCH_FWD
     }
     return iadr1_check_launch("attn_fwd");
+}
+
+// Chunked teacher-forced forward (include/iadr1_hip.h): the query rows seg_view[i] = {q_first, q_count, ..} of every segment against all its keys so far.
+extern "C" int iadr1_attn_fwd_chunk(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start, const int* seg_end,
+                                    const int* seg_prefix, const int* seg_view, int nseg, int max_q_count, int T, int Hq, int Hkv, int D, long long ldq,
+                                    long long ldk, long long ldv, long long ldo, float scale, hipStream_t stream) {
+    if (int e = check_common(T, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return e;
+    IADR1_REQUIRE(nseg > 0 && max_q_count > 0 && seg_view != nullptr, "attn_fwd_chunk: empty segment list / no segment views");
+    AttnArgs p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
+    p.seg_start = seg_start; p.seg_end = seg_end; p.seg_prefix = seg_prefix; p.seg_view = seg_view; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = 1; p.scale = scale;
+    const int smem = (2 * 64 * Cfg<128>::LD) * 2;
+    if (D == 128) {
+        set_smem(attn_fwd_kernel<128, 1>, smem);
+        hipLaunchKernelGGL((attn_fwd_kernel<128, 1>), dim3((max_q_count + 63) / 64, nseg, Hq), dim3(256), smem, stream, p);
+    } else {
+        set_smem(attn_fwd_kernel<80, 1>, smem);
+        hipLaunchKernelGGL((attn_fwd_kernel<80, 1>), dim3((max_q_count + 63) / 64, nseg, Hq), dim3(256), smem, stream, p);
+    }
+    return iadr1_check_launch("attn_fwd_chunk");
 }
 
 extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta,

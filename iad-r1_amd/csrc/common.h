@@ -114,6 +114,8 @@ struct SideOut {                   // same layout as iadr1_side_out_t
 int iadr1_side_arg(const void* side, SideOut* out);
 // IADR1_* A/B switches of the launchers: read ONCE (`static const int x = iadr1_env_int(...)`, thread-safe static initialisation), constant afterwards
 int iadr1_env_int(const char* name, int dflt);
+// CU count the decode-step launchers size persistent grids for (runtime.hip: the device's, or what iadr1_set_decode_cus / IADR1_DECODE_CUS says)
+int iadr1_decode_cus(void);
 // read the step counter ONCE, at kernel entry (a dependent global load in an epilogue is a memory latency on the critical path of a latency-bound kernel)
 __device__ __forceinline__ long long side_base(const SideOut& so) { return so.step ? so.base + (long long)*so.step : -1; }
 

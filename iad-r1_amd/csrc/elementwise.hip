@@ -531,6 +531,30 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(const long long* sa
 }
 }  // namespace
 
+// wait_counter: a stream-ordered wait on a DEVICE counter another stream's kernels bump (the decode step counter above).  One wave polls the counter
+// with agent-scope loads (sleeping ~4 us between polls) and returns once it has reached `target` -- or after `timeout_ms`, so that a counter that never
+// arrives cannot hang the queue.  Used instead of hipEventRecord / hipStreamWaitEvent pairs between the decode replays and the shadow pass: both release a
+// chunk on time, but the event records between the graph launches cost the decode stream 0.06 ms per step (3.22 vs 3.16 ms, profiles/EXPERIMENTS.md round 5).
+namespace {
+__global__ __launch_bounds__(64) void wait_counter_kernel(const unsigned* counter, unsigned target, unsigned long long timeout_ticks, int* timed_out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(127);
+        if (wall_clock64() - t0 > timeout_ticks) {
+            if (timed_out) *timed_out = 1;
+            break;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int iadr1_wait_counter(const unsigned* counter, unsigned target, int timeout_ms, int* timed_out, hipStream_t stream) {
+    IADR1_REQUIRE(counter != nullptr && timeout_ms > 0 && timeout_ms <= 60000, "wait_counter: a device counter and a timeout in (0, 60000] ms are required");
+    hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, stream, counter, target, (unsigned long long)timeout_ms * 100000ull, timed_out);     // wall_clock64: 100 MHz
+    return iadr1_check_launch("wait_counter");
+}
+
 extern "C" int iadr1_rope_table(const int* pos, const float* inv_freq, float* cos_t, float* sin_t, int B, int half, hipStream_t stream) {
     IADR1_REQUIRE(B > 0 && half > 0, "rope_table: empty");
     hipLaunchKernelGGL(rope_table_kernel, dim3((B * half + 255) / 256), dim3(256), 0, stream, pos, inv_freq, cos_t, sin_t, B, half);

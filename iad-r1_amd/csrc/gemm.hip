@@ -1601,7 +1601,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     // launcher configuration, fixed at first use: A/B switches, the CU count, LDS opt-ins of every kernel this entry point can launch
     static const int wide_nb = iadr1_env_int("IADR1_SKINNY_WIDE_NB", -1);  // -1: 4 with packed X, 8 with row-major X
     static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1);
-    static const int ncu = [] {
+    static const int dev_cus_ = [] {
         int dev = 0;
         hipDeviceProp_t prop;
         (void)hipGetDevice(&dev);
@@ -1616,6 +1616,8 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS);
         return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }();
+    (void)dev_cus_;
+    const int ncu = iadr1_decode_cus();      // the CUs the decode stream owns (runtime.hip): persistent grids are one block per such CU
     // wide kernels: NB=8 (128 columns / block) for the big-N streams (gate|up, lm_head); NB=4 with K split over
     // grid.z for the long-K narrow-N down projection; the narrow kernel for the small projections (latency-bound)
     // persistent X-resident kernel for the big un-split streams (gate|up, lm_head): K = 32 * 8 waves * KSW exactly, >= 2 tile groups per CU.
@@ -1677,7 +1679,7 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
     p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.slot = slot; p.kcache = (bf16_t*)kcache; p.vcache = (bf16_t*)vcache; p.Hq = Hq; p.Hkv = Hkv;
     if (int e = iadr1_side_arg(side, &p.so)) return e;
     constexpr int SM1 = 16 * 64 * 17 * 4;
-    static const int ncu = [] {
+    static const int dev_cus_ = [] {
         int dev = 0;
         hipDeviceProp_t prop;
         (void)hipGetDevice(&dev);
@@ -1685,6 +1687,8 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SM1);
         return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }();
+    (void)dev_cus_;
+    const int ncu = iadr1_decode_cus();      // the CUs the decode stream owns (runtime.hip): persistent grids are one block per such CU
     static const int fuse_v = iadr1_env_int("IADR1_QKV_FUSE_V", 1);
     // more tiles than CUs, but the q and k tiles alone fit: the K-head blocks take their V tile along (one round of blocks instead of two)
     const int tiles = p.N / 16, rope_tiles = (Hq + Hkv) * (D / 16);
@@ -1735,7 +1739,7 @@ extern "C" int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const floa
     p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.out_mode = out_mode;
     constexpr int SMW = 8 * 64 * 33 * 4, SMS = 8 * 64 * 17 * 4;
     static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1) && iadr1_env_int("IADR1_SKINNY_PERS_FP8", 1);
-    static const int ncu = [] {
+    static const int dev_cus_ = [] {
         int dev = 0;
         hipDeviceProp_t prop;
         (void)hipGetDevice(&dev);
@@ -1746,6 +1750,8 @@ extern "C" int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const floa
         (void)hipFuncSetAttribute((const void*)gemm_skinny_pers_split_kernel<8, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMS);
         return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }();
+    (void)dev_cus_;
+    const int ncu = iadr1_decode_cus();      // the CUs the decode stream owns (runtime.hip): persistent grids are one block per such CU
     const int mz = (M + 63) / 64;
     // the persistent X-resident forms (same shape rules as the bf16 launcher): split-K slabs for the long-K down projection, one block per CU for the
     // big un-split streams (gate|up, lm_head).  The one-shot wide kernel takes everything else (K = 3584 of the 7B widths: the X fragments of a wave's

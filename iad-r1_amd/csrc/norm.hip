@@ -354,7 +354,11 @@ extern "C" int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, co
     SideOut so;
     if (int e = iadr1_side_arg(side, &so)) return e;
     IADR1_REQUIRE(!so.step || T <= 256, "rmsnorm_fwd: side outputs exist in the few-row (decode) kernel only, T=%d", T);
-    if (T <= 256) {
+    // The few-row kernel (one block per row) serves the DECODE-form calls: decode-packed output, fp32 partial slabs as the branch input, side outputs.  Everything
+    // else -- the training / prefill / teacher-forced passes -- runs the wave-per-row kernel at ANY row count: the two kernels add a row's squares in different
+    // orders, so a choice by T made a row's bits depend on how many OTHER rows the launch held (round 5: the chunked reference pass runs the same rows in
+    // launches of different sizes and must reproduce the one-shot pass bit for bit).
+    if (T <= 256 && (ldy == 0 || x32 != nullptr || so.step != nullptr)) {
         hipLaunchKernelGGL(rmsnorm_fwd_row_kernel, dim3(T), dim3(256), 0, stream, p, so);
         return iadr1_check_launch("rmsnorm_fwd");
     }

@@ -37,7 +37,51 @@ int iadr1_env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// CUs the decode-step launchers size their persistent grids for: the device's CU count unless the rollout runs on a CU-masked stream
+// (iadr1_stream_create_cu_mask) next to the teacher-forced training forward -- a persistent kernel launched with one block per CU of the WHOLE
+// device onto a stream that owns fewer would run its blocks in two rounds.  Process-wide, set before the decode graph is captured.
+static int g_decode_cus = 0;
+int iadr1_decode_cus(void) {
+    if (g_decode_cus > 0) return g_decode_cus;
+    static const int dev_cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        const int env = iadr1_env_int("IADR1_DECODE_CUS", 0);
+        if (env > 0) return env;
+        return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }();
+    return dev_cus;
+}
+extern "C" int iadr1_set_decode_cus(int n_cus) {
+    IADR1_REQUIRE(n_cus >= 0 && n_cus <= 1024, "set_decode_cus: 0 (device default) .. 1024, got %d", n_cus);
+    g_decode_cus = n_cus;
+    return IADR1_OK;
+}
+
+extern "C" int iadr1_stream_create_cu_mask(const unsigned* cu_mask, int n_words, void** stream_out) {
+    IADR1_REQUIRE(cu_mask != nullptr && n_words > 0 && stream_out != nullptr, "stream_create_cu_mask: a mask of >= 1 words and an output slot are required");
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, (const uint32_t*)cu_mask);
+    if (e != hipSuccess) {
+        iadr1_set_error("stream_create_cu_mask: %s", hipGetErrorString(e));
+        return IADR1_ERR_LAUNCH;
+    }
+    *stream_out = (void*)s;
+    return IADR1_OK;
+}
+extern "C" int iadr1_stream_destroy(void* stream) {
+    IADR1_REQUIRE(stream != nullptr, "stream_destroy: null stream");
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        iadr1_set_error("stream_destroy: %s", hipGetErrorString(e));
+        return IADR1_ERR_LAUNCH;
+    }
+    return IADR1_OK;
+}
+
 extern "C" const char* iadr1_last_error(void) { return g_err; }
+// 105: round 5 -- CU-masked streams + decode CU count (co-scheduled rollout / teacher-forced forward)
 // 104: round 4 -- iadr1_decode_advance gained the all_done / rotary-table arguments, the FP8-MFMA pair (iadr1_quant_rows_fp8, iadr1_gemm_nt_fp8) is gone
-extern "C" int iadr1_version(void) { return 104; }
+extern "C" int iadr1_version(void) { return 105; }
 

@@ -93,3 +93,27 @@ def call(name: str, *args):
 
 def version() -> int:
     return lib().iadr1_version()
+
+
+def cu_mask_stream(first_cu: int, n_cus: int, total_cus: int | None = None) -> "torch.cuda.ExternalStream":
+    """A HIP stream confined to CUs [first_cu, first_cu + n_cus) of the driver's numbering (include/iadr1_hip.h iadr1_stream_create_cu_mask: consecutive
+    bits go round-robin over the XCDs, so a multiple of 8 CUs is the same share of every XCD).  The stream is owned by the caller for the life of the process."""
+    import numpy as np
+    total = total_cus or torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    if not (0 <= first_cu and n_cus > 0 and first_cu + n_cus <= total):
+        raise ValueError(f"CU range [{first_cu}, {first_cu + n_cus}) outside the device's {total} CUs")
+    words = np.zeros((total + 31) // 32, dtype=np.uint32)
+    for cu in range(first_cu, first_cu + n_cus):
+        words[cu // 32] |= np.uint32(1 << (cu % 32))
+    out = np.zeros(1, dtype=np.uint64)
+    rc = lib().iadr1_stream_create_cu_mask(words.ctypes.data, len(words), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"iadr1_stream_create_cu_mask failed ({rc}): {lib().iadr1_last_error().decode()}")
+    return torch.cuda.ExternalStream(int(out[0]))
+
+
+def set_decode_cus(n_cus: int):
+    """CUs the decode-step launchers size their persistent grids for (0 = the device's); set before the decode graph is captured."""
+    rc = lib().iadr1_set_decode_cus(int(n_cus))
+    if rc != 0:
+        raise RuntimeError(f"iadr1_set_decode_cus failed ({rc}): {lib().iadr1_last_error().decode()}")

@@ -405,6 +405,7 @@ class Segments:
         self.lo, self.hi = (int(min(starts)), int(max(ends))) if self.n else (0, 0)
         self.start = torch.tensor(starts, dtype=torch.int32, device=device)
         self.end = torch.tensor(ends, dtype=torch.int32, device=device)
+        self.start_host, self.end_host = [int(z) for z in starts], [int(z) for z in ends]      # (host copies: reading the device arrays back would drain the stream)
         self.prefix = None
         # launch hint (include/iadr1_hip.h nseg_head / max_seqlen_tail): a leading run of long segments followed by shorter ones
         self.n_head, self.max_tail = 0, 0

@@ -1,0 +1,346 @@
+"""Co-scheduled reference pass (OPT-IN: IADR1_OVERLAP_CUS=64): the frozen reference model's teacher-forced forward + per-token log-probs
+(/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:737-743, `_get_per_token_logps` :384-514 on `ref_model`) run UNDER the group
+rollout (:637-683) instead of after it.
+
+Why: the rollout is a chain of latency-bound decode steps that leaves the MFMA pipes idle (0.34 of the HBM roofline, no matrix work to speak
+of), the reference forward is MFMA-bound and leaves HBM idle, and the reference's log-prob of completion token j depends only on tokens <= j --
+nothing of the sampled tokens' FUTURE.  The reference runs the two on different GPUs at the same time (vLLM GPU vs training ranks,
+REF:scripts/train/SC_GRPO/SC_GRPO_Qwen_Instruct_2_5_VL_3B.sh:40-42); here they share one MI355X: every `steps` decode steps the rows those steps
+produced (N sequences x steps tokens) go through the frozen decoder on a second HIP stream while the decode replay continues on the first.
+
+What it takes on this part, and what it buys (all measured, round 5: profiles/EXPERIMENTS.md, profiles/r05_overlap_*.txt):
+  * two ordinary streams do NOT share the device usefully: a big-grid kernel of the shadow pass holds every CU slot, the decode step's ~250 small dependent
+    launches each wait for slots, and the replay all but stops while a chunk runs (decode window 724 -> 864 ms for 125 ms of shadow work);
+  * disjoint CU masks (hipExtStreamCreateWithCUMask: decode on 192 CUs, shadow on 64) fix that ONLY when the two hardware queues sit on different dispatch
+    pipes of the command processor -- every fourth queue created shares the decode queue's pipe, and then every decode launch waits ~50-70 us behind the
+    other queue's kernel-in-dispatch although the CUs are disjoint (pick_concurrent_stream below finds a clean pair at start-up);
+  * CU-masked streams are BLOCKING streams: with the caller on the null stream every chunk started one chunk period late (SCGRPOEngine.step moves the step
+    onto a stream of its own);
+  * gating a chunk on an event recorded between two graph launches costs the decode stream 0.06 ms per step; the gate is a one-wave poll of the device step
+    counter instead (iadr1_wait_counter);
+  * with all that the shadow pass tracks the rollout exactly (every chunk starts the moment its last token exists, profiles/r05_overlap_phases.txt) and
+    125 ms of reference forward leave the critical path -- but the decode step on 192 CUs costs 3.16 instead of 2.77 ms (x 255), and the last block of rows
+    runs after the rollout: 1249.9 -> 1235.5 / 1243.5 ms per step, +0.5 ... +1.1 %, inside the box-to-box spread.  Hence opt-in, not the default.
+
+Layout.  Completion rows are TIME-BLOCKED: with block = 2^k steps, row (sequence s, token j) lives at
+    n_prompt_rows + (j // block) * N * block + s * block + j % block,
+so the rows of a chunk are one contiguous range for every token-wise kernel and GEMM; only attention needs to know
+(iadr1_attn_fwd_chunk: query sub-range + blocked row map per segment).  Per-layer q|k|v rows of everything processed so far are kept
+([L, T, qkv_width] bf16: 3.8 GB at the 3B bench shape) so that later chunks attend to earlier ones.
+
+Results are BIT-equal to the one-shot pass (Engine.text_forward + Engine.logprobs over the whole [prompts ++ completions] batch): same kernels,
+row-independent GEMMs (tools/gemm_rowdep_probe.py), the same 64-key attention tiles in the same order, RMSNorm kernel choice independent of the row count
+(tests/test_hip_model.py::test_chunked_reference_pass_is_bit_equal_to_the_one_shot_pass).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import hip, ops
+from .vlm import Engine, TextPlan
+
+BF16, F32 = torch.bfloat16, torch.float32
+BLOCK = 16          # steps per time block of the completion-row layout (a power of two; chunk boundaries are multiples of it)
+
+STATS = {"passes": 0, "chunks": 0, "rows": 0}
+
+
+def shadow_cus() -> int:
+    """IADR1_OVERLAP_CUS: 0 (default) = the reference pass runs after the rollout, on the whole device; n > 0 = it runs under the rollout on a stream confined to n CUs
+    while the decode replays own the others (SCGRPOEngine._cu_split); -1 = under the rollout on an ordinary second stream (no CU split: measured slower, kept for
+    A/B and for the parity tests of the chunked pass itself)."""
+    return int(os.environ.get("IADR1_OVERLAP_CUS", "0"))
+
+
+def enabled() -> bool:
+    return shadow_cus() != 0
+
+
+def chunk_steps_default() -> int:
+    return int(os.environ.get("IADR1_OVERLAP_STEPS", "32"))
+
+
+def pick_concurrent_stream(anchor, make_candidate, weight: torch.Tensor, tries: int = 6, log=None):
+    """A stream whose kernels really run NEXT TO `anchor`'s.  Measured on MI355X (tools/stream_pair_probe.py, profiles/r05_stream_pairs.txt): hardware queues are
+    dealt round-robin onto the command processor's four dispatch pipes, and two queues on the SAME pipe take turns at kernel granularity -- a kernel stays "in
+    dispatch" until its last workgroup has been placed, so next to a big-grid GEMM every dependent launch of the other queue waits ~70 us (a 64-row RMSNorm chain:
+    18x slower), even when the two streams own disjoint CU masks.  Every fourth stream created collides; the others do not interfere at all (1.03x).  So: time a
+    chain of small dependent launches on `anchor` alone and next to big-grid GEMMs on each candidate, keep the first candidate that leaves the chain alone.
+    make_candidate() -> a new stream; weight: any [N >= 8192, K] bf16 matrix (the GEMM's B operand).  Returns (stream, ratio) or (None, ratio of the best)."""
+    dev = weight.device
+    K = weight.shape[1]
+    x = torch.zeros(64, K, dtype=BF16, device=dev)
+    g = torch.ones(K, dtype=BF16, device=dev)
+    y = torch.empty_like(x)
+    a = torch.zeros(2048, K, dtype=BF16, device=dev)
+    c = torch.empty(2048, weight.shape[0], dtype=BF16, device=dev)
+
+    def chain(stream, other=None):
+        torch.cuda.synchronize(dev)
+        if other is not None:
+            with torch.cuda.stream(other):
+                for _ in range(6):
+                    ops.gemm_nt(a, weight, out=c)
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(150):
+                ops.hip.call("rmsnorm_fwd", x, None, 0, None, None, None, g, y, None, 64, K, K, K, K, 1e-6, None)
+            e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1)
+
+    chain(anchor)
+    alone = chain(anchor)
+    best = (None, float("inf"))
+    for i in range(tries):
+        cand = make_candidate()
+        ratio = chain(anchor, cand) / max(alone, 1e-3)
+        if log is not None:
+            log(f"[iadr1] stream pairing: candidate {i}: the dependent chain runs {ratio:.2f}x its stand-alone time next to it")
+        if ratio < best[1]:
+            best = (cand, ratio)
+        if ratio < 1.5:
+            return cand, ratio
+    return None, best[1]
+
+
+class ChunkedRefPass:
+    """One instance per SCGRPOEngine; `begin` per rollout.  All device work of this object is enqueued on `self.stream` (the side stream)."""
+
+    def __init__(self, ref: Engine, steps: int | None = None, stream=None):
+        self.e = ref
+        self.steps = max(BLOCK, (steps or chunk_steps_default()) // BLOCK * BLOCK)
+        self.stream = stream if stream is not None else (torch.cuda.Stream() if ref.dev.type == "cuda" else None)
+        self.vision = None          # (pixel tensor, vision plan) of the current batch, set by the owner before the rollout
+        self.store = None           # [L, T, qkv_width] roped q|k|v rows of the reference model (prompt rows + time-blocked completion rows)
+        self.active = False
+
+    @staticmethod
+    def unmasked() -> bool:
+        return shadow_cus() < 0
+
+    @staticmethod
+    def applicable(cfg, C: int) -> bool:
+        """Qwen-VL families, completion length a multiple of the time block.  (The LLaVA branches of the reference rotate right-padded rows before the model
+        runs -- REF:516-567 -- which makes the scored positions depend on where a sequence ENDS: not known while it is being generated.)"""
+        return enabled() and not cfg.is_llava and C % BLOCK == 0 and C >= BLOCK
+
+    # ---- set-up --------------------------------------------------------------------------------------------------
+    def begin(self, plan: TextPlan, G: int, C: int, first_pos: np.ndarray, out_tokens: torch.Tensor, step_counter: torch.Tensor | None = None):
+        """plan: the rollout's prompt plan (Bp left-padded prompts of S columns); self.vision = (pixel tensor, vision plan) of the batch was set by the owner -- the
+        reference's own vision tower runs here, on the side stream; first_pos [N]: rotary position of completion token 0 of every sequence; out_tokens: the rollout's
+        device-resident [N, >= C] token matrix (column j is final once decode replay j has run)."""
+        e, c = self.e, self.e.cfg
+        dev = e.dev
+        Bp, S = plan.B, plan.S
+        N = Bp * G
+        self.plan, self.G, self.C, self.N, self.Bp, self.S = plan, G, C, N, Bp, S
+        self.T0 = Bp * S
+        self.T = self.T0 + N * C
+        self.out_tokens = out_tokens
+        # gate of every chunk: the rollout's device-resident step counter (it reads k + 1 once decode replay k has run) polled by iadr1_wait_counter on the side
+        # stream; None (IADR1_OVERLAP_GATE=event): HIP events recorded by the caller between the replays (0.06 ms per decode step dearer)
+        self.step_counter = step_counter if os.environ.get("IADR1_OVERLAP_GATE", "counter") == "counter" else None
+        if self.__dict__.get("_timed_out_host") is not None and int(self._timed_out_host[0]):
+            raise RuntimeError("overlap.ChunkedRefPass: a counter wait of the previous rollout timed out (the decode stream never reached the awaited step)")
+        if self.step_counter is not None and self.__dict__.get("_timed_out") is None:
+            self._timed_out = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._timed_out_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        L = c.num_hidden_layers
+        if self.store is None or self.store.shape[1] < self.T:
+            self.store = None
+            self.store = torch.empty(L, self.T, c.qkv_width, dtype=BF16, device=dev)
+        # rotary table of the completion rows in time-blocked order: text tokens carry the same position on all three M-RoPE axes (TF:1042-1176), so the
+        # table is  (first_pos[s] + j) * inv_freq  evaluated exactly like Engine.text_plan_shared does
+        nb = C // BLOCK
+        j = (np.arange(nb)[:, None, None] * BLOCK + np.arange(BLOCK)[None, None, :])                      # [nb, 1, BLOCK]
+        pos = (np.asarray(first_pos, dtype=np.int64)[None, :, None] + j).reshape(-1)                          # [nb * N * BLOCK]
+        pos_t = ops.h2d(np.broadcast_to(pos[None, :], (3, pos.size)).copy(), dev)
+        ang = pos_t[e.mrope_comp].t().to(F32) * e.inv_freq[None, :]
+        self.cos, self.sin = ang.cos().contiguous(), ang.sin().contiguous()
+        # attention tables: one segment per sequence; prefix = its prompt's rows (all visible).  seg_end / the query sub-range depend on the chunk.
+        starts_p = np.asarray(plan.seg.start_host, dtype=np.int64)
+        ends_p = np.asarray(plan.seg.end_host, dtype=np.int64)
+        self.seg_start = ops.h2d((self.T0 + np.arange(N) * BLOCK).astype(np.int32), dev)
+        pre = np.zeros((N, 4), dtype=np.int32)
+        pre[:, 0] = np.repeat(starts_p, G)
+        pre[:, 1] = np.repeat(ends_p - starts_p, G)
+        self.seg_prefix = ops.h2d(pre, dev)
+        self._tables = {}
+        self.logp = torch.zeros(N, C, dtype=F32, device=dev)
+        self.trace = [] if os.environ.get("IADR1_OVERLAP_STATS") == "1" else None      # (label, start event, end event) per phase, on the side stream
+        if self.trace is not None:
+            self.t_ref = torch.cuda.Event(enable_timing=True)
+            self.t_ref.record()
+        self.done_rows = 0          # completion tokens [0, done_rows) of every sequence have gone through the layers
+        self.active = True
+        STATS["passes"] += 1
+
+    def _chunk_tables(self, c0, c1):
+        key = (c0, c1)
+        t = self._tables.get(key)
+        if t is None:
+            N = self.N
+            view = np.zeros((N, 4), dtype=np.int32)
+            view[:, 0], view[:, 1], view[:, 2], view[:, 3] = c0, c1 - c0, int(np.log2(BLOCK)), N * BLOCK
+            dev = self.e.dev
+            t = self._tables[key] = (ops.h2d((self.T0 + np.arange(N) * BLOCK + c1).astype(np.int32), dev), ops.h2d(view, dev))
+        return t
+
+    # ---- the decoder over a contiguous row range -------------------------------------------------------------------
+    def _layers(self, x, r0, r1, cos, sin, attend):
+        """Rows [r0, r1) of the T-row batch through the frozen decoder; the arithmetic and the buffer roles are Engine.text_forward(save=False)'s.
+        attend(i, store_i, o_all): attention of layer i for these rows (absolute row addressing).  Returns the final-norm output rows."""
+        e, c, P = self.e, self.e.cfg, self.e.p
+        H, D, Hq, Hkv = c.hidden_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        Tl = r1 - r0
+        B = e._text_buffers(self.T, False)
+        eps = float(c.rms_norm_eps)
+        res, branch = x, None
+        o_all = B["o"][0, :self.T]
+        for i in range(c.num_hidden_layers):
+            b = f"layers.{i}."
+            h1 = B["h1"][0, r0:r1]
+            if branch is None:
+                x_in = res
+                ops.hip.call("rmsnorm_fwd", res, None, 0, None, None, None, P.w(b + "ln1"), h1, None, Tl, H, H, H, H, eps, None)
+            else:
+                x_in = res
+                ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, x_in, P.w(b + "ln1"), h1, None, Tl, H, H, H, H, eps, None)
+            qkv = ops.gemm_nt(h1, P.w(b + "qkv.w"), bias=P.w(b + "qkv.b"), out=self.store[i, r0:r1])
+            ops.rope_(qkv, cos, sin, Hq + Hkv, D)
+            attend(i, self.store[i, :self.T], o_all)
+            ab = ops.gemm_nt(o_all[r0:r1], P.w(b + "o.w"), out=B["x_mid"][0, r0:r1])
+            h2 = B["h2"][0, r0:r1]
+            ops.hip.call("rmsnorm_fwd", ab, None, 0, None, x_in, x_in, P.w(b + "ln2"), h2, None, Tl, H, H, H, H, eps, None)
+            _, a = ops.gemm_swiglu(h2, P.w(b + "gu.w"), gu_out=B["gu"][0, r0:r1], a_out=B["a"][0, r0:r1], keep_gu=False)
+            branch = ops.gemm_nt(a, P.w(b + "down.w"), out=B["x_mid"][0, r0:r1])
+            res = x_in
+        hf = B["h1"][0, r0:r1]
+        ops.hip.call("rmsnorm_fwd", branch, None, 0, None, res, res, P.w("norm"), hf, None, Tl, H, H, H, H, eps, None)
+        return hf
+
+    # ---- phases ---------------------------------------------------------------------------------------------------
+    def prompt_phase(self, after: torch.cuda.Event | None):
+        """The reference's vision tower + its forward over the prompt rows (K/V kept for the chunks) + the log-prob of completion token 0 of every sequence
+        (predicted by its prompt's last row).  `after`: event on the decode stream behind the sampling of token 0."""
+        e, c, P = self.e, self.e.cfg, self.e.p
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        qw = Hq * D
+        plan, T0 = self.plan, self.T0
+        with torch.cuda.stream(self.stream):
+            if after is not None:
+                self.stream.wait_event(after)
+            ev0 = self._mark()
+            px, plan_v = self.vision
+            img_ref, _ = e.vision_forward(px, plan_v, save=False)
+            B = e._text_buffers(self.T, False)
+            x = ops.embed_fwd(plan.ids, plan.img_index, P.w("embed"), img_ref, out=B["x_in"][0, :T0])
+            if not plan.seg.covers(0, T0):
+                B["o"][0, :T0].zero_()
+
+            def attend(i, st, o_all):
+                ops.hip.call("attn_fwd", st[:, :qw], st[:, qw: qw + Hkv * D], st[:, qw + Hkv * D:], o_all, None, plan.seg.start, plan.seg.end, plan.seg.prefix, plan.seg.n,
+                             plan.seg.max_len, plan.seg.n_head, plan.seg.max_tail, self.T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, 1, c.attn_scale)
+
+            hf = self._layers(x, 0, T0, plan.cos, plan.sin, attend)
+            last = (torch.arange(self.Bp, device=e.dev, dtype=torch.int64) * self.S + (self.S - 1)).repeat_interleave(self.G)
+            lp, _ = e.logprobs(hf, last, self.out_tokens[:, 0].contiguous(), save=False)
+            self.logp[:, 0] = lp
+            self._img_ref = img_ref
+            self._mark("prompt", ev0)
+
+    def chunk(self, c1: int, after: torch.cuda.Event | None):
+        """Completion tokens [done_rows, c1) of every sequence (c1 a multiple of BLOCK).  `after`: event on the decode stream behind the replay that produced
+        token min(c1, C - 1) -- the targets of these rows reach one token further than the rows themselves."""
+        e, c, P = self.e, self.e.cfg, self.e.p
+        c0, N, C = self.done_rows, self.N, self.C
+        assert c0 < c1 <= C and c1 % BLOCK == 0 and c0 % BLOCK == 0
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        qw = Hq * D
+        nb = (c1 - c0) // BLOCK
+        r0, r1 = self.T0 + (c0 // BLOCK) * N * BLOCK, self.T0 + (c1 // BLOCK) * N * BLOCK
+        blocked = lambda t: t.view(N, nb, BLOCK).permute(1, 0, 2).reshape(-1)       # [N, nb*BLOCK] (sequence-major) -> time-blocked row order
+        with torch.cuda.stream(self.stream):
+            if self.step_counter is not None:
+                ops.hip.call("wait_counter", self.step_counter, min(c1, C - 1) + 1, 30000, self._timed_out)
+            elif after is not None:
+                self.stream.wait_event(after)
+            ev0 = self._mark()
+            seg_end, view = self._chunk_tables(c0, c1)          # (uploaded on THIS stream: ordered before the kernels that read them)
+            ids = blocked(self.out_tokens[:, c0:c1])
+            B = e._text_buffers(self.T, False)
+            x = ops.embed_fwd(ids, None, P.w("embed"), None, out=B["x_in"][0, r0:r1])
+
+            def attend(i, st, o_all):
+                ops.hip.call("attn_fwd_chunk", st[:, :qw], st[:, qw: qw + Hkv * D], st[:, qw + Hkv * D:], o_all, None, self.seg_start, seg_end, self.seg_prefix, view, N, c1 - c0,
+                             self.T, Hq, Hkv, D, c.qkv_width, c.qkv_width, c.qkv_width, qw, c.attn_scale)
+
+            hf = self._layers(x, r0, r1, self.cos[r0 - self.T0: r1 - self.T0], self.sin[r0 - self.T0: r1 - self.T0], attend)
+            # row (s, j) predicts token j + 1; the last token of a sequence predicts nothing that is scored
+            n_ok = min(c1, C - 1) - c0
+            tg = torch.full((N, c1 - c0), -1, dtype=torch.int64, device=e.dev)
+            if n_ok > 0:
+                tg[:, :n_ok] = self.out_tokens[:, c0 + 1: c0 + 1 + n_ok]
+            rows = torch.arange(r1 - r0, device=e.dev, dtype=torch.int64)
+            lp, _ = e.logprobs(hf, rows, blocked(tg), save=False)
+            if n_ok > 0:
+                self.logp[:, c0 + 1: c0 + 1 + n_ok] = lp.view(nb, N, BLOCK).permute(1, 0, 2).reshape(N, c1 - c0)[:, :n_ok]
+            self._mark(f"rows[{c0},{c1})", ev0)
+        self.done_rows = c1
+        STATS["chunks"] += 1
+        STATS["rows"] += r1 - r0
+
+    def boundaries(self, C: int) -> set:
+        """Decode steps after which a chunk is handed to the side stream: every `steps`, and once more one block before the end, so that what is left when the
+        rollout ends (it runs on the caller's stream, on the whole device: finish) is one block of rows."""
+        b = set(range(self.steps, C, self.steps))
+        if C - BLOCK > 0:
+            b.add(C - BLOCK)
+        return b
+
+    def finish(self, n_tokens: int, after: torch.cuda.Event | None) -> torch.Tensor:
+        """The rollout has ended with `n_tokens` columns of out_tokens produced (== C unless every sequence hit EOS earlier): run what is left (columns past the
+        end hold pad tokens and are masked by the caller's completion mask).  Returns the [N, C] reference log-probs; the CALLER's stream must wait for
+        `self.stream` before reading them (`join`)."""
+        need = min(self.C, (int(n_tokens) + BLOCK - 1) // BLOCK * BLOCK)
+        # the decode replays are over: the rest runs on the CALLER's stream -- every CU instead of the side stream's share -- behind what the side stream still holds
+        side, cur = self.stream, torch.cuda.current_stream()
+        cur.wait_stream(side)
+        if after is not None:
+            cur.wait_event(after)
+        self.stream, gate = cur, self.step_counter
+        self.step_counter = None
+        try:
+            while self.done_rows < need:
+                self.chunk(min(need, self.done_rows + self.steps), None)
+        finally:
+            self.stream, self.step_counter = side, gate
+        if self.step_counter is not None:
+            self._timed_out_host.copy_(self._timed_out, non_blocking=True)      # read at the next begin()
+        self.active = False
+        return self.logp
+
+    def _mark(self, label=None, start=None):
+        if self.trace is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if label is not None:
+            self.trace.append((label, start, ev))
+        return ev
+
+    def report(self) -> list:
+        """IADR1_OVERLAP_STATS=1: [(phase, start ms, end ms)] on the side stream, relative to begin(); synchronises."""
+        if not self.trace:
+            return []
+        torch.cuda.synchronize(self.e.dev)
+        return [(lb, round(self.t_ref.elapsed_time(a), 1), round(self.t_ref.elapsed_time(b), 1)) for lb, a, b in self.trace]
+
+    def join(self):
+        """Nothing is left on the side stream after finish() (which ran on the caller's stream behind it); kept for callers on OTHER streams."""
+        torch.cuda.current_stream().wait_stream(self.stream)

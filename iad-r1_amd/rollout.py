@@ -29,7 +29,10 @@ STATS = {"pool_builds": 0, "graph_captures": 0, "capture_seconds": 0.0, "trace_r
 
 
 class Rollout:
-    def __init__(self, engine: Engine, max_seqs: int, max_prompt: int, max_new: int, max_prompts: int | None = None, use_graph: bool = True):
+    def __init__(self, engine: Engine, max_seqs: int, max_prompt: int, max_new: int, max_prompts: int | None = None, use_graph: bool = True, decode_cus: int = 0,
+                 decode_stream=None):
+        """decode_cus / decode_stream: the decode replays run on `decode_stream`, a CU-masked stream that owns `decode_cus` CUs (hip.cu_mask_stream), next to the
+        shadow pass on the other CUs (overlap.ChunkedRefPass); 0 / None: the current stream, the whole device."""
         self.e = engine
         c = engine.cfg
         dev = engine.dev
@@ -76,6 +79,9 @@ class Rollout:
         # (H / 64) x ks ~ the CU count (7B: 56 x 4).  Measured on the 7B shapes, decode step in ms: (2, 8) 4.83, (1, 8) 4.80, (2, 4) 4.71, (1, 4) 4.64, (1, 6) 4.96,
         # (1, 2) 5.18 (profiles/r04_decode_ksplit_7b.txt).
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+        self.decode_cus, self.decode_stream = int(decode_cus), decode_stream
+        if self.decode_cus:
+            ncu = self.decode_cus
         if H * Hq * D >= 1 << 20:
             self.ks_o = max(1, min(2, ncu // max(1, H // 16)))
             self.ks_down = 8 if (I // 32 + 7) // 8 <= int(os.environ.get("IADR1_SPLIT_MAXSTEPS", "80")) else max(1, min(8, ncu // max(1, H // 64)))
@@ -183,9 +189,11 @@ class Rollout:
 
     # ---- public ---------------------------------------------------------------------------------------------------
     def generate(self, plan: TextPlan, img_embeds, G: int, max_new: int, temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress_eos=False,
-                 stop_at_eos=True, train_carry=None, train_trace=False) -> torch.Tensor:
+                 stop_at_eos=True, train_carry=None, train_trace=False, shadow=None) -> torch.Tensor:
         """plan: the Bp left-padded prompts.  Returns completion ids [Bp*G, max_new] (prompt-major order: p0 x G,
-        p1 x G, ...), pad after the first EOS."""
+        p1 x G, ...), pad after the first EOS.
+        shadow: an overlap.ChunkedRefPass -- the frozen reference's teacher-forced pass over the tokens produced so far is enqueued on ITS stream every
+        `shadow.steps` decode steps, behind one event per chunk (the caller reads shadow.logp after shadow.join())."""
         e, c = self.e, self.e.cfg
         dev = e.dev
         Bp, S = plan.B, plan.S
@@ -315,6 +323,19 @@ class Rollout:
             for t, s_ in zip(state, saved):
                 t.copy_(s_)
             STATS["capture_seconds"] += _time.perf_counter() - _t0
+        bounds = shadow.boundaries(max_new) if shadow is not None else ()
+        gates = []          # every gate event stays alive until the rollout returns (a destroyed event's handle goes back to torch's pool and is re-recorded by the next gate)
+        if shadow is not None:
+            shadow.begin(plan, G, max_new, first_pos, self.out_tokens, step_counter=self.step)
+            gate = torch.cuda.Event()
+            gates.append(gate)
+            gate.record()                  # behind the sampling of token 0 (and the prefill): the reference's vision tower, prompt rows and first log-prob start now
+            shadow.prompt_phase(gate)
+        ds = self.decode_stream
+        if ds is not None:                 # hand the rest of the rollout over to the CU-masked decode stream (the prefill above ran on the whole device)
+            ds.wait_stream(torch.cuda.current_stream())
+            _outer = torch.cuda.current_stream()
+            torch.cuda.set_stream(ds)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.decode_events is not None else None
         if ev:
             ev[0].record()
@@ -332,6 +353,13 @@ class Rollout:
             else:
                 self._decode_step()
             nsteps += 1
+            if shadow is not None and it in bounds:      # replay `it` has produced token `it`: rows [.., it) of every sequence and their targets are final
+                gate = None
+                if shadow.step_counter is None:         # (event gating; the default gate is the device step counter, overlap.ChunkedRefPass.begin)
+                    gate = torch.cuda.Event()
+                    gates.append(gate)
+                    gate.record()
+                shadow.chunk(it, gate)
             if live and it % POLL == 0:
                 k = (it // POLL) % self.done_host.numel()
                 self.done_host[k: k + 1].copy_(self.all_done, non_blocking=True)
@@ -349,4 +377,11 @@ class Rollout:
         if ev:
             ev[1].record()
             self.decode_events.append((ev[0], ev[1], nsteps, int(np.sum(lengths)) * G))
+        if ds is not None:
+            torch.cuda.set_stream(_outer)
+            _outer.wait_stream(ds)
+        if shadow is not None:
+            shadow.finish(nsteps + 1, None)        # (the current stream is ordered behind the last replay)
+            if shadow.trace is not None:
+                print("[iadr1 overlap] side-stream phases (ms after the start of the decode loop):", shadow.report(), flush=True)
         return self.out_tokens[:, :max_new].clone()

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import hip, ops
+from .overlap import ChunkedRefPass
 from .params import ParamStore, VLMConfig
 from .rollout import Rollout
 from .vlm import Engine
@@ -287,6 +288,8 @@ class SCGRPOEngine:
         self.opt_step = 0
         self.accum = 0
         self._rollout = None
+        self.shadow_logps, self.last_step_shadowed = None, False
+        self._shadow = None         # overlap.ChunkedRefPass: the frozen reference's pass over the sampled tokens runs under the rollout (step())
         self.norm2 = torch.zeros(1, dtype=F32, device=self.dev)
         self.norm_scratch = torch.zeros(2048, dtype=F32, device=self.dev)
 
@@ -310,8 +313,11 @@ class SCGRPOEngine:
         img, vctx = self.pol.vision_forward(px, plan_v, save=save)
         return {"grids": grids, "plan": plan_v, "px": px, "rows": rows, "img": img, "ctx": vctx}
 
-    def rollout(self, batch, vis=None, greedy=False, train_carry=None) -> np.ndarray:
-        """Completion ids [Bp*G, <=C] (numpy, right-padded with pad after EOS like REF:680-683)."""
+    def rollout(self, batch, vis=None, greedy=False, train_carry=None, shadow_ref: bool = False) -> np.ndarray:
+        """Completion ids [Bp*G, <=C] (numpy, right-padded with pad after EOS like REF:680-683).
+        shadow_ref: also run the frozen reference's teacher-forced pass over the tokens as they are produced, on a second stream under the decode replays
+        (overlap.ChunkedRefPass); afterwards self.shadow_logps is the [N, C] reference log-prob tensor (None when the pass does not apply) and the consumer
+        must `self._shadow.join()` before reading it."""
         a = self.args
         ids, mask = np.asarray(batch["input_ids"]), np.asarray(batch["attention_mask"])
         if a.max_prompt_length is not None:
@@ -327,18 +333,54 @@ class SCGRPOEngine:
         if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_prompt < ids.shape[1]:
             grow = max(ids.shape[1], self._rollout.max_prompt if self._rollout is not None else 0)
             self._rollout = None        # release the old pool before the new one is allocated
-            self._rollout = Rollout(self.pol, N, grow, a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph)
+            split = self._cu_split()
+            if self.dev.type == "cuda":
+                hip.set_decode_cus(split.get("decode_cus", 0))      # process-wide launcher configuration: what THIS rollout's graph is captured with
+            self._rollout = Rollout(self.pol, N, grow, a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph, **split)
         c, st = self.cfg, self.pol.p
         # decode steps that also fill the training arena (no policy forward over the completions afterwards): needs the fused decode kernels that carry
         # the side outputs (q|k|v + rotary + cache append, persistent fused-SwiGLU gate|up GEMM)
         # (not with the opt-in FP8 weight stream: the policy's training activations must come from its bf16 weights, so its forward runs after the rollout)
         trace = (train_carry is not None and a.reuse_decode and st.qkv_rope_packed and not st.decode_fp8 and self._rollout_fuses_swiglu(N))
+        shadow = None
+        self.shadow_logps = None
+        if shadow_ref and self.dev.type == "cuda" and ChunkedRefPass.applicable(c, a.max_completion_length) and (self._rollout.decode_stream is not None or ChunkedRefPass.unmasked()):
+            if self._shadow is None:
+                self._shadow = ChunkedRefPass(self.ref, stream=self.__dict__.get("_shadow_stream"))
+            shadow = self._shadow
+            shadow.vision = (vis["px"], vis["plan"])
         toks = self._rollout.generate(plan, img_pol, a.num_generations, a.max_completion_length, temperature=0.0 if greedy else a.temperature,
                                       top_k=a.top_k, top_p=a.top_p, seed=a.seed + 1000003 * self.opt_step + 7919 * self.accum, suppress_eos=a.suppress_eos,
-                                      train_carry=train_carry, train_trace=trace)
+                                      train_carry=train_carry, train_trace=trace, shadow=shadow)
+        if shadow is not None:
+            self.shadow_logps = shadow.logp
         if trace:
             train_carry["traced"] = True
         return toks.cpu().numpy()
+
+    def _cu_split(self) -> dict:
+        """IADR1_OVERLAP_CUS=n > 0: the shadow pass is confined to n CUs and the decode replays to the others -- two CU-masked streams (include/iadr1_hip.h
+        iadr1_stream_create_cu_mask) on different dispatch pipes (overlap.pick_concurrent_stream); the decode launchers size their persistent grids for the smaller
+        device (iadr1_set_decode_cus).  Masked streams are BLOCKING streams: `step` moves off the null stream while they are in use."""
+        from .overlap import pick_concurrent_stream, shadow_cus
+        n = shadow_cus()
+        if n <= 0 or self.dev.type != "cuda" or not ChunkedRefPass.applicable(self.cfg, self.args.max_completion_length):
+            return {}
+        if "_decode_stream" not in self.__dict__:
+            import sys
+            total = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            if not (0 < n < total and n % 8 == 0):
+                raise ValueError(f"IADR1_OVERLAP_CUS={n}: a multiple of 8 (the same share of every XCD) below the device's {total} CUs is required")
+            self._decode_stream = hip.cu_mask_stream(n, total - n)
+            log = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("IADR1_QUIET") != "1" else None
+            self._shadow_stream, ratio = pick_concurrent_stream(self._decode_stream, lambda: hip.cu_mask_stream(0, n), self.ref.p.w("layers.0.gu.w"), log=log)
+            if self._shadow_stream is None:       # no candidate on another dispatch pipe: no co-scheduling at all (the one-shot reference pass after the rollout)
+                self._decode_stream, self._decode_cus = None, 0
+            else:
+                self._decode_cus = total - n
+        if self._decode_stream is None:
+            return {}
+        return {"decode_cus": self._decode_cus, "decode_stream": self._decode_stream}
 
     def _rollout_fuses_swiglu(self, N) -> bool:
         """True when the decode gate|up projection runs on the persistent fused-SwiGLU kernel (the one with side outputs): include/iadr1_hip.h."""
@@ -349,9 +391,12 @@ class SCGRPOEngine:
                 and N2 % 128 == 0 and N2 // 32 >= 2 * ncu and N <= 256)
 
     # ---- loss + gradients for given completions ------------------------------------------------------------------
-    def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None, train_carry=None, defer_metrics: bool = False):
+    def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None, train_carry=None, defer_metrics: bool = False,
+                       ref_logps=None):
         """completions: list of Bp*G id lists (prompt-major) or an [N,C] array already padded;
-        rewards_per_func: [N, n_funcs] float tensor/array.  Accumulates gradients into policy.grad."""
+        rewards_per_func: [N, n_funcs] float tensor/array.  Accumulates gradients into policy.grad.
+        ref_logps: [N, C] reference log-probs already computed for exactly these completions by the rollout's shadow pass (rollout(shadow_ref=True)): the
+        reference forward is then not run here; the shadow stream is joined right before the loss kernel reads them."""
         a, c = self.args, self.cfg
         G = a.num_generations
         ids_p, mask_p = np.asarray(batch["input_ids"]), np.asarray(batch["attention_mask"])
@@ -384,7 +429,8 @@ class SCGRPOEngine:
         if vis is None or (backward and vis["ctx"] is None):
             vis = self.vision_policy(batch, save=backward)
         grids, plan_v, px, rows, img_pol, vctx = vis["grids"], vis["plan"], vis["px"], vis["rows"], vis["img"], vis["ctx"]
-        img_ref, _ = self.ref.vision_forward(px, plan_v, save=False)
+        have_ref = ref_logps is not None and tuple(ref_logps.shape) == (N, C)
+        img_ref = None if have_ref else self.ref.vision_forward(px, plan_v, save=False)[0]
         gpr, off = self._per_row_images(batch, grids, rows)
         dimg32 = torch.zeros(img_pol.shape, dtype=F32, device=self.dev) if backward else None
 
@@ -435,9 +481,10 @@ class SCGRPOEngine:
                 sel = sel.reshape(-1)
             rows_d = ops.h2d(sel.astype(np.int64), self.dev)
             tgt_d = ops.h2d(tgt.reshape(-1), self.dev)
-            hf, _ = self.ref.text_forward(plan, img_ref, save=False)
-            rl, _ = self.ref.logprobs(hf, rows_d, tgt_d, save=False)
-            del hf
+            if not have_ref:
+                hf, _ = self.ref.text_forward(plan, img_ref, save=False)
+                rl, _ = self.ref.logprobs(hf, rows_d, tgt_d, save=False)
+                del hf
             if train_carry is not None and "x0" in train_carry and share and backward and n == N and C == a.max_completion_length and vis is not None and vis["ctx"] is not None:
                 # the rollout's prefill already ran (and saved) the prompt rows of this batch: only the completion rows go through the layers
                 T_all = plan.ids.numel()
@@ -450,6 +497,10 @@ class SCGRPOEngine:
                 hf, ctx = self.pol.text_forward(plan, img_pol, save=backward, recompute=backward and self.pol.recompute_wanted(plan.ids.numel(), a.recompute))
             lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel)
             adv_d = advantages()["adv_d"]
+            if have_ref:
+                if si == 0:
+                    self._shadow.join()          # the tail chunk of the shadow pass ran next to the policy's lm_head; everything after this reads its log-probs
+                rl = ref_logps[r0:r1].contiguous()
             dlogp, kl, rloss, rkl = ops.grpo_loss(lp.view(n, C), rl.view(n, C), adv_d[r0:r1].contiguous(), cmask_d[r0:r1].contiguous(), a.beta, n_total_rows=N)
             logp_all[r0:r1], ref_all[r0:r1], kl_all[r0:r1] = lp.view(n, C), rl.view(n, C), kl
             row_loss[r0:r1], row_kl[r0:r1] = rloss, rkl
@@ -499,7 +550,23 @@ class SCGRPOEngine:
         return float(self.norm2.sqrt().item()) * getattr(self, "grad_scale", 1.0)
 
     # ---- the whole micro-step ----------------------------------------------------------------------------------------
-    def step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False, defer_metrics=False, completions=None):
+    def step(self, *args, **kw):
+        """`_step` on a stream of the engine's own when the caller is on the NULL stream and the CU split is in use: the two CU-masked streams are blocking
+        streams (hipExtStreamCreateWithCUMask has no non-blocking form), i.e. every operation on the null stream waits for both of them and holds back what they
+        enqueue afterwards -- measured: each chunk of the shadow pass then started exactly one chunk period late.  The caller's stream is ordered before and
+        after the step as usual."""
+        if self.dev.type == "cuda" and int(os.environ.get("IADR1_OVERLAP_CUS", "0")) > 0 and torch.cuda.current_stream(self.dev).cuda_stream == 0:
+            if "_main_stream" not in self.__dict__:
+                self._main_stream = torch.cuda.Stream(self.dev)
+            outer = torch.cuda.current_stream(self.dev)
+            self._main_stream.wait_stream(outer)
+            with torch.cuda.stream(self._main_stream):
+                out = self._step(*args, **kw)
+            outer.wait_stream(self._main_stream)
+            return out
+        return self._step(*args, **kw)
+
+    def _step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False, defer_metrics=False, completions=None):
         """One SC-GRPO micro-step: vision tower -> group rollout -> rewards -> reference / policy passes + backward (-> optimizer).  This is the path
         `SCGRPOTrainer.compute_loss` (the reference's API, REF:586) runs and the one bench.py times.
         reward_fn(completion_ids: np.ndarray [N,C]) -> [N, n_funcs] rewards (decode + plugin functions live with the caller, which owns the tokenizer).
@@ -527,7 +594,8 @@ class SCGRPOEngine:
             P_ = np.asarray(batch["input_ids"]).shape[1] if a.max_prompt_length is None else min(np.asarray(batch["input_ids"]).shape[1], a.max_prompt_length)
             if self.pol.recompute_wanted(len(batch["input_ids"]) * P_ + N * a.max_completion_length, a.recompute):
                 carry = None       # gradient checkpointing: nothing of the rollout is kept, the policy forward runs (checkpointed) before backward
-        comp = self.rollout(batch, vis=vis, train_carry=carry) if completions is None else np.asarray(completions)
+        comp = self.rollout(batch, vis=vis, train_carry=carry, shadow_ref=True) if completions is None else np.asarray(completions)
+        ref_lp = self.shadow_logps if completions is None else None
         t2 = mark()
         # rewards are computed on the host inside loss_and_grads, after the first forward passes are in the GPU queue (in the
         # phase-timing mode they are evaluated here so that they get their own column)
@@ -535,7 +603,9 @@ class SCGRPOEngine:
         t3 = mark()
         self.last_step_traced = bool(carry and carry.get("traced"))     # the decode steps filled the completion rows of the training arena
         last = do_optimizer_step if last_micro_step is None else last_micro_step
-        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=last, vis=vis, train_carry=carry, defer_metrics=defer_metrics or do_optimizer_step)
+        out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=last, vis=vis, train_carry=carry, defer_metrics=defer_metrics or do_optimizer_step,
+                                  ref_logps=ref_lp)
+        self.last_step_shadowed = ref_lp is not None
         t4 = mark()
         if do_optimizer_step:
             self.optimizer_step()

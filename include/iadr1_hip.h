@@ -26,6 +26,19 @@ typedef void* iadr1_stream_t; /* hipStream_t */
 
 int iadr1_version(void);
 const char* iadr1_last_error(void);
+/* Co-scheduling of the rollout and the teacher-forced training forward (round 5).  The reference runs its rollout engine and its training ranks on
+ * DIFFERENT GPUs at the same time (REF:scripts/train/SC_GRPO/SC_GRPO_Qwen_Instruct_2_5_VL_3B.sh:40-42: 3 training ranks + one vLLM GPU,
+ * REF:train/stage_rl/trainer/sc_grpo_trainer.py:637-683 || :737-743); here one MI355X is split by CU masks instead: the latency-bound decode
+ * replay keeps most CUs, the MFMA-bound forward over the tokens already sampled runs on the rest, each on its own HIP stream.
+ *   iadr1_stream_create_cu_mask: hipExtStreamCreateWithCUMask.  `cu_mask` is a HOST array of `n_words` 32-bit words; bit i enables CU i in the
+ *     driver's numbering (round-robin over the 8 XCDs: bits [8k, 8k+8) are one CU of every XCD).  `stream_out` (HOST) receives the hipStream_t.
+ *   iadr1_stream_destroy: hipStreamDestroy of such a stream.
+ *   iadr1_set_decode_cus: the number of CUs the decode-step launchers (iadr1_gemm_skinny_bf16, iadr1_gemm_qkv_rope_kv_bf16, iadr1_gemm_skinny_fp8w)
+ *     size their persistent one-block-per-CU grids for; 0 = the device's CU count.  Process-wide launcher configuration (like the IADR1_* switches):
+ *     set it before the decode graph is captured, not concurrently with launches. */
+int iadr1_stream_create_cu_mask(const unsigned* cu_mask, int n_words, void** stream_out);
+int iadr1_stream_destroy(void* stream);
+int iadr1_set_decode_cus(int n_cus);
 /* Rollout -> training hand-over.  The four decode-step entry points that take a trailing `side` argument can ALSO write what they compute into
  * row-major training buffers, at row  base + s * seq_stride + *step  for sequence s (`step`: device-resident decode step counter).  `side` is a
  * HOST pointer to this struct, read during the call (NULL: no side outputs); the struct holds DEVICE pointers:
@@ -185,6 +198,17 @@ int iadr1_f32_bias_to_bf16(float* in_zeroed_after, const void* bias, void* out, 
 int iadr1_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start,
                    const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int nseg_head, int max_seqlen_tail, int T, int Hq, int Hkv, int D, long long ldq,
                    long long ldk, long long ldv, long long ldo, int causal, float scale, iadr1_stream_t stream);
+/* Chunked teacher-forced forward (round 5: the frozen reference's pass over the completion tokens runs UNDER the rollout, a few decode steps' worth of rows
+ * at a time, REF:train/stage_rl/trainer/sc_grpo_trainer.py:737-743 next to :637-683).  Same kernel and arithmetic as iadr1_attn_fwd (causal), plus per segment
+ * seg_view[i] = {q_first, q_count, blk_log2, blk_stride}: only the query rows [q_first, +q_count) of segment i are computed -- against its prefix and ALL its
+ * own rows [0, seg_end - seg_start) written so far (causal) -- and logical row j of the segment lives at flat row
+ *     seg_start + (j >> blk_log2) * blk_stride + (j & (2^blk_log2 - 1))
+ * (time-blocked completion rows: the rows all sequences produce in the same 2^blk_log2 decode steps are contiguous, so every token-wise kernel and GEMM of a
+ * chunk runs on one contiguous row range; blk_log2 = 31, blk_stride = 0: a plain contiguous segment).  A query row's result is bit-identical to the one
+ * iadr1_attn_fwd computes for it over the whole sequence: same 64-key tiles in the same order.  max_q_count >= every q_count.  Prefix ranges are plain. */
+int iadr1_attn_fwd_chunk(const void* q, const void* k, const void* v, void* o, float* lse, const int* seg_start, const int* seg_end,
+                         const int* seg_prefix, const int* seg_view, int nseg, int max_q_count, int T, int Hq, int Hkv, int D, long long ldq,
+                         long long ldk, long long ldv, long long ldo, float scale, iadr1_stream_t stream);
 int iadr1_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    float* delta, void* dq, void* dk, void* dv, float* dkv_ws, int head_splits, const int* seg_start,
                    const int* seg_end, const int* seg_prefix, int nseg, int max_seqlen, int nseg_head, int max_seqlen_tail, int T, int Hq, int Hkv, int D, long long ldq, long long ldk, long long ldv,
@@ -261,6 +285,11 @@ int iadr1_decode_advance(const long long* sampled, long long* cur_tok, long long
                          long long* slot, const int* block_table, int max_pages, int* finished, unsigned* step, int eos,
                          int pad, int B, int* all_done, const float* inv_freq, float* cos_t, float* sin_t, int half,
                          iadr1_stream_t stream);
+/* wait_counter: stream-ordered wait until the device counter `counter` (the decode step counter iadr1_decode_advance bumps, on another stream) has reached
+ * `target`: one wave polls it with agent-scope loads.  `timed_out` (optional, device int) is set to 1 when `timeout_ms` (<= 60000) elapsed first -- the wait then
+ * returns anyway, a counter that never arrives cannot hang the queue.  The chunked reference pass (iadr1_attn_fwd_chunk) gates each chunk on the decode
+ * step that produced its last target token with this instead of an event recorded between two hipGraph launches (0.06 ms per decode step cheaper). */
+int iadr1_wait_counter(const unsigned* counter, unsigned target, int timeout_ms, int* timed_out, iadr1_stream_t stream);
 /* all_done (optional): 1 when every sequence has finished after this token -- the host polls it through pinned memory without draining the
  * queue (the reference's vLLM stops a request at EOS, REF:343-358).  inv_freq (optional, with cos_t / sin_t [B, half]): the rotary table
  * of the NEXT step's positions is written here, bit-identical to iadr1_rope_table on the bumped positions (one launch less per decode step). */
