@@ -121,6 +121,43 @@ def test_make_conversation_structure():
         m.make_conversation({"problem": "q", "image": [3]}, "/d", False, 1)
 
 
+def test_prompt_templates_and_make_conversation_match_the_reference_golden(golden_dir):
+    """SURVEY section 8 row a20, pinned: the four prompt templates (single_img 1 / 0 x system / question) are byte-equal to the constants inside the reference's
+    main() (REF train/stage_rl/grpo_ad.py:72-118, read from its AST), and make_conversation returns what the reference's nested function returns for every row
+    form it accepts (REF:135-181, compiled from the AST and executed by tools/make_golden_prompts.py).  Stated divergences, both stricter / fixed here: a row
+    without an image makes the reference return None (datasets.map then keeps the row without a prompt and the trainer fails on it later) -- here ValueError at once;
+    `image` given as ONE dict hits an unbound local in the reference (:151) -- here it is accepted like a one-element list."""
+    import copy
+    import json
+    m = _load("train/stage_rl/grpo_ad.py")
+    g = json.load(open(os.path.join(golden_dir, "prompts.json")))
+    for k in ("1", "0"):
+        assert m.PROMPTS[int(k)]["system"] == g["templates"][k]["system"] and m.PROMPTS[int(k)]["question"] == g["templates"][k]["question"], k
+    seen = {"returns": 0, "TypeError": 0, "None": 0, "UnboundLocalError": 0}
+    for c in g["cases"]:
+        row = copy.deepcopy(g["rows"][c["row"]])
+        call = lambda: m.make_conversation(copy.deepcopy(row), "/data/Expert-AD", c["use_system_prompt"], c["single_img"])
+        if c.get("raises") == "TypeError":
+            with pytest.raises(TypeError):
+                call()
+            seen["TypeError"] += 1
+        elif c.get("raises") == "UnboundLocalError":          # the reference's bug for a single-dict image; fixed here
+            out = call()
+            assert out["image"] == [os.path.join("/data/Expert-AD", row["image"]["path"])] and len(out["prompt"][-1]["content"]) == 2
+            seen["UnboundLocalError"] += 1
+        elif c["returns"] is None:
+            with pytest.raises(ValueError, match="without an image"):
+                call()
+            seen["None"] += 1
+        else:
+            out = call()
+            assert out["prompt"] == c["returns"]["prompt"] and out["image"] == c["returns"]["image"], c
+            # datasets.map merges the returned columns into the row; `messages` is dropped afterwards (REF:183-185)
+            assert {k: v for k, v in out.items() if k not in ("prompt", "image")} == {k: v for k, v in row.items() if k not in ("messages", "image")}
+            seen["returns"] += 1
+    assert seen["returns"] >= 16 and min(seen.values()) >= 4, seen
+
+
 def test_trainer_constructor_errors_match_reference():
     import iadr1_amd  # noqa: F401
     from iadr1_amd.trainer import GRPOConfig, SCGRPOTrainer
