@@ -63,6 +63,20 @@ def _skinny_pmc():
         return None
 
 
+def power_limit():
+    """Shader clock and socket power under a back-to-back gemm_nt stream, from the newest record tools/gemm_power.py left under profiles/ (a separate run: rocm-smi
+    sampling next to the bench would perturb it)."""
+    for f in ("r05_gemm_power.json",):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f)))
+            d["dense_bf16_peak_at_that_clock_tflops"] = MFMA_BF16_DENSE_PEAK_TFLOPS * d["sclk_mhz_under_gemm_stream"] / 2400.0
+            return d
+        except Exception:
+            pass
+    return {"source": "profiles/r02_gemm_power.txt", "sclk_mhz_under_gemm_stream": 1900, "sclk_mhz_idle": 2400, "socket_power_w": 1388,
+            "dense_bf16_peak_at_that_clock_tflops": MFMA_BF16_DENSE_PEAK_TFLOPS * 1900 / 2400}
+
+
 def decode_roofline(cfg, pol, events, n_seq, gen_len):
     """HBM roofline of the rollout's decode step (one hipGraph replay = ~250 kernels, 64 live sequences): algorithmic bytes per step
     = every decode-packed weight once + the K/V of every live context, / the HIP-event time of the replay loop (events on the
@@ -1364,9 +1378,7 @@ def main():
                                           "(64 resident 256x256 tiles arranged 4 x 16 reuse a panel 6.4x) and are served by the 256 MB memory-side cache -- A + B of this launch are 174 MB; "
                                           "the kernel is MFMA / power bound (mfma_busy, power_limit), not traffic bound"),
                          "mfma_busy": mfma_busy,
-                         "power_limit": {"source": "profiles/r02_gemm_power.txt (tools/gemm_power.py: rocm-smi during a 6 s back-to-back gemm_nt stream, separate run)",
-                                         "sclk_mhz_under_gemm_stream": 1900, "sclk_mhz_idle": 2400, "socket_power_w": 1388,
-                                         "dense_bf16_peak_at_that_clock_tflops": MFMA_BF16_DENSE_PEAK_TFLOPS * 1900 / 2400},
+                         "power_limit": power_limit(),
                          "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt,
                          "timing": "sum of algorithmic FLOPs of the launches / length of the union of their HIP-event intervals (weight-gradient GEMMs run on a side stream "
                                    "concurrently with the dgrad GEMMs; equals FLOPs / sum of launch durations when nothing overlaps: IADR1_WGRAD_STREAM=0)",

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void quick_gelu_bwd_kernel(const bf16_t* da, c
 // Column sums of a bf16 matrix into fp32 (bias gradients): out[n] += sum_t dY[t][n].
 // Block = 64 columns x 4 row-lanes... each thread owns 8 columns (16 B) and strides over rows.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, long long ld, float* out, int T, int N) {
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, long long ld, float* ws, int T, int N) {
     __shared__ float red[8][32 * 8 + 1];
     const int cchunk = threadIdx.x & 31, rlane = threadIdx.x >> 5;  // 32 chunks (256 cols) x 8 row lanes
     const int col = blockIdx.x * 256 + cchunk * 8;
@@ -179,8 +179,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, long long
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += red[r][c];
-        atomicAdd(out + blockIdx.x * 256 + c, s);
+        ws[(long long)blockIdx.y * N + blockIdx.x * 256 + c] = s;       // this row group's partial; summed in group order by colsum_reduce_kernel (no atomics)
     }
+}
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* ws, int nparts, float* out, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float s = 0.f;
+    for (int q = 0; q < nparts; ++q) s += ws[(long long)q * N + i];
+    out[i] += s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,28 +207,27 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* ids, co
         *(u32x4_t*)(out + t * H + c * 8) = *(const u32x4_t*)(src + c * 8);
     }
 }
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* ids, const int* img_index, const bf16_t* dx, float* dE,
-                                                        float* dimg, int T, int H) {
-    const int cpr = H >> 3;
-    const long long total = (long long)T * cpr;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long t = i / cpr;
-        const int c = (int)(i % cpr);
-        const int ii = img_index ? img_index[t] : -1;
-        float* dst;
-        if (ii >= 0) {
-            if (!dimg) continue;
-            dst = dimg + (long long)ii * H + c * 8;
-        } else {
-            if (!dE) continue;
-            dst = dE + ids[t] * (long long)H + c * 8;
-        }
-        const u32x4_t v = *(const u32x4_t*)(dx + t * H + c * 8);
+// Backward of the gather (and of every "several rows read one row" map of the path): dst[rows[u]] += sum_{k in [ptr[u], ptr[u+1])} src[idx[k]], fp32, the terms of a
+// row added in the order the CSR lists them.  One block per destination row: a single writer per row and a fixed order -- no atomics, bit-reproducible (round 5; the
+// scatter this replaces added the token rows of one vocabulary entry with float atomics in arrival order).
+__global__ __launch_bounds__(256) void rows_scatter_acc_kernel(const bf16_t* src, const long long* rows, const int* ptr, const int* idx, float* dst, int H) {
+    const int u = blockIdx.x;
+    const int k0 = ptr[u], k1 = ptr[u + 1];
+    float* out = dst + rows[u] * (long long)H;
+    for (int ch = threadIdx.x; ch < (H >> 3); ch += 256) {
+        float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            atomicAdd(dst + 2 * e, lo_bf(v[e]));
-            atomicAdd(dst + 2 * e + 1, hi_bf(v[e]));
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const u32x4_t a = *(const u32x4_t*)(src + (long long)idx[k] * H + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(a[e]); v[2 * e + 1] += hi_bf(a[e]); }
         }
+        f32x4_t o0 = *(const f32x4_t*)(out + ch * 8), o1 = *(const f32x4_t*)(out + ch * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] += v[e]; o1[e] += v[4 + e]; }
+        *(f32x4_t*)(out + ch * 8) = o0;
+        *(f32x4_t*)(out + ch * 8 + 4) = o1;
     }
 }
 
@@ -410,11 +416,17 @@ extern "C" int iadr1_quick_gelu_bwd(const void* da, const void* z, void* dz, lon
     hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (const bf16_t*)da, (const bf16_t*)z, (bf16_t*)dz, n / 8);
     return iadr1_check_launch("quick_gelu_bwd");
 }
-extern "C" int iadr1_colsum_acc(const void* dy, long long ld, float* out, int T, int N, hipStream_t stream) {
+static int colsum_groups(int T) {
+    const int gy = (T + 63) / 64;
+    return gy > 64 ? 64 : gy;
+}
+extern "C" long long iadr1_colsum_workspace_bytes(int T, int N) { return (T <= 0 || N <= 0) ? 0 : (long long)colsum_groups(T) * N * 4; }
+extern "C" int iadr1_colsum_acc(const void* dy, long long ld, float* out, float* workspace, int T, int N, hipStream_t stream) {
     IADR1_REQUIRE(T > 0 && N > 0 && (N % 8) == 0 && (ld % 8) == 0, "colsum: N, ld must be multiples of 8");
-    int gy = (T + 63) / 64;
-    if (gy > 64) gy = 64;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, gy), dim3(256), 0, stream, (const bf16_t*)dy, ld, out, T, N);
+    IADR1_REQUIRE(workspace != nullptr, "colsum: the partial-sum workspace is required (iadr1_colsum_workspace_bytes)");
+    const int gy = colsum_groups(T);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, gy), dim3(256), 0, stream, (const bf16_t*)dy, ld, workspace, T, N);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, gy, out, N);
     return iadr1_check_launch("colsum_acc");
 }
 extern "C" int iadr1_embed_fwd(const long long* ids, const int* img_index, const void* E, const void* img, void* out, int T, int H,
@@ -423,11 +435,10 @@ extern "C" int iadr1_embed_fwd(const long long* ids, const int* img_index, const
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)E, (const bf16_t*)img, (bf16_t*)out, T, H);
     return iadr1_check_launch("embed_fwd");
 }
-extern "C" int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
-                               hipStream_t stream) {
-    IADR1_REQUIRE(T > 0 && (H % 8) == 0, "embed_bwd: H must be a multiple of 8");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((long long)T * (H / 8))), dim3(256), 0, stream, ids, img_index, (const bf16_t*)dx, dE, dimg, T, H);
-    return iadr1_check_launch("embed_bwd");
+extern "C" int iadr1_rows_scatter_acc(const void* src, const long long* rows, const int* ptr, const int* idx, float* dst, int U, int H, hipStream_t stream) {
+    IADR1_REQUIRE(U > 0 && H > 0 && (H % 8) == 0 && ((((uintptr_t)dst) & 15) == 0), "rows_scatter_acc: H must be a multiple of 8, dst 16-byte aligned");
+    hipLaunchKernelGGL(rows_scatter_acc_kernel, dim3(U), dim3(256), 0, stream, (const bf16_t*)src, rows, ptr, idx, dst, H);
+    return iadr1_check_launch("rows_scatter_acc");
 }
 extern "C" int iadr1_gelu_tanh_fwd(const void* z, void* a, long long n, hipStream_t stream) {
     IADR1_REQUIRE(n > 0 && (n % 8) == 0, "gelu_tanh_fwd: n must be a multiple of 8");

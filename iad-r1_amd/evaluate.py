@@ -190,7 +190,9 @@ def encode_prompts(processor, prompts, images, family: str):
     (vLLM_LLaVA_detect_format.py:330-340, vLLM_LLaVA_1_5_detect_format.py, vLLM_Qwen_detect_format.py:340-352), whose tokenizer call is `encode(prompt)` with
     the tokenizer's DEFAULT `add_special_tokens=True`.  For the Llama / Vicuna / Mistral tokenizers of LLaVA-1.5 / 1.6 that prepends `<s>` (the llava-hf chat
     templates emit no BOS themselves); the Qwen2 tokenizers of Qwen2(.5)-VL and LLaVA-OneVision define no BOS, so the flag changes nothing there.
-    (The TRAINING path is different on purpose: REF sc_grpo_trainer.py:615 passes `add_special_tokens=False`; trainer.prepare_batch keeps that.)"""
+    (The TRAINING path is different on purpose: REF sc_grpo_trainer.py:615 passes `add_special_tokens=False`; trainer.prepare_batch keeps that.)
+    A chat template that renders `<s>` ITSELF would get a second BOS here -- and from vLLM's `encode(prompt)` in the reference just the same (vLLM only warns about
+    it): the ids stay what the reference's engine would see, so nothing is stripped."""
     return processor(text=prompts, images=images, return_tensors="pt", padding=True, padding_side="left", add_special_tokens=(family != "qwen"))
 
 

@@ -245,11 +245,17 @@ def rmsnorm_fwd(x, w, eps, res=None, res_out=None, x32=None, xbias=None, want_rs
     return y, rstd
 
 
+def _ws_floats(nbytes, device):
+    """fp32 scratch of the ordered two-stage reductions (norm gains, bias column sums): the grow-only per-(device, stream) buffer of the split-K GEMMs."""
+    return _splitk_workspace((int(nbytes) + 3) // 4, device)
+
+
 def rmsnorm_bwd(dy, x, w, rstd, dres=None, dw=None, out=None):
     T, H = x.shape
     dx = out if out is not None else torch.empty(T, H, dtype=BF16, device=x.device)
     assert _ld(dy) == _ld(x) == _ld(dx) and (dres is None or _ld(dres) == _ld(x))
-    hip.call("rmsnorm_bwd", dy, x, w, rstd, dres, dx, dw, T, H, _ld(x))
+    ws = _ws_floats(hip.lib().iadr1_rmsnorm_bwd_workspace_bytes(T, H), x.device) if dw is not None else None
+    hip.call("rmsnorm_bwd", dy, x, w, rstd, dres, dx, dw, ws, T, H, _ld(x))
     return dx
 
 
@@ -332,13 +338,14 @@ def layernorm_fwd(x, w, b, eps, res=None, res_out=None, want_stats=False):
 def layernorm_bwd(dy, x, w, mean, rstd, dres=None, dw=None, db=None):
     T, H = x.shape
     dx = torch.empty(T, H, dtype=BF16, device=x.device)
-    hip.call("layernorm_bwd", dy, x, w, mean, rstd, dres, dx, dw, db, T, H, _ld(x))
+    ws = _ws_floats(hip.lib().iadr1_layernorm_bwd_workspace_bytes(T, H), x.device) if dw is not None else None
+    hip.call("layernorm_bwd", dy, x, w, mean, rstd, dres, dx, dw, db, ws, T, H, _ld(x))
     return dx
 
 
 def colsum_acc(dy, out32):
     T, N = dy.shape
-    hip.call("colsum_acc", dy, _ld(dy), out32, T, N)
+    hip.call("colsum_acc", dy, _ld(dy), out32, _ws_floats(hip.lib().iadr1_colsum_workspace_bytes(T, N), dy.device), T, N)
     return out32
 
 
@@ -350,9 +357,31 @@ def embed_fwd(ids, img_index, E, img, out=None):
     return o
 
 
-def embed_bwd(ids, img_index, dx, dE, dimg):
-    T, H = dx.shape
-    hip.call("embed_bwd", ids, img_index, dx, dE, dimg, T, H)
+def scatter_plan(dst_rows, device):
+    """Host side of rows_scatter_acc: dst_rows[t] >= 0 = destination row of source row t (< 0: dropped) -> (rows int64 [U], ptr int32 [U + 1], idx int32 [R]) on the
+    device: the distinct destination rows in ascending order, and for each the source rows that feed it, ascending (np.unique / stable argsort: integer work)."""
+    import numpy as np
+    d = np.asarray(dst_rows).reshape(-1)
+    src = np.flatnonzero(d >= 0)
+    if src.size == 0:
+        return None
+    order = np.argsort(d[src], kind="stable")
+    idx = src[order].astype(np.int32)
+    rows, counts = np.unique(d[src], return_counts=True)
+    ptr = np.zeros(len(rows) + 1, dtype=np.int32)
+    np.cumsum(counts, out=ptr[1:])
+    return h2d(rows.astype(np.int64), device), h2d(ptr, device), h2d(idx, device)
+
+
+def rows_scatter_acc(src, plan, dst32):
+    """dst32[rows[u]] += sum of src[idx[k]] over the CSR list of u, in list order (include/iadr1_hip.h iadr1_rows_scatter_acc): deterministic scatter-add."""
+    if plan is None:
+        return dst32
+    rows, ptr, idx = plan
+    T, H = src.shape
+    assert src.is_contiguous() and dst32.dtype == F32 and dst32.is_contiguous() and dst32.shape[-1] == H
+    hip.call("rows_scatter_acc", src, rows, ptr, idx, dst32, rows.numel(), H)
+    return dst32
 
 
 def rows_gather_sum(src, ptr, idx, T, weights=None):

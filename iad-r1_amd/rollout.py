@@ -84,7 +84,9 @@ class Rollout:
             ncu = self.decode_cus
         if H * Hq * D >= 1 << 20:
             self.ks_o = max(1, min(2, ncu // max(1, H // 16)))
-            self.ks_down = 8 if (I // 32 + 7) // 8 <= int(os.environ.get("IADR1_SPLIT_MAXSTEPS", "80")) else max(1, min(8, ncu // max(1, H // 64)))
+            # (the persistent split kernel takes <= 80 k-steps per slice, <= 48 with IADR1_SPLIT_KSW10=0 -- the launcher's own gate, gemm.hip: ONE switch for both sides)
+            split_max = int(os.environ.get("IADR1_SPLIT_MAXSTEPS", "80" if os.environ.get("IADR1_SPLIT_KSW10", "1") != "0" else "48"))
+            self.ks_down = 8 if (I // 32 + 7) // 8 <= split_max else max(1, min(8, ncu // max(1, H // 64)))
         else:
             self.ks_o, self.ks_down = 1, 1
         if os.environ.get("IADR1_DECODE_KS"):

@@ -149,11 +149,25 @@ class GradReducer:
         self.wire = (wire or os.environ.get("IADR1_REDUCE_DTYPE", "bf16")).lower()
         if self.wire not in ("bf16", "fp32"):
             raise ValueError("IADR1_REDUCE_DTYPE must be bf16 or fp32")
+        # collective per bucket: "all_reduce" (the library picks ring / tree), or "rs_ag": reduce_scatter_tensor + all_gather_into_tensor -- the two halves of an
+        # all-reduce issued explicitly, which on the fully connected xGMI mesh of one node can run as direct exchanges (every rank sends 1/N of the bucket to every
+        # peer at once: SURVEY section 5 estimates ~12 ms against ~86 ms for a ring over 7.5 GB).  Bit-identical sums on every rank either way (each shard is reduced
+        # on ONE rank, then copied).  Needs a backend with reduce_scatter_tensor (RCCL); on others (gloo, the CPU tests) the request falls back to all_reduce.
+        self.algo = os.environ.get("IADR1_REDUCE_ALGO", "all_reduce").lower()
+        if self.algo not in ("all_reduce", "rs_ag"):
+            raise ValueError("IADR1_REDUCE_ALGO must be all_reduce or rs_ag")
+        if self.algo == "rs_ag" and not (self.active and self.cuda and dist.get_backend(group) == "nccl"):
+            self.algo = "all_reduce"
+        pad = 8 * self.world                    # rs_ag: equal 16-byte aligned shards
         self.bucket_elems = max(1, min(int(bucket_bytes) // (2 if self.wire == "bf16" else 4), store.n_total))
+        if self.algo == "rs_ag":
+            self.bucket_elems = (self.bucket_elems + pad - 1) // pad * pad
         # staging: a RING of bucket-sized bf16 buffers (<= 768 MB), not a second copy of the model (16.6 GB at 7B, which the 7B / LLaVA-OneVision
         # configurations do not have to spare next to 245 GB of training state).  A buffer is reused only after its previous bucket has been cast
         # back into the fp32 gradient buffer -- stream order on the side stream guarantees it (the cast-back is enqueued before the next cast-in)
         self.ring = [torch.empty(self.bucket_elems, dtype=BF16, device=store.grad.device) for _ in range(self.RING)] if (self.active and self.wire == "bf16") else None
+        if self.active and self.algo == "rs_ag" and self.ring is None:        # fp32 wire: the padded bucket is staged too (the gradient buffer's tail is not a multiple of the shard)
+            self.ring = [torch.empty(self.bucket_elems, dtype=F32, device=store.grad.device) for _ in range(self.RING)]
         self.pending = [None] * self.RING
         self.slot = 0
         self.bytes_on_wire = 0          # per step, for the bench line
@@ -191,10 +205,12 @@ class GradReducer:
         work, st, lo, hi = p
         work.wait()
         g = self.store.grad[lo:hi]
-        if self.cuda:
+        if st.dtype == F32:
+            g.copy_(st[: hi - lo])
+        elif self.cuda:
             hip.call("cast_bf16_to_f32", st, g, hi - lo)
         else:
-            g.copy_(st)
+            g.copy_(st[: hi - lo])
         self.pending[k] = None
 
     def _bucket(self, lo, hi):
@@ -205,11 +221,25 @@ class GradReducer:
         k = self.slot
         self.slot = (k + 1) % self.RING
         self._complete(k)                  # the slot's previous bucket (RING buckets ago) leaves the buffer first
-        st = self.ring[k][: hi - lo]
-        if self.cuda:   # fp32 -> bf16 (round to nearest even) and back through the library's cast kernels
-            hip.call("cast_f32_to_bf16", g, hi - lo, st, hi - lo, 1, hi - lo, hi - lo)
+        n = hi - lo
+        st = self.ring[k][:n]
+        if st.dtype == F32:
+            st.copy_(g)
+        elif self.cuda:   # fp32 -> bf16 (round to nearest even) and back through the library's cast kernels
+            hip.call("cast_f32_to_bf16", g, n, st, n, 1, n, n)
         else:
             st.copy_(g)
+        if self.algo == "rs_ag":
+            # the bucket padded to world equal shards (the pad is zeroed: it is summed and gathered like data, nobody reads it back)
+            npad = (n + 8 * self.world - 1) // (8 * self.world) * (8 * self.world)
+            full = self.ring[k][:npad]
+            if npad > n:
+                full[n:].zero_()
+            shard = full.view(self.world, -1)[self.dist.get_rank(self.group)]
+            self.dist.reduce_scatter_tensor(shard, full, group=self.group, async_op=True)       # in place: rank r's shard of `full` receives the sum (NCCL's in-place form)
+            work = self.dist.all_gather_into_tensor(full, shard, group=self.group, async_op=True)   # same communicator, same stream: ordered behind the reduce-scatter
+            self.pending[k] = (work, st, lo, hi)
+            return
         self.pending[k] = (self.dist.all_reduce(st, group=self.group, async_op=True), st, lo, hi)
 
     def _drain(self):
@@ -543,7 +573,10 @@ class SCGRPOEngine:
                          a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd, self.opt_step, scale, self.norm2, a.max_grad_norm)
         st.refresh_shadows()
         self.accum = 0
-        self.pol.check_ddp_headroom(a.recompute)
+        if self.pol.check_ddp_headroom(a.recompute):
+            # the rollout's captured graph and its training-arena views keep the freed arena's blocks alive: drop them too, THEN hand the memory back to the device
+            self._rollout = None
+            torch.cuda.empty_cache()
 
     def grad_norm(self) -> float:
         """Global L2 norm of the last optimizer step's (averaged, unclipped) gradient; synchronises the device."""

@@ -60,6 +60,13 @@ class SiglipPlan:
     assemble_t: tuple = None
     select: tuple = None
     select_t: tuple = None
+    _pos_scatter: tuple = None
+
+    def pos_scatter(self, device, seq):
+        """Ordered scatter plan of the learned position rows: tower row r reads position row r % seq (backward: rows_scatter_acc)."""
+        if self._pos_scatter is None:
+            self._pos_scatter = ops.scatter_plan(np.tile(np.arange(seq, dtype=np.int64), self.n_crops), device)
+        return self._pos_scatter
 
 
 @dataclass
@@ -75,6 +82,17 @@ class TextPlan:
     lengths: np.ndarray          # [B] number of real tokens
     shared: tuple = None         # (ng, P, n, C, G) when built by text_plan_shared
     tail: "TextPlan" = None      # completion rows only (two-phase forward), set by text_plan_shared
+    host: tuple = None           # (ids [T], img_index [T]) numpy copies: the backward's ordered scatter plans are built from them (scatter_plans)
+    _scatter: tuple = None
+
+    def scatter_plans(self, device):
+        """(embedding-row plan, image-row plan) for ops.rows_scatter_acc: which token rows feed which embedding row (by token id) / image-embedding row, as CSR
+        lists in ascending order -- the backward of the embedding gather as an ORDERED sum (no atomics).  Built once per plan, on first use, from the host ids."""
+        if self._scatter is None:
+            ids, img = self.host
+            text = np.where(img < 0, ids, -1)
+            self._scatter = (ops.scatter_plan(text, device), ops.scatter_plan(img, device))
+        return self._scatter
 
 
 class _Ring:
@@ -294,7 +312,8 @@ class Engine:
         sel = pos_t[self.mrope_comp]                                   # [D/2, T]: component per frequency
         ang = sel.t().to(F32) * self.inv_freq[None, :]                  # [T, D/2] fp32, as TF::525-538
         return TextPlan(B, S, ops.h2d(input_ids.reshape(-1).astype(np.int64), self.dev), ops.h2d(img_index.reshape(-1), self.dev),
-                        ops.Segments(starts, ends, self.dev), ang.cos().contiguous(), ang.sin().contiguous(), deltas, lengths)
+                        ops.Segments(starts, ends, self.dev), ang.cos().contiguous(), ang.sin().contiguous(), deltas, lengths,
+                        host=(input_ids.reshape(-1).astype(np.int64), img_index.reshape(-1).astype(np.int64)))
 
     def text_plan_shared(self, ids_p: np.ndarray, mask_p: np.ndarray, comp: np.ndarray, cmask: np.ndarray, G: int, grids_per_prompt, img_off_per_prompt) -> TextPlan:
         """Shared-prefix layout of a GRPO micro-batch: the reference feeds [ng*G, P+C] rows whose first P positions are the
@@ -350,6 +369,7 @@ class Engine:
         plan = TextPlan(n, P + C, ops.h2d(ids_flat, self.dev), ops.h2d(img_index, self.dev),
                         ops.Segments(starts, ends, self.dev, prefix=prefix), ang.cos().contiguous(), ang.sin().contiguous(), deltas, mask_full.sum(1).astype(np.int64))
         plan.shared = (ng, P, n, C, G)
+        plan.host = (ids_flat, img_index.astype(np.int64))
         # the completion rows alone (two-phase forward: the prompt rows were already run by the rollout's prefill); segment indices stay absolute
         T0 = ng * P
         plan.tail = TextPlan(n, P + C, plan.ids[T0:], plan.img_index[T0:], ops.Segments(starts[ng:], ends[ng:], self.dev, prefix=prefix[ng:]),
@@ -547,7 +567,7 @@ class Engine:
             x_pre, mu0, rs0 = ctx["pre"]
             dres = ops.layernorm_bwd(dres, x_pre, P.w("visual.pre_ln"), mu0, rs0, dw=P.g("visual.pre_ln"), db=P.g("visual.pre_ln.b"))
         # dres = gradient of (patch / class embedding + position embedding)
-        ops.embed_bwd(plan.pos_ids, None, dres, P.g("visual.pos"), None)
+        ops.rows_scatter_acc(dres, plan.pos_scatter(self.dev, c.v_seq), P.g("visual.pos"))
         if clip:
             dsrcA = ops.rows_gather_sum(dres, plan.assemble_t[0], plan.assemble_t[1], n_pe + 1, weights=plan.assemble_t[2])
             ops.colsum_acc(dsrcA[n_pe: n_pe + 1], P.g("visual.cls"))
@@ -786,6 +806,9 @@ class Engine:
                 print(f"[iadr1] gradient checkpointing (auto): {bucket} token rows need {need / 2**30:.1f} GiB of saved activations, budget 0.6 x {budget / 2**30:.1f} GiB "
                       f"-> {'recompute one decoder layer at a time' if cache[bucket] else 'keep'}", file=sys.stderr, flush=True)
         if cache[bucket]:
+            # monotone: once one bucket needs recomputation the run keeps recomputing -- micro-batches whose token counts straddle the threshold
+            # (ragged any-resolution prompts) would otherwise free and re-allocate the multi-GB arena on alternating steps, with both buffers resident at the peak
+            self._recompute_forced = True
             self._ws.pop("act_save", None)          # a stale arena of an earlier (smaller) bucket must not sit next to the checkpoint buffers
         return cache[bucket]
 
@@ -793,23 +816,33 @@ class Engine:
         """Data-parallel runs only, policy "auto", called once per optimizer step by the trainers: the static budget above cannot see everything a model family
         keeps (LLaVA-OneVision's 40 saved SigLIP crops and its 4 000-token KV pool: 261 GB reserved although the decoder arena alone fits).  If a COMPLETED step
         peaked above `limit_bytes` of reserved memory (235 GB: what VERDICT r3 #5 asks to stay under so that RCCL's channel buffers have room), every later step
-        recomputes.  Deterministic for given shapes (the allocator's peak of a whole step, not its free memory at some call), logged once."""
+        recomputes.  Deterministic for given shapes (the allocator's peak of a whole step, not its free memory at some call), logged once.  Returns True when it
+        switched: the caller then releases what still references the arena and calls torch.cuda.empty_cache() (RCCL allocates outside torch's caching allocator)."""
         if mode != "auto" or self.__dict__.get("_recompute_forced") or os.environ.get("IADR1_RECOMPUTE") == "0":
-            return
+            return False
+        n_checked = self.__dict__.get("_headroom_checks", 0)
+        if n_checked >= 4:                      # the peak of a step is a property of the shapes: settled after the first few steps, no more synchronising reads
+            return False
         try:
             import torch.distributed as dist
             if not (dist.is_available() and dist.is_initialized()):
-                return
+                return False
         except Exception:
-            return
+            return False
+        self._headroom_checks = n_checked + 1
         peak = torch.cuda.max_memory_reserved(self.dev)
-        if peak > limit_bytes:
+        torch.cuda.reset_peak_memory_stats(self.dev)            # (ADVICE r4) the peak of THIS step, not of everything since start-up (a checkpoint export, a graph capture)
+        # every rank takes the same decision: one rank recomputing next to seven that do not would run different kernels (and a different number of them) per step
+        over = torch.tensor([1 if peak > limit_bytes else 0], dtype=torch.int32, device=self.dev)
+        dist.all_reduce(over, op=dist.ReduceOp.MAX)
+        if int(over.item()):
             self._recompute_forced = True
             self._ws.pop("act_save", None)
-            torch.cuda.empty_cache()            # hand the arena's blocks back to the DEVICE: RCCL allocates outside torch's caching allocator
             if os.environ.get("IADR1_QUIET") != "1":
-                print(f"[iadr1] gradient checkpointing (auto): a step peaked at {peak / 2**30:.1f} GiB reserved (> {limit_bytes / 2**30:.0f}) under a process group -> "
-                      "decoder activations are recomputed from the next step on", file=sys.stderr, flush=True)
+                print(f"[iadr1] gradient checkpointing (auto): a step peaked at {peak / 2**30:.1f} GiB reserved on this rank (limit {limit_bytes / 2**30:.0f}, decision shared by all ranks) "
+                      "under a process group -> decoder activations are recomputed from the next step on", file=sys.stderr, flush=True)
+            return True           # the CALLER drops what still points into the arena (rollout trace / captured graph) and then empties the cache
+        return False
 
     def _recompute_layer(self, i, ctx):
         """Gradient checkpointing: the activations of decoder layer i, rebuilt from its checkpointed input rows with the forward's own kernels (bit-identical to
@@ -1020,7 +1053,11 @@ class Engine:
                         layer_done(i)
                 else:
                     layer_done(i)
-        ops.embed_bwd(plan.ids, plan.img_index if dimg32 is not None else None, dres, P.g("embed"), dimg32)
+        # backward of the embedding gather: ordered sums per vocabulary row / image-embedding row (host-built CSR, no atomics)
+        emb_plan, img_plan = plan.scatter_plans(self.dev)
+        ops.rows_scatter_acc(dres, emb_plan, P.g("embed"))
+        if dimg32 is not None:
+            ops.rows_scatter_acc(dres, img_plan, dimg32)
         self.join_wgrads()
 
     # ========================================================================================================

@@ -125,16 +125,20 @@ int iadr1_transpose_bf16(const void* in, long long ldi, void* out, long long ldo
 int iadr1_rmsnorm_fwd(const void* x, const float* x32, int nsplit, const void* xbias, const void* res, void* res_out,
                       const void* w, void* y, float* rstd, int T, int H, long long ldx, long long ldr, long long ldy,
                       float eps, const iadr1_side_out_t* side, iadr1_stream_t stream);
-/* dx = dres + d rmsnorm / dx ; dw (fp32, may be NULL) += sum_t dy * x * rstd */
+/* dx = dres + d rmsnorm / dx ; dw (fp32, may be NULL) += sum_t dy * x * rstd.  The sum over token rows is two-stage and ORDERED (round 5): every block writes its
+ * partial gain gradient to `workspace` (iadr1_rmsnorm_bwd_workspace_bytes, fp32, needed when dw != NULL), a second launch adds the partials in block order -- no float
+ * atomics anywhere in the backward path, two runs of the same step give the same bits. */
+long long iadr1_rmsnorm_bwd_workspace_bytes(int T, int H);
 int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
-                      float* dw, int T, int H, long long ld, iadr1_stream_t stream);
+                      float* dw, float* workspace, int T, int H, long long ld, iadr1_stream_t stream);
 
 /* ---- LayerNorm with bias (Qwen2-VL vision tower: nn.LayerNorm(eps=1e-6), TF:models/qwen2_vl/modeling_qwen2_vl.py:281,428-429)
  * y = ((x [+ res]) - mean) * rstd * w + b; backward returns dx (+ dres) and accumulates dw, db (fp32). */
 int iadr1_layernorm_fwd(const void* x, const void* res, void* res_out, const void* w, const void* b, void* y, float* mean,
                         float* rstd, int T, int H, long long ldx, long long ldr, long long ldy, float eps, iadr1_stream_t stream);
+long long iadr1_layernorm_bwd_workspace_bytes(int T, int H);
 int iadr1_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres,
-                        void* dx, float* dw, float* db, int T, int H, long long ld, iadr1_stream_t stream);
+                        void* dx, float* dw, float* db, float* workspace, int T, int H, long long ld, iadr1_stream_t stream);
 
 /* ---- rotary embeddings: vision 2-D rotary TF:153-171 and decoder M-RoPE TF:557-599 -----------------------
  * In place on `nheads` consecutive heads of width D per token row; cos/sin fp32 [T, D/2] (the M-RoPE
@@ -155,15 +159,18 @@ int iadr1_gelu_tanh_bwd(const void* da, const void* z, void* dz, long long n, ia
 /* QuickGELU x*sigmoid(1.702x): Qwen2-VL vision MLP (TF:models/qwen2_vl/modeling_qwen2_vl.py:293-301) */
 int iadr1_quick_gelu_fwd(const void* z, void* a, long long n, iadr1_stream_t stream);
 int iadr1_quick_gelu_bwd(const void* da, const void* z, void* dz, long long n, iadr1_stream_t stream);
-/* out[n] (fp32) += sum_t dy[t][n]   (bias gradients) */
-int iadr1_colsum_acc(const void* dy, long long ld, float* out, int T, int N, iadr1_stream_t stream);
+/* out[n] (fp32) += sum_t dy[t][n]   (bias gradients); partial sums of <= 64 row groups in `workspace` (iadr1_colsum_workspace_bytes), added in group order: no atomics */
+long long iadr1_colsum_workspace_bytes(int T, int N);
+int iadr1_colsum_acc(const void* dy, long long ld, float* out, float* workspace, int T, int N, iadr1_stream_t stream);
 
 /* ---- embedding lookup + image-feature scatter (TF:1204-1215 masked_scatter) -----------------------------------
- * out[t] = img_index[t] >= 0 ? img[img_index[t]] : E[ids[t]].  Backward accumulates fp32 with atomics. */
+ * out[t] = img_index[t] >= 0 ? img[img_index[t]] : E[ids[t]].
+ * Backward = iadr1_rows_scatter_acc: dst[rows[u]] (fp32 [., H]) += sum_{k in [ptr[u], ptr[u+1])} src[idx[k]] (src bf16 [T, H]) for the U DISTINCT destination rows `rows`
+ * (embedding rows by token id / image-embedding rows), the token rows of each listed by a host-built CSR; one block per destination row adds them in list order:
+ * single writer, fixed order, no atomics (round 5: replaces iadr1_embed_bwd's float atomics). */
 int iadr1_embed_fwd(const long long* ids, const int* img_index, const void* E, const void* img, void* out, int T, int H,
                     iadr1_stream_t stream);
-int iadr1_embed_bwd(const long long* ids, const int* img_index, const void* dx, float* dE, float* dimg, int T, int H,
-                    iadr1_stream_t stream);
+int iadr1_rows_scatter_acc(const void* src, const long long* rows, const int* ptr, const int* idx, float* dst, int U, int H, iadr1_stream_t stream);
 
 /* out[t] (bf16 [T,H]) = sum_k weights[k] * src[idx[k]], k in [ptr[t], ptr[t+1]) (fp32 sum, one rounding; an empty list gives zeros; weights NULL = 1).
  * Two uses: (1) the gradient of the rows the lm_head consumed (REF:...sc_grpo_trainer.py:505-513 only reads P-1 .. S-2 of each row; PA-SFT the

@@ -315,7 +315,14 @@ def test_embed():
     assert torch.equal(out, ref)
     dx = rnd(T, H, seed=4)
     dE, dimg = torch.zeros(V, H, dtype=F32, device=DEV), torch.zeros(7, H, dtype=F32, device=DEV)
-    ops.embed_bwd(ids, idx, dx, dE, dimg)
+    # backward = ordered scatter-add over host-built CSR plans (no atomics): which token rows feed which embedding row / image row
+    ids_h, idx_h = ids.cpu().numpy(), idx.cpu().numpy().astype(np.int64)
+    ops.rows_scatter_acc(dx, ops.scatter_plan(np.where(idx_h < 0, ids_h, -1), DEV), dE)
+    ops.rows_scatter_acc(dx, ops.scatter_plan(idx_h, DEV), dimg)
+    dE2, dimg2 = torch.zeros_like(dE), torch.zeros_like(dimg)
+    ops.rows_scatter_acc(dx, ops.scatter_plan(np.where(idx_h < 0, ids_h, -1), DEV), dE2)
+    ops.rows_scatter_acc(dx, ops.scatter_plan(idx_h, DEV), dimg2)
+    assert torch.equal(dE, dE2) and torch.equal(dimg, dimg2)          # bit-reproducible
     rE, rI = torch.zeros_like(dE), torch.zeros_like(dimg)
     rE.index_add_(0, ids[~m], dx.float()[~m])
     rI.index_add_(0, idx[m].long(), dx.float()[m])
