@@ -337,11 +337,32 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(RmsBwdArgs p) {
 // Second stage of every gradient reduction over token rows (norm gains / biases, bias column sums): out[i] += sum_p ws[p][i], p ascending -- ONE thread per column adds the
 // partials in a fixed order, so a run is bit-reproducible (round 5; the float atomics this replaces made two runs of the same step differ in the last bits: VERDICT r4 weak #13)
 __global__ __launch_bounds__(256) void partial_reduce_acc_kernel(const float* ws, int nparts, long long stride, float* out, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    // block = 32 columns x 8 partial groups: thread (g, c) adds partials q = g, g + 8, g + 16, ... of column c, eight independent loads in flight at a time (one thread
+    // walking all the partials of a column is a chain of several hundred load latencies: +5 % on a PA-SFT step); the eight group sums are then added in group order.
+    // The order of additions depends on nparts only, never on timing.
+    __shared__ float red[8][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int q = 0; q < nparts; ++q) s += ws[(long long)q * stride + i];
-    out[i] += s;
+    if (i < n) {
+        int q = g;
+        for (; q + 56 < nparts; q += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(long long)(q + 8 * u) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; q < nparts; q += 8) s += ws[(long long)q * stride + i];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += red[u][c];
+        out[i] += t;
+    }
 }
 
 }  // namespace
@@ -398,7 +419,7 @@ extern "C" int iadr1_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
 #define CALL(NC) hipLaunchKernelGGL(rmsnorm_bwd_kernel<NC>, grid, block, (size_t)(dw ? 4 * H * sizeof(float) : 0), stream, p)
     DISPATCH_NC(H, CALL);
 #undef CALL
-    if (dw) hipLaunchKernelGGL(partial_reduce_acc_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, (const float*)workspace, blocks, (long long)H, dw, H);
+    if (dw) hipLaunchKernelGGL(partial_reduce_acc_kernel, dim3((H + 31) / 32), dim3(256), 0, stream, (const float*)workspace, blocks, (long long)H, dw, H);
     return iadr1_check_launch("rmsnorm_bwd");
 }
 
@@ -605,8 +626,8 @@ extern "C" int iadr1_layernorm_bwd(const void* dy, const void* x, const void* w,
     DISPATCH_NC(H, CALL);
 #undef CALL
     if (dw) {
-        hipLaunchKernelGGL(partial_reduce_acc_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, (const float*)workspace, blocks, (long long)2 * H, dw, H);
-        hipLaunchKernelGGL(partial_reduce_acc_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, (const float*)workspace + H, blocks, (long long)2 * H, db, H);
+        hipLaunchKernelGGL(partial_reduce_acc_kernel, dim3((H + 31) / 32), dim3(256), 0, stream, (const float*)workspace, blocks, (long long)2 * H, dw, H);
+        hipLaunchKernelGGL(partial_reduce_acc_kernel, dim3((H + 31) / 32), dim3(256), 0, stream, (const float*)workspace + H, blocks, (long long)2 * H, db, H);
     }
     return iadr1_check_launch("layernorm_bwd");
 }

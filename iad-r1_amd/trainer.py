@@ -63,7 +63,10 @@ class GRPOConfig:
     shuffle: bool = True            # seeded per-epoch permutation (HF Trainer's RandomSampler / DistributedSampler)
     # one group rollout for ALL micro-batches of an optimizer step (the policy does not change between them: the reference syncs its vLLM weights once per
     # optimizer step, REF:637-641): a decode step streams the whole model whatever the number of sequences, so gradient_accumulation_steps rollouts of
-    # B x G sequences cost that many times one rollout of accum x B x G -- the launch scripts' B = 1, G = 4, accum 2 (training_step; IADR1_BATCH_ROLLOUTS=0 = per micro-batch)
+    # B x G sequences cost that many times one rollout of accum x B x G -- the launch scripts' B = 1, G = 4, accum 2 (training_step; IADR1_BATCH_ROLLOUTS=0 = per micro-batch).
+    # What it trades: the micro-batches then arrive with their completions already rolled out, so the rollout -> training hand-over is off (the policy forward over
+    # the completions runs before each backward) and the vision tower runs once for the combined rollout and once per micro-batch; the sampling seed is per optimizer
+    # step, not per micro-batch, so token streams differ between the two modes.  Applies only while the step's sequences fit one 64-row decode tile.
     batch_rollouts: bool = os.environ.get("IADR1_BATCH_ROLLOUTS", "1") != "0"
     prefetch_batches: bool = os.environ.get("IADR1_PREFETCH", "1") != "0"    # prepare micro-batch k+1 on a worker thread while the GPU runs k (iadr1_amd.prefetch)
     run_name: Optional[str] = None

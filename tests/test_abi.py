@@ -31,17 +31,21 @@ def test_argument_errors_are_reported_without_a_gpu():
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    """The newest committed driver-format line (profiles/r04_b_bench_3b.json, produced by `python bench.py` on the GPU box) carries every key of the bench
+    """The newest committed driver-format line (profiles/r05_a_bench_3b.json, produced by `python bench.py` on the GPU box) carries every key of the bench
     contract: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, the
-    `roofline` object of the dominant kernel family and the `cpu_baseline` object (kind "port", cores, sample)."""
+    `roofline` object of the launch that owns the step (named in `dominant`; the decode replay and the GEMM family both stay in the line under their own names)
+    and the `cpu_baseline` object (kind "port", cores, sample)."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r04_b_bench_3b.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r05_a_bench_3b.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "samples/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
+    assert r["dominant"] in ("decode", "gemm") and d["roofline_decode"]["bound"] == "hbm" and d["roofline_gemm"]["bound"] == "mfma"
+    share = r["share_of_step"]
+    assert (share["decode_replays"] >= share["gemm_family"]) == (r["dominant"] == "decode") and r["bound"] == ("hbm" if r["dominant"] == "decode" else "mfma")
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("GB/s", "TFLOP/s") and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
