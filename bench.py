@@ -1357,7 +1357,7 @@ def main():
             "config": {"workload": f"{model_name} SC-GRPO step: {a.prompts} prompts x group {a.group} per GPU, {image_note}, {a.gen_len} generated tokens (EOS suppressed), random-init weights, rollout + ref fwd + policy fwd/bwd + AdamW",
                        "api_entry": "SCGRPOTrainer.training_step -> SCGRPOTrainer.compute_loss (REF sc_grpo_trainer.py:586) -> SCGRPOEngine.step; reward plugins accuracy_reward + consistency_reward on canned completion strings",
                        "per_gpu_sequences": N, "micro_batch_seqs": a.micro_batch, "gradient_checkpointing": a.gradient_checkpointing, "reference_forward": "bf16", "decode_weights": a.decode_weights, "hip_graph_rollout": not a.no_graph, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks, "collective_backend": backend if (world > 1 or os.environ.get("IADR1_FORCE_REDUCE")) else None,
-                       "grad_exchange": ({"wire": eng.reducer.wire, "bytes_on_wire": getattr(eng.reducer, "last_bytes_on_wire", 0), "n_buckets": getattr(eng.reducer, "last_n_buckets", 0),
+                       "grad_exchange": ({"wire": eng.reducer.wire, "algo": eng.reducer.algo, "bytes_on_wire": getattr(eng.reducer, "last_bytes_on_wire", 0), "n_buckets": getattr(eng.reducer, "last_n_buckets", 0),
                                           "exposed_ms": exposed_ms, "exposed_note": "GPU time the compute stream waited in GradReducer.finish() for the exchange after backward ended (last timed step, this rank): what did not hide under backward",
                                           "staging_bytes": eng.reducer.staging_bytes()}
                                          if eng.reducer.active else None),

@@ -734,10 +734,13 @@ struct SkinnyArgs {
 // FUSEV (out_mode 4, NB == 1 only): the blocks of the K heads also compute the V tile of the same head and 16-dim slice from the X fragments they have already
 // loaded, and the grid holds the q and k tiles only.  For the 7B-class widths (28 q + 4 k + 4 v heads = 288 tiles on 256 CUs) that is ONE round of blocks
 // instead of two: the second round cost 8 us of a 20 us launch (tools/narrow_ab.py), while a second 115 KB weight tile next to 458 KB of X costs a block ~25 %.
-template <int NB, int WAVES, bool FUSEV = false>
+// MG = 16-row groups of X the block multiplies (4 = the 64-row decode tile).  Rollouts of <= 16 / <= 32 sequences (the reference launch scripts' B = 1 x G = 4,
+// the evaluation harness) run MG = 1 / 2: a quarter / half of the X fragment loads (each 16-column block re-reads ALL X rows from L2: 41 MB per q|k|v launch at 64 rows
+// against 10.5 MB of weights), of the MFMAs and of the cross-wave reduction.  Row groups are independent: a row's bits do not depend on MG.
+template <int NB, int WAVES, bool FUSEV = false, int MG = 4>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     constexpr int U = 2, BNC = 16 * NB, RLD = BNC + 1;
-    static_assert(!FUSEV || NB == 1, "the fused V tile exists for the 16-column q|k|v kernel");
+    static_assert(!FUSEV || (NB == 1 && MG == 4), "the fused V tile exists for the 16-column q|k|v kernel at the full 64-row tile");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [WAVES][64][RLD] (+ a second one for the fused V tile)
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -749,9 +752,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     const int s_begin = blockIdx.z * per_z, s_end = min(nslab, s_begin + per_z);
     STAMP(0);
 
-    f32x4_t acc[4][NB];
+    f32x4_t acc[MG][NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MG; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // fused V tile of a K-head block (block-uniform): tile index of the same (kv head, 16-dim slice) among the V tiles
@@ -781,16 +784,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     const bf16_t* wrow_v = p.W + ((long long)min(vtile, (p.N >> 4) - 1) * ksteps) * 512 + l * 8;
     const bool xpk = p.ldx == 0;  // decode-packed X (see the wide kernel)
     const long long xstep = xpk ? 2048 : 32;
-    const bf16_t* xrow[4];
+    const bf16_t* xrow[MG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MG; ++i)
         xrow[i] = xpk ? p.X + (long long)blockIdx.y * p.K * 64 + i * 512 + l * 8 : p.X + (long long)min(m_base + i * 16 + lm, p.M - 1) * p.ldx + lq * 8;
 
     // unpredicated loads (see the wide kernel): full trips of U slabs, then single-slab tail trips
     auto trip = [&](int sb, auto u_tag, auto v_tag) {
         constexpr int UU = decltype(u_tag)::value;
         constexpr bool WV = decltype(v_tag)::value;      // this block also walks its V tile (block-uniform: chosen once, outside the loops)
-        bf16x8_t wf[UU][2][NB], xf[UU][2][4], wv[FUSEV ? UU : 1][2];
+        bf16x8_t wf[UU][2][NB], xf[UU][2][MG], wv[FUSEV ? UU : 1][2];
 #pragma unroll
         for (int u = 0; u < UU; ++u)
 #pragma unroll
@@ -801,14 +804,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
                     wf[u][kk][j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + (long long)(k >> 5) * 512)));
                 if constexpr (WV) wv[u][kk] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wrow_v + (long long)(k >> 5) * 512)));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xf[u][kk][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + (long long)(k >> 5) * xstep));
+                for (int i = 0; i < MG; ++i) xf[u][kk][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + (long long)(k >> 5) * xstep));
             }
 #pragma unroll
         for (int u = 0; u < UU; ++u)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < MG; ++i) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][kk][j], xf[u][kk][i], acc[i][j], 0, 0, 0);
@@ -825,13 +828,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     }
     if ((p.K & 32) && w == 0 && blockIdx.z == gridDim.z - 1) {  // wave-uniform: the odd 32-wide tail of K
         const int k = nslab * 64;
-        bf16x8_t wt[NB], xt[4];
+        bf16x8_t wt[NB], xt[MG];
 #pragma unroll
         for (int j = 0; j < NB; ++j) wt[j] = __builtin_bit_cast(bf16x8_t, __builtin_nontemporal_load((const u32x4_t*)(wrow[j] + (long long)(k >> 5) * 512)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xt[i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + (long long)(k >> 5) * xstep));
+        for (int i = 0; i < MG; ++i) xt[i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xrow[i] + (long long)(k >> 5) * xstep));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MG; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[j], xt[i], acc[i][j], 0, 0, 0);
     }
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     STAMP(1);
     float* mine = red + (size_t)w * 64 * RLD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MG; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         // bf16(x.W + b), rotary in fp32 on those bf16 values (TF:153-171), bf16 result.
         constexpr int D = 128, HALF = 64;
         const int head = blockIdx.x >> 3, j = blockIdx.x & 7;
-        for (int idx = t; idx < 64 * 16; idx += WAVES * 64) {
+        for (int idx = t; idx < MG * 16 * 16; idx += WAVES * 64) {
             const int m = idx >> 4, n = idx & 15, gm = m_base + m;
             if (gm >= p.M) continue;
             float vs = 0.f;
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         STAMP(3);
         return;
     }
-    for (int idx = t; idx < 64 * BNC; idx += WAVES * 64) {
+    for (int idx = t; idx < MG * 16 * BNC; idx += WAVES * 64) {
         const int m = idx / BNC, n = idx - m * BNC;
         const int gm = m_base + m, gn = n0 + n;
         if (gm >= p.M || gn >= p.N) continue;
@@ -1606,6 +1609,8 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
         hipDeviceProp_t prop;
         (void)hipGetDevice(&dev);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SM2);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SMW);
@@ -1655,6 +1660,8 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     else if (big && (N % 128) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
     else if (ksplit > 1 && (N % 64) == 0 && (N / 64) * ksplit >= 192) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3((N + 63) / 64, mz, ksplit), dim3(512), SMW, stream, p);
     else if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_kernel<2, 8>), dim3((N + 31) / 32, mz, ksplit), dim3(512), SM2, stream, p);
+    else if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<1, 16, false, 1>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);      // (see MG at the kernel)
+    else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<1, 16, false, 2>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);
     else hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3((N + 15) / 16, mz, ksplit), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_skinny_bf16");
 }
@@ -1684,6 +1691,8 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
         hipDeviceProp_t prop;
         (void)hipGetDevice(&dev);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SM1);
         (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SM1);
         return (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }();
@@ -1696,7 +1705,9 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
         hipLaunchKernelGGL((gemm_skinny_kernel<1, 16, true>), dim3(rope_tiles, (M + 63) / 64, 1), dim3(1024), 2 * SM1, stream, p);
         return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
     }
-    hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3(p.N / 16, (M + 63) / 64, 1), dim3(1024), SM1, stream, p);
+    if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<1, 16, false, 1>), dim3(p.N / 16, 1, 1), dim3(1024), SM1, stream, p);
+    else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<1, 16, false, 2>), dim3(p.N / 16, 1, 1), dim3(1024), SM1, stream, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<1, 16>), dim3(p.N / 16, (M + 63) / 64, 1), dim3(1024), SM1, stream, p);
     return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
 }
 
