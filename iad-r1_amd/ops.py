@@ -358,29 +358,36 @@ def embed_fwd(ids, img_index, E, img, out=None):
 
 
 def scatter_plan(dst_rows, device):
-    """Host side of rows_scatter_acc: dst_rows[t] >= 0 = destination row of source row t (< 0: dropped) -> (rows int64 [U], ptr int32 [U + 1], idx int32 [R]) on the
-    device: the distinct destination rows in ascending order, and for each the source rows that feed it, ascending (np.unique / stable argsort: integer work)."""
+    """Host side of rows_scatter_acc: dst_rows[t] >= 0 = destination row of source row t (< 0: dropped) -> (rows int64, ptr int32, idx int32, U) with the device
+    arrays padded to the number of source rows: the distinct destination rows in ascending order, and for each the source rows that feed it, ascending (np.unique /
+    stable argsort: integer work).  Padded, because the number of DISTINCT token ids changes from step to step: arrays of a fixed size per batch shape come out of the
+    caching allocator's free list instead of asking the device for a new block now and then (no allocator traffic in the step)."""
     import numpy as np
     d = np.asarray(dst_rows).reshape(-1)
     src = np.flatnonzero(d >= 0)
     if src.size == 0:
         return None
     order = np.argsort(d[src], kind="stable")
-    idx = src[order].astype(np.int32)
     rows, counts = np.unique(d[src], return_counts=True)
-    ptr = np.zeros(len(rows) + 1, dtype=np.int32)
-    np.cumsum(counts, out=ptr[1:])
-    return h2d(rows.astype(np.int64), device), h2d(ptr, device), h2d(idx, device)
+    T, U = d.size, len(rows)
+    idx = np.zeros(T, dtype=np.int32)
+    idx[: src.size] = src[order]
+    rows_p = np.zeros(T, dtype=np.int64)
+    rows_p[:U] = rows
+    ptr = np.full(T + 1, src.size, dtype=np.int32)
+    ptr[0] = 0
+    np.cumsum(counts, out=ptr[1: U + 1])
+    return h2d(rows_p, device), h2d(ptr, device), h2d(idx, device), U
 
 
 def rows_scatter_acc(src, plan, dst32):
     """dst32[rows[u]] += sum of src[idx[k]] over the CSR list of u, in list order (include/iadr1_hip.h iadr1_rows_scatter_acc): deterministic scatter-add."""
     if plan is None:
         return dst32
-    rows, ptr, idx = plan
+    rows, ptr, idx, U = plan
     T, H = src.shape
     assert src.is_contiguous() and dst32.dtype == F32 and dst32.is_contiguous() and dst32.shape[-1] == H
-    hip.call("rows_scatter_acc", src, rows, ptr, idx, dst32, rows.numel(), H)
+    hip.call("rows_scatter_acc", src, rows, ptr, idx, dst32, U, H)
     return dst32
 
 
