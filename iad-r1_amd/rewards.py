@@ -231,3 +231,85 @@ def accuracy_reward(completions, solution, **kwargs):
 
 
 REWARD_FUNCS = {"accuracy": accuracy_reward, "format": consistency_reward}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The reference's ablation variants (REF train/stage_rl/reward.py:107-347).  The entry point registers none of them (grpo_ad.py:126-129), they
+# are here so that the whole reward module has a counterpart under the same names; pinned value for value by tests/golden/reward_variants.json.
+# ------------------------------------------------------------------------------------------------------------------------------------
+_ANSWER_I = re.compile(r"<answer>(.*?)</answer>", re.IGNORECASE)
+_COT_TAGS = tuple(re.compile(rf"<{t}>.*?</{t}>", re.IGNORECASE | re.DOTALL) for t in ("type", "location", "description"))
+_COT_SCORE = {3: 1.0, 2: 0.7, 1: 0.4, 0: 0.0}
+_FMT_BASE = re.compile(r".*<think>.*?</think><answer>.*?</answer>.*", re.DOTALL)
+
+
+def _texts(completions):
+    return [c[0]["content"] for c in completions]
+
+
+def consistency_reward_cot(completions, solution, **kwargs):
+    """REF reward.py:107-159: the answer (case-insensitive tag and value) must equal the ground truth; then "no" scores 1 only WITHOUT any of the <type> / <location> /
+    <description> tags, "yes" scores 1.0 / 0.7 / 0.4 / 0 for three / two / one / none of them."""
+    out = []
+    for text, sol in zip(_texts(completions), solution):
+        m = _ANSWER_I.search(sol)
+        gt = (m.group(1) if m else sol).strip().lower()
+        a = _ANSWER_I.search(text)
+        ans = a.group(1).strip().lower() if a else None
+        if ans is None or ans != gt:
+            out.append(0.0)
+            continue
+        n = sum(1 for rx in _COT_TAGS if rx.search(text))
+        out.append((1.0 if n == 0 else 0.0) if ans == "no" else (_COT_SCORE[n] if ans == "yes" else 0.0))
+    return out
+
+
+format_consistency_reward_cot = consistency_reward_cot        # REF reward.py:161-212: the same rule under a second name
+
+
+def _accuracy_with_one_part(text: str, sol: str, part: str) -> float:
+    """REF reward.py:215-301: the accuracy reward with ONE localisation term (weight 1) instead of the mean of two.  A missing tag on either side raises before the
+    answer bonus is added (the reference catches it and keeps the value it had: 0)."""
+    gt = _gt_answer(sol)
+    if gt == "no":
+        m = _TAG["answer"].search(text)
+        return 1.0 if (m and m.group(1).strip().lower() == "no") else 0.0
+    if gt != "yes":
+        return 0.0
+    pred, want = _TAG[part].search(text), _TAG[part].search(sol)
+    if pred is None or want is None:
+        return 0.0
+    a, b = pred.group(1).strip().lower(), want.group(1).strip().lower()
+    r = float(location_score(a, b)) if part == "location" else float(type_score(a, b))
+    m = _TAG["answer"].search(text)
+    if m and m.group(1).strip().lower() == "yes":
+        r += 1.0
+    return r
+
+
+def accuracy_reward_cot_wo_type(completions, solution, **kwargs):
+    return [_accuracy_with_one_part(t, s, "location") for t, s in zip(_texts(completions), solution)]
+
+
+def accuracy_reward_cot_wo_location(completions, solution, **kwargs):
+    return [_accuracy_with_one_part(t, s, "type") for t, s in zip(_texts(completions), solution)]
+
+
+def format_reward_cot_base(completions, solution, **kwargs):
+    """REF reward.py:303-312: <think>..</think><answer>..</answer> somewhere in the text, whatever the ground truth."""
+    return [1.0 if _FMT_BASE.fullmatch(t) else 0.0 for t in _texts(completions)]
+
+
+def accuracy_reward_cot_base(completions, solution, **kwargs):
+    """REF reward.py:314-343: 1 when the (case-sensitive tag, case-insensitive value) answer equals a yes / no ground truth."""
+    out = []
+    for text, sol in zip(_texts(completions), solution):
+        gt = _gt_answer(sol)
+        m = _TAG["answer"].search(text)
+        out.append(1.0 if (gt in ("yes", "no") and m and m.group(1).strip().lower() == gt) else 0.0)
+    return out
+
+
+def wo_format(completions, solution, **kwargs):
+    """REF reward.py:345-347 returns the INT 0, not a list (the trainer's float conversion of a per-sample list would fail on it); reproduced."""
+    return 0

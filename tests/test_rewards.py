@@ -29,3 +29,18 @@ def test_format_quirk_neither_yes_no(golden_dir):
 
 def test_registry_keys():
     assert set(rewards.REWARD_FUNCS) == {"accuracy", "format"}
+
+
+def test_ablation_reward_variants_bit_exact(golden_dir):
+    """The reference's unregistered ablation rewards (REF reward.py:107-347) under the same names: value for value on 708 cases captured by importing and running the
+    reference (tools/make_golden_reward_variants.py), including its failure modes (a missing tag zeroes the whole sample, `wo_format` returns the int 0)."""
+    g = json.load(open(os.path.join(golden_dir, "reward_variants.json")))
+    comps = [[{"role": "assistant", "content": c}] for c in g["completions"]]
+    assert len(comps) >= 600
+    for name, want in g["values"].items():
+        got = getattr(rewards, name)(comps, g["solutions"])
+        if name == "wo_format":
+            assert got == want == 0 and isinstance(got, int)
+            continue
+        bad = [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b]
+        assert len(got) == len(want) and not bad, (name, bad[:5])
