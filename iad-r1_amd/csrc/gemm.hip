@@ -51,9 +51,13 @@ struct GemmArgs {
     // [z * kslice, min(K, (z + 1) * kslice)) of A and B and stores its fp32 partial tile at C + z * zstride (a workspace the reduce kernel sums)
     int ksplit, kslice;
     long long zstride;
+    // OUT_SWIGLU_ROWS (iadr1_gemm_swiglu_rows_bf16): GEMM row r is row (r >> rb_shift) * rb_stride + (r & (2^rb_shift - 1)) of A, C and C2 -- blocks of 2^rb_shift
+    // consecutive rows rb_stride rows apart (the rows a chunk of decode steps produced in a sequence-major arena)
+    int rb_shift;
+    long long rb_stride;
 };
 
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_SWIGLU = 3, OUT_LSE = 4, OUT_DLOGITS = 5 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_SWIGLU = 3, OUT_LSE = 4, OUT_DLOGITS = 5, OUT_SWIGLU_ROWS = 6 };
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -324,8 +328,13 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
         for (int h = 0; h < 2; ++h) {
             const int arow = (rl >> 6) * 128 + h * 64 + (rl & 63);          // A half h: rows wm*128 + h*64 + ..
             const int bcol = (rl >> 5) * 64 + h * 32 + (rl & 31);           // B half h: cols wn*64 + h*32 + ..
-            src[h][i] = p.A + (long long)min(m0 + arow, p.M - 1) * p.lda + cs * 8;
-            if constexpr (OUT == OUT_SWIGLU) {
+            if constexpr (OUT == OUT_SWIGLU_ROWS) {
+                const int ar = m0 + arow;       // (M % 256 == 0: no clamp)
+                src[h][i] = p.A + ((long long)(ar >> p.rb_shift) * p.rb_stride + (ar & ((1 << p.rb_shift) - 1))) * p.lda + cs * 8;
+            } else {
+                src[h][i] = p.A + (long long)min(m0 + arow, p.M - 1) * p.lda + cs * 8;
+            }
+            if constexpr (OUT == OUT_SWIGLU || OUT == OUT_SWIGLU_ROWS) {
                 // fused SwiGLU: B = [gate rows 0..I) | up rows I..2I).  The block's 256 columns are 128 gate + 128 up columns of the SAME 128 outputs,
                 // arranged so that B half 0 of every wave is gate and half 1 is up: a lane then holds gate (n-tiles 0,1) and up (n-tiles 2,3) of the
                 // same (row, column) and the activation is computed in registers.
@@ -454,13 +463,18 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     const int lm = l & 15, lq = l >> 4;
-    if constexpr (OUT == OUT_SWIGLU) {
+    if constexpr (OUT == OUT_SWIGLU || OUT == OUT_SWIGLU_ROWS) {
         // interior tiles only (the launcher guarantees M % 256 == 0, N % 256 == 0, 16-byte aligned outputs)
         __syncthreads();  // every wave is done with the operand buffers
         bf16_t* slab = (bf16_t*)smem + (size_t)w * 128 * EP_LD;
         const int I = p.N >> 1;
         const long long row0 = m0 + wm * 128;
         const int ca = (n0 >> 1) + wn * 32;           // first of this wave's 32 output columns
+        // row of the output matrices that GEMM row r lands in (the identity but for the row-blocked form)
+        auto orow = [&](long long r) -> long long {
+            if constexpr (OUT == OUT_SWIGLU_ROWS) return (r >> p.rb_shift) * p.rb_stride + (r & ((1 << p.rb_shift) - 1));
+            else return r;
+        };
         if (p.C) {   // the gate|up matrix itself (backward needs it): slab columns 0..31 = gate, 32..63 = up
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -469,13 +483,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
                     *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + j * 16 + lq * 4) = (u32x2_t){pack2bf(acc[i][j][0], acc[i][j][1]), pack2bf(acc[i][j][2], acc[i][j][3])};
             bf16_t* C = (bf16_t*)p.C;
             const int ch = l & 7;
-            bf16_t* dst0 = C + (row0 + (l >> 3)) * p.ldc + (ch < 4 ? ca + ch * 8 : I + ca + (ch - 4) * 8);
+            bf16_t* dstc = C + (ch < 4 ? ca + ch * 8 : I + ca + (ch - 4) * 8);
+            bf16_t* dst0 = dstc + (row0 + (l >> 3)) * p.ldc;
             const bf16_t* src0 = slab + (l >> 3) * EP_LD + ch * 8;
             u32x4_t rv[16];
 #pragma unroll
             for (int it = 0; it < 16; ++it) rv[it] = *(const u32x4_t*)(src0 + it * 8 * EP_LD);
 #pragma unroll
-            for (int it = 0; it < 16; ++it) *(u32x4_t*)(dst0 + (long long)it * 8 * p.ldc) = rv[it];
+            for (int it = 0; it < 16; ++it) {
+                if constexpr (OUT == OUT_SWIGLU_ROWS) *(u32x4_t*)(dstc + orow(row0 + (l >> 3) + it * 8) * p.ldc) = rv[it];
+                else *(u32x4_t*)(dst0 + (long long)it * 8 * p.ldc) = rv[it];
+            }
         }
         // a = bf16(silu(bf16 gate)) * bf16 up, the arithmetic of swiglu_fwd_kernel on the rounded gate|up values
 #pragma unroll
@@ -491,13 +509,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
                 *(u32x2_t*)(slab + (i * 16 + lm) * EP_LD + j * 16 + lq * 4) = (u32x2_t){pack2bf(av[0], av[1]), pack2bf(av[2], av[3])};
             }
         {
-            bf16_t* dst0 = p.C2 + (row0 + (l >> 2)) * p.ldc2 + ca + (l & 3) * 8;      // 4 lanes per 64-byte row segment, 16 rows per instruction
+            bf16_t* dstc = p.C2 + ca + (l & 3) * 8;      // 4 lanes per 64-byte row segment, 16 rows per instruction
+            bf16_t* dst0 = dstc + (row0 + (l >> 2)) * p.ldc2;
             const bf16_t* src0 = slab + (l >> 2) * EP_LD + (l & 3) * 8;
             u32x4_t rv[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) rv[it] = *(const u32x4_t*)(src0 + it * 16 * EP_LD);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) *(u32x4_t*)(dst0 + (long long)it * 16 * p.ldc2) = rv[it];
+            for (int it = 0; it < 8; ++it) {
+                if constexpr (OUT == OUT_SWIGLU_ROWS) *(u32x4_t*)(dstc + orow(row0 + (l >> 2) + it * 16) * p.ldc2) = rv[it];
+                else *(u32x4_t*)(dst0 + (long long)it * 16 * p.ldc2) = rv[it];
+            }
         }
     } else if constexpr (OUT == OUT_LSE) {
         // linear_logprob forward: per row and 64-column wave slice the pair (max, sum exp(x - max)) and the logit at the row's target column; the
@@ -1582,6 +1604,25 @@ extern "C" int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, vo
     (void)attr_done;
     hipLaunchKernelGGL(gemm_nt_256<OUT_SWIGLU>, dim3((M / 256) * (I / 128)), dim3(NT2), SMEM2_BYTES, stream, p);
     return iadr1_check_launch("gemm_swiglu_bf16");
+}
+
+// The same contraction over ROW BLOCKS of a larger matrix: GEMM row r (0 <= r < M) is row (r / block) * block_stride + r % block of A, GU and Aout (block a power
+// of two >= 16, all three matrices addressed from the given base pointers).  Per row the arithmetic is iadr1_gemm_swiglu_bf16's, bit for bit.
+extern "C" int iadr1_gemm_swiglu_rows_bf16(const void* A, const void* W, void* GU, void* Aout, int M, int I, int K, long long lda, long long ldw,
+                                           long long ldgu, long long ldaout, int block, long long block_stride, hipStream_t stream) {
+    IADR1_REQUIRE(M > 0 && I > 0 && K > 0 && Aout != nullptr, "gemm_swiglu_rows: empty problem");
+    IADR1_REQUIRE((M % 256) == 0 && (I % 128) == 0 && (K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldaout % 8) == 0 && (GU == nullptr || (ldgu % 8) == 0),
+                  "gemm_swiglu_rows: needs M %% 256 == 0, I %% 128 == 0 and 16-byte row strides (M=%d I=%d K=%d)", M, I, K);
+    IADR1_REQUIRE(block >= 16 && (block & (block - 1)) == 0 && (M % block) == 0 && block_stride >= block, "gemm_swiglu_rows: block must be a power of two >= 16 dividing M, block_stride >= block (block=%d)", block);
+    IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)GU) & 15) == 0 && (((uintptr_t)Aout) & 15) == 0, "gemm_swiglu_rows: operands must be 16-byte aligned");
+    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    GemmArgs p{(const bf16_t*)A, (const bf16_t*)W, GU, nullptr, zeros_ptr(), M, 2 * I, K, lda, ldw, ldgu, 0, band_rows, (bf16_t*)Aout, ldaout};
+    p.rb_shift = __builtin_ctz((unsigned)block);
+    p.rb_stride = block_stride;
+    static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_SWIGLU_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
+    (void)attr_done;
+    hipLaunchKernelGGL(gemm_nt_256<OUT_SWIGLU_ROWS>, dim3((M / 256) * (I / 128)), dim3(NT2), SMEM2_BYTES, stream, p);
+    return iadr1_check_launch("gemm_swiglu_rows_bf16");
 }
 
 extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, const void* bias, int M, int N, int K, long long ldx,

@@ -273,6 +273,14 @@ def gemm_swiglu_fused(x, w_gu, gu, a):
     hip.call("gemm_swiglu_bf16", x, w_gu, gu, a, T, I, K, _ld(x), _ld(w_gu), _ld(gu) if gu is not None else 0, _ld(a))
 
 
+def gemm_swiglu_rows(x, w_gu, gu, a, n_blocks: int, block: int, block_stride: int):
+    """include/iadr1_hip.h iadr1_gemm_swiglu_rows_bf16: the fused gate|up + SwiGLU contraction over n_blocks row blocks of `block` rows, `block_stride` rows apart,
+    of x / gu / a (all addressed from their first row; gu may be None)."""
+    K = x.shape[1]
+    I = w_gu.shape[0] // 2
+    hip.call("gemm_swiglu_rows_bf16", x, w_gu, gu, a, n_blocks * block, I, K, _ld(x), _ld(w_gu), _ld(gu) if gu is not None else 0, _ld(a), block, block_stride)
+
+
 def gemm_swiglu(x, w_gu, gu_out=None, a_out=None, keep_gu=True):
     """(gu, a) with gu = x @ w_gu^T ([T, 2I], None when keep_gu is False and the fused launch ran) and a = swiglu(gu) ([T, I]).  One launch when the
     shape allows (T % 256 == 0, I % 128 == 0, enough tiles for the 256x256 kernel), gemm_nt + swiglu_fwd otherwise -- same bits either way."""

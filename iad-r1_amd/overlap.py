@@ -45,7 +45,7 @@ from .vlm import Engine, TextPlan
 BF16, F32 = torch.bfloat16, torch.float32
 BLOCK = 16          # steps per time block of the completion-row layout (a power of two; chunk boundaries are multiples of it)
 
-STATS = {"passes": 0, "chunks": 0, "rows": 0}
+STATS = {"passes": 0, "chunks": 0, "rows": 0, "policy_mlp_rows": 0}
 
 
 def shadow_cus() -> int:
@@ -61,6 +61,14 @@ def enabled() -> bool:
 
 def chunk_steps_default() -> int:
     return int(os.environ.get("IADR1_OVERLAP_STEPS", "32"))
+
+
+def policy_mlp_wanted() -> bool:
+    """IADR1_OVERLAP_GU (default 1): while the co-scheduled pass is on, the POLICY's gate|up and SwiGLU rows of the completion tokens are rebuilt on the side stream
+    from the decode steps' `h2` rows (iadr1_gemm_swiglu_rows_bf16) instead of being stored by the decode step's gate|up kernel: those two side stores are 4.5 of
+    the 7.5 us per layer the rollout -> training hand-over costs the decode step (profiles/EXPERIMENTS.md round 4), the GEMM that replaces them is 23 ms of side-stream
+    time per 32 steps at the 3B bench shape."""
+    return os.environ.get("IADR1_OVERLAP_GU", "1") != "0"
 
 
 def pick_concurrent_stream(anchor, make_candidate, weight: torch.Tensor, tries: int = 6, log=None):
@@ -129,12 +137,20 @@ class ChunkedRefPass:
         runs -- REF:516-567 -- which makes the scored positions depend on where a sequence ENDS: not known while it is being generated.)"""
         return enabled() and not cfg.is_llava and C % BLOCK == 0 and C >= BLOCK
 
+    @staticmethod
+    def rebuilds_policy_mlp(cfg, N: int) -> bool:
+        """Shapes the row-blocked fused gate|up GEMM takes: N sequences x one time block = whole 256-row tiles, I a multiple of 128."""
+        return policy_mlp_wanted() and (N * BLOCK) % 256 == 0 and cfg.intermediate_size % 128 == 0
+
     # ---- set-up --------------------------------------------------------------------------------------------------
-    def begin(self, plan: TextPlan, G: int, C: int, first_pos: np.ndarray, out_tokens: torch.Tensor, step_counter: torch.Tensor | None = None):
+    def begin(self, plan: TextPlan, G: int, C: int, first_pos: np.ndarray, out_tokens: torch.Tensor, step_counter: torch.Tensor | None = None, policy=None):
         """plan: the rollout's prompt plan (Bp left-padded prompts of S columns); self.vision = (pixel tensor, vision plan) of the batch was set by the owner -- the
         reference's own vision tower runs here, on the side stream; first_pos [N]: rotary position of completion token 0 of every sequence; out_tokens: the rollout's
-        device-resident [N, >= C] token matrix (column j is final once decode replay j has run)."""
+        device-resident [N, >= C] token matrix (column j is final once decode replay j has run).
+        policy: None, or (the policy's Engine, the training arena the decode steps fill -- Rollout.trace): every chunk then also rebuilds the policy's gate|up and
+        SwiGLU rows of its tokens from the arena's `h2` rows (policy_mlp_wanted above; the decode graph was captured without those two side stores)."""
         e, c = self.e, self.e.cfg
+        self.policy = policy
         dev = e.dev
         Bp, S = plan.B, plan.S
         N = Bp * G
@@ -291,15 +307,35 @@ class ChunkedRefPass:
             if n_ok > 0:
                 self.logp[:, c0 + 1: c0 + 1 + n_ok] = lp.view(nb, N, BLOCK).permute(1, 0, 2).reshape(N, c1 - c0)[:, :n_ok]
             self._mark(f"rows[{c0},{c1})", ev0)
+            if self.policy is not None:
+                ev0 = self._mark()
+                self._policy_mlp(c0, c1)
+                self._mark(f"policy mlp[{c0},{c1})", ev0)
         self.done_rows = c1
         STATS["chunks"] += 1
         STATS["rows"] += r1 - r0
+
+    def _policy_mlp(self, c0: int, c1: int):
+        """gate|up + SwiGLU rows of completion tokens [c0, c1) of every sequence, every layer of the POLICY, written where the decode step's side stores would have
+        put them (sequence-major arena: row T0 + s * C + j).  Input: the `h2` rows decode replays c0 + 1 .. c1 stored (replay C never runs: the last token's rows are
+        zero, finite, and outside every loss term -- as in the stored form).  Row blocks are powers of two: a 48-step chunk is a 32- and a 16-step launch."""
+        pe, tr = self.policy
+        P, L = pe.p, pe.cfg.num_hidden_layers
+        j = c0
+        while j < c1:
+            blk = 1 << ((c1 - j).bit_length() - 1)
+            r = self.T0 + j
+            for i in range(L):
+                ops.gemm_swiglu_rows(tr["h2"][i][r:], P.w(f"layers.{i}.gu.w"), tr["gu"][i][r:], tr["a"][i][r:], self.N, blk, self.C)
+            STATS["policy_mlp_rows"] += self.N * blk
+            j += blk
 
     def boundaries(self, C: int) -> set:
         """Decode steps after which a chunk is handed to the side stream: every `steps`, and once more one block before the end, so that what is left when the
         rollout ends (it runs on the caller's stream, on the whole device: finish) is one block of rows."""
         b = set(range(self.steps, C, self.steps))
-        if C - BLOCK > 0:
+        tail = os.environ.get("IADR1_OVERLAP_TAIL", "auto")
+        if C - BLOCK > 0 and (tail == "block" or (tail == "auto" and self.policy is None)):
             b.add(C - BLOCK)
         return b
 

@@ -145,7 +145,7 @@ class Rollout:
             ops.rmsnorm_fwd(None, P.w(b + "ln2"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_o, out=self.h,
                             side=side(p0=T_("x_mid", i), p1=T_("h2", i), p2=T_("rstd2", i)))
             if self.fuse_swiglu:
-                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True, side=side(p0=T_("gu", i), p1=T_("a", i)))
+                ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.a, swiglu=True, side=None if (tr is not None and tr["mlp_on_shadow"]) else side(p0=T_("gu", i), p1=T_("a", i)))
             else:
                 assert tr is None
                 ops.gemm_skinny(self.h, P.wpk(b + "gu.w"), 2 * c.intermediate_size, out=self.gu)
@@ -209,6 +209,8 @@ class Rollout:
             self.sampling = sampling
             self.graph = None  # sampling parameters are kernel arguments frozen in the graph
         want_trace = bool(train_trace and train_carry is not None)
+        # overlap mode: the gate|up / SwiGLU rows of the training arena are rebuilt by the shadow pass (overlap.ChunkedRefPass._policy_mlp) instead of stored here
+        mlp_on_shadow = bool(want_trace and shadow is not None and shadow.rebuilds_policy_mlp(c, N))
         if not want_trace and self.trace is not None:
             self.trace, self.graph = None, None
         lengths = plan.lengths
@@ -287,7 +289,7 @@ class Rollout:
                 tr.update(rstd1=[A["rstd1"][i, :T_all] for i in range(L)], rstd2=[A["rstd2"][i, :T_all] for i in range(L)],
                           lse=[A["lse"][i].view(-1)[: c.num_attention_heads * T_all].view(c.num_attention_heads, T_all) for i in range(L)],
                           x_last=train_carry["x_last"], hf=train_carry["hf"], rstdf=train_carry["rstdf"], base=Bp * S - 1, stride=max_new)
-                key = (A["x_in"].data_ptr(), train_carry["hf"].data_ptr(), T_all, max_new)
+                key = (A["x_in"].data_ptr(), train_carry["hf"].data_ptr(), T_all, max_new, mlp_on_shadow)
                 if self.trace is None or self.trace.get("key") != key:
                     self.graph = None       # the arena pointers are kernel arguments frozen in the graph
                     STATS["trace_rekeys"] += 1
@@ -297,7 +299,7 @@ class Rollout:
                         for t_ in (v if isinstance(v, list) else [v]):
                             if isinstance(t_, torch.Tensor):
                                 (t_[:, Bp * S:] if (t_.dim() == 2 and t_.shape[0] == c.num_attention_heads and k == "lse") else t_[Bp * S:]).zero_()
-                tr["key"] = key
+                tr["key"], tr["mlp_on_shadow"] = key, mlp_on_shadow
                 self.trace = tr
         else:
             hf, _ = e.text_forward(plan, img_embeds, save=False, kv_sink=kv_sink)
@@ -325,10 +327,11 @@ class Rollout:
             for t, s_ in zip(state, saved):
                 t.copy_(s_)
             STATS["capture_seconds"] += _time.perf_counter() - _t0
-        bounds = shadow.boundaries(max_new) if shadow is not None else ()
+        bounds = ()
         gates = []          # every gate event stays alive until the rollout returns (a destroyed event's handle goes back to torch's pool and is re-recorded by the next gate)
         if shadow is not None:
-            shadow.begin(plan, G, max_new, first_pos, self.out_tokens, step_counter=self.step)
+            shadow.begin(plan, G, max_new, first_pos, self.out_tokens, step_counter=self.step, policy=(e, self.trace) if mlp_on_shadow else None)
+            bounds = shadow.boundaries(max_new)
             gate = torch.cuda.Event()
             gates.append(gate)
             gate.record()                  # behind the sampling of token 0 (and the prefill): the reference's vision tower, prompt rows and first log-prob start now

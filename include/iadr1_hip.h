@@ -77,6 +77,13 @@ int iadr1_gemm_nt_splitk_acc_bf16(const void* A, const void* B, float* C, void* 
  * (down_proj(act_fn(gate_proj(x)) * up_proj(x))) up to the down projection. */
 int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, void* Aout, int M, int I, int K, long long lda, long long ldw,
                            long long ldgu, long long ldaout, iadr1_stream_t stream);
+/* The same contraction over ROW BLOCKS of larger matrices: GEMM row r (0 <= r < M) is row (r / block) * block_stride + r % block of A, GU and Aout, counted from
+ * the given base pointers (block: a power of two >= 16 dividing M; M %% 256 == 0).  Per row the arithmetic is iadr1_gemm_swiglu_bf16's, bit for bit.  Used by the
+ * co-scheduled pass (iad-r1_amd/overlap.py) to rebuild the POLICY's gate|up and SwiGLU rows of a chunk of decode steps -- `block` steps of every sequence,
+ * sequences `block_stride` rows apart in the sequence-major training arena -- on the side stream, so that the decode step's gate|up kernel need not store them
+ * (the same mlp rows of REF:train/stage_rl/trainer/sc_grpo_trainer.py:722-735's policy forward, TF:552-554). */
+int iadr1_gemm_swiglu_rows_bf16(const void* A, const void* W, void* GU, void* Aout, int M, int I, int K, long long lda, long long ldw,
+                                long long ldgu, long long ldaout, int block, long long block_stride, iadr1_stream_t stream);
 /* Decode-time skinny GEMM: Y[M,N] = X[M,K] . W[N,K]^T (M small, 64 rows per pass); HBM-bound weight stream,
  * K spread over 8-16 waves per block (+ optional grid split `ksplit`), no atomics.  out_mode 0: bf16 + bias;
  * 1: fp32 (logits); 2: fp32 partial slabs Y[ksplit][M][ldy] summed by iadr1_rmsnorm_fwd (x32 path); 3: fused

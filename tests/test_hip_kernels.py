@@ -710,6 +710,36 @@ def test_gemm_swiglu_is_bit_identical_to_gemm_then_swiglu(M, I, K, keep):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nseq,block,stride,I,K,keep", [(64, 32, 256, 1664, 512, True), (32, 16, 48, 3072, 256, True), (64, 16, 40, 11008, 2048, False)])
+def test_gemm_swiglu_rows_equals_the_plain_launch_on_gathered_rows(nseq, block, stride, I, K, keep):
+    """iadr1_gemm_swiglu_rows_bf16 (row blocks of a sequence-major arena) vs iadr1_gemm_swiglu_bf16 on the same rows gathered into a dense matrix: bit-equal gate|up
+    and SwiGLU rows at the mapped positions, every other row of the outputs untouched."""
+    g = torch.Generator(device="cpu").manual_seed(nseq + block + I)
+    base = 24
+    T = base + nseq * stride + 8
+    X = (torch.randn(T, K, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    w = (torch.randn(2 * I, K, generator=g) * K ** -0.5 * 2.0).to(torch.bfloat16).cuda()
+    off = 8                                             # the chunk starts 8 rows into every sequence
+    rows = (base + off + torch.arange(nseq)[:, None] * stride + torch.arange(block)[None, :]).reshape(-1).cuda()
+    xg = X[rows].contiguous()
+    gu_ref = torch.empty(rows.numel(), 2 * I, dtype=torch.bfloat16, device="cuda")
+    a_ref = torch.empty(rows.numel(), I, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_swiglu_fused(xg, w, gu_ref, a_ref)
+    GU = torch.full((T, 2 * I), float("nan"), dtype=torch.bfloat16, device="cuda")
+    A = torch.full((T, I), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_swiglu_rows(X[base + off:], w, GU[base + off:] if keep else None, A[base + off:], nseq, block, stride)
+    assert torch.equal(A[rows].view(torch.int16), a_ref.view(torch.int16))
+    other = torch.ones(T, dtype=torch.bool, device="cuda"); other[rows] = False
+    assert bool(torch.isnan(A[other].float()).all())
+    if keep:
+        assert torch.equal(GU[rows].view(torch.int16), gu_ref.view(torch.int16)) and bool(torch.isnan(GU[other].float()).all())
+    else:
+        assert bool(torch.isnan(GU.float()).all())
+    with pytest.raises(RuntimeError):
+        ops.gemm_swiglu_rows(X[base:], w, None, A[base:], nseq, 24, stride)        # not a power of two
+
+
+@pytest.mark.gpu
 def test_decode_side_outputs_equal_the_main_outputs():
     """iadr1_side_out_t (`side` argument of the four decode-step entry points): every kernel that carries side outputs writes, at row
     base + s * stride + *step of row-major training buffers, exactly what its main (decode-packed / paged) output holds; without `side` nothing else
