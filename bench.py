@@ -190,7 +190,9 @@ def synth_batch(cfg, n_prompts, prompt_len, seed):
 
 
 class GemmTimer:
-    """HIP-event timing of every gemm_nt launch on the launch stream (torch's current stream)."""
+    """HIP-event timing of every gemm_nt launch on the launch stream (torch's current stream).  A launch on a CU-masked stream (the co-scheduled reference pass:
+    iadr1_amd/overlap.py, 64 of 256 CUs) is priced against THAT share of the device: its interval counts share x length (a GEMM confined to a quarter of the
+    CUs for 4 ms has used what a whole-device GEMM uses in 1 ms), so `achieved` stays FLOPs per whole-device second."""
 
     def __init__(self):
         self.records = []
@@ -208,7 +210,7 @@ class GemmTimer:
             e0.record()
             r = orig(a, b, bias=bias, out=out, out_dtype=out_dtype, accumulate=accumulate, act=act)
             e1.record()
-            timer.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], (a.shape[0], b.shape[0], a.shape[1], 'acc' if accumulate else str(out_dtype if out is None else out.dtype)[6:])))
+            timer.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], (a.shape[0], b.shape[0], a.shape[1], ('acc' if accumulate else str(out_dtype if out is None else out.dtype)[6:]) + timer.tag()), timer.share()))
             return r
 
         ops.gemm_nt = timed
@@ -221,7 +223,7 @@ class GemmTimer:
             e0.record()
             orig_f(x, w_gu, gu, a_out)
             e1.record()
-            timer.records.append((e0, e1, 2.0 * x.shape[0] * w_gu.shape[0] * x.shape[1], (x.shape[0], w_gu.shape[0], x.shape[1], 'bfloat16+swiglu' if gu is not None else 'swiglu only')))
+            timer.records.append((e0, e1, 2.0 * x.shape[0] * w_gu.shape[0] * x.shape[1], (x.shape[0], w_gu.shape[0], x.shape[1], ('bfloat16+swiglu' if gu is not None else 'swiglu only') + timer.tag()), timer.share()))
 
         ops.gemm_swiglu_fused = timed_f
 
@@ -237,42 +239,60 @@ class GemmTimer:
                 e0.record()
                 r = orig_h(h, w, *a, **kw)
                 e1.record()
-                timer.records.append((e0, e1, 2.0 * h.shape[0] * w.shape[0] * h.shape[1], (h.shape[0], w.shape[0], h.shape[1], tag)))
+                timer.records.append((e0, e1, 2.0 * h.shape[0] * w.shape[0] * h.shape[1], (h.shape[0], w.shape[0], h.shape[1], tag + timer.tag()), timer.share()))
                 return r
             setattr(ops, name, timed_h)
         wrap_head("linear_logprob", "lse epilogue")
         wrap_head("linear_logprob_dlogits", "dlogits epilogue")
 
+    @staticmethod
+    def share():
+        from iadr1_amd import hip
+        return hip.cu_share()
+
+    def tag(self):
+        sh = self.share()
+        return "" if sh >= 1.0 else f" @{sh:.2f} of the CUs"
+
     def summary(self):
-        t = sum(r[0].elapsed_time(r[1]) for r in self.records) * 1e-3
+        """(launches, CU-share-weighted sum of launch durations in s, FLOPs)"""
+        t = sum(r[0].elapsed_time(r[1]) * r[4] for r in self.records) * 1e-3
         fl = sum(r[2] for r in self.records)
         return len(self.records), t, fl
 
+    def masked_launches(self):
+        return sum(1 for r in self.records if r[4] < 1.0)
+
     def busy_seconds(self):
-        """Length of the UNION of the launch intervals.  The weight-gradient GEMMs run on a side stream concurrently with the dgrad GEMMs of the
-        main stream; the sum of per-launch durations then counts shared time twice, the union counts it once (= the sum when nothing overlaps)."""
+        """Length of the UNION of the launch intervals, per CU share, weighted by the share.  The weight-gradient GEMMs run on a side stream concurrently with the
+        dgrad GEMMs of the main stream; the sum of per-launch durations then counts shared time twice, the union counts it once (= the sum when nothing
+        overlaps).  Launches on a CU-masked stream form their own group (they run next to the decode replays, never next to other GEMMs)."""
         if not self.records:
             return 0.0
         ref = self.records[0][0]
-        iv = sorted((ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1, _, _ in self.records)
-        busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
-        for s_, e_ in iv[1:]:
-            if s_ > cur_e:
-                busy += cur_e - cur_s
-                cur_s, cur_e = s_, e_
-            else:
-                cur_e = max(cur_e, e_)
-        return (busy + cur_e - cur_s) * 1e-3
+        total = 0.0
+        for sh in sorted({r[4] for r in self.records}):
+            iv = sorted((ref.elapsed_time(e0), ref.elapsed_time(e1)) for e0, e1, _, _, s_ in self.records if s_ == sh)
+            busy, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+            for s_, e_ in iv[1:]:
+                if s_ > cur_e:
+                    busy += cur_e - cur_s
+                    cur_s, cur_e = s_, e_
+                else:
+                    cur_e = max(cur_e, e_)
+            total += (busy + cur_e - cur_s) * sh
+        return total * 1e-3
 
     def by_shape(self, top=14):
         agg = {}
-        for e0, e1, f, key in self.records:
-            a = agg.setdefault(key, [0, 0.0, 0.0])
+        for e0, e1, f, key, sh in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0, sh])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += f
-        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
-        return [{"MNK_out": list(k), "calls": v[0], "ms": round(v[1] * 1e3, 2), "TF": round(v[2] / max(v[1], 1e-9) / 1e12, 1)} for k, v in rows]
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1] * kv[1][3])[:top]
+        return [{"MNK_out": list(k), "calls": v[0], "ms": round(v[1] * 1e3, 2), "TF": round(v[2] / max(v[1], 1e-9) / 1e12, 1),
+                 **({"TF_per_whole_device": round(v[2] / max(v[1] * v[3], 1e-9) / 1e12, 1)} if v[3] < 1.0 else {})} for k, v in rows]
 
 
 def cpu_baseline(cfg_dict_3b, seconds_budget, P=512, C=256, G=8):
@@ -1275,6 +1295,21 @@ def main():
                     print(f"[alloc-trace] {ev['action']:13s} {ev['size'] / 2**20:9.1f} MiB  {' <- '.join(fr)}", file=sys.stderr)
     metrics = {k: (sum(v) / len(v) if v else None) for k, v in tr._metrics.items()}
     traced = bool(getattr(eng, "last_step_traced", False))      # read now: the extra (untimed) leg below runs the other layout
+    co_sched = None
+    if getattr(eng, "last_step_shadowed", False):
+        ro, sh = eng._rollout, eng._shadow
+        ncu_dev = torch.cuda.get_device_properties(dev).multi_processor_count
+        mlp = bool(ro.trace and ro.trace.get("mlp_on_shadow"))
+        co_sched = {"what": "the frozen reference's teacher-forced pass (vision tower, decoder, lm_head log-probs) runs UNDER the rollout on a second HIP stream, one chunk of decode steps' "
+                            "rows at a time (iadr1_amd/overlap.py; bit-equal to the one-shot pass: tests/test_hip_model.py::test_chunked_reference_pass_is_bit_equal_to_the_one_shot_pass)",
+                    "side_stream_cus": (ncu_dev - ro.decode_cus) if ro.decode_cus else None, "decode_stream_cus": ro.decode_cus or ncu_dev, "chunk_decode_steps": sh.steps,
+                    "policy_mlp_rows_rebuilt_on_side_stream": mlp,
+                    "rebuilt_gemm_tflop_per_step": (2.0 * N * a.gen_len * 2 * cfg.intermediate_size * cfg.hidden_size * cfg.num_hidden_layers / 1e12) if mlp else 0.0,
+                    "rebuilt_note": "the policy's gate|up + SwiGLU rows of the completion tokens are recomputed from the decode steps' stored h2 rows instead of being stored by the decode "
+                                    "kernel (iadr1_gemm_swiglu_rows_bf16); REDUNDANT FLOPs: not counted in roofline_gemm's achieved" if mlp else None,
+                    "switch": "IADR1_OVERLAP_CUS=" + os.environ.get("IADR1_OVERLAP_CUS", "auto") + " (0: the reference pass after the rollout on the whole device)",
+                    "roofline_note": "roofline_decode is measured WHILE the side stream runs: the decode replays own decode_stream_cus CUs and share HBM with the reference pass, so their "
+                                     "ms_per_decode_step is higher (3B: 3.06 vs 2.80 ms alone on 256 CUs) although the step is shorter; roofline_gemm prices side-stream launches at their CU share"}
     dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
     per_rank_ms = [dt / a.steps * 1e3]
     exposed_ms = eng.reducer.exposed_ms() if eng.reducer.active else None
@@ -1379,12 +1414,14 @@ def main():
                                           "the kernel is MFMA / power bound (mfma_busy, power_limit), not traffic bound"),
                          "mfma_busy": mfma_busy,
                          "power_limit": power_limit(),
-                         "launches": n_launch, "kernel_time_frac_of_step": t_gemm / dt,
+                         "launches": n_launch, "launches_on_cu_masked_streams": timer.masked_launches(), "kernel_time_frac_of_step": t_gemm / dt,
                          "timing": "sum of algorithmic FLOPs of the launches / length of the union of their HIP-event intervals (weight-gradient GEMMs run on a side stream "
-                                   "concurrently with the dgrad GEMMs; equals FLOPs / sum of launch durations when nothing overlaps: IADR1_WGRAD_STREAM=0)",
+                                   "concurrently with the dgrad GEMMs; equals FLOPs / sum of launch durations when nothing overlaps: IADR1_WGRAD_STREAM=0); intervals of launches on a "
+                                   "CU-masked stream (co_scheduling) count share-of-CUs x length, i.e. whole-device seconds",
                          "achieved_by_sum_of_launch_durations": fl_gemm / max(t_sum, 1e-9) / 1e12,
                          "whole_step_executed_gemm_tflops": fl_gemm / dt / 1e12, "whole_step_frac_of_mfma_peak": fl_gemm / dt / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS},
             "roofline_decode": decode_roofline(cfg, pol, dec_ev, N, a.gen_len),
+            "co_scheduling": co_sched,
             "last_step_metrics": metrics,
             "gemm_by_shape": timer.by_shape(),
             "hbm": hbm,

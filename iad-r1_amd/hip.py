@@ -109,7 +109,17 @@ def cu_mask_stream(first_cu: int, n_cus: int, total_cus: int | None = None) -> "
     rc = lib().iadr1_stream_create_cu_mask(words.ctypes.data, len(words), out.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"iadr1_stream_create_cu_mask failed ({rc}): {lib().iadr1_last_error().decode()}")
+    _CU_SHARE[int(out[0])] = n_cus / total
     return torch.cuda.ExternalStream(int(out[0]))
+
+
+_CU_SHARE: dict = {}      # raw stream handle -> fraction of the device's CUs a CU-masked stream owns
+
+
+def cu_share(stream=None) -> float:
+    """Fraction of the device's CUs the given (default: torch's current) stream may use: 1.0 unless it came from cu_mask_stream."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    return _CU_SHARE.get(int(st.cuda_stream), 1.0)
 
 
 def set_decode_cus(n_cus: int):

@@ -48,15 +48,26 @@ BLOCK = 16          # steps per time block of the completion-row layout (a power
 STATS = {"passes": 0, "chunks": 0, "rows": 0, "policy_mlp_rows": 0}
 
 
-def shadow_cus() -> int:
-    """IADR1_OVERLAP_CUS: 0 (default) = the reference pass runs after the rollout, on the whole device; n > 0 = it runs under the rollout on a stream confined to n CUs
-    while the decode replays own the others (SCGRPOEngine._cu_split); -1 = under the rollout on an ordinary second stream (no CU split: measured slower, kept for
-    A/B and for the parity tests of the chunked pass itself)."""
-    return int(os.environ.get("IADR1_OVERLAP_CUS", "0"))
+AUTO_CUS = 64       # CUs of the side stream in the automatic mode (the decode replays own the other 192): the measured optimum of 32 / 48 / 64 / 96 at the 3B bench shape
 
 
-def enabled() -> bool:
-    return shadow_cus() != 0
+def auto_applies(cfg, n_seq: int, C: int) -> bool:
+    """Shapes for which co-scheduling is ON by default -- where it was measured to pay (profiles/r05_overlap_ab.txt, EXPERIMENTS round 5), ms per step without -> with:
+    Qwen2.5-VL-3B, 8 prompts x G 8, C 256: 1256 -> 1222 (+2.8 %); Qwen2-VL-2B, same shape: 833 -> 783 (+6.4 %).  NOT: rollouts of fewer than 64 sequences (3B, 4 prompts
+    x G 8: 944 -> 954; 2 x 8: 788 -> 827 -- the side stream hides little there and the masked decode stream costs +0.2 ms per step whatever the batch), the 7B-class models
+    (hidden 3584: the decode step on 192 CUs costs 5.77 instead of 4.38 ms, 2402 -> 2514 ms), the LLaVA families (`applicable`)."""
+    return (cfg is not None and not cfg.is_llava and cfg.hidden_size <= 2048 and n_seq >= 64 and n_seq % 16 == 0 and C % BLOCK == 0 and C >= 4 * BLOCK
+            and n_seq * C >= 8192)
+
+
+def shadow_cus(cfg=None, n_seq: int = 0, C: int = 0) -> int:
+    """IADR1_OVERLAP_CUS: `auto` (the default) = AUTO_CUS where auto_applies(cfg, sequences, completion length), else 0; 0 = the reference pass runs after the
+    rollout, on the whole device; n > 0 = it runs under the rollout on a stream confined to n CUs while the decode replays own the others (cu_split); -1 = under the
+    rollout on an ordinary second stream (no CU split: measured slower, kept for A/B and for the parity tests of the chunked pass itself)."""
+    v = os.environ.get("IADR1_OVERLAP_CUS", "auto").strip().lower()
+    if v in ("", "auto"):
+        return AUTO_CUS if auto_applies(cfg, n_seq, C) else 0
+    return int(v)
 
 
 def chunk_steps_default() -> int:
@@ -116,6 +127,28 @@ def pick_concurrent_stream(anchor, make_candidate, weight: torch.Tensor, tries: 
     return None, best[1]
 
 
+_SPLITS: dict = {}       # (device index, side-stream CUs) -> (decode stream, side stream, decode CUs), or None when no clean stream pair was found
+
+
+def cu_split(dev: torch.device, n: int, weight: torch.Tensor):
+    """The process's two CU-masked streams for a side stream of n CUs on `dev` -- decode replays on the device's other CUs -- created and calibrated ONCE
+    (pick_concurrent_stream; hardware queues are a finite resource and the calibration takes ~0.2 s).  Returns (decode stream, side stream, decode CUs), or None
+    when no candidate on another dispatch pipe was found: the caller then does not co-schedule at all."""
+    import sys
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(n))
+    if key not in _SPLITS:
+        total = torch.cuda.get_device_properties(dev).multi_processor_count
+        if not (0 < n < total and n % 8 == 0):
+            raise ValueError(f"IADR1_OVERLAP_CUS={n}: a multiple of 8 (the same share of every XCD) below the device's {total} CUs is required")
+        decode = hip.cu_mask_stream(n, total - n)
+        log = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("IADR1_OVERLAP_LOG") == "1" else None
+        side, ratio = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(0, n), weight, log=log)
+        if side is None and os.environ.get("IADR1_QUIET") != "1":
+            print(f"[iadr1] co-scheduling off: no stream pair on separate dispatch pipes found (best: the dependent chain at {ratio:.1f}x its stand-alone time)", file=sys.stderr, flush=True)
+        _SPLITS[key] = None if side is None else (decode, side, total - n)
+    return _SPLITS[key]
+
+
 class ChunkedRefPass:
     """One instance per SCGRPOEngine; `begin` per rollout.  All device work of this object is enqueued on `self.stream` (the side stream)."""
 
@@ -132,10 +165,10 @@ class ChunkedRefPass:
         return shadow_cus() < 0
 
     @staticmethod
-    def applicable(cfg, C: int) -> bool:
+    def applicable(cfg, n_seq: int, C: int) -> bool:
         """Qwen-VL families, completion length a multiple of the time block.  (The LLaVA branches of the reference rotate right-padded rows before the model
         runs -- REF:516-567 -- which makes the scored positions depend on where a sequence ENDS: not known while it is being generated.)"""
-        return enabled() and not cfg.is_llava and C % BLOCK == 0 and C >= BLOCK
+        return shadow_cus(cfg, n_seq, C) != 0 and not cfg.is_llava and C % BLOCK == 0 and C >= BLOCK
 
     @staticmethod
     def rebuilds_policy_mlp(cfg, N: int) -> bool:

@@ -202,6 +202,8 @@ class Rollout:
         N = Bp * G
         assert N == self.N, f"rollout was built for {self.N} sequences, got {N}"
         assert max_new <= self.max_new
+        if dev.type == "cuda":
+            ops.hip.set_decode_cus(self.decode_cus)      # process-wide launcher configuration (persistent grids): this rollout's, whatever another engine set since
         self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)   # device-resident: a new seed per rollout does not invalidate the captured graph
         sampling = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p),
                         suppress=c.eos_token_id if suppress_eos else -1, eos=c.eos_token_id if stop_at_eos and not suppress_eos else -1, pad=c.pad_token_id)

@@ -363,7 +363,7 @@ class SCGRPOEngine:
         if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_prompt < ids.shape[1]:
             grow = max(ids.shape[1], self._rollout.max_prompt if self._rollout is not None else 0)
             self._rollout = None        # release the old pool before the new one is allocated
-            split = self._cu_split()
+            split = self._cu_split(N)
             if self.dev.type == "cuda":
                 hip.set_decode_cus(split.get("decode_cus", 0))      # process-wide launcher configuration: what THIS rollout's graph is captured with
             self._rollout = Rollout(self.pol, N, grow, a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph, **split)
@@ -374,8 +374,8 @@ class SCGRPOEngine:
         trace = (train_carry is not None and a.reuse_decode and st.qkv_rope_packed and not st.decode_fp8 and self._rollout_fuses_swiglu(N))
         shadow = None
         self.shadow_logps = None
-        if shadow_ref and self.dev.type == "cuda" and ChunkedRefPass.applicable(c, a.max_completion_length) and (self._rollout.decode_stream is not None or ChunkedRefPass.unmasked()):
-            if self._shadow is None:
+        if shadow_ref and self.dev.type == "cuda" and ChunkedRefPass.applicable(c, N, a.max_completion_length) and (self._rollout.decode_stream is not None or ChunkedRefPass.unmasked()):
+            if self._shadow is None or self._shadow.stream is not (self.__dict__.get("_shadow_stream") or self._shadow.stream):
                 self._shadow = ChunkedRefPass(self.ref, stream=self.__dict__.get("_shadow_stream"))
             shadow = self._shadow
             shadow.vision = (vis["px"], vis["plan"])
@@ -388,29 +388,21 @@ class SCGRPOEngine:
             train_carry["traced"] = True
         return toks.cpu().numpy()
 
-    def _cu_split(self) -> dict:
-        """IADR1_OVERLAP_CUS=n > 0: the shadow pass is confined to n CUs and the decode replays to the others -- two CU-masked streams (include/iadr1_hip.h
-        iadr1_stream_create_cu_mask) on different dispatch pipes (overlap.pick_concurrent_stream); the decode launchers size their persistent grids for the smaller
-        device (iadr1_set_decode_cus).  Masked streams are BLOCKING streams: `step` moves off the null stream while they are in use."""
-        from .overlap import pick_concurrent_stream, shadow_cus
-        n = shadow_cus()
-        if n <= 0 or self.dev.type != "cuda" or not ChunkedRefPass.applicable(self.cfg, self.args.max_completion_length):
+    def _cu_split(self, N: int) -> dict:
+        """Co-scheduling with a CU split (IADR1_OVERLAP_CUS = auto for this shape, or n > 0): the shadow pass is confined to n CUs and the decode replays to the
+        others -- two CU-masked streams (include/iadr1_hip.h iadr1_stream_create_cu_mask) on different dispatch pipes (overlap.cu_split, one pair per process); the
+        decode launchers size their persistent grids for the smaller device (iadr1_set_decode_cus).  Masked streams are BLOCKING streams: `step` moves off the null
+        stream while they are in use."""
+        from .overlap import cu_split, shadow_cus
+        n = shadow_cus(self.cfg, N, self.args.max_completion_length)
+        self._shadow_stream = None
+        if n <= 0 or self.dev.type != "cuda" or not ChunkedRefPass.applicable(self.cfg, N, self.args.max_completion_length):
             return {}
-        if "_decode_stream" not in self.__dict__:
-            import sys
-            total = torch.cuda.get_device_properties(self.dev).multi_processor_count
-            if not (0 < n < total and n % 8 == 0):
-                raise ValueError(f"IADR1_OVERLAP_CUS={n}: a multiple of 8 (the same share of every XCD) below the device's {total} CUs is required")
-            self._decode_stream = hip.cu_mask_stream(n, total - n)
-            log = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("IADR1_QUIET") != "1" else None
-            self._shadow_stream, ratio = pick_concurrent_stream(self._decode_stream, lambda: hip.cu_mask_stream(0, n), self.ref.p.w("layers.0.gu.w"), log=log)
-            if self._shadow_stream is None:       # no candidate on another dispatch pipe: no co-scheduling at all (the one-shot reference pass after the rollout)
-                self._decode_stream, self._decode_cus = None, 0
-            else:
-                self._decode_cus = total - n
-        if self._decode_stream is None:
+        sp = cu_split(self.dev, n, self.ref.p.w("layers.0.gu.w"))
+        if sp is None:       # no candidate on another dispatch pipe: no co-scheduling at all (the one-shot reference pass after the rollout)
             return {}
-        return {"decode_cus": self._decode_cus, "decode_stream": self._decode_stream}
+        self._shadow_stream = sp[1]
+        return {"decode_cus": sp[2], "decode_stream": sp[0]}
 
     def _rollout_fuses_swiglu(self, N) -> bool:
         """True when the decode gate|up projection runs on the persistent fused-SwiGLU kernel (the one with side outputs): include/iadr1_hip.h."""
@@ -588,7 +580,7 @@ class SCGRPOEngine:
         streams (hipExtStreamCreateWithCUMask has no non-blocking form), i.e. every operation on the null stream waits for both of them and holds back what they
         enqueue afterwards -- measured: each chunk of the shadow pass then started exactly one chunk period late.  The caller's stream is ordered before and
         after the step as usual."""
-        if self.dev.type == "cuda" and int(os.environ.get("IADR1_OVERLAP_CUS", "0")) > 0 and torch.cuda.current_stream(self.dev).cuda_stream == 0:
+        if self.dev.type == "cuda" and torch.cuda.current_stream(self.dev).cuda_stream == 0 and self._splits_cus(args[0] if args else kw.get("batch")):
             if "_main_stream" not in self.__dict__:
                 self._main_stream = torch.cuda.Stream(self.dev)
             outer = torch.cuda.current_stream(self.dev)
@@ -598,6 +590,14 @@ class SCGRPOEngine:
             outer.wait_stream(self._main_stream)
             return out
         return self._step(*args, **kw)
+
+    def _splits_cus(self, batch) -> bool:
+        from .overlap import shadow_cus
+        try:
+            n_seq = len(batch["input_ids"]) * self.args.num_generations
+        except Exception:
+            return False
+        return shadow_cus(self.cfg, n_seq, self.args.max_completion_length) > 0
 
     def _step(self, batch, reward_fn, do_optimizer_step=True, last_micro_step=None, return_outputs=False, defer_metrics=False, completions=None):
         """One SC-GRPO micro-step: vision tower -> group rollout -> rewards -> reference / policy passes + backward (-> optimizer).  This is the path

@@ -34,7 +34,7 @@ for c in a.cus:
         n = int(c)
         hip.set_decode_cus(0 if n == NCU else n)
         split = {"decode_cus": 0 if n == NCU else n, "decode_stream": hip.cu_mask_stream(NCU - n, n)}
-    eng._cu_split = lambda split=split: split
+    eng._cu_split = lambda N=None, split=split: split
     for rep in range(3):
         carry = {} if a.trace else None
         vis = eng.vision_policy(batch, save=bool(a.trace))
