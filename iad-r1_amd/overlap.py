@@ -82,6 +82,12 @@ def policy_mlp_wanted() -> bool:
     return os.environ.get("IADR1_OVERLAP_GU", "1") != "0"
 
 
+def policy_head_wanted() -> bool:
+    """IADR1_OVERLAP_HEAD (default 1): with the training hand-over on, the POLICY's lm_head log-probs (fused linear_logprob: log p and log-sum-exp per scored position)
+    are computed on the side stream too, chunk by chunk, from the final-norm rows the decode steps stored; the loss then starts without that 10 TFLOP launch."""
+    return os.environ.get("IADR1_OVERLAP_HEAD", "1") != "0"
+
+
 def pick_concurrent_stream(anchor, make_candidate, weight: torch.Tensor, tries: int = 6, log=None):
     """A stream whose kernels really run NEXT TO `anchor`'s.  Measured on MI355X (tools/stream_pair_probe.py, profiles/r05_stream_pairs.txt): hardware queues are
     dealt round-robin onto the command processor's four dispatch pipes, and two queues on the SAME pipe take turns at kernel granularity -- a kernel stays "in
@@ -184,6 +190,12 @@ class ChunkedRefPass:
         SwiGLU rows of its tokens from the arena's `h2` rows (policy_mlp_wanted above; the decode graph was captured without those two side stores)."""
         e, c = self.e, self.e.cfg
         self.policy = policy
+        # the policy's lm_head log-probs on the side stream: needs the fused head (the same launch the one-shot path runs, so the values are bit-equal) and the arena's
+        # final-norm rows.  lse starts at +1e30: a position the pass never reaches (rollout cut short by EOS; masked in the loss) then gives exp(logit - lse) = 0 in backward.
+        self.pol_logp = self.pol_lse = None
+        if policy is not None and policy_head_wanted() and policy[0].head_mode == "fused" and policy[1].get("hf") is not None:
+            self.pol_logp = torch.zeros(plan.B * G, C, dtype=F32, device=e.dev)
+            self.pol_lse = torch.full((plan.B * G, C), 1e30, dtype=F32, device=e.dev)
         dev = e.dev
         Bp, S = plan.B, plan.S
         N = Bp * G
@@ -300,6 +312,8 @@ class ChunkedRefPass:
             last = (torch.arange(self.Bp, device=e.dev, dtype=torch.int64) * self.S + (self.S - 1)).repeat_interleave(self.G)
             lp, _ = e.logprobs(hf, last, self.out_tokens[:, 0].contiguous(), save=False)
             self.logp[:, 0] = lp
+            if self.pol_logp is not None:       # the policy's log-prob of token 0: its prefill's final-norm rows are in the arena (rows [0, T0))
+                self._policy_head(last, self.out_tokens[:, 0].contiguous(), slice(0, 1))
             self._img_ref = img_ref
             self._mark("prompt", ev0)
 
@@ -343,7 +357,10 @@ class ChunkedRefPass:
             if self.policy is not None:
                 ev0 = self._mark()
                 self._policy_mlp(c0, c1)
-                self._mark(f"policy mlp[{c0},{c1})", ev0)
+                if self.pol_logp is not None and n_ok > 0:
+                    idx = (self.T0 + torch.arange(N, device=e.dev, dtype=torch.int64)[:, None] * C + torch.arange(c0, c1, device=e.dev, dtype=torch.int64)[None, :]).reshape(-1)
+                    self._policy_head(idx, tg.reshape(-1), slice(c0 + 1, c0 + 1 + n_ok), n_ok)
+                self._mark(f"policy mlp + head[{c0},{c1})", ev0)
         self.done_rows = c1
         STATS["chunks"] += 1
         STATS["rows"] += r1 - r0
@@ -362,6 +379,23 @@ class ChunkedRefPass:
                 ops.gemm_swiglu_rows(tr["h2"][i][r:], P.w(f"layers.{i}.gu.w"), tr["gu"][i][r:], tr["a"][i][r:], self.N, blk, self.C)
             STATS["policy_mlp_rows"] += self.N * blk
             j += blk
+
+    def _policy_head(self, rows: torch.Tensor, targets: torch.Tensor, cols: slice, n_ok: int | None = None):
+        """log p / log-sum-exp of the policy's lm_head at arena rows `rows` ([N x k], sequence-major; targets < 0: not scored) -> columns `cols` of pol_logp / pol_lse
+        (the first n_ok of the k positions per sequence).  Engine.logprobs' fused launch on other rows: per row the same bits."""
+        pe, tr = self.policy
+        W = pe.p.w(pe.p.lm_head_name())
+        hsel = ops.embed_fwd(rows, None, tr["hf"], None)
+        R = rows.numel()
+        need = ops.linear_logprob_ws_bytes(R, W.shape[0])
+        ws = self.__dict__.get("_head_ws")
+        if ws is None or ws.numel() < need:
+            ws = self._head_ws = torch.empty(need, dtype=torch.uint8, device=self.e.dev)
+        lp, ls = ops.linear_logprob(hsel, W, targets, ws=ws)
+        k = R // self.N
+        n_ok = k if n_ok is None else n_ok
+        self.pol_logp[:, cols] = lp.view(self.N, k)[:, :n_ok]
+        self.pol_lse[:, cols] = ls.view(self.N, k)[:, :n_ok]
 
     def boundaries(self, C: int) -> set:
         """Decode steps after which a chunk is handed to the side stream: every `steps`, and once more one block before the end, so that what is left when the

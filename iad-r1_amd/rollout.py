@@ -99,6 +99,7 @@ class Rollout:
         self.cos = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.graph = None
+        self._toks_host, self._toks_event = None, None
         self.trace = None           # training arena filled by the decode steps (generate(train_trace=...)); part of the captured graph
         self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -387,8 +388,21 @@ class Rollout:
         if ds is not None:
             torch.cuda.set_stream(_outer)
             _outer.wait_stream(ds)
+        toks = self.out_tokens[:, :max_new].clone()
+        # the host copy of the tokens leaves BEFORE the shadow pass's tail is enqueued: the caller (rewards, the training batch's plans) waits for the decode replays
+        # only, and prepares the next phase while the tail runs (tokens_host)
+        if self._toks_host is None or self._toks_host.shape != toks.shape:
+            self._toks_host = torch.empty(toks.shape, dtype=toks.dtype).pin_memory()
+        self._toks_host.copy_(toks, non_blocking=True)
+        self._toks_event = torch.cuda.Event()
+        self._toks_event.record()
         if shadow is not None:
             shadow.finish(nsteps + 1, None)        # (the current stream is ordered behind the last replay)
             if shadow.trace is not None:
                 print("[iadr1 overlap] side-stream phases (ms after the start of the decode loop):", shadow.report(), flush=True)
-        return self.out_tokens[:, :max_new].clone()
+        return toks
+
+    def tokens_host(self) -> np.ndarray:
+        """The last generate()'s completion ids on the host (waits for the decode replays, not for what was enqueued behind them)."""
+        self._toks_event.synchronize()
+        return self._toks_host.numpy().copy()

@@ -318,7 +318,7 @@ class SCGRPOEngine:
         self.opt_step = 0
         self.accum = 0
         self._rollout = None
-        self.shadow_logps, self.last_step_shadowed = None, False
+        self.shadow_logps, self.shadow_policy_head, self.last_step_shadowed = None, None, False
         self._shadow = None         # overlap.ChunkedRefPass: the frozen reference's pass over the sampled tokens runs under the rollout (step())
         self.norm2 = torch.zeros(1, dtype=F32, device=self.dev)
         self.norm_scratch = torch.zeros(2048, dtype=F32, device=self.dev)
@@ -373,7 +373,7 @@ class SCGRPOEngine:
         # (not with the opt-in FP8 weight stream: the policy's training activations must come from its bf16 weights, so its forward runs after the rollout)
         trace = (train_carry is not None and a.reuse_decode and st.qkv_rope_packed and not st.decode_fp8 and self._rollout_fuses_swiglu(N))
         shadow = None
-        self.shadow_logps = None
+        self.shadow_logps, self.shadow_policy_head = None, None
         if shadow_ref and self.dev.type == "cuda" and ChunkedRefPass.applicable(c, N, a.max_completion_length) and (self._rollout.decode_stream is not None or ChunkedRefPass.unmasked()):
             if self._shadow is None or self._shadow.stream is not (self.__dict__.get("_shadow_stream") or self._shadow.stream):
                 self._shadow = ChunkedRefPass(self.ref, stream=self.__dict__.get("_shadow_stream"))
@@ -384,9 +384,10 @@ class SCGRPOEngine:
                                       train_carry=train_carry, train_trace=trace, shadow=shadow)
         if shadow is not None:
             self.shadow_logps = shadow.logp
+            self.shadow_policy_head = (shadow.pol_logp, shadow.pol_lse) if shadow.pol_logp is not None else None
         if trace:
             train_carry["traced"] = True
-        return toks.cpu().numpy()
+        return self._rollout.tokens_host() if os.environ.get("IADR1_EARLY_TOKENS", "1") != "0" else toks.cpu().numpy()
 
     def _cu_split(self, N: int) -> dict:
         """Co-scheduling with a CU split (IADR1_OVERLAP_CUS = auto for this shape, or n > 0): the shadow pass is confined to n CUs and the decode replays to the
@@ -414,7 +415,7 @@ class SCGRPOEngine:
 
     # ---- loss + gradients for given completions ------------------------------------------------------------------
     def loss_and_grads(self, batch, completions, rewards_per_func, backward: bool = True, last_micro_step: bool = True, vis=None, train_carry=None, defer_metrics: bool = False,
-                       ref_logps=None):
+                       ref_logps=None, policy_head=None):
         """completions: list of Bp*G id lists (prompt-major) or an [N,C] array already padded;
         rewards_per_func: [N, n_funcs] float tensor/array.  Accumulates gradients into policy.grad.
         ref_logps: [N, C] reference log-probs already computed for exactly these completions by the rollout's shadow pass (rollout(shadow_ref=True)): the
@@ -517,7 +518,12 @@ class SCGRPOEngine:
                     hf, ctx = self.pol.text_forward(plan.tail, None, save=True, rows=((b1 - b0) * P, T_all, T_all), carry=train_carry)
             else:
                 hf, ctx = self.pol.text_forward(plan, img_pol, save=backward, recompute=backward and self.pol.recompute_wanted(plan.ids.numel(), a.recompute))
-            lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel)
+            pre = None
+            if have_ref and policy_head is not None and share and n == N and train_carry is not None and train_carry.get("traced") and not (c.is_llava and a.llava_rotate_right_padded_rows):
+                pre = (policy_head[0].reshape(-1), policy_head[1].reshape(-1))       # the shadow pass scored the policy's rows too (same rows, same targets, same launch)
+            lp, lctx = self.pol.logprobs(hf, rows_d, tgt_d, save=backward, rows_host=sel, precomputed=pre)
+            if pre is not None and si == 0:
+                self._shadow.join()
             adv_d = advantages()["adv_d"]
             if have_ref:
                 if si == 0:
@@ -629,6 +635,7 @@ class SCGRPOEngine:
                 carry = None       # gradient checkpointing: nothing of the rollout is kept, the policy forward runs (checkpointed) before backward
         comp = self.rollout(batch, vis=vis, train_carry=carry, shadow_ref=True) if completions is None else np.asarray(completions)
         ref_lp = self.shadow_logps if completions is None else None
+        pol_head = self.shadow_policy_head if completions is None else None
         t2 = mark()
         # rewards are computed on the host inside loss_and_grads, after the first forward passes are in the GPU queue (in the
         # phase-timing mode they are evaluated here so that they get their own column)
@@ -637,7 +644,7 @@ class SCGRPOEngine:
         self.last_step_traced = bool(carry and carry.get("traced"))     # the decode steps filled the completion rows of the training arena
         last = do_optimizer_step if last_micro_step is None else last_micro_step
         out = self.loss_and_grads(batch, comp, rewards, backward=True, last_micro_step=last, vis=vis, train_carry=carry, defer_metrics=defer_metrics or do_optimizer_step,
-                                  ref_logps=ref_lp)
+                                  ref_logps=ref_lp, policy_head=pol_head)
         self.last_step_shadowed = ref_lp is not None
         t4 = mark()
         if do_optimizer_step:

@@ -1072,15 +1072,25 @@ class Engine:
         np.cumsum(np.bincount(rows_host, minlength=T), out=ptr[1:])
         return ops.h2d(ptr, device), ops.h2d(order, device)
 
-    def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool, dup=None, rows_host=None):
+    def logprobs(self, hf: torch.Tensor, rows: torch.Tensor, targets: torch.Tensor, save: bool, dup=None, rows_host=None, precomputed=None):
         """logp[r] = log_softmax(lm_head(hf[rows[r]]))[targets[r]]  (targets < 0 -> 0).  The [R,V] logits exist
         only as fp32 chunks of `lm_chunk` rows.  `rows` may repeat a hidden row only where `dup` = (sel, dest, group) says so:
         entries rows[sel] all equal dest[group] (shared-prefix layout: the prompt's last token predicts the first token of
-        every completion of its group); the backward sums their gradients."""
+        every completion of its group); the backward sums their gradients.
+        precomputed: (logp [R], lse [R]) of exactly these rows / targets, already produced by the same fused launch elsewhere (overlap.ChunkedRefPass._policy_head, on
+        the side stream under the rollout): nothing is launched here but the gather of the selected rows, which the backward reads."""
         P = self.p
         W = P.w(P.lm_head_name())
         hsel = ops.embed_fwd(rows, None, hf, None)
         R = rows.numel()
+        if precomputed is not None:
+            logp, lse = precomputed
+            assert logp.numel() == R and lse.numel() == R and self.head_mode == "fused"
+            ctx = None
+            if save:
+                ptr, idx = self.scatter_plan(rows_host if rows_host is not None else rows.cpu().numpy(), hf.shape[0], self.dev)
+                ctx = {"hsel": hsel, "rows": rows, "targets": targets, "lse": lse, "T": hf.shape[0], "scatter": (ptr, idx), "logits": None}
+            return logp, ctx
         logp = torch.empty(R, dtype=F32, device=self.dev)
         lse = torch.empty(R, dtype=F32, device=self.dev)
         V = W.shape[0]

@@ -1811,14 +1811,15 @@ def test_chunked_reference_pass_is_bit_equal_to_the_one_shot_pass(monkeypatch, s
     assert cos > 0.99999, cos            # (float atomics in the norm-gain / embedding gradients: run-to-run order noise)
 
 
-@pytest.mark.parametrize("steps,cus", [(32, -1), (16, 64)])
-def test_policy_mlp_rows_rebuilt_under_the_rollout(monkeypatch, steps, cus):
+@pytest.mark.parametrize("steps,cus,eos_live", [(32, -1, False), (16, 64, False), (32, -1, True)])
+def test_policy_mlp_rows_rebuilt_under_the_rollout(monkeypatch, steps, cus, eos_live):
     """Overlap mode, IADR1_OVERLAP_GU=1 (its default): the decode step's gate|up kernel stores nothing for the training hand-over; the policy's gate|up and SwiGLU
     rows of the completion tokens are rebuilt on the side stream, chunk by chunk, from the `h2` rows the decode steps did store (iadr1_gemm_swiglu_rows_bf16).
     (1) After a rollout every such row of the arena is BIT-equal to iadr1_gemm_swiglu_bf16 of its `h2` row; (2) a whole step against the same step with the stores
     (IADR1_OVERLAP_GU=0): same tokens, log-probs of both models, KL and loss bit-equal (the forward never reads those rows), gradients equal to bf16 rounding of the
-    two kernels' gate|up sums (training-GEMM vs decode-kernel summation order: cosine > 0.9999).  3B widths, 2 layers, 2 prompts x G 8 (16 sequences x one time
-    block = one 256-row tile), C = 48 (chunks of 32 + 16 or 16 + 16 + 16)."""
+    two kernels' gate|up sums (training-GEMM vs decode-kernel summation order: cosine > 0.9999).  The policy's lm_head log-probs come from the side stream as well
+    (IADR1_OVERLAP_HEAD, same fused launch: bit-equal).  3B widths, 2 layers, 2 prompts x G 8 (16 sequences x one time block = one 256-row tile), C = 48 (chunks of
+    32 + 16 or 16 + 16 + 16).  eos_live: ragged completions, some rows cut short (positions the side stream never scores are masked; their lse stays +1e30)."""
     import dataclasses
     from iadr1_amd import ops, overlap
     cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
@@ -1833,12 +1834,22 @@ def test_policy_mlp_rows_rebuilt_under_the_rollout(monkeypatch, steps, cus):
     rows = [fx.synth_prompt(grids[0], 37, cd, 5), fx.synth_prompt(grids[1], 21, cd, 6)]
     ids, mask = fx.left_pad(rows, cfg.pad_token_id)
     batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values(grids, cd, seed=5), "image_grid_thw": grids}
-    args = lambda: GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, micro_batch_seqs=Bp * G, seed=11, beta=0.04, suppress_eos=True)
+    args = lambda: GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, micro_batch_seqs=Bp * G, seed=11, beta=0.04, suppress_eos=not eos_live)
     reward_fn = lambda comp: np.stack([(np.asarray(comp)[:, 0] % 5).astype(np.float32), (np.asarray(comp)[:, 1] % 3).astype(np.float32) * 0.5], 1)
     monkeypatch.setenv("IADR1_OVERLAP_STEPS", str(steps))
     monkeypatch.setenv("IADR1_OVERLAP_CUS", str(cus))
     if cus > 0:
         monkeypatch.setenv("IADR1_DECODE_KS", "1,8")
+    if eos_live:      # declare the token that ends the most rows early to be EOS (sampling is a pure function of seed / step / row / logits)
+        monkeypatch.setenv("IADR1_OVERLAP_CUS", "0")
+        comp0 = SCGRPOEngine(cfg, pol, ref, args()).rollout(batch, vis=None)
+        monkeypatch.setenv("IADR1_OVERLAP_CUS", str(cus))
+        best, best_rows = None, []
+        for tok in np.unique(comp0[:, 2: C - 2]):
+            hit = [r for r in range(Bp * G) if tok in comp0[r, 2: C - 2] and tok not in comp0[r, :2]]
+            if len(hit) > len(best_rows):
+                best, best_rows = int(tok), hit
+        cfg.eos_token_id = best
     # (1) the rows themselves
     monkeypatch.setenv("IADR1_OVERLAP_GU", "1")
     eng = SCGRPOEngine(cfg, pol, ref, args())
@@ -1859,7 +1870,7 @@ def test_policy_mlp_rows_rebuilt_under_the_rollout(monkeypatch, steps, cus):
     else:
         roll()
     N = Bp * G
-    assert overlap.STATS["policy_mlp_rows"] - before == N * C
+    assert overlap.STATS["policy_mlp_rows"] - before == N * C and eng.shadow_policy_head is not None
     tr = eng._rollout.trace
     assert tr["mlp_on_shadow"]
     T0 = ids.shape[0] * ids.shape[1]
@@ -1884,9 +1895,14 @@ def test_policy_mlp_rows_rebuilt_under_the_rollout(monkeypatch, steps, cus):
         res[mode] = (out, pol.grad.clone())
         del eng
     (o1, g1), (o0, g0) = res["1"], res["0"]
-    assert np.array_equal(o1["completion_ids"], o0["completion_ids"])
-    assert torch.equal(o1["ref_logps"], o0["ref_logps"]) and torch.equal(o1["logps"], o0["logps"])
+    assert np.array_equal(o1["completion_ids"], o0["completion_ids"]) and np.array_equal(o1["completion_mask"], o0["completion_mask"])
+    m = torch.from_numpy(o1["completion_mask"].astype(bool)).to(DEV)
+    if eos_live:
+        lens = o1["completion_mask"].sum(1)
+        assert (lens < C).any() and (lens == C).any(), lens
+    assert torch.equal(o1["ref_logps"][m], o0["ref_logps"][m]) and torch.equal(o1["logps"][m], o0["logps"][m])
     assert o1["metrics"]["kl"] == o0["metrics"]["kl"] and o1["metrics"]["loss"] == o0["metrics"]["loss"]
+    assert bool(torch.isfinite(g1).all())
     cos = float((g0.double() @ g1.double()) / (g0.double().norm() * g1.double().norm()))
     rel = float((g0 - g1).norm() / g0.norm())
     print(f"[parity] policy mlp rows rebuilt on the side stream vs stored by the decode step: gradient cosine {cos:.7f}, relative difference {rel:.3e}")
