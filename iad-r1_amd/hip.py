@@ -95,22 +95,35 @@ def version() -> int:
     return lib().iadr1_version()
 
 
-def cu_mask_stream(first_cu: int, n_cus: int, total_cus: int | None = None) -> "torch.cuda.ExternalStream":
+def cu_mask_stream(first_cu: int, n_cus: int, total_cus: int | None = None, cus=None) -> "torch.cuda.ExternalStream":
     """A HIP stream confined to CUs [first_cu, first_cu + n_cus) of the driver's numbering (include/iadr1_hip.h iadr1_stream_create_cu_mask: consecutive
-    bits go round-robin over the XCDs, so a multiple of 8 CUs is the same share of every XCD).  The stream is owned by the caller for the life of the process."""
+    bits go round-robin over the XCDs, so a multiple of 8 CUs is the same share of every XCD), or to the explicit list `cus` (e.g. every CU of some XCDs:
+    xcd_cus).  The stream is owned by the caller for the life of the process."""
     import numpy as np
     total = total_cus or torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    if not (0 <= first_cu and n_cus > 0 and first_cu + n_cus <= total):
-        raise ValueError(f"CU range [{first_cu}, {first_cu + n_cus}) outside the device's {total} CUs")
+    if cus is None:
+        if not (0 <= first_cu and n_cus > 0 and first_cu + n_cus <= total):
+            raise ValueError(f"CU range [{first_cu}, {first_cu + n_cus}) outside the device's {total} CUs")
+        cus = range(first_cu, first_cu + n_cus)
+    cus = sorted(set(int(c) for c in cus))
+    if not cus or cus[0] < 0 or cus[-1] >= total:
+        raise ValueError(f"CU list outside the device's {total} CUs")
     words = np.zeros((total + 31) // 32, dtype=np.uint32)
-    for cu in range(first_cu, first_cu + n_cus):
+    for cu in cus:
         words[cu // 32] |= np.uint32(1 << (cu % 32))
     out = np.zeros(1, dtype=np.uint64)
     rc = lib().iadr1_stream_create_cu_mask(words.ctypes.data, len(words), out.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"iadr1_stream_create_cu_mask failed ({rc}): {lib().iadr1_last_error().decode()}")
-    _CU_SHARE[int(out[0])] = n_cus / total
+    _CU_SHARE[int(out[0])] = len(cus) / total
     return torch.cuda.ExternalStream(int(out[0]))
+
+
+def xcd_cus(xcds, total_cus: int | None = None, n_xcd: int = 8) -> list:
+    """Mask bits of every CU of the given XCDs (bit i of a CU mask is CU i // n_xcd of XCD i % n_xcd)."""
+    total = total_cus or torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    xs = set(int(x) for x in xcds)
+    return [i for i in range(total) if i % n_xcd in xs]
 
 
 _CU_SHARE: dict = {}      # raw stream handle -> fraction of the device's CUs a CU-masked stream owns

@@ -6,6 +6,7 @@ from __future__ import annotations
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 from . import hip
@@ -447,15 +448,17 @@ class Segments:
         # rows the (disjoint) segments hold and the range they span: callers skip zero-filling outputs when every row belongs to a segment
         self.rows = int(sum(e - s for s, e in zip(starts, ends)))
         self.lo, self.hi = (int(min(starts)), int(max(ends))) if self.n else (0, 0)
-        self.start = torch.tensor(starts, dtype=torch.int32, device=device)
-        self.end = torch.tensor(ends, dtype=torch.int32, device=device)
+        # (through pinned memory, h2d above: a tensor built from a Python list directly on the device is a pageable copy -- the host would wait for everything enqueued
+        # so far; measured on the co-scheduled 3B step: text_plan_shared blocked for the whole 24 ms tail of the shadow pass)
+        self.start = h2d(np.asarray(starts, dtype=np.int32).reshape(-1), device)
+        self.end = h2d(np.asarray(ends, dtype=np.int32).reshape(-1), device)
         self.start_host, self.end_host = [int(z) for z in starts], [int(z) for z in ends]      # (host copies: reading the device arrays back would drain the stream)
         self.prefix = None
         # launch hint (include/iadr1_hip.h nseg_head / max_seqlen_tail): a leading run of long segments followed by shorter ones
         self.n_head, self.max_tail = 0, 0
         if prefix is not None:
             assert len(prefix) == self.n and all(e > s for s, e in zip(starts, ends)), "shared-prefix segments must be non-empty"
-            self.prefix = torch.tensor(prefix, dtype=torch.int32, device=device).contiguous()
+            self.prefix = h2d(np.ascontiguousarray(np.asarray(prefix, dtype=np.int32).reshape(self.n, 4)), device)
             parents = [i for i, pr in enumerate(prefix) if pr[3] > 0]
             nh = (max(parents) + 1) if parents else 0
             if 0 < nh < self.n and parents == list(range(nh)):

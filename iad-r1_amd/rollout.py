@@ -100,6 +100,7 @@ class Rollout:
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.graph = None
         self._toks_host, self._toks_event = None, None
+        self._join_timed_out = self._join_timed_out_host = None
         self.trace = None           # training arena filled by the decode steps (generate(train_trace=...)); part of the captured graph
         self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -203,6 +204,8 @@ class Rollout:
         N = Bp * G
         assert N == self.N, f"rollout was built for {self.N} sequences, got {N}"
         assert max_new <= self.max_new
+        if self._join_timed_out_host is not None and int(self._join_timed_out_host[0]):
+            raise RuntimeError("Rollout.generate: the counter join of the previous rollout timed out (the decode stream never finished its replays)")
         if dev.type == "cuda":
             ops.hip.set_decode_cus(self.decode_cus)      # process-wide launcher configuration (persistent grids): this rollout's, whatever another engine set since
         self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)   # device-resident: a new seed per rollout does not invalidate the captured graph
@@ -387,7 +390,24 @@ class Rollout:
             self.decode_events.append((ev[0], ev[1], nsteps, int(np.sum(lengths)) * G))
         if ds is not None:
             torch.cuda.set_stream(_outer)
-            _outer.wait_stream(ds)
+            # Join on the HOST: anything left pending on the outer stream's hardware queue while the replays run -- the dependency packet of `_outer.wait_stream(ds)`
+            # (the host is hundreds of replays ahead), or a kernel polling the step counter -- costs every decode launch ~8 us when that queue happens to share a
+            # dispatch pipe with the decode queue: 5.0 instead of 3.0 ms per step (tools/decode_mask_probe.py plain 192, profiles/r05_decode_join.txt).  Which queues
+            # share a pipe depends on the order in which the process created them, so nothing may be pending: the host waits for the last replay (it needs the
+            # tokens next anyway) and enqueues the rest behind it.  IADR1_DECODE_JOIN=event|counter are the A/B forms.
+            join = os.environ.get("IADR1_DECODE_JOIN", "host")
+            if join == "event":
+                _outer.wait_stream(ds)
+            elif join == "counter":
+                if self._join_timed_out is None:
+                    self._join_timed_out = torch.zeros(1, dtype=torch.int32, device=dev)
+                    self._join_timed_out_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                ops.hip.call("wait_counter", self.step, nsteps + 1, 30000, self._join_timed_out)
+                self._join_timed_out_host.copy_(self._join_timed_out, non_blocking=True)      # read at the next generate()
+            else:
+                _je = torch.cuda.Event()
+                _je.record(ds)
+                _je.synchronize()
         toks = self.out_tokens[:, :max_new].clone()
         # the host copy of the tokens leaves BEFORE the shadow pass's tail is enqueued: the caller (rewards, the training batch's plans) waits for the decode replays
         # only, and prepares the next phase while the tail runs (tokens_host)

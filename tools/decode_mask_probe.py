@@ -30,6 +30,11 @@ for c in a.cus:
     if c == "plain":
         hip.set_decode_cus(0)
         split = {}
+    elif c.startswith("x"):       # whole XCDs: x6 = every CU of XCDs 0..5
+        nx = int(c[1:])
+        cus = hip.xcd_cus(range(nx))
+        hip.set_decode_cus(len(cus))
+        split = {"decode_cus": len(cus), "decode_stream": hip.cu_mask_stream(0, 0, cus=cus)}
     else:
         n = int(c)
         hip.set_decode_cus(0 if n == NCU else n)
