@@ -1,6 +1,6 @@
-"""Co-scheduled reference pass (OPT-IN: IADR1_OVERLAP_CUS=64): the frozen reference model's teacher-forced forward + per-token log-probs
-(/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:737-743, `_get_per_token_logps` :384-514 on `ref_model`) run UNDER the group
-rollout (:637-683) instead of after it.
+"""Co-scheduled side pass (IADR1_OVERLAP_CUS=auto: on where `auto_applies`): the frozen reference model's teacher-forced forward + per-token log-probs
+(/root/reference/train/stage_rl/trainer/sc_grpo_trainer.py:737-743, `_get_per_token_logps` :384-514 on `ref_model`), the policy's gate|up / SwiGLU rows and the
+policy's lm_head log-probs of the tokens produced so far run UNDER the group rollout (:637-683) instead of after it.
 
 Why: the rollout is a chain of latency-bound decode steps that leaves the MFMA pipes idle (0.34 of the HBM roofline, no matrix work to speak
 of), the reference forward is MFMA-bound and leaves HBM idle, and the reference's log-prob of completion token j depends only on tokens <= j --
@@ -8,19 +8,21 @@ nothing of the sampled tokens' FUTURE.  The reference runs the two on different 
 REF:scripts/train/SC_GRPO/SC_GRPO_Qwen_Instruct_2_5_VL_3B.sh:40-42); here they share one MI355X: every `steps` decode steps the rows those steps
 produced (N sequences x steps tokens) go through the frozen decoder on a second HIP stream while the decode replay continues on the first.
 
-What it takes on this part, and what it buys (all measured, round 5: profiles/EXPERIMENTS.md, profiles/r05_overlap_*.txt):
-  * two ordinary streams do NOT share the device usefully: a big-grid kernel of the shadow pass holds every CU slot, the decode step's ~250 small dependent
-    launches each wait for slots, and the replay all but stops while a chunk runs (decode window 724 -> 864 ms for 125 ms of shadow work);
-  * disjoint CU masks (hipExtStreamCreateWithCUMask: decode on 192 CUs, shadow on 64) fix that ONLY when the two hardware queues sit on different dispatch
-    pipes of the command processor -- every fourth queue created shares the decode queue's pipe, and then every decode launch waits ~50-70 us behind the
-    other queue's kernel-in-dispatch although the CUs are disjoint (pick_concurrent_stream below finds a clean pair at start-up);
+What it takes on this part, and what it buys (all measured, round 5: profiles/EXPERIMENTS.md, profiles/r05_overlap_ab.txt, r05_decode_join.txt, r05_step_timeline.txt):
+  * two ordinary streams do NOT share the device usefully: a big-grid kernel of the side pass holds every CU slot, the decode step's ~250 small dependent
+    launches each wait for slots, and the replay all but stops while a chunk runs (decode window 724 -> 864 ms for 125 ms of side work);
+  * disjoint CU masks (hipExtStreamCreateWithCUMask: decode on 192 CUs, side pass on 64) fix that ONLY when the two hardware queues sit on different dispatch
+    pipes of the command processor -- every fourth queue created shares the decode queue's pipe, and then every decode launch waits behind whatever is PENDING on the
+    other queue: ~50-70 us behind a big-grid kernel in dispatch, ~8 us behind a lone dependency packet or a one-wave polling kernel (pick_concurrent_stream below finds
+    a clean pair at start-up; Rollout.generate joins the decode stream on the host so that the caller's queue is empty while the replays run);
   * CU-masked streams are BLOCKING streams: with the caller on the null stream every chunk started one chunk period late (SCGRPOEngine.step moves the step
     onto a stream of its own);
   * gating a chunk on an event recorded between two graph launches costs the decode stream 0.06 ms per step; the gate is a one-wave poll of the device step
     counter instead (iadr1_wait_counter);
-  * with all that the shadow pass tracks the rollout exactly (every chunk starts the moment its last token exists, profiles/r05_overlap_phases.txt) and
-    125 ms of reference forward leave the critical path -- but the decode step on 192 CUs costs 3.16 instead of 2.77 ms (x 255), and the last block of rows
-    runs after the rollout: 1249.9 -> 1235.5 / 1243.5 ms per step, +0.5 ... +1.1 %, inside the box-to-box spread.  Hence opt-in, not the default.
+  * the decode step on 192 CUs costs 3.02 instead of 2.80 ms (x 255 = 56 ms per step): what the side stream hides (reference pass ~125 ms, the decode gate|up
+    kernel's two side stores 26 ms, the policy's lm_head 9 ms) has to beat that -- it does for the 2B / 3B models at 64 sequences (1260 -> 1202 ms, +4.7 %; 2B + 8.6 %),
+    not for 7B-class models or small groups (auto_applies);
+  * the host must never block while the side pass's tail runs: index arrays go up through pinned memory (ops.h2d), the tokens leave before the tail is enqueued.
 
 Layout.  Completion rows are TIME-BLOCKED: with block = 2^k steps, row (sequence s, token j) lives at
     n_prompt_rows + (j // block) * N * block + s * block + j % block,
