@@ -286,8 +286,32 @@ constexpr int SMEM2_BYTES = SMEM2_EPI > SMEM2_MAIN ? SMEM2_EPI : SMEM2_MAIN;
 
 #define IADR1_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int OUT>
+// TN form (template flag, OUT_F32 / OUT_F32_ACC only: the weight gradients  dW[M, N] (+)= A[K, M]^T . B[K, N],  A = dY and B = X as they lie in memory, the
+// contraction running over their ROWS): the same pipeline and epilogue; a half-tile image is [64 contraction rows][128 columns] with 256-byte rows (chunk c of
+// row r at chunk position c ^ 2 * tn_rho(r), the swizzle of the attention tiles), filled by the same 2 x 16-byte DMA per thread from row-major sources, and the
+// MFMA fragments -- 8 consecutive contraction elements of one column per lane -- come out of LDS through the hardware transpose read (ds_read_b64_tr_b16, two
+// per fragment: common.h tr_frag_ld).  No transposed copies of dY / X exist anywhere.
+__device__ __forceinline__ int tn_rho(int r) { return (r & 3) | ((r >> 1) & 4); }
+// One MFMA fragment of the TN form: contraction rows 32 kk + {0..3} and {4..7} (+ this lane's row) of the lane's column, two transpose reads at byte offsets
+// kk * 8192 and + 1024.  Inline asm, not the builtin: the compiler orders every LDS-reading INTRINSIC behind all outstanding global_load_lds (it put s_waitcnt
+// vmcnt(0) in front of each group of reads -- the DMA queue drained four times per K tile: 872 instead of 1230 TF/s); the kernel's own counted vmcnt / lgkmcnt
+// waits and barriers are what orders these reads, exactly as for the plain ds_read_b128 of the NT form.
+__device__ __forceinline__ bf16x8_t tr_frag_asm(const char* lds_addr, int kk) {
+    s16x4_t a, b;
+    const unsigned addr = (unsigned)(uintptr_t)lds_ptr(lds_addr);
+    if (kk == 0) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(b) : "v"(addr));
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(a) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(b) : "v"(addr));
+    }
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int OUT, bool TN = false>
 __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
+    static_assert(!TN || OUT == OUT_F32 || OUT == OUT_F32_ACC, "the TN form exists for the fp32 (accumulate) outputs only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -301,8 +325,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
         if (p.ksplit > 1) {      // block-uniform: this block's K slice and its slab of the partial-sum workspace
             const int z = bid / nwg;
             bid -= z * nwg;
-            p.A += (long long)z * p.kslice;
-            p.B += (long long)z * p.kslice;
+            p.A += (long long)z * p.kslice * (TN ? p.lda : 1);
+            p.B += (long long)z * p.kslice * (TN ? p.ldb : 1);
             p.K = min(p.kslice, p.K - z * p.kslice);
             p.C = (float*)p.C + (long long)z * p.zstride;
         }
@@ -317,10 +341,24 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 
     // ---- DMA sources: per half-tile 2 x 16 B per thread ----------------------------------------------------
     const bf16_t* src[4][2];  // [A0, A1, B0, B1][instr]
-    int chunk_k[2];
+    int chunk_k[2];           // NT: element offset of the slot's chunk inside the K tile; TN: the slot's row inside the K tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int L = (i * 8 + w) * 64 + l;   // 16-B slot inside the half-tile image
+        if constexpr (TN) {
+            const int rl = L >> 4, cpos = L & 15;                  // row of the 64-row K tile, chunk POSITION inside its 256-byte row
+            const int cl = (cpos ^ (2 * tn_rho(rl))) * 8;          // first of the 8 half-image columns this slot holds
+            chunk_k[i] = rl;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int acol = m0 + (cl >> 6) * 128 + h * 64 + (cl & 63);     // A half h: output rows wm*128 + h*64 + ..  (columns of A)
+                const int bcol = n0 + h * 128 + cl;      // B half h: 128 CONSECUTIVE columns of B (whole 128-byte lines per DMA row piece; wave wn owns columns
+                                                         // h*128 + wn*32 + .. of the tile, see `coln` in the epilogue -- with the NT form's wn*64 + h*32 + .. a
+                                                         // row piece would be 64 bytes and every line of B would be requested twice)
+                src[h][i] = p.A + (long long)rl * p.lda + min(acol, p.M - 8);
+                src[2 + h][i] = p.B + (long long)rl * p.ldb + min(bcol, p.N - 8);
+            }
+        } else {
         const int rl = L >> 3, c = L & 7;
         const int cs = c ^ ((rl >> 1) & 7);
         chunk_k[i] = cs * 8;
@@ -343,6 +381,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
                 src[2 + h][i] = p.B + (long long)min(n0 + bcol, p.N - 1) * p.ldb + cs * 8;
             }
         }
+        }
     }
     auto stage_half = [&](int buf, int half /*0..3 = A0 A1 B0 B1*/, int kt) {
         char* base = smem + buf * BUF2_BYTES + half * HALF_BYTES;
@@ -350,18 +389,32 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool ok = k0 + chunk_k[i] < p.K;
-            glds16(ok ? (const void*)(src[half][i] + k0) : p.zeros, base + (i * 8 + w) * 1024);
+            if constexpr (TN) glds16(ok ? (const void*)(src[half][i] + (long long)k0 * (half < 2 ? p.lda : p.ldb)) : p.zeros, base + (i * 8 + w) * 1024);
+            else glds16(ok ? (const void*)(src[half][i] + k0) : p.zeros, base + (i * 8 + w) * 1024);
         }
     };
 
     // ---- fragment read offsets inside a half-tile image -------------------------------------------------------
     int a_off[2], b_off[2];  // per k-step; add mi*2048 / ni*2048
+    int ta_off[4], tb_off[2];  // TN: per m-tile / n-tile; add kk*8192 (+1024 for the second four contraction rows)
+    if constexpr (TN) {
+        // lane (lg = l & 15, g = l >> 4) addresses row 8g + (lg >> 2) [+ 32 kk, + 4] and the 8-byte half (lg & 1) of chunk  2 * tile16 + ((lg & 3) >> 1)  of the
+        // half image; tn_rho of that row is ((lg >> 2) & 3) | ((g & 1) << 2) for every kk and both halves of a fragment, so the swizzle is a per-lane constant
+        const int lg = l & 15, g = l >> 4;
+        const int x = 2 * (((lg >> 2) & 3) | ((g & 1) << 2));
+        const int rowpart = (8 * g + (lg >> 2)) * 256 + (lg & 1) * 8, cb = (lg & 3) >> 1;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) ta_off[mi] = rowpart + (((wm * 8 + mi * 2 + cb) ^ x) << 4);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) tb_off[ni] = rowpart + (((wn * 4 + ni * 2 + cb) ^ x) << 4);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int chunk = kk * 4 + (l >> 4);
         const int ra = wm * 64 + (l & 15), rb = wn * 32 + (l & 15);
         a_off[kk] = ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4);
         b_off[kk] = rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4);
+    }
     }
 
     f32x4_t acc[8][4];  // [m-tile][n-tile] of the 128x64 wave tile
@@ -371,28 +424,45 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     bf16x8_t af[4][2], bfr[2][2];  // current A half (4 m-tiles x 2 k-steps), current B half (2 n-tiles x 2 k-steps)
+    bf16x8_t bfr1[TN ? 2 : 1][2];  // TN: B half 1 in registers of its own, so that B half 0 survives phases 2 - 3 and phase 4 reads nothing (transpose reads are the
+                                   // form's bottleneck: 48 instead of 56 per K tile)
     auto read_a = [&](int buf, int h) {
         const char* base = smem + buf * BUF2_BYTES + h * HALF_BYTES;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8_t*)(base + a_off[kk] + mi * 2048);
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (TN) af[mi][kk] = tr_frag_asm(base + ta_off[mi], kk);
+                else af[mi][kk] = *(const bf16x8_t*)(base + a_off[kk] + mi * 2048);
+            }
     };
     auto read_b = [&](int buf, int h) {
         const char* base = smem + buf * BUF2_BYTES + (2 + h) * HALF_BYTES;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) bfr[ni][kk] = *(const bf16x8_t*)(base + b_off[kk] + ni * 2048);
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (TN) {
+                    if (h == 0) bfr[ni][kk] = tr_frag_asm(base + tb_off[ni], kk);
+                    else bfr1[ni][kk] = tr_frag_asm(base + tb_off[ni], kk);
+                } else {
+                    bfr[ni][kk] = *(const bf16x8_t*)(base + b_off[kk] + ni * 2048);
+                }
+            }
     };
-#define IADR1_QUAD(MH, NH)                                                                                                   \
+#define IADR1_QUAD_B(MH, NH, BF)                                                                                             \
     do {                                                                                                                     \
         __builtin_amdgcn_s_setprio(1);                                                                                       \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                     \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                     \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                     \
-            acc[(MH) * 4 + mi][(NH) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni][kk], af[mi][kk], acc[(MH) * 4 + mi][(NH) * 2 + ni], 0, 0, 0); \
+            acc[(MH) * 4 + mi][(NH) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ni][kk], af[mi][kk], acc[(MH) * 4 + mi][(NH) * 2 + ni], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                       \
+    } while (0)
+#define IADR1_QUAD(MH, NH)                                                                                                   \
+    do {                                                                                                                     \
+        if constexpr (TN) { if ((NH) == 0) IADR1_QUAD_B(MH, NH, bfr); else IADR1_QUAD_B(MH, NH, bfr1); }                     \
+        else IADR1_QUAD_B(MH, NH, bfr);                                                                                      \
     } while (0)
 
     const int nk = (p.K + BK - 1) / BK;
@@ -450,7 +520,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
         IADR1_QUAD(1, 1);
         __builtin_amdgcn_s_barrier();
 
-        read_b(cur, 0);
+        if constexpr (!TN) read_b(cur, 0);
         if (more2) { stage_half(cur, 1, kt + 2); IADR1_VMCNT(6); } else if (more1) { IADR1_VMCNT(0); }
         IADR1_LGKM0();
         __builtin_amdgcn_s_barrier();
@@ -460,6 +530,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();
 #undef IADR1_LGKM0
 #undef IADR1_QUAD
+#undef IADR1_QUAD_B
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     const int lm = l & 15, lq = l >> 4;
@@ -640,10 +711,15 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     } else {
         float* C = (float*)p.C;
         const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
-        if (vec_ok && !p.bias && p.act == 0 && m0 + wm * 128 + 128 <= p.M && n0 + wn * 64 + 64 <= p.N) {
+        // first output column of n-tile j of this lane (TN: the wave's 64 columns are two 32-column runs 128 apart, see the B half images)
+        auto coln = [&](int j) -> int {
+            if constexpr (TN) return n0 + (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + lq * 4;
+            else return n0 + wn * 64 + j * 16 + lq * 4;
+        };
+        if (vec_ok && !p.bias && p.act == 0 && m0 + wm * 128 + 128 <= p.M && (TN ? n0 + T2 <= p.N : n0 + wn * 64 + 64 <= p.N)) {
             // interior sub-tile, plain store / accumulate (every wgrad and the lm_head): no predicates, and for the accumulate form the 8 loads
             // of two row groups are in flight together instead of one load -> add -> store round trip per 16 bytes
-            float* base = C + (long long)(m0 + wm * 128 + lm) * p.ldc + n0 + wn * 64 + lq * 4;
+            float* base = C + (long long)(m0 + wm * 128 + lm) * p.ldc;
 #pragma unroll
             for (int i0 = 0; i0 < 8; i0 += 2) {
                 f32x4_t old[2][4];
@@ -651,7 +727,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) old[u][j] = *(const f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + j * 16);
+                        for (int j = 0; j < 4; ++j) old[u][j] = *(const f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + coln(j));
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -659,7 +735,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
                     for (int j = 0; j < 4; ++j) {
                         f32x4_t o = acc[i0 + u][j];
                         if constexpr (OUT == OUT_F32_ACC) o += old[u][j];
-                        *(f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + j * 16) = o;
+                        *(f32x4_t*)(base + (long long)(i0 + u) * 16 * p.ldc + coln(j)) = o;
                     }
             }
             return;
@@ -670,7 +746,7 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
             if (gm >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + wn * 64 + j * 16 + lq * 4;
+                const int gn = coln(j);
                 if (gn >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -1544,6 +1620,41 @@ extern "C" int iadr1_gemm_nt_splitk_acc_bf16(const void* A, const void* B, float
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_acc_kernel, dim3((int)blocks), dim3(256), 0, stream, (const float*)workspace, C, ldc, M, N, ksplit, (long long)M * N);
     return iadr1_check_launch("gemm_nt_splitk (reduce)");
+}
+
+// Weight gradients without transposed copies:  C[M, N] (fp32) += A[K, M]^T . B[K, N]  with A (= dY) and B (= X) row-major as the backward holds them, the contraction
+// over their K rows (gemm_nt_256<.., TN = true>).  ksplit >= 2: the split form above (K slices of whole 64-row tiles, fp32 partial tiles in `workspace` --
+// iadr1_gemm_nt_splitk_workspace_bytes(M, N, ksplit) -- added to C in slice order); ksplit <= 1: one accumulating launch.  Bit-equal to iadr1_gemm_nt_bf16 /
+// iadr1_gemm_nt_splitk_acc_bf16 on transposed copies (same tiles, same order of the contraction).
+extern "C" int iadr1_gemm_tn_acc_bf16(const void* A, const void* B, float* C, void* workspace, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                                      int ksplit, hipStream_t stream) {
+    IADR1_REQUIRE(M >= 256 && N >= 256 && K > 0, "gemm_tn: needs M >= 256, N >= 256, K > 0 (M=%d N=%d K=%d)", M, N, K);
+    IADR1_REQUIRE((M % 8) == 0 && (N % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (N % 4) == 0 && (ldc % 4) == 0, "gemm_tn: M, N, lda, ldb multiples of 8, ldc a multiple of 4");
+    IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 && (((uintptr_t)C) & 15) == 0, "gemm_tn: A, B, C must be 16-byte aligned");
+    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    static const bool attr_done = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32_ACC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+        return true;
+    }();
+    (void)attr_done;
+    const int tiles = ((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
+    if (ksplit <= 1) {
+        GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, zeros_ptr(), M, N, K, lda, ldb, ldc, 0, band_rows, nullptr, 0};
+        hipLaunchKernelGGL((gemm_nt_256<OUT_F32_ACC, true>), dim3(tiles), dim3(NT2), SMEM2_BYTES, stream, p);
+        return iadr1_check_launch("gemm_tn_acc_bf16");
+    }
+    IADR1_REQUIRE(workspace && (((uintptr_t)workspace) & 15) == 0, "gemm_tn: the split form needs a 16-byte aligned workspace");
+    const int kslice = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;      // whole 64-row K tiles per slice
+    IADR1_REQUIRE((long long)(ksplit - 1) * kslice < K, "gemm_tn: ksplit %d leaves an empty slice for K = %d", ksplit, K);
+    GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, workspace, nullptr, zeros_ptr(), M, N, K, lda, ldb, (long long)N, 0, band_rows, nullptr, 0};
+    p.ksplit = ksplit; p.kslice = kslice; p.zstride = (long long)M * N;
+    hipLaunchKernelGGL((gemm_nt_256<OUT_F32, true>), dim3(tiles * ksplit), dim3(NT2), SMEM2_BYTES, stream, p);
+    if (int rc = iadr1_check_launch("gemm_tn (partials)")) return rc;
+    long long blocks = ((long long)M * (N / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_acc_kernel, dim3((int)blocks), dim3(256), 0, stream, (const float*)workspace, C, ldc, M, N, ksplit, (long long)M * N);
+    return iadr1_check_launch("gemm_tn (reduce)");
 }
 
 // linear_logprob: logp[r] = log_softmax(H[r] . W^T)[targets[r]] and lse[r] without the [M, V] logits ever reaching HBM (gemm_nt_256 with the OUT_LSE

@@ -81,9 +81,10 @@ extern "C" int iadr1_stream_destroy(void* stream) {
 }
 
 extern "C" const char* iadr1_last_error(void) { return g_err; }
+// 108: round 5 -- iadr1_gemm_tn_acc_bf16 (weight gradients from row-major dY / X: the 256 x 256 kernel with transpose reads out of LDS, no transposed copies)
 // 107: round 5 -- iadr1_gemm_swiglu_rows_bf16 (row-blocked fused gate|up + SwiGLU: the policy's mlp rows of a chunk of decode steps, rebuilt on the side stream)
 // 106: round 5 -- CU-masked streams, decode CU count, iadr1_attn_fwd_chunk, iadr1_wait_counter (co-scheduled rollout / teacher-forced forward); ordered two-stage
 //      gradient reductions: workspace arguments on iadr1_rmsnorm_bwd / iadr1_layernorm_bwd / iadr1_colsum_acc, iadr1_rows_scatter_acc replaces iadr1_embed_bwd
 // 104: round 4 -- iadr1_decode_advance gained the all_done / rotary-table arguments, the FP8-MFMA pair (iadr1_quant_rows_fp8, iadr1_gemm_nt_fp8) is gone
-extern "C" int iadr1_version(void) { return 107; }
+extern "C" int iadr1_version(void) { return 108; }
 

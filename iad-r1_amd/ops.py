@@ -52,6 +52,29 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
+_GEMM_TN = os.environ.get("IADR1_GEMM_TN", "1")      # 0: never; 1: split-K shapes only (probe); 2: every shape the 256 x 256 kernel takes
+
+
+def gemm_tn_acc(dy, x, out):
+    """out[N, K] (fp32) += dy[T, N]^T @ x[T, K] -- a weight gradient from the two operands as the backward holds them (include/iadr1_hip.h iadr1_gemm_tn_acc_bf16: no
+    transposed copies) where the 256 x 256 kernel is the one gemm_nt would run on the transposed copies; otherwise (small / ragged shapes, IADR1_GEMM_TN=0) the
+    transposes + gemm_nt(accumulate).  Same bits either way."""
+    T, N = dy.shape
+    T2, K = x.shape
+    assert T == T2 and dy.dtype == BF16 and x.dtype == BF16 and out.dtype == F32 and tuple(out.shape) == (N, K)
+    if _GEMM_TN != "0" and N >= 256 and K >= 256 and N % 8 == 0 and K % 8 == 0 and _ld(dy) % 8 == 0 and _ld(x) % 8 == 0 and _ld(out) % 4 == 0:
+        Tp = (T + 7) // 8 * 8                      # (what the transposed form contracts over: rows padded to 8)
+        ks = splitk_slices(N, K, Tp)
+        tiles = ((N + 255) // 256) * ((K + 255) // 256)
+        if ks > 1:
+            hip.call("gemm_tn_acc_bf16", dy, x, out, _splitk_workspace(ks * N * K, dy.device), N, K, T, _ld(dy), _ld(x), _ld(out), ks)
+            return out
+        if _GEMM_TN == "2" and N >= 512 and K >= 512 and tiles >= 192:
+            hip.call("gemm_tn_acc_bf16", dy, x, out, None, N, K, T, _ld(dy), _ld(x), _ld(out), 1)
+            return out
+    return gemm_nt(transpose(dy, pad_rows_to=8), transpose(x, pad_rows_to=8), out=out, accumulate=True)
+
+
 _SPLITK = os.environ.get("IADR1_GEMM_SPLITK", "1") != "0"
 _splitk_ws = {}
 

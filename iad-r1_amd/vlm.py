@@ -672,7 +672,8 @@ class Engine:
         return s
 
     def _wgrad(self, name, dy, x, slot=None):
-        """grad[name] ([N,K] fp32) += dy[T,N]^T . x[T,K]   (NT kernel on transposed copies).
+        """grad[name] ([N,K] fp32) += dy[T,N]^T . x[T,K]   (ops.gemm_tn_acc: the TN form of the 256 x 256 kernel straight from dy / x; transposed copies + the NT
+        kernel only for small / ragged shapes).
         slot: dy lives in a `_Ring` slot (static scratch): the slot is marked busy until the side stream has read it, instead of a record_stream mark.
         Weight gradients are leaves of the backward graph: by default they (transposes + GEMM) are issued on a side stream, so the dgrad chain
         on the main stream never waits for them and the two queues fill each other's tile-quantisation tails and launch bubbles (a 640-tile
@@ -680,11 +681,11 @@ class Engine:
         no gain, the win is GEMM/GEMM overlap.  IADR1_WGRAD_STREAM=0 issues everything on one stream (exclusive per-launch timings)."""
         ws = self.wgrad_stream
         if ws is None:
-            ops.gemm_nt(ops.transpose(dy, pad_rows_to=8), ops.transpose(x, pad_rows_to=8), out=self.p.g(name), accumulate=True)
+            ops.gemm_tn_acc(dy, x, self.p.g(name))
             return
         ws.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ws):
-            ops.gemm_nt(ops.transpose(dy, pad_rows_to=8), ops.transpose(x, pad_rows_to=8), out=self.p.g(name), accumulate=True)
+            ops.gemm_tn_acc(dy, x, self.p.g(name))
         if slot is not None:
             slot[0].busy(slot[1], ws)
         else:
@@ -1135,7 +1136,6 @@ class Engine:
         fused = kept is None and self.head_mode == "fused"
         lg_buf = None if kept is not None or fused else self._workspace("lm_logits", (nc, V), F32)
         dl_buf = self._workspace("lm_dlogits", (nc, V), BF16)
-        dlT_buf = self._workspace("lm_dlogits_t", (V, (nc + 7) // 8 * 8), BF16)
         for r0 in range(0, R, self.lm_chunk):
             r1 = min(R, r0 + self.lm_chunk)
             n = r1 - r0
@@ -1145,12 +1145,7 @@ class Engine:
                 lg = kept[r0:r1] if kept is not None else ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[:n])
                 dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1], out=dl_buf[:n])
             ops.gemm_nt(dl, WT, out=dhsel[r0:r1])
-            np8 = (n + 7) // 8 * 8
-            dlT = dlT_buf[:, :np8]
-            if np8 != n:
-                dlT[:, n:].zero_()
-            ops.transpose(dl, out=dlT)
-            ops.gemm_nt(dlT, ops.transpose(hsel[r0:r1], pad_rows_to=8), out=self.p.g(name), accumulate=True)
+            ops.gemm_tn_acc(dl, hsel[r0:r1], self.p.g(name))          # dW_head += dl^T . h  (no [V, n] transposed copy of the logit gradients)
         # scatter back onto the token rows: dhf[t] = sum of the selected rows that read hidden row t (0 for rows nothing read)
         ptr, idx = ctx["scatter"]
         return ops.rows_gather_sum(dhsel, ptr, idx, ctx["T"])

@@ -71,6 +71,13 @@ int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const void* bias, 
 long long iadr1_gemm_nt_splitk_workspace_bytes(int M, int N, int ksplit);
 int iadr1_gemm_nt_splitk_acc_bf16(const void* A, const void* B, float* C, void* workspace, int M, int N, int K, long long lda, long long ldb,
                                   long long ldc, int ksplit, iadr1_stream_t stream);
+/* Weight gradients WITHOUT transposed copies:  C[M,N] (fp32) += A[K,M]^T . B[K,N]  with A (= dY) and B (= X) row-major as the backward holds them, the contraction over
+ * their K rows (the 256 x 256 kernel with hardware transpose reads out of LDS, ds_read_b64_tr_b16).  ksplit >= 2: K slices of whole 64-row tiles, fp32 partial tiles in
+ * `workspace` (iadr1_gemm_nt_splitk_workspace_bytes(M, N, ksplit)), added to C in slice order; ksplit <= 1: one accumulating launch (workspace unused).  M, N >= 256 and
+ * multiples of 8.  Bit-equal to iadr1_gemm_nt_bf16 (out_mode 2) / iadr1_gemm_nt_splitk_acc_bf16 on transposed copies.  Replaces autograd's weight-gradient matmuls of every
+ * Linear on the path (TF:552-554, 660-700 backward; REF:train/stage_rl/trainer/sc_grpo_trainer.py:794 `loss.backward()` via accelerate). */
+int iadr1_gemm_tn_acc_bf16(const void* A, const void* B, float* C, void* workspace, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                           int ksplit, iadr1_stream_t stream);
 /* gate|up projection + SwiGLU in one launch (training / prefill shapes): GU[M, 2I] = A[M,K] . W[2I,K]^T is stored when GU != NULL (the backward
  * pass reads it), Aout[M, I] = bf16(silu(gate)) * up with gate = GU[:, :I], up = GU[:, I:], computed in the GEMM epilogue from the rounded gate|up
  * values: bit-identical to iadr1_gemm_nt_bf16 followed by iadr1_swiglu_fwd.  M %% 256 == 0, I %% 128 == 0.  Replaces TF:552-554

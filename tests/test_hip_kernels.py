@@ -740,6 +740,33 @@ def test_gemm_swiglu_rows_equals_the_plain_launch_on_gathered_rows(nseq, block, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K,T", [(2560, 2048, 12288), (22016, 2048, 4096), (2048, 11008, 20480), (2568, 2048, 4100), (22024, 2056, 1000), (1280, 1280, 8192)])
+def test_gemm_tn_acc_is_bit_identical_to_the_transposed_nt_form(N, K, T):
+    """iadr1_gemm_tn_acc_bf16 (weight gradient straight from row-major dY [T, N] and X [T, K]: hardware transpose reads out of LDS) vs the two transposes +
+    gemm_nt(accumulate) -- plain and split-K launches, ragged T (not a multiple of 64 / of 8), N / K that are not multiples of 256: the same bits, accumulated
+    onto a non-zero gradient buffer; row strides larger than the width (views of wider buffers)."""
+    g = torch.Generator(device="cpu").manual_seed(N + K + T)
+    dyb = (torch.randn(T, N + 8, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    xb = (torch.randn(T, K + 16, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    dy, x = dyb[:, :N], xb[:, :K]
+    base = torch.randn(N, K, generator=g).cuda()
+    want = ops.gemm_nt(ops.transpose(dy, pad_rows_to=8), ops.transpose(x, pad_rows_to=8), out=base.clone(), accumulate=True)
+    got = base.clone()
+    calls = []
+    orig, mode = ops.hip.call, ops._GEMM_TN
+    ops.hip.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    ops._GEMM_TN = "2"                                               # every shape the 256 x 256 kernel takes
+    try:
+        ops.gemm_tn_acc(dy, x, got)
+    finally:
+        ops.hip.call, ops._GEMM_TN = orig, mode
+    assert calls == ["gemm_tn_acc_bf16"], calls                     # the TN kernel is what ran (no transposes)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    ref = base.double() + dy.double().t() @ x.double()
+    assert float((got.double() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
 def test_decode_side_outputs_equal_the_main_outputs():
     """iadr1_side_out_t (`side` argument of the four decode-step entry points): every kernel that carries side outputs writes, at row
     base + s * stride + *step of row-major training buffers, exactly what its main (decode-packed / paged) output holds; without `side` nothing else
