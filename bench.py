@@ -104,7 +104,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)     # (the caching allocator settles in the SECOND step: 7 device allocations there, none later -- tools/alloc_steps.py)
     ap.add_argument("--model", default="3b", choices=["3b", "7b", "qwen2vl_2b", "llava_ov_7b", "llava15_7b", "llava_next_7b", "tiny"])
     ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the rollout streams gate|up / down / lm_head as e4m3 + per-row scales (opt-in, BASELINE config 5; NOT the headline precision)")
