@@ -52,13 +52,15 @@ def gemm_nt(a, b, bias=None, out=None, out_dtype=BF16, accumulate=False, act=0):
     return out
 
 
-_GEMM_TN = os.environ.get("IADR1_GEMM_TN", "1")      # 0: never; 1: split-K shapes only (probe); 2: every shape the 256 x 256 kernel takes
+_GEMM_TN = os.environ.get("IADR1_GEMM_TN", "auto")   # 0: never; 1: the split-K shapes only; 2: every shape the 256 x 256 kernel takes; auto: 2 where the caller asks for it
+                                                     # (the PA-SFT engine), else 1 -- profiles/r05_gemm_tn.txt: PA-SFT 358.9 / 354.7 / 351.3 ms, SC-GRPO 1205.7 / 1198.9 / 1207.6
 
 
-def gemm_tn_acc(dy, x, out):
+def gemm_tn_acc(dy, x, out, wide=False):
     """out[N, K] (fp32) += dy[T, N]^T @ x[T, K] -- a weight gradient from the two operands as the backward holds them (include/iadr1_hip.h iadr1_gemm_tn_acc_bf16: no
     transposed copies) where the 256 x 256 kernel is the one gemm_nt would run on the transposed copies; otherwise (small / ragged shapes, IADR1_GEMM_TN=0) the
-    transposes + gemm_nt(accumulate).  Same bits either way."""
+    transposes + gemm_nt(accumulate).  Same bits either way.  wide: also the shapes with enough output tiles for an un-split launch (gate|up, lm_head: the TN
+    kernel runs at 88 % of the NT kernel's rate, so there it pays only where the transposes are not hidden under another stream's GEMMs)."""
     T, N = dy.shape
     T2, K = x.shape
     assert T == T2 and dy.dtype == BF16 and x.dtype == BF16 and out.dtype == F32 and tuple(out.shape) == (N, K)
@@ -69,7 +71,7 @@ def gemm_tn_acc(dy, x, out):
         if ks > 1:
             hip.call("gemm_tn_acc_bf16", dy, x, out, _splitk_workspace(ks * N * K, dy.device), N, K, T, _ld(dy), _ld(x), _ld(out), ks)
             return out
-        if _GEMM_TN == "2" and N >= 512 and K >= 512 and tiles >= 192:
+        if (_GEMM_TN == "2" or (_GEMM_TN == "auto" and wide)) and N >= 512 and K >= 512 and tiles >= 192:
             hip.call("gemm_tn_acc_bf16", dy, x, out, None, N, K, T, _ld(dy), _ld(x), _ld(out), 1)
             return out
     return gemm_nt(transpose(dy, pad_rows_to=8), transpose(x, pad_rows_to=8), out=out, accumulate=True)

@@ -132,6 +132,7 @@ class Engine:
         self.lm_chunk = 4096
         # side stream of the weight-gradient GEMMs (_wgrad).  Same priority as the main stream: measured with the dgrad chain on a high-priority stream
         # (torch priority -1; the range here is (0, -1)): 1294-1306 ms/step against 1272 -- the starved wgrad queue lengthens the join at the end
+        self.wgrad_tn_wide = False      # ops.gemm_tn_acc(wide=...): the owner sets it (sft.SFTEngine: True)
         # (which pool stream -- hardware queue -- the side stream is does not matter for two ordinary streams: PA-SFT 3B 356.4 - 358.4 ms per step over six choices)
         self.wgrad_stream = torch.cuda.Stream() if (self.dev.type == "cuda" and os.environ.get("IADR1_WGRAD_STREAM", "1") != "0") else None
         self.keep_logits_bytes = 24 << 30
@@ -681,11 +682,11 @@ class Engine:
         no gain, the win is GEMM/GEMM overlap.  IADR1_WGRAD_STREAM=0 issues everything on one stream (exclusive per-launch timings)."""
         ws = self.wgrad_stream
         if ws is None:
-            ops.gemm_tn_acc(dy, x, self.p.g(name))
+            ops.gemm_tn_acc(dy, x, self.p.g(name), wide=self.wgrad_tn_wide)
             return
         ws.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(ws):
-            ops.gemm_tn_acc(dy, x, self.p.g(name))
+            ops.gemm_tn_acc(dy, x, self.p.g(name), wide=self.wgrad_tn_wide)
         if slot is not None:
             slot[0].busy(slot[1], ws)
         else:
@@ -1145,7 +1146,7 @@ class Engine:
                 lg = kept[r0:r1] if kept is not None else ops.gemm_nt(hsel[r0:r1], W, out=lg_buf[:n])
                 dl = ops.dlogits_rows(lg, targets[r0:r1], lse[r0:r1], g[r0:r1], out=dl_buf[:n])
             ops.gemm_nt(dl, WT, out=dhsel[r0:r1])
-            ops.gemm_tn_acc(dl, hsel[r0:r1], self.p.g(name))          # dW_head += dl^T . h  (no [V, n] transposed copy of the logit gradients)
+            ops.gemm_tn_acc(dl, hsel[r0:r1], self.p.g(name), wide=self.wgrad_tn_wide)          # dW_head += dl^T . h  (no [V, n] transposed copy of the logit gradients)
         # scatter back onto the token rows: dhf[t] = sum of the selected rows that read hidden row t (0 for rows nothing read)
         ptr, idx = ctx["scatter"]
         return ops.rows_gather_sum(dhsel, ptr, idx, ctx["T"])
