@@ -403,6 +403,9 @@ class ChunkedRefPass:
         """Decode steps after which a chunk is handed to the side stream: every `steps`, and once more one block before the end, so that what is left when the
         rollout ends (it runs on the caller's stream, on the whole device: finish) is one block of rows."""
         b = set(range(self.steps, C, self.steps))
+        until = int(os.environ.get("IADR1_OVERLAP_UNTIL", "0"))      # (probe: hand only the chunks up to this decode step to the side stream; the rest runs after the rollout)
+        if until > 0:
+            return {x for x in b if x <= until}
         tail = os.environ.get("IADR1_OVERLAP_TAIL", "auto")
         if C - BLOCK > 0 and (tail == "block" or (tail == "auto" and self.policy is None)):
             b.add(C - BLOCK)
