@@ -1957,6 +1957,43 @@ def test_co_scheduling_is_on_by_default_at_the_bench_shape_and_changes_no_forwar
     assert cos > 0.9999, cos
 
 
+def test_weight_gradient_forms_leave_the_same_bits(monkeypatch):
+    """The three ways a weight gradient is formed -- transposed copies + the NT kernel (IADR1_GEMM_TN=0), the TN kernel straight from row-major dY / X for the split-K
+    shapes (1) or for every shape the 256 x 256 kernel takes (2; what the PA-SFT engine runs) -- leave the SAME BITS in the whole gradient buffer of a PA-SFT step at the
+    3B widths (2 layers, 8 rows x ~600 tokens = 4.9 k token rows: q|k|v, o, down through the split-K form, gate|up and the 151 936-row lm_head through the plain one)."""
+    import dataclasses
+    from iadr1_amd import ops
+    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
+    cd = _oracle_cfg_dict(cfg)
+    grids = [(1, 16, 16), (1, 16, 12), (1, 16, 16), (1, 12, 16)] * 2
+    rows = [fx.synth_prompt(grids[k], 520 + 7 * k, cd, 5 + k) for k in range(8)]
+    ids, mask = fx.left_pad(rows, cfg.pad_token_id)
+    ids, mask = np.asarray(ids), np.asarray(mask)
+    assert ids.size >= 4608
+    labels = np.where((np.arange(ids.shape[1])[None, :] >= ids.shape[1] - 120) & (mask != 0), ids, -100)
+    batch = {"input_ids": ids, "attention_mask": mask, "labels": labels, "pixel_values": fx.synth_pixel_values(grids, cd, seed=5), "image_grid_thw": grids}
+    p = ParamStore(cfg, DEV, trainable=True)
+    p.init_random(seed=3)
+    grads, calls = {}, {}
+    orig = ops.hip.call
+    for mode in ("0", "1", "2"):
+        monkeypatch.setattr(ops, "_GEMM_TN", mode)
+        seen = []
+        ops.hip.call = lambda name, *a, _s=seen: (_s.append(name), orig(name, *a))[1]
+        try:
+            p.grad.zero_()
+            eng = SFTEngine(cfg, p, SFTArgs(learning_rate=1e-5, weight_decay=0.0, max_grad_norm=0.0))
+            eng.loss_and_grads(batch)
+            torch.cuda.synchronize()
+        finally:
+            ops.hip.call = orig
+        grads[mode], calls[mode] = p.grad.clone(), seen
+    assert "gemm_tn_acc_bf16" not in calls["0"] and calls["1"].count("gemm_tn_acc_bf16") > 0 and calls["2"].count("gemm_tn_acc_bf16") > calls["1"].count("gemm_tn_acc_bf16")
+    assert calls["2"].count("transpose_bf16") < calls["1"].count("transpose_bf16") < calls["0"].count("transpose_bf16")
+    assert float(grads["0"].abs().sum()) > 0
+    assert torch.equal(grads["0"], grads["1"]) and torch.equal(grads["0"], grads["2"])
+
+
 def test_full_size_3b_parity_at_the_headline_shape_forward():
     """Driver-witnessed parity AT THE BENCHMARK'S SHAPE (VERDICT r4 #2a): the unreduced Qwen2.5-VL-3B (36 + 32 layers, 151 936-token head), one prompt of 448 x 448
     image + 512 positions, G = 8 completions of 256 tokens sampled by the engine's own hipGraph rollout (one row cut by EOS), policy = reference x (1 + 2 % noise):
