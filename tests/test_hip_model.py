@@ -1909,20 +1909,25 @@ def test_policy_mlp_rows_rebuilt_under_the_rollout(monkeypatch, steps, cus, eos_
     assert cos > 0.9999 and rel < 1.5e-2, (cos, rel)
 
 
-def test_co_scheduling_is_on_by_default_at_the_bench_shape_and_changes_no_forward_bit(monkeypatch):
+@pytest.mark.parametrize("full_depth", [False, True])
+def test_co_scheduling_is_on_by_default_at_the_bench_shape_and_changes_no_forward_bit(monkeypatch, full_depth):
     """IADR1_OVERLAP_CUS unset (= auto): at the benchmark's shape class (hidden <= 2048, 8 prompts x G 8 = 64 sequences, C a multiple of 64) SCGRPOEngine.step
     co-schedules the reference pass on 64 CUs with the decode replays on the other 192 and rebuilds the policy's mlp rows there; against IADR1_OVERLAP_CUS=0 (the
     reference pass after the rollout): same tokens, BIT-equal log-probs of both models, KL and loss; gradients equal to the bf16 rounding of the rebuilt gate|up
-    rows.  Small shapes stay un-co-scheduled (overlap.auto_applies).  3B widths, 2 layers."""
+    rows.  Small shapes stay un-co-scheduled (overlap.auto_applies).  3B widths; 2 layers, and the UNREDUCED model (36 decoder + 32 vision layers: the chunked
+    attention, the time-blocked rows and the side-stream lm_head through the whole depth; policy and reference independently initialised)."""
     import dataclasses
     from iadr1_amd import overlap
-    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
+    cfg = VLMConfig.qwen25vl_3b() if full_depth else dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
     assert overlap.auto_applies(cfg, 64, 256) and not overlap.auto_applies(cfg, 8, 512) and not overlap.auto_applies(VLMConfig.qwen25vl_7b(), 64, 256)
     ref = ParamStore(cfg, DEV, trainable=False)
     ref.init_random(seed=0)
-    w_ref = {k: v.float().numpy() for k, v in ref.export_named().items()}
     pol = ParamStore(cfg, DEV, trainable=True)
-    pol.load_named(fx.perturb_weights(w_ref, 1, scale=0.25))
+    if full_depth:
+        pol.init_random(seed=1)
+    else:
+        w_ref = {k: v.float().numpy() for k, v in ref.export_named().items()}
+        pol.load_named(fx.perturb_weights(w_ref, 1, scale=0.25))
     G, C, Bp = 8, 128, 8
     cd = _oracle_cfg_dict(cfg)
     grids = [(1, 16, 16), (1, 16, 12)] * 4
@@ -1953,8 +1958,11 @@ def test_co_scheduling_is_on_by_default_at_the_bench_shape_and_changes_no_forwar
     assert np.array_equal(o1["completion_ids"], o0["completion_ids"])
     assert torch.equal(o1["ref_logps"], o0["ref_logps"]) and torch.equal(o1["logps"], o0["logps"])
     assert o1["metrics"]["kl"] == o0["metrics"]["kl"] and o1["metrics"]["loss"] == o0["metrics"]["loss"]
-    cos = float((g0.double() @ g1.double()) / (g0.double().norm() * g1.double().norm()))
-    assert cos > 0.9999, cos
+    step_ = 1 << 27                      # (chunked: torch's dot takes at most 2^31 - 1 elements, the full model has 3.75 G)
+    dot = lambda a, b: sum(float((a[k: k + step_].double() * b[k: k + step_].double()).sum()) for k in range(0, a.numel(), step_))
+    cos = dot(g0, g1) / (dot(g0, g0) * dot(g1, g1)) ** 0.5
+    print(f"[parity] co-scheduled vs sequential step ({'36 + 32' if full_depth else '2 + 2'} layers): forward bits equal, gradient cosine {cos:.7f}")
+    assert cos > (0.9995 if full_depth else 0.9999), cos       # (measured 0.99983 through 36 layers of rebuilt gate|up rows, 0.99999 through 2)
 
 
 def test_weight_gradient_forms_leave_the_same_bits(monkeypatch):
