@@ -39,11 +39,25 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
+def _newest_profile(suffix: str):
+    """profiles/rNN_<suffix> with the highest round NN (the counters / records of the newest build that re-took them), or None."""
+    import re
+    best = None
+    try:
+        for f in os.listdir(os.path.join(ROOT, "profiles")):
+            m = re.fullmatch(r"r(\d+)_" + re.escape(suffix), f)
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), f)
+    except OSError:
+        pass
+    return best[1] if best else None
+
+
 def _skinny_pmc():
     """HBM-side bytes of the decode step from the PMC passes recorded under profiles/ (3B shapes): every kernel of the step (r02_decode_pmc.json: FETCH / WRITE per
     kernel, summed over the launches of one step), else the heaviest kernel alone (r01_skinny_pmc.json)."""
     try:
-        rec = next(f for f in ("r04_decode_pmc.json", "r03_decode_pmc.json", "r02_decode_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        rec = _newest_profile("decode_pmc.json")
         d = json.load(open(os.path.join(ROOT, "profiles", rec)))
         attn = next(k for k in d["kernels"] if "attn_decode" in k["kernel"])
         steps = attn["launches"] / 36.0
@@ -53,12 +67,14 @@ def _skinny_pmc():
                 "kv_bytes_fetched_per_step": kv_fetched,
                 "kv_note": ("bytes the paged-attention launches of one step pull through the L2's fabric side: the G sequences of a prompt group share their prompt's pages and run on one "
                             "XCD, so its L2 serves all but the first reader -- a fraction of the ALGORITHMIC K/V bytes (every sequence reading its whole context) counted in `achieved`"),
-                "source": f"profiles/{rec} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)"}
+                "source": f"profiles/{rec} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)", "round": int(rec[1:3]),
+                "decode_cus_profiled": d.get("decode_cus")}
     except Exception:
         pass
     try:
-        k = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r04_skinny_pmc.json", "r03_skinny_pmc.json", "r01_skinny_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f))))))
-        return {"kernel": k["kernel"], "bytes_per_launch": k["traffic_bytes"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"], "MNK": k["MNK"], "source": "profiles/r01_skinny_pmc.json"}
+        rec = _newest_profile("skinny_pmc.json")
+        k = json.load(open(os.path.join(ROOT, "profiles", rec)))
+        return {"kernel": k["kernel"], "bytes_per_launch": k["traffic_bytes"], "algorithmic_bytes_per_launch": k["algorithmic_bytes"], "MNK": k["MNK"], "source": "profiles/" + rec, "round": int(rec[1:3])}
     except Exception:
         return None
 
@@ -66,7 +82,7 @@ def _skinny_pmc():
 def power_limit():
     """Shader clock and socket power under a back-to-back gemm_nt stream, from the newest record tools/gemm_power.py left under profiles/ (a separate run: rocm-smi
     sampling next to the bench would perturb it)."""
-    for f in ("r05_gemm_power.json",):
+    for f in (_newest_profile("gemm_power.json"),):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
             d["dense_bf16_peak_at_that_clock_tflops"] = MFMA_BF16_DENSE_PEAK_TFLOPS * d["sclk_mhz_under_gemm_stream"] / 2400.0
@@ -1361,16 +1377,17 @@ def main():
         # HBM-side traffic of the heaviest GEMM shape and the MFMA-pipe busy fraction from the PMC passes recorded under profiles/ (separate rocprofv3
         # --pmc runs, gfx950 FETCH_SIZE correction applied there); null when the record is absent
         traffic = None
-        pmc_file = next((f for f in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+        pmc_file = _newest_profile("gemm_pmc.json")
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             k0 = pmc["kernels"][0]
-            traffic = {"bytes_per_launch": k0["traffic_bytes"], "algorithmic_bytes_per_launch": k0["algorithmic_bytes"], "MNK": k0["MNK"], "source": "profiles/" + pmc_file}
+            traffic = {"bytes_per_launch": k0["traffic_bytes"], "algorithmic_bytes_per_launch": k0["algorithmic_bytes"], "MNK": k0["MNK"], "source": "profiles/" + pmc_file, "round": int(pmc_file[1:3]),
+                       "other_forms": [{"kernel": k.get("kernel"), "MNK": k.get("MNK"), "traffic_bytes": k.get("traffic_bytes"), "algorithmic_bytes": k.get("algorithmic_bytes")} for k in pmc["kernels"][1:]]}
         except Exception:
             pass
         mfma_busy = None
         try:
-            mb_file = next(f for f in ("r04_mfma_busy.json", "r03_mfma_busy.json", "r02_mfma_busy.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            mb_file = _newest_profile("mfma_busy.json")
             mb = json.load(open(os.path.join(ROOT, "profiles", mb_file)))
             g0 = next(k for k in mb["kernels"] if "gemm_nt_256<0>" in k.get("kernel", "") and k.get("grid") == 3522560)
             mfma_busy = {"kernel": "gemm_nt_256 [20480 x 22016 x 2048]", "mfma_busy_frac": g0["mfma_busy_frac"], "lds_conflict_frac": g0.get("lds_conflict_frac"),
@@ -1444,11 +1461,12 @@ def main():
                 # The QUOTED baseline is the one complete full-size step of the same oracle (bench.py --cpu-full-step: ~12 minutes of host time and 127 GB, run once on the
                 # GPU box's host, committed under profiles/): the bounded component sample of this run -- each component timed in isolation, multiplied by its count -- is
                 # 2.1-2.5x optimistic and is carried beside it as `live_component_sample`, so that a change of host shows up.
-                full = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_full_step.json")))["cpu_full_step"]
+                full_file = _newest_profile("cpu_full_step.json")
+                full = json.load(open(os.path.join(ROOT, "profiles", full_file)))["cpu_full_step"]
                 out["cpu_baseline"] = {"value": full["value"], "unit": "samples/s", "cores": full["cores"], "kind": "port", "seconds_per_step_B1_G8": full["seconds_per_step_B1_G8"],
                                        "sample": ("ONE complete B=1 x G=8 SC-GRPO step of the oracle at full Qwen2.5-VL-3B size (P=512, C=256), nothing extrapolated, measured once on this pool's "
-                                                  "GPU-box host with bench.py --cpu-full-step (profiles/r03_cpu_full_step.json); this run's own bounded sample: live_component_sample"),
-                                       "parts_seconds": full.get("parts_seconds"), "source": "profiles/r03_cpu_full_step.json",
+                                                  "GPU-box host with bench.py --cpu-full-step (profiles/" + full_file + "); this run's own bounded sample: live_component_sample"),
+                                       "parts_seconds": full.get("parts_seconds"), "source": "profiles/" + full_file, "round": int(full_file[1:3]),
                                        "live_component_sample": live, "live_over_record": live["value"] / full["value"]}
             except Exception:
                 pass

@@ -109,6 +109,8 @@ struct SideOut {                   // same layout as iadr1_side_out_t
     void* p2; long long ld2;
     const unsigned* step;          // device-resident decode step counter; nullptr = side outputs off
     long long base, seq_stride;
+    unsigned* mark;                // progress word of the decode step (iadr1_rmsnorm_fwd, few-row kernel): *mark = *step * mark_mul + mark_add at kernel entry; nullptr = none
+    unsigned mark_mul, mark_add;
 };
 // the caller's struct (host memory, may be null) -> the by-value kernel argument; argument checks in runtime.hip
 int iadr1_side_arg(const void* side, SideOut* out);

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_row_kernel(RmsFwdArgs p, Side
     __shared__ float scratch[16];
     const int row = blockIdx.x, t = threadIdx.x;
     const long long sb = side_base(so), srow = sb + (long long)row * so.seq_stride;
+    // progress mark of the decode step (the first kernel of a decoder layer: paces iadr1_weight_prefetch); write-through, nothing waits for it
+    if (so.mark && row == 0 && t == 0) __hip_atomic_store(so.mark, (unsigned)(sb - so.base) * so.mark_mul + so.mark_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nchunk = p.H >> 3;
     constexpr int MC = 4;  // H <= 8192
     float v[MC][8];

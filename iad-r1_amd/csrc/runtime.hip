@@ -39,8 +39,10 @@ int iadr1_env_int(const char* name, int dflt) {
 
 // CUs the decode-step launchers size their persistent grids for: the device's CU count unless the rollout runs on a CU-masked stream
 // (iadr1_stream_create_cu_mask) next to the teacher-forced training forward -- a persistent kernel launched with one block per CU of the WHOLE
-// device onto a stream that owns fewer would run its blocks in two rounds.  Process-wide, set before the decode graph is captured.
-static int g_decode_cus = 0;
+// device onto a stream that owns fewer would run its blocks in two rounds.  THREAD-LOCAL (like iadr1_last_error): it is launcher configuration of the thread that
+// captures / launches a decode step, set right before and reset (0) right after -- the ABI keeps no process-wide mutable state.  It cannot
+// be read off the launch stream: the decode graph is CAPTURED on torch's capture stream and only REPLAYED on the masked one.
+static thread_local int g_decode_cus = 0;
 int iadr1_decode_cus(void) {
     if (g_decode_cus > 0) return g_decode_cus;
     static const int dev_cus = [] {
@@ -81,10 +83,11 @@ extern "C" int iadr1_stream_destroy(void* stream) {
 }
 
 extern "C" const char* iadr1_last_error(void) { return g_err; }
+// 109: round 6 -- iadr1_weight_prefetch (persistent memory-side-cache prefetcher of the rollout, paced by iadr1_side_out_t.mark: three new fields at the END of the struct)
 // 108: round 5 -- iadr1_gemm_tn_acc_bf16 (weight gradients from row-major dY / X: the 256 x 256 kernel with transpose reads out of LDS, no transposed copies)
 // 107: round 5 -- iadr1_gemm_swiglu_rows_bf16 (row-blocked fused gate|up + SwiGLU: the policy's mlp rows of a chunk of decode steps, rebuilt on the side stream)
 // 106: round 5 -- CU-masked streams, decode CU count, iadr1_attn_fwd_chunk, iadr1_wait_counter (co-scheduled rollout / teacher-forced forward); ordered two-stage
 //      gradient reductions: workspace arguments on iadr1_rmsnorm_bwd / iadr1_layernorm_bwd / iadr1_colsum_acc, iadr1_rows_scatter_acc replaces iadr1_embed_bwd
 // 104: round 4 -- iadr1_decode_advance gained the all_done / rotary-table arguments, the FP8-MFMA pair (iadr1_quant_rows_fp8, iadr1_gemm_nt_fp8) is gone
-extern "C" int iadr1_version(void) { return 108; }
+extern "C" int iadr1_version(void) { return 109; }
 

@@ -135,15 +135,18 @@ class SideOut(ctypes.Structure):
     """include/iadr1_hip.h iadr1_side_out_t: where a decode-step kernel also writes its rows of the training arena.  Built once per (kernel, layer)
     by the rollout (the pointers are static) and handed to the four entry points that take `side`."""
     _fields_ = [("p0", ctypes.c_void_p), ("ld0", ctypes.c_longlong), ("p1", ctypes.c_void_p), ("ld1", ctypes.c_longlong), ("p2", ctypes.c_void_p),
-                ("ld2", ctypes.c_longlong), ("step", ctypes.c_void_p), ("base", ctypes.c_longlong), ("seq_stride", ctypes.c_longlong)]
+                ("ld2", ctypes.c_longlong), ("step", ctypes.c_void_p), ("base", ctypes.c_longlong), ("seq_stride", ctypes.c_longlong),
+                ("mark", ctypes.c_void_p), ("mark_mul", ctypes.c_uint), ("mark_add", ctypes.c_uint)]
 
     @staticmethod
-    def make(step, base, seq_stride, p0=None, p1=None, p2=None, ld1=None):
-        """p0 / p1 are [rows, width] tensors (ld = row stride) except where the header says otherwise (ld1 overrides, e.g. the [Hq][T] log-sum-exp)."""
+    def make(step, base, seq_stride, p0=None, p1=None, p2=None, ld1=None, mark=None, mark_mul=0, mark_add=0):
+        """p0 / p1 are [rows, width] tensors (ld = row stride) except where the header says otherwise (ld1 overrides, e.g. the [Hq][T] log-sum-exp).
+        mark: the decode step's progress word (uint32 / int32 device tensor; rmsnorm_fwd only): *mark = *step * mark_mul + mark_add when the kernel starts."""
         ld = lambda t: 0 if t is None else (t.stride(0) if t.dim() > 1 else 1)
         ptr = lambda t: None if t is None else t.data_ptr()
-        so = SideOut(ptr(p0), ld(p0), ptr(p1), ld(p1) if ld1 is None else ld1, ptr(p2), ld(p2), step.data_ptr(), int(base), int(seq_stride))
-        so._keep = (step, p0, p1, p2)      # the struct holds raw device pointers: keep their owners alive with it
+        so = SideOut(ptr(p0), ld(p0), ptr(p1), ld(p1) if ld1 is None else ld1, ptr(p2), ld(p2), step.data_ptr(), int(base), int(seq_stride),
+                     ptr(mark), int(mark_mul), int(mark_add))
+        so._keep = (step, p0, p1, p2, mark)      # the struct holds raw device pointers: keep their owners alive with it
         return so
 
 

@@ -122,38 +122,70 @@ def pick_concurrent_stream(anchor, make_candidate, weight: torch.Tensor, tries: 
 
     chain(anchor)
     alone = chain(anchor)
-    best = (None, float("inf"))
+    best = float("inf")
     for i in range(tries):
         cand = make_candidate()
         ratio = chain(anchor, cand) / max(alone, 1e-3)
         if log is not None:
             log(f"[iadr1] stream pairing: candidate {i}: the dependent chain runs {ratio:.2f}x its stand-alone time next to it")
-        if ratio < best[1]:
-            best = (cand, ratio)
+        best = min(best, ratio)
         if ratio < 1.5:
             return cand, ratio
-    return None, best[1]
+        destroy_stream(cand)        # a rejected candidate's hardware queue is given back (queues are finite, and leaked ones shift later streams' pipes)
+    return None, best
 
 
-_SPLITS: dict = {}       # (device index, side-stream CUs) -> (decode stream, side stream, decode CUs), or None when no clean stream pair was found
+def destroy_stream(stream):
+    """hipStreamDestroy of a stream made by hip.cu_mask_stream (iadr1_stream_destroy); the device is idle on it (chain() synchronises)."""
+    torch.cuda.synchronize()
+    rc = hip.lib().iadr1_stream_destroy(int(stream.cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"iadr1_stream_destroy failed ({rc}): {hip.lib().iadr1_last_error().decode()}")
+    hip._CU_SHARE.pop(int(stream.cuda_stream), None)
 
 
-def cu_split(dev: torch.device, n: int, weight: torch.Tensor):
-    """The process's two CU-masked streams for a side stream of n CUs on `dev` -- decode replays on the device's other CUs -- created and calibrated ONCE
-    (pick_concurrent_stream; hardware queues are a finite resource and the calibration takes ~0.2 s).  Returns (decode stream, side stream, decode CUs), or None
-    when no candidate on another dispatch pipe was found: the caller then does not co-schedule at all."""
+def agree_across_ranks(ok_local: bool, group=None, device=None) -> bool:
+    """Whether EVERY rank of the process group found a clean stream pair: co-scheduling changes the structure of a step (which kernels rebuild the policy's mlp
+    rows, what runs on which stream), so either all ranks of a data-parallel run co-schedule or none does (the same MIN/MAX vote
+    Engine.check_ddp_headroom takes for recomputation).  One small all-reduce, at the first rollout of a run; without a process group: the local answer."""
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return bool(ok_local)
+    except Exception:
+        return bool(ok_local)
+    dev = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
+    t = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+_SPLITS: dict = {}       # (device index, side-stream CUs, prefetch CUs) -> (decode stream, side stream, decode CUs, prefetch stream | None), or None when no clean stream pair was found
+
+
+def cu_split(dev: torch.device, n: int, weight: torch.Tensor, prefetch_cus: int = 0):
+    """The process's CU-masked streams for a side stream of n CUs on `dev` -- decode replays on the device's other CUs -- created and calibrated ONCE
+    (pick_concurrent_stream; hardware queues are a finite resource and the calibration takes ~0.2 s).  Returns (decode stream, side stream, decode CUs, prefetch stream
+    or None), or None when no candidate on another dispatch pipe was found: the caller then does not co-schedule at all.
+    prefetch_cus > 0 (IADR1_WPREFETCH_CUS): the first `prefetch_cus` of the n CUs go to a third stream for the rollout's weight prefetcher (wprefetch.py), the side
+    stream keeps the other n - prefetch_cus; no clean third queue -> no prefetcher (the split itself stands)."""
     import sys
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(n))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(n), int(prefetch_cus))
     if key not in _SPLITS:
         total = torch.cuda.get_device_properties(dev).multi_processor_count
-        if not (0 < n < total and n % 8 == 0):
-            raise ValueError(f"IADR1_OVERLAP_CUS={n}: a multiple of 8 (the same share of every XCD) below the device's {total} CUs is required")
+        if not (0 < n < total and n % 8 == 0 and 0 <= prefetch_cus < n and prefetch_cus % 8 == 0):
+            raise ValueError(f"IADR1_OVERLAP_CUS={n} / IADR1_WPREFETCH_CUS={prefetch_cus}: multiples of 8 (the same share of every XCD), prefetch < side < the device's {total} CUs")
         decode = hip.cu_mask_stream(n, total - n)
         log = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("IADR1_OVERLAP_LOG") == "1" else None
-        side, ratio = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(0, n), weight, log=log)
-        if side is None and os.environ.get("IADR1_QUIET") != "1":
-            print(f"[iadr1] co-scheduling off: no stream pair on separate dispatch pipes found (best: the dependent chain at {ratio:.1f}x its stand-alone time)", file=sys.stderr, flush=True)
-        _SPLITS[key] = None if side is None else (decode, side, total - n)
+        side, ratio = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(prefetch_cus, n - prefetch_cus), weight, log=log)
+        pf = None
+        if side is None:
+            destroy_stream(decode)
+            if os.environ.get("IADR1_QUIET") != "1":
+                print(f"[iadr1] co-scheduling off: no stream pair on separate dispatch pipes found (best: the dependent chain at {ratio:.1f}x its stand-alone time)", file=sys.stderr, flush=True)
+        elif prefetch_cus > 0:
+            pf, _ = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(0, prefetch_cus), weight, log=log)
+        _SPLITS[key] = None if side is None else (decode, side, total - n, pf)
     return _SPLITS[key]
 
 
@@ -429,9 +461,26 @@ class ChunkedRefPass:
         finally:
             self.stream, self.step_counter = side, gate
         if self.step_counter is not None:
-            self._timed_out_host.copy_(self._timed_out, non_blocking=True)      # read at the next begin()
+            self._timed_out_host.copy_(self._timed_out, non_blocking=True)      # read by check_timed_out(), before the optimizer step that would apply this pass's numbers
+            self._timed_out_event = torch.cuda.Event()
+            self._timed_out_event.record()
         self.active = False
         return self.logp
+
+    def check_timed_out(self):
+        """Raise if a counter wait of the last pass timed out (the chunk then ran on rows that were not final: its log-probs and the rebuilt policy rows are wrong).
+        Called by the owner after the backward has been enqueued and BEFORE the optimizer step: the flag's copy was enqueued behind the rollout, ~300 ms of
+        GPU time before the point where the host asks, so the wait is over when it is called."""
+        ev = self.__dict__.get("_timed_out_event")
+        if ev is None:
+            return
+        ev.synchronize()
+        self._timed_out_event = None
+        if int(self._timed_out_host[0]):
+            self._timed_out.zero_()
+            self._timed_out_host.zero_()
+            raise RuntimeError("overlap.ChunkedRefPass: a counter wait of this step's co-scheduled pass timed out (the decode stream never reached the awaited step); "
+                               "the step's gradients were NOT applied")
 
     def _mark(self, label=None, start=None):
         if self.trace is None:

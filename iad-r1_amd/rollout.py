@@ -99,6 +99,11 @@ class Rollout:
         self.cos = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.sin = torch.empty(N, D // 2, dtype=F32, device=dev)
         self.graph = None
+        # progress word of the decode step (step * layers + layer, stored by the first kernel of every decoder layer) and the weight prefetcher it paces
+        # (wprefetch.WeightPrefetcher, set by the owner; None: no marks in the captured step)
+        self.mark = torch.zeros(1, dtype=i32, device=dev)
+        self.wprefetch = None
+        self._marks_in_graph = False
         self._toks_host, self._toks_event = None, None
         self._join_timed_out = self._join_timed_out_host = None
         self.trace = None           # training arena filled by the decode steps (generate(train_trace=...)); part of the captured graph
@@ -111,12 +116,20 @@ class Rollout:
         e, c, P = self.e, self.e.cfg, self.e.p
         tr = self.trace      # None, or the training arena the step also fills (Rollout.generate(train_trace=...))
 
-        def side(**kw):
+        marks = self.wprefetch is not None
+        self._marks_in_graph = marks
+
+        def side(mark_layer=None, **kw):
             """iadr1_side_out_t for one launch of this step: rows base + s * stride + *step of the given arena tensors (None without a trace).
-            The structs are host memory read at launch time; they are kept in self._sides so that a re-capture builds them anew."""
+            The structs are host memory read at launch time; they are kept in self._sides so that a re-capture builds them anew.
+            mark_layer: this launch opens decoder layer `mark_layer` -- with a weight prefetcher attached it also stores the step's progress mark."""
+            mk = dict(mark=self.mark, mark_mul=c.num_hidden_layers, mark_add=mark_layer) if (marks and mark_layer is not None) else {}
             if tr is None:
-                return None
-            so = ops.SideOut.make(self.step, tr["base"], tr["stride"], **kw)
+                if not mk:
+                    return None
+                so = ops.SideOut.make(self.step, 0, 0, **mk)
+            else:
+                so = ops.SideOut.make(self.step, tr["base"], tr["stride"], **kw, **mk)
             self._sides.append(so)
             return so
 
@@ -131,10 +144,10 @@ class Rollout:
         for i in range(c.num_hidden_layers):
             b = f"layers.{i}."
             if not have_branch:      # layer 0 enters with the embedding rows (filled after the rollout)
-                ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h, side=side(p1=T_("h1", i), p2=T_("rstd1", i)))
+                ops.rmsnorm_fwd(self.x, P.w(b + "ln1"), c.rms_norm_eps, out=self.h, side=side(mark_layer=i, p1=T_("h1", i), p2=T_("rstd1", i)))
             else:
                 ops.rmsnorm_fwd(None, P.w(b + "ln1"), c.rms_norm_eps, res=self.x, res_out=self.x, x32=self.part_d, out=self.h,
-                                side=side(p0=T_("x_in", i), p1=T_("h1", i), p2=T_("rstd1", i)))
+                                side=side(mark_layer=i, p0=T_("x_in", i), p1=T_("h1", i), p2=T_("rstd1", i)))
             if P.qkv_rope_packed:   # q|k|v projection + rotary + K/V cache append in one launch
                 ops.gemm_qkv_rope_kv(self.h, P.wpk(b + "qkv.w"), P.wpk_bias(b + "qkv.w"), self.qkv, self.cos, self.sin, self.slot, self.kc[i], self.vc[i], Hq, Hkv, D,
                                      side=side(p0=T_("qkv", i)))
@@ -192,8 +205,17 @@ class Rollout:
         STATS["graph_captures"] += 1
 
     # ---- public ---------------------------------------------------------------------------------------------------
-    def generate(self, plan: TextPlan, img_embeds, G: int, max_new: int, temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress_eos=False,
-                 stop_at_eos=True, train_carry=None, train_trace=False, shadow=None) -> torch.Tensor:
+    def generate(self, *args, **kw) -> torch.Tensor:
+        """`_generate` with this thread's launcher configuration (iadr1_set_decode_cus: the CU count the persistent decode grids are sized for) set for the
+        duration of the call only: whatever ends the call, later skinny-GEMM callers of this thread size their grids for the whole device again."""
+        try:
+            return self._generate(*args, **kw)
+        finally:
+            if self.e.dev.type == "cuda":
+                ops.hip.set_decode_cus(0)
+
+    def _generate(self, plan: TextPlan, img_embeds, G: int, max_new: int, temperature=0.9, top_k=50, top_p=0.9, seed=0, suppress_eos=False,
+                  stop_at_eos=True, train_carry=None, train_trace=False, shadow=None) -> torch.Tensor:
         """plan: the Bp left-padded prompts.  Returns completion ids [Bp*G, max_new] (prompt-major order: p0 x G,
         p1 x G, ...), pad after the first EOS.
         shadow: an overlap.ChunkedRefPass -- the frozen reference's teacher-forced pass over the tokens produced so far is enqueued on ITS stream every
@@ -207,7 +229,7 @@ class Rollout:
         if self._join_timed_out_host is not None and int(self._join_timed_out_host[0]):
             raise RuntimeError("Rollout.generate: the counter join of the previous rollout timed out (the decode stream never finished its replays)")
         if dev.type == "cuda":
-            ops.hip.set_decode_cus(self.decode_cus)      # process-wide launcher configuration (persistent grids): this rollout's, whatever another engine set since
+            ops.hip.set_decode_cus(self.decode_cus)      # this thread's launcher configuration (persistent grids) for the duration of the call: generate() resets it
         self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)   # device-resident: a new seed per rollout does not invalidate the captured graph
         sampling = dict(temperature=float(temperature), top_k=int(top_k), top_p=float(top_p),
                         suppress=c.eos_token_id if suppress_eos else -1, eos=c.eos_token_id if stop_at_eos and not suppress_eos else -1, pad=c.pad_token_id)
@@ -219,6 +241,8 @@ class Rollout:
         mlp_on_shadow = bool(want_trace and shadow is not None and shadow.rebuilds_policy_mlp(c, N))
         if not want_trace and self.trace is not None:
             self.trace, self.graph = None, None
+        if (self.wprefetch is not None) != self._marks_in_graph:
+            self.graph = None      # the progress marks are part of the captured step
         lengths = plan.lengths
         # ---- page tables ------------------------------------------------------------------------------------
         next_page = 1  # page 0 is a scratch page for unused table entries
@@ -342,54 +366,68 @@ class Rollout:
             gates.append(gate)
             gate.record()                  # behind the sampling of token 0 (and the prefill): the reference's vision tower, prompt rows and first log-prob start now
             shadow.prompt_phase(gate)
-        ds = self.decode_stream
+        if self.wprefetch is not None:     # one persistent launch for the whole rollout, on its own CU-masked stream; it polls the progress word the replays store
+            Lm = c.num_hidden_layers
+            self.mark.zero_()
+            self.wprefetch.stream.wait_stream(torch.cuda.current_stream())
+            self.wprefetch.start(self.mark, 1 * Lm, (max_new - 1) * Lm + Lm - 1)
+        # the CU-masked decode stream (and the host join that goes with it) only when something runs NEXT TO the replays: a rollout without the shadow pass
+        # (SCGRPOTrainer.training_step's batched rollouts, step(completions=...), the evaluation harness) has nothing to hide behind the +0.2 ms per step
+        ds = self.decode_stream if (shadow is not None or self.wprefetch is not None) else None
+        _outer = torch.cuda.current_stream()
         if ds is not None:                 # hand the rest of the rollout over to the CU-masked decode stream (the prefill above ran on the whole device)
-            ds.wait_stream(torch.cuda.current_stream())
-            _outer = torch.cuda.current_stream()
+            ds.wait_stream(_outer)
             torch.cuda.set_stream(ds)
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.decode_events is not None else None
-        if ev:
-            ev[0].record()
-        nsteps = 0
-        # EOS live: stop once every sequence has finished, WITHOUT draining the queue.  Every POLL steps the device flag decode_advance maintains is copied
-        # to pinned host memory behind the step; the host reads the copy that is LAG polls old (it waits for that copy's event, never for the newest work), so the
-        # GPU always has >= (LAG - 1) * POLL queued steps and at most LAG * POLL steps run past the last EOS.  (Round 3 read `finished.all()` every 32 steps: a full
-        # drain of the queue each time and 16 wasted steps on average.)
-        POLL, LAG = 4, 3
-        polls = []
-        live = sampling["eos"] >= 0
-        for it in range(1, max_new):
-            if self.graph is not None:
-                self.graph.replay()
-            else:
-                self._decode_step()
-            nsteps += 1
-            if shadow is not None and it in bounds:      # replay `it` has produced token `it`: rows [.., it) of every sequence and their targets are final
-                gate = None
-                if shadow.step_counter is None:         # (event gating; the default gate is the device step counter, overlap.ChunkedRefPass.begin)
-                    gate = torch.cuda.Event()
-                    gates.append(gate)
-                    gate.record()
-                shadow.chunk(it, gate)
-            if live and it % POLL == 0:
-                k = (it // POLL) % self.done_host.numel()
-                self.done_host[k: k + 1].copy_(self.all_done, non_blocking=True)
-                pe = torch.cuda.Event()
-                pe.record()
-                polls.append((pe, k))
-                if len(polls) >= LAG:
-                    ev0, k0 = polls.pop(0)
-                    ev0.synchronize()
-                    STATS["eos_polls"] += 1
-                    if int(self.done_host[k0]):
-                        break
-        STATS["decode_steps"] += nsteps
-        STATS["rollouts"] += 1
-        if ev:
-            ev[1].record()
-            self.decode_events.append((ev[0], ev[1], nsteps, int(np.sum(lengths)) * G))
+        try:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.decode_events is not None else None
+            if ev:
+                ev[0].record()
+            nsteps = 0
+            # EOS live: stop once every sequence has finished, WITHOUT draining the queue.  Every POLL steps the device flag decode_advance maintains is copied
+            # to pinned host memory behind the step; the host reads the copy that is LAG polls old (it waits for that copy's event, never for the newest work), so the
+            # GPU always has >= (LAG - 1) * POLL queued steps and at most LAG * POLL steps run past the last EOS.  (Round 3 read `finished.all()` every 32 steps: a full
+            # drain of the queue each time and 16 wasted steps on average.)
+            POLL, LAG = 4, 3
+            polls = []
+            live = sampling["eos"] >= 0
+            for it in range(1, max_new):
+                if self.graph is not None:
+                    self.graph.replay()
+                else:
+                    self._decode_step()
+                nsteps += 1
+                if shadow is not None and it in bounds:      # replay `it` has produced token `it`: rows [.., it) of every sequence and their targets are final
+                    gate = None
+                    if shadow.step_counter is None:         # (event gating; the default gate is the device step counter, overlap.ChunkedRefPass.begin)
+                        gate = torch.cuda.Event()
+                        gates.append(gate)
+                        gate.record()
+                    shadow.chunk(it, gate)
+                if live and it % POLL == 0:
+                    k = (it // POLL) % self.done_host.numel()
+                    self.done_host[k: k + 1].copy_(self.all_done, non_blocking=True)
+                    pe = torch.cuda.Event()
+                    pe.record()
+                    polls.append((pe, k))
+                    if len(polls) >= LAG:
+                        ev0, k0 = polls.pop(0)
+                        ev0.synchronize()
+                        STATS["eos_polls"] += 1
+                        if int(self.done_host[k0]):
+                            break
+            if self.wprefetch is not None:
+                self.mark.fill_(-1)            # behind the last replay: releases the prefetcher (also when EOS ended the rollout early)
+            STATS["decode_steps"] += nsteps
+            STATS["rollouts"] += 1
+            if ev:
+                ev[1].record()
+                self.decode_events.append((ev[0], ev[1], nsteps, int(np.sum(lengths)) * G))
+        finally:
+            # whatever happened in the loop (a failed launch, an exception of the shadow pass): the process's current stream must not stay the CU-masked blocking
+            # stream
+            if ds is not None:
+                torch.cuda.set_stream(_outer)
         if ds is not None:
-            torch.cuda.set_stream(_outer)
             # Join on the HOST: anything left pending on the outer stream's hardware queue while the replays run -- the dependency packet of `_outer.wait_stream(ds)`
             # (the host is hundreds of replays ahead), or a kernel polling the step counter -- costs every decode launch ~8 us when that queue happens to share a
             # dispatch pipe with the decode queue: 5.0 instead of 3.0 ms per step (tools/decode_mask_probe.py plain 192, profiles/r05_decode_join.txt).  Which queues

@@ -13,6 +13,7 @@ this at per_device_train_batch_size=1, the only setting its scripts use (SURVEY.
 from __future__ import annotations
 
 import os
+import sys
 
 from dataclasses import dataclass
 
@@ -363,10 +364,12 @@ class SCGRPOEngine:
         if self._rollout is None or self._rollout.N != N or self._rollout.max_new < a.max_completion_length or self._rollout.max_prompt < ids.shape[1]:
             grow = max(ids.shape[1], self._rollout.max_prompt if self._rollout is not None else 0)
             self._rollout = None        # release the old pool before the new one is allocated
-            split = self._cu_split(N)
-            if self.dev.type == "cuda":
-                hip.set_decode_cus(split.get("decode_cus", 0))      # process-wide launcher configuration: what THIS rollout's graph is captured with
+            split = self._cu_split(N)      # (the launcher configuration that goes with it is set by Rollout.generate for the duration of each call)
             self._rollout = Rollout(self.pol, N, grow, a.max_completion_length, max_prompts=Bp, use_graph=a.use_hip_graph, **split)
+            if split and self.__dict__.get("_wprefetch_stream") is not None:
+                # opt-in (IADR1_WPREFETCH_CUS): the NEXT layer's narrow projections (q|k|v, o: 18 MiB at the 3B widths) pulled into the memory-side cache while a layer runs
+                from .wprefetch import WeightPrefetcher, wanted_cus
+                self._rollout.wprefetch = WeightPrefetcher(self.pol, self._wprefetch_stream, wanted_cus(), what=(), next_what=("qkv", "o"), lead=0)
         c, st = self.cfg, self.pol.p
         # decode steps that also fill the training arena (no policy forward over the completions afterwards): needs the fused decode kernels that carry
         # the side outputs (q|k|v + rotary + cache append, persistent fused-SwiGLU gate|up GEMM)
@@ -379,6 +382,15 @@ class SCGRPOEngine:
                 self._shadow = ChunkedRefPass(self.ref, stream=self.__dict__.get("_shadow_stream"))
             shadow = self._shadow
             shadow.vision = (vis["px"], vis["plan"])
+        if os.environ.get("IADR1_QUIET") != "1" and self.__dict__.get("_path_logged") != (shadow is not None):
+            self._path_logged = shadow is not None      # once per change: WHICH step structure runs (the two differ in the last bf16 bit of the policy's mlp rows)
+            if shadow is not None:
+                rb = trace and shadow.rebuilds_policy_mlp(c, N)
+                print(f"[iadr1] co-scheduled step: the frozen reference's pass{', the policy mlp rows (REBUILT by the training GEMM)' if rb else ''} and the lm_head log-probs run on "
+                      f"{torch.cuda.get_device_properties(self.dev).multi_processor_count - self._rollout.decode_cus if self._rollout.decode_cus else 'all'} CUs under the rollout (IADR1_OVERLAP_CUS=0: sequential step; IADR1_OVERLAP_GU=0: rows stored by the decode step)",
+                      file=sys.stderr, flush=True)
+            elif shadow_ref:
+                print("[iadr1] sequential step: the frozen reference's pass runs after the rollout, on the whole device", file=sys.stderr, flush=True)
         toks = self._rollout.generate(plan, img_pol, a.num_generations, a.max_completion_length, temperature=0.0 if greedy else a.temperature,
                                       top_k=a.top_k, top_p=a.top_p, seed=a.seed + 1000003 * self.opt_step + 7919 * self.accum, suppress_eos=a.suppress_eos,
                                       train_carry=train_carry, train_trace=trace, shadow=shadow)
@@ -399,10 +411,24 @@ class SCGRPOEngine:
         self._shadow_stream = None
         if n <= 0 or self.dev.type != "cuda" or not ChunkedRefPass.applicable(self.cfg, N, self.args.max_completion_length):
             return {}
-        sp = cu_split(self.dev, n, self.ref.p.w("layers.0.gu.w"))
-        if sp is None:       # no candidate on another dispatch pipe: no co-scheduling at all (the one-shot reference pass after the rollout)
+        from .wprefetch import wanted_cus
+        sp = cu_split(self.dev, n, self.ref.p.w("layers.0.gu.w"), prefetch_cus=wanted_cus())
+        # one decision for the whole data-parallel job, taken once (the first rollout of a run, the same call on every rank: N and the completion length are the
+        # launch configuration's, identical across ranks): a rank without a clean stream pair switches co-scheduling off for all of them
+        agreed = self.__dict__.setdefault("_co_sched_agreed", {})
+        if n not in agreed:
+            from .overlap import agree_across_ranks
+            agreed[n] = agree_across_ranks(sp is not None, self.reducer.group, self.dev)
+            if sp is not None and not agreed[n] and os.environ.get("IADR1_QUIET") != "1":
+                print("[iadr1] co-scheduling off on this rank too: another rank of the process group found no clean stream pair", file=sys.stderr, flush=True)
+        if sp is None or not agreed[n]:       # no candidate on another dispatch pipe (here or on some rank): no co-scheduling at all (the one-shot reference pass after the rollout)
+            if sp is None and os.environ.get("IADR1_OVERLAP_CUS", "auto").strip().lower() not in ("", "auto") and os.environ.get("IADR1_OVERLAP_STRICT", "1") != "0":
+                # a FORCED split that cannot be had is an error, not a silent change of the step's structure (the rebuilt policy rows differ from the stored ones in the
+                # last bf16 bit: ADVICE r5 -- a run that asked for one path must not get the other)
+                raise RuntimeError(f"IADR1_OVERLAP_CUS={n}: no stream pair on separate dispatch pipes was found; unset it (auto: sequential fallback) or set IADR1_OVERLAP_STRICT=0")
             return {}
         self._shadow_stream = sp[1]
+        self._wprefetch_stream = sp[3]
         return {"decode_cus": sp[2], "decode_stream": sp[0]}
 
     def _rollout_fuses_swiglu(self, N) -> bool:
@@ -560,6 +586,8 @@ class SCGRPOEngine:
     # ---- optimizer -------------------------------------------------------------------------------------------------
     def optimizer_step(self):
         a, st = self.args, self.pol.p
+        if self._shadow is not None:
+            self._shadow.check_timed_out()      # a co-scheduled pass that ran on unfinished rows must not reach the weights
         self.reducer.finish()
         self.opt_step += 1
         scale = 1.0 / (self.reducer.world * max(1, self.accum))
@@ -571,7 +599,7 @@ class SCGRPOEngine:
                          a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd, self.opt_step, scale, self.norm2, a.max_grad_norm)
         st.refresh_shadows()
         self.accum = 0
-        if self.pol.check_ddp_headroom(a.recompute):
+        if self.pol.check_ddp_headroom(a.recompute, group=self.reducer.group):
             # the rollout's captured graph and its training-arena views keep the freed arena's blocks alive: drop them too, THEN hand the memory back to the device
             self._rollout = None
             torch.cuda.empty_cache()

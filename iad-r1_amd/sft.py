@@ -141,7 +141,7 @@ class SFTEngine:
                      a.adam_beta1, a.adam_beta2, a.adam_epsilon, a.weight_decay if decays else 0.0, self.opt_step, scale, self.norm2, a.max_grad_norm)
         st.refresh_shadows()
         self.accum = 0
-        if self.eng.check_ddp_headroom(a.recompute):
+        if self.eng.check_ddp_headroom(a.recompute, group=self.reducer.group):
             torch.cuda.empty_cache()
 
     def grad_norm(self) -> float:

@@ -815,13 +815,17 @@ class Engine:
             self._ws.pop("act_save", None)          # a stale arena of an earlier (smaller) bucket must not sit next to the checkpoint buffers
         return cache[bucket]
 
-    def check_ddp_headroom(self, mode: str, limit_bytes: int = 235 << 30):
+    def check_ddp_headroom(self, mode: str, limit_bytes: int = 235 << 30, group=None):
         """Data-parallel runs only, policy "auto", called once per optimizer step by the trainers: the static budget above cannot see everything a model family
         keeps (LLaVA-OneVision's 40 saved SigLIP crops and its 4 000-token KV pool: 261 GB reserved although the decoder arena alone fits).  If a COMPLETED step
         peaked above `limit_bytes` of reserved memory (235 GB: what VERDICT r3 #5 asks to stay under so that RCCL's channel buffers have room), every later step
         recomputes.  Deterministic for given shapes (the allocator's peak of a whole step, not its free memory at some call), logged once.  Returns True when it
-        switched: the caller then releases what still references the arena and calls torch.cuda.empty_cache() (RCCL allocates outside torch's caching allocator)."""
-        if mode != "auto" or self.__dict__.get("_recompute_forced") or os.environ.get("IADR1_RECOMPUTE") == "0":
+        switched: the caller then releases what still references the arena and calls torch.cuda.empty_cache() (RCCL allocates outside torch's caching allocator).
+
+        The all-reduce below is reached by EVERY rank or by none: only the mode, the environment, the process-group state and the call count -- all
+        identical across ranks -- may return before it.  A rank whose own token-row bucket already forced recomputation (recompute_wanted: ragged prompts put ranks in
+        different buckets) contributes that as a vote, so after the first check all ranks recompute or none does.  `group`: the engine's process group."""
+        if mode != "auto" or os.environ.get("IADR1_RECOMPUTE") in ("0", "1"):
             return False
         n_checked = self.__dict__.get("_headroom_checks", 0)
         if n_checked >= 4:                      # the peak of a step is a property of the shapes: settled after the first few steps, no more synchronising reads
@@ -833,17 +837,19 @@ class Engine:
         except Exception:
             return False
         self._headroom_checks = n_checked + 1
-        peak = torch.cuda.max_memory_reserved(self.dev)
-        torch.cuda.reset_peak_memory_stats(self.dev)            #  the peak of THIS step, not of everything since start-up (a checkpoint export, a graph capture)
+        was_forced = bool(self.__dict__.get("_recompute_forced"))
+        peak = torch.cuda.max_memory_reserved(self.dev) if self.dev.type == "cuda" else 0
+        if self.dev.type == "cuda":
+            torch.cuda.reset_peak_memory_stats(self.dev)        #  the peak of THIS step, not of everything since start-up (a checkpoint export, a graph capture)
         # every rank takes the same decision: one rank recomputing next to seven that do not would run different kernels (and a different number of them) per step
-        over = torch.tensor([1 if peak > limit_bytes else 0], dtype=torch.int32, device=self.dev)
-        dist.all_reduce(over, op=dist.ReduceOp.MAX)
-        if int(over.item()):
+        over = torch.tensor([1 if (peak > limit_bytes or was_forced) else 0], dtype=torch.int32, device=self.dev)
+        dist.all_reduce(over, op=dist.ReduceOp.MAX, group=group)
+        if int(over.item()) and not was_forced:
             self._recompute_forced = True
             self._ws.pop("act_save", None)
             if os.environ.get("IADR1_QUIET") != "1":
-                print(f"[iadr1] gradient checkpointing (auto): a step peaked at {peak / 2**30:.1f} GiB reserved on this rank (limit {limit_bytes / 2**30:.0f}, decision shared by all ranks) "
-                      "under a process group -> decoder activations are recomputed from the next step on", file=sys.stderr, flush=True)
+                print(f"[iadr1] gradient checkpointing (auto): a step peaked at {peak / 2**30:.1f} GiB reserved on this rank (limit {limit_bytes / 2**30:.0f}; the decision is shared: "
+                      "some rank peaked above it or had already switched) under a process group -> decoder activations are recomputed from the next step on", file=sys.stderr, flush=True)
             return True           # the CALLER drops what still points into the arena (rollout trace / captured graph) and then empties the cache
         return False
 

@@ -34,8 +34,8 @@ const char* iadr1_last_error(void);
  *     driver's numbering (round-robin over the 8 XCDs: bits [8k, 8k+8) are one CU of every XCD).  `stream_out` (HOST) receives the hipStream_t.
  *   iadr1_stream_destroy: hipStreamDestroy of such a stream.
  *   iadr1_set_decode_cus: the number of CUs the decode-step launchers (iadr1_gemm_skinny_bf16, iadr1_gemm_qkv_rope_kv_bf16, iadr1_gemm_skinny_fp8w)
- *     size their persistent one-block-per-CU grids for; 0 = the device's CU count.  Process-wide launcher configuration (like the IADR1_* switches):
- *     set it before the decode graph is captured, not concurrently with launches. */
+ *     size their persistent one-block-per-CU grids for; 0 = the device's CU count.  THREAD-LOCAL launcher configuration (like iadr1_last_error): the thread
+ *     that captures or launches a decode step sets it right before and resets it to 0 right after; other threads and other engines never see it. */
 int iadr1_stream_create_cu_mask(const unsigned* cu_mask, int n_words, void** stream_out);
 int iadr1_stream_destroy(void* stream);
 int iadr1_set_decode_cus(int n_cus);
@@ -54,6 +54,10 @@ typedef struct iadr1_side_out {
     void* p2; long long ld2;
     const unsigned* step;
     long long base, seq_stride;
+    /* progress mark (iadr1_rmsnorm_fwd's few-row kernel only; NULL: none): block 0 stores *step * mark_mul + mark_add into *mark when it starts -- the rollout
+     * sets it on the first kernel of every decoder layer (mark_mul = layers, mark_add = layer) so that iadr1_weight_prefetch can pace itself by the decode step */
+    unsigned* mark;
+    unsigned mark_mul, mark_add;
 } iadr1_side_out_t;
 
 /* ---- dense contractions ----------------------------------------------------------------------------
@@ -311,6 +315,15 @@ int iadr1_decode_advance(const long long* sampled, long long* cur_tok, long long
  * returns anyway, a counter that never arrives cannot hang the queue.  The chunked reference pass (iadr1_attn_fwd_chunk) gates each chunk on the decode
  * step that produced its last target token with this instead of an event recorded between two hipGraph launches (0.06 ms per decode step cheaper). */
 int iadr1_wait_counter(const unsigned* counter, unsigned target, int timeout_ms, int* timed_out, iadr1_stream_t stream);
+/* weight_prefetch: ONE persistent launch for a whole group rollout (REF:train/stage_rl/trainer/sc_grpo_trainer.py:637-683) that pulls the decode step's weights
+ * into the 256 MB memory-side cache just ahead of the launches that stream them.  Launch it on a CU-masked stream of its own (iadr1_stream_create_cu_mask), with
+ * `n_blocks` = the CUs that stream owns.  `segs`: DEVICE table [n_units][n_seg][2] of (address, bytes; bytes %% 16 == 0) -- unit u = the weight segments of decoder
+ * layer u in the order the step reads them.  `mark`: the decode step's progress word (iadr1_side_out_t.mark: step * n_units + layer, stored by the first kernel of
+ * every layer).  On seeing mark m in [first_mark, last_mark] a block reads its share of unit (m + lead) %% n_units; it never runs further ahead than that, drops a
+ * unit the decode step has passed, returns when the word exceeds last_mark (store ~0 behind the last replay) or after `timeout_ms` (<= 60000).  `nt`: 1 =
+ * non-temporal loads.  `status` (optional DEVICE int[4]): timed-out flag, units read, units dropped as stale, MiB read (the last three from block 0). */
+int iadr1_weight_prefetch(const long long* segs, int n_units, int n_seg, const unsigned* mark, unsigned first_mark, unsigned last_mark, int lead, int nt,
+                          int n_blocks, int timeout_ms, int* status, iadr1_stream_t stream);
 /* all_done (optional): 1 when every sequence has finished after this token -- the host polls it through pinned memory without draining the
  * queue (the reference's vLLM stops a request at EOS, REF:343-358).  inv_freq (optional, with cos_t / sin_t [B, half]): the rotary table
  * of the NEXT step's positions is written here, bit-identical to iadr1_rope_table on the bumped positions (one launch less per decode step). */

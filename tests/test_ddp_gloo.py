@@ -194,3 +194,51 @@ def test_bench_multi_rank_launch_contract():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=120,
                          env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)
+
+
+def _decisions_worker(rank, world, port, q):
+    """The two per-rank decisions that change the STRUCTURE of a step are taken collectively: gradient recomputation
+    (Engine.check_ddp_headroom: a rank whose own token-row bucket already forced it must still reach the all-reduce -- it used to return early and leave the
+    others waiting in it) and co-scheduling (overlap.agree_across_ranks: one rank without a clean stream pair switches it off everywhere)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IADR1_QUIET="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fixture_util as fx
+    import iadr1_amd  # noqa: F401
+    from iadr1_amd import overlap
+    from iadr1_amd.params import ParamStore, VLMConfig
+    from iadr1_amd.vlm import Engine
+
+    cfg = VLMConfig.from_dict(fx.TINY)
+    eng = Engine(ParamStore(cfg, "cpu", trainable=True, with_transposes=False, with_decode_pack=False))
+    if rank == 1:
+        eng._recompute_forced = True           # what recompute_wanted() sets when THIS rank's bucket crossed the budget (ragged prompts: the other rank's did not)
+    switched = eng.check_ddp_headroom("auto")  # every rank reaches the collective; a mismatch would pair it with the all_reduce below or hang (test timeout)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    forced = bool(eng.__dict__.get("_recompute_forced"))
+    # co-scheduling: rank 1's start-up probe found no clean stream pair -> nobody co-schedules; both fine -> both do
+    agreed_mixed = overlap.agree_across_ranks(rank == 0)
+    agreed_all = overlap.agree_across_ranks(True)
+    q.put((rank, switched, forced, float(t.item()), agreed_mixed, agreed_all))
+    dist.destroy_process_group()
+
+
+def test_step_structure_decisions_are_collective():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decisions_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, sw0, f0, t0, m0, a0), (_, sw1, f1, t1, m1, a1) = res
+    assert sw0 is True and sw1 is False          # rank 0 switched because rank 1 had; rank 1 was already there
+    assert f0 and f1                             # from the next step on BOTH recompute
+    assert t0 == t1 == 2.0                       # the collectives stayed paired
+    assert m0 is False and m1 is False and a0 is True and a1 is True

@@ -1158,14 +1158,22 @@ def _oracle_cfg_dict(cfg):
             "vision_end_token_id": cfg.vision_end_token_id, "eos_token_id": cfg.eos_token_id, "pad_token_id": cfg.pad_token_id, "tie_word_embeddings": cfg.tie_word_embeddings}
 
 
-def test_api_step_with_rollout_handover_matches_the_oracle():
+@pytest.mark.parametrize("overlap_cus", ["0", "64"])
+def test_api_step_with_rollout_handover_matches_the_oracle(monkeypatch, overlap_cus):
     """The path bench.py times and SCGRPOTrainer.compute_loss runs (SCGRPOEngine.step with the rollout's prefill as the prompt part of the policy
     forward and the decode steps filling the completion rows of the training arena) against the CPU oracle, at BASELINE widths (Qwen2.5-VL-3B
     hidden 2048 / 16:2 heads / MLP 11008 / vocabulary 151936 / ViT 1280; 2 decoder layers, 2 ViT blocks), policy != reference, EOS ENABLED with
     ragged completion lengths, two left-padded prompts of different length.  The tokens are whatever the device sampled; the oracle then runs
-    the reference's arithmetic (oracle.sc_grpo.sc_grpo_step, fp32) on exactly those tokens and rewards."""
+    the reference's arithmetic (oracle.sc_grpo.sc_grpo_step, fp32) on exactly those tokens and rewards.
+
+    overlap_cus (VERDICT r5 #3a): "0" = the SEQUENTIAL step (reference pass after the rollout); "64" = the CO-SCHEDULED step the bench times by default -- the frozen
+    reference's chunked pass, the policy's REBUILT gate|up / SwiGLU rows and its lm_head log-probs on a 64-CU side stream under the decode replays on the other CUs
+    -- forced at this small shape (2 prompts x G 8 = 16 sequences: one 256-row tile per time block, C = 32 = two time blocks).  Same tolerances both ways, INCLUDING
+    the gradient cosines: the backward of the co-scheduled step reads rows rebuilt by the training GEMM, and this holds them to the oracle directly.  A box without a
+    clean stream pair SKIPS the co-scheduled case with that reason (a forced split raises; nothing passes on a fallback)."""
     import dataclasses
     import sys
+    monkeypatch.setenv("IADR1_OVERLAP_CUS", overlap_cus)
     if os.environ.get("IADR1_SKINNY_PERS", "1") == "0" or os.environ.get("IADR1_DECODE_PACKED", "1") == "0":
         pytest.skip("the side outputs live in the persistent / fused decode kernels")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -1178,7 +1186,7 @@ def test_api_step_with_rollout_handover_matches_the_oracle():
     w_pol = fx.perturb_weights(w_ref, 1, scale=0.25)                  # a policy well away from the reference: KL ~ 0.1, so relative tolerances bind
     pol = ParamStore(cfg, DEV, trainable=True)
     pol.load_named(w_pol)
-    G, C, Bp = 4, 24, 2
+    G, C, Bp = 8, 32, 2
     cd = _oracle_cfg_dict(cfg)
     grids = [(1, 16, 16), (1, 16, 12)]
     rows = [fx.synth_prompt(grids[0], 37, cd, 5), fx.synth_prompt(grids[1], 21, cd, 6)]
@@ -1191,7 +1199,12 @@ def test_api_step_with_rollout_handover_matches_the_oracle():
     # pass 1 (EOS can practically not be sampled from 151936 tokens): find out what the sampler draws, then declare the token that ends the most rows
     # early to be EOS -- sampling is a pure function of (seed, step, row, logits), so pass 2 draws the same tokens up to each row's first EOS
     eng0 = SCGRPOEngine(cfg, pol, ref, args())
-    comp0 = eng0.rollout(batch, vis=None)
+    try:
+        comp0 = eng0.rollout(batch, vis=None)
+    except RuntimeError as exc:
+        if overlap_cus != "0" and "no stream pair" in str(exc):
+            pytest.skip(f"co-scheduled case NOT RUN on this box: {exc}")
+        raise
     best, best_rows = None, []
     for tok in np.unique(comp0[:, 2: C - 2]):
         hit = [r for r in range(Bp * G) if tok in comp0[r, 2: C - 2] and tok not in comp0[r, :2]]
@@ -1204,6 +1217,12 @@ def test_api_step_with_rollout_handover_matches_the_oracle():
     out = eng.step(batch, reward_fn, do_optimizer_step=False, return_outputs=True)
     torch.cuda.synchronize()
     assert eng.last_step_traced                  # no policy forward ran over the completions: backward read what the decode steps wrote
+    if overlap_cus == "0":
+        assert not eng.last_step_shadowed and eng._rollout.decode_cus == 0
+    else:                                        # the co-scheduled structure really ran: side-stream reference pass, rebuilt policy mlp rows, side-stream lm_head
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        assert eng.last_step_shadowed and eng._rollout.decode_cus == ncu - int(overlap_cus) and eng._rollout.trace["mlp_on_shadow"] and eng.shadow_policy_head is not None
+    print(f"[parity] api step: IADR1_OVERLAP_CUS={overlap_cus} -> {'CO-SCHEDULED' if eng.last_step_shadowed else 'sequential'} step")
     comp = out["completion_ids"]
     lens = out["completion_mask"].sum(1)
     assert (lens < C).any() and (lens == C).any(), lens           # ragged: some rows stopped at EOS, some ran to the end
@@ -1808,7 +1827,7 @@ def test_chunked_reference_pass_is_bit_equal_to_the_one_shot_pass(monkeypatch, s
     assert torch.equal(o1["logps"][m], o0["logps"][m])
     assert o1["metrics"]["kl"] == o0["metrics"]["kl"] and o1["metrics"]["loss"] == o0["metrics"]["loss"]
     cos = float((g0 @ g1) / (g0.norm() * g1.norm()))
-    assert cos > 0.99999, cos            # (float atomics in the norm-gain / embedding gradients: run-to-run order noise)
+    assert cos > 0.99999, cos            # (the forward bits are equal; the backward's reductions are ordered two-stage sums since round 5 -- no float atomics --, the margin is kept for the two-stream launch order of the weight-gradient GEMMs' fp32 accumulation into shared buffers)
 
 
 @pytest.mark.parametrize("steps,cus,eos_live", [(32, -1, False), (16, 64, False), (32, -1, True)])
@@ -1948,9 +1967,15 @@ def test_co_scheduling_is_on_by_default_at_the_bench_shape_and_changes_no_forwar
         out = eng.step(batch, reward_fn, do_optimizer_step=False, return_outputs=True)
         torch.cuda.synchronize()
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
-        if mode == "auto" and overlap.cu_split(torch.device("cuda", 0), overlap.AUTO_CUS, ref.w("layers.0.gu.w")) is not None:
+        if mode == "auto":
+            if ncu != 256:
+                pytest.skip(f"the default split (192 + 64 CUs) is defined for the 256-CU MI355X; this device has {ncu}")
+            if not eng.last_step_shadowed and overlap.cu_split(torch.device("cuda", 0), overlap.AUTO_CUS, ref.w("layers.0.gu.w")) is None:
+                pytest.skip("co-scheduling did NOT run: no stream pair on separate dispatch pipes was found on this box (the engine fell back to the sequential step)")
+            # on an MI355X with a clean stream pair the default step IS the co-scheduled one (VERDICT r5 #3b: this test cannot pass on the fallback branch)
             assert eng.last_step_shadowed and eng._rollout.decode_cus == ncu - overlap.AUTO_CUS and eng._rollout.trace["mlp_on_shadow"]
-        else:       # (no stream pair on separate dispatch pipes on this box: the engine falls back to the one-shot pass)
+            print(f"[parity] default step at the bench shape class: CO-SCHEDULED (decode on {eng._rollout.decode_cus} CUs, side stream on {overlap.AUTO_CUS})")
+        else:
             assert not eng.last_step_shadowed and eng._rollout.decode_cus == 0
         res[mode] = (out, pol.grad.clone())
         del eng
@@ -2002,7 +2027,7 @@ def test_weight_gradient_forms_leave_the_same_bits(monkeypatch):
     assert torch.equal(grads["0"], grads["1"]) and torch.equal(grads["0"], grads["2"])
 
 
-def test_full_size_3b_parity_at_the_headline_shape_forward():
+def test_full_size_3b_parity_at_the_headline_shape():
     """Driver-witnessed parity AT THE BENCHMARK'S SHAPE (VERDICT r4 #2a): the unreduced Qwen2.5-VL-3B (36 + 32 layers, 151 936-token head), one prompt of 448 x 448
     image + 512 positions, G = 8 completions of 256 tokens sampled by the engine's own hipGraph rollout (one row cut by EOS), policy = reference x (1 + 2 % noise):
     `SCGRPOEngine.loss_and_grads` on the GPU against `oracle.sc_grpo.sc_grpo_step` in fp32 on the host, forward quantities only (per-token log-probs of both models,
@@ -2012,14 +2037,23 @@ def test_full_size_3b_parity_at_the_headline_shape_forward():
     Stated tolerances (fp32 oracle = truth): |dlogp| max <= 1.5 x the bf16 oracle's + 0.02 and mean <= 1.5 x + 0.005 (measured r04: 0.264 / 0.055 vs 0.282 / 0.057);
     KL within max(5 %, 1.5 x the bf16 oracle's error) (measured 2.7 % vs 3.5 %); loss within beta x that KL tolerance (the loss is beta x KL - mean advantage term:
     RELATIVE to the KL, at |loss| ~ 7e-3); greedy token ids: >= 19 of 24 equal, every disagreement at an oracle top-2 gap below 4 x the measured spread of the
-    decode kernels' top-2-gap error."""
+    decode kernels' top-2-gap error.
+    Round 6 (VERDICT r5 #3c): the BACKWARD runs here too -- the oracle's autograd through the unreduced model on the host (~4 more minutes, ~115 GB of host memory):
+    six named gradients from the head (final norm) to the first ViT block, cosine > 0.99 and norm within 3 % of the fp32 oracle's (builder-run record of round 4:
+    0.9977 - 0.9992, norms within 0.5 %).  IADR1_TEST_FULL_BACKWARD=0 keeps the forward-only form (a host with < 160 GB of memory)."""
     import argparse
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    a = argparse.Namespace(model="3b", prompt_len=512, gen_len=256, group=8, check_forward_only=True, check_noise=0.02, check_greedy_tokens=24)
+    with_backward = os.environ.get("IADR1_TEST_FULL_BACKWARD", "1") != "0"
+    a = argparse.Namespace(model="3b", prompt_len=512, gen_len=256, group=8, check_forward_only=not with_backward, check_noise=0.02, check_greedy_tokens=24)
     rec = bench.full_size_parity(a)
-    print("[full-size parity, forward] " + json.dumps(rec), flush=True)
+    print(f"[full-size parity, forward{' + backward' if with_backward else ''}] " + json.dumps(rec), flush=True)
+    if with_backward:
+        gr = rec["hip_vs_fp32_oracle"]["gradients"]
+        assert len(gr) == 6 and "skipped" not in gr, gr
+        for n, v in gr.items():
+            assert v["cosine"] > 0.99 and 0.97 < v["norm_ratio"] < 1.03, (n, v)
     h, b, g = rec["hip_vs_fp32_oracle"], rec["bf16_oracle_vs_fp32_oracle"], rec["greedy_ids"]
     assert rec["shape"]["scored_tokens"] >= 7 * 256 and "error" not in b, (rec["shape"], b)
     for k in ("policy", "ref"):
