@@ -1389,7 +1389,8 @@ def main():
         try:
             mb_file = _newest_profile("mfma_busy.json")
             mb = json.load(open(os.path.join(ROOT, "profiles", mb_file)))
-            g0 = next(k for k in mb["kernels"] if "gemm_nt_256<0>" in k.get("kernel", "") and k.get("grid") == 3522560)
+            import re as _re
+            g0 = next(k for k in mb["kernels"] if _re.search(r"gemm_nt_256<0(, false)*>", k.get("kernel", "")) and k.get("grid") == 3522560)
             mfma_busy = {"kernel": "gemm_nt_256 [20480 x 22016 x 2048]", "mfma_busy_frac": g0["mfma_busy_frac"], "lds_conflict_frac": g0.get("lds_conflict_frac"),
                          "source": f"profiles/{mb_file} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, separate profiled pass)"}
         except Exception:

@@ -62,11 +62,7 @@ struct Cfg {
     static constexpr int DQK = (D + 31) / 32 * 32;  // contraction length of QK^T, zero padded
     static constexpr int KS = DQK / 32;             // MFMA k-steps over d
     static constexpr int DT = D / 16;               // 16-wide output tiles over d
-#ifdef IADR1_ATTN_NOSWZ
-    static constexpr int LD = DQK + 8;              // LDS row stride (elements) of row-major [rows][d] tiles (padded form: A/B probe of the swizzle)
-#else
     static constexpr int LD = 128;                  // 256-byte tile rows = exactly one LDS bank row, 16 chunks of 16 B (swizzled, see tile_off)
-#endif
 };
 
 // LDS image of a staged [rows][d] tile.  Row r is 256 bytes; its 16-byte chunk c sits at chunk position  c ^ 2*rho(r),  rho(r) = (r & 3) | ((r >> 1) & 4).
@@ -77,13 +73,9 @@ struct Cfg {
 //    the first set lands on the even chunk positions (relative to 4*ks + g) and the second, one chunk further, on the odd ones;
 //  * transpose reads (ds_read_b64_tr_b16; a 32-lane half reads 8-byte halves of chunks 2*dt, 2*dt+1 of rows (li>>2) + 8*(g&1) [+4]): the rows differ
 //    in bits {0, 1, 3}, exactly the bits of rho, so the eight rows use eight different chunk pairs = all 64 banks once.
-#ifndef IADR1_ATTN_NOSWZ
+// (the padded 272-byte-row form this replaced -- conflicts 0.40 -> 0.00, 1-5 % on the kernels -- is in profiles/EXPERIMENTS.md rounds 1-2; its compile-time switch was removed in round 6)
 __device__ __forceinline__ int swz_rho(int r) { return (r & 3) | ((r >> 1) & 4); }
 __device__ __forceinline__ int tile_off(int r, int c, int /*LD*/) { return r * 256 + ((c ^ (2 * swz_rho(r))) << 4); }    // byte offset of chunk c of row r
-#else
-__device__ __forceinline__ int swz_rho(int) { return 0; }
-__device__ __forceinline__ int tile_off(int r, int c, int LD) { return (r * LD + c * 8) * 2; }
-#endif
 
 __device__ __forceinline__ bf16x8_t ld_frag_g(const bf16_t* p, bool ok) {
     u32x4_t v = {0, 0, 0, 0};
@@ -180,11 +172,7 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ __forceinline__ uint32_t tr_lane_off(int li, int g, int LD) { return (uint32_t)(((g * 8 + (li >> 2)) * LD + 4 * (li & 3)) * 2); }
 // byte offset of d-tile dt (16 columns = chunks 2*dt, 2*dt+1) relative to tr_lane_off, for THIS lane's rows (swizzled image: the chunk pair moves with rho of the row)
 __device__ __forceinline__ uint32_t tr_dt_off(int dt, int li, int g) {
-#ifndef IADR1_ATTN_NOSWZ
     return (uint32_t)((dt ^ ((li >> 2) | ((g & 1) << 2))) << 5);
-#else
-    return (uint32_t)(dt * 32);
-#endif
 }
 
 // =====================================================================================================
@@ -1256,7 +1244,7 @@ extern "C" int iadr1_attn_fwd(const void* q, const void* k, const void* v, void*
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
     p.seg_start = seg_start; p.seg_end = seg_end; p.seg_prefix = seg_prefix; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.T = T; p.Hq = Hq; p.Hkv = Hkv; p.causal = causal; p.scale = scale;
-    static const int force_r = iadr1_env_int("IADR1_ATTN_R", 1);
+    constexpr int force_r = 1;      // query tiles per block (2 measured slower: profiles/EXPERIMENTS.md rounds 1-2)
     SegRange rg[2];
     const int nr = seg_ranges(nseg, max_seqlen, nseg_head, max_seqlen_tail, rg);
     for (int ri = 0; ri < nr; ++ri) {
@@ -1317,8 +1305,7 @@ extern "C" int iadr1_attn_bwd(const void* q, const void* k, const void* v, const
     IADR1_REQUIRE((Hq / Hkv) % hs_all == 0, "attn_bwd: head_splits=%d must divide the GQA group %d", hs_all, Hq / Hkv);
     p.dkv_ws = dkv_ws;
     const long long items = (long long)T * Hq * 16;
-    static const int dq_r = iadr1_env_int("IADR1_ATTN_BWD_R", 2);
-    static const int kv_waves = iadr1_env_int("IADR1_ATTN_DKDV_WAVES", 8);
+    constexpr int dq_r = 2, kv_waves = 8;      // the measured choices (8-wave dK/dV, two query tiles per dQ block: profiles/EXPERIMENTS.md rounds 1-2)
     SegRange rg[2];
     const int nr = seg_ranges(nseg, max_seqlen, nseg_head, max_seqlen_tail, rg);
 #define LAUNCH_BWD(DD)                                                                                                                   \
@@ -1361,13 +1348,12 @@ extern "C" int iadr1_attn_decode(const void* q, const void* kcache, const void* 
     IADR1_REQUIRE(B > 0 && Hq % Hkv == 0 && Hq / Hkv <= 16, "attn_decode: GQA group must be <= 16");
     IADR1_REQUIRE((ldq % 8) == 0, "attn_decode: ldq must be a multiple of 8");
     IADR1_REQUIRE(seqs_per_group >= 0 && (seqs_per_group <= 1 || B % seqs_per_group == 0), "attn_decode: B must be a multiple of seqs_per_group");
-    static const int xcd_groups = iadr1_env_int("IADR1_DECODE_ATTN_XCD_GROUPS", 1);
-    const int gseq = (xcd_groups && seqs_per_group > 1) ? seqs_per_group : 0;
+    const int gseq = seqs_per_group > 1 ? seqs_per_group : 0;      // the blocks of a prompt group on one XCD: its L2 dedupes the shared prompt pages
     DecodeArgs p{(const bf16_t*)q, (const bf16_t*)kcache, (const bf16_t*)vcache, block_table, ctx_len, (bf16_t*)o, ldq, ldo, B, Hq, Hkv, max_pages, scale, gseq};
     const dim3 grid = gseq ? dim3(8 * ((B / gseq + 7) / 8) * gseq * Hkv) : dim3(B, Hkv);
     // 16 waves per (sequence, kv head) block: a wave then walks ~1.5 pages instead of ~3 at ctx ~ 640 (the kernel is a chain of dependent
-    // page loads on only B*Hkv = 128 CUs); IADR1_DECODE_ATTN_WAVES=8 keeps the 8-wave form
-    static const int waves = iadr1_env_int("IADR1_DECODE_ATTN_WAVES", 16) == 8 ? 8 : 16;
+    // page loads on only B*Hkv = 128 CUs)
+    constexpr int waves = 16;
     const int gs = (Hq / Hkv <= 8) ? 9 : 17;
     SideOut so;
     if (int e = iadr1_side_arg(side, &so)) return e;

@@ -309,9 +309,16 @@ __device__ __forceinline__ bf16x8_t tr_frag_asm(const char* lds_addr, int kk) {
     return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int OUT, bool TN = false>
+// M32 (round 6 experiment, probe builds with -DIADR1_PROBE_MFMA32 only; plain NT form, OUT_BF16 / OUT_F32 / OUT_F32_ACC): the same pipeline on v_mfma_f32_32x32x16_bf16 -- the wave's 128 x 64
+// tile as 4 x 2 accumulators of 32 x 32, four 16-deep k-steps per K tile.  The LDS traffic is the wave TILE's and does not change (24 ds_read_b128 per K tile either
+// way: a register-blocked wave reads its A and B sub-tiles once whatever the instruction shape); what changes is the MFMA issue count (32 instead of 64 per K tile)
+// and the operand-register reads per FLOP.  The swizzled half images serve the 32-row fragments conflict-free as they are (rows r .. r + 31 of one 16-byte chunk
+// column: the 16 lanes of every ds_read_b128 service group land in 16 different bank groups).  Results differ from the 16x16x32 form in fp32 summation order.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <int OUT, bool TN = false, bool M32 = false>
 __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     static_assert(!TN || OUT == OUT_F32 || OUT == OUT_F32_ACC, "the TN form exists for the fp32 (accumulate) outputs only");
+    static_assert(!M32 || (!TN && (OUT == OUT_BF16 || OUT == OUT_F32 || OUT == OUT_F32_ACC)), "the 32x32x16 form exists for the plain NT outputs only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -417,17 +424,43 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     }
     }
 
+    int a_off32[4], b_off32[4];  // M32: per 16-deep k-step; add mt*4096 (32 rows)
+    if constexpr (M32) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = ks * 2 + (l >> 5);
+            const int ra = wm * 64 + (l & 31), rb = wn * 32 + (l & 31);
+            a_off32[ks] = ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4);
+            b_off32[ks] = rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4);
+        }
+    }
+
     f32x4_t acc[8][4];  // [m-tile][n-tile] of the 128x64 wave tile
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x16_t acc32[4][2];  // M32: [32-row m-tile][32-column n-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    bf16x8_t af32[2][4], bf32[2][4];   // M32: current A half (2 m-tiles x 4 k-steps), BOTH B halves (n-tile x 4 k-steps)
 
     bf16x8_t af[4][2], bfr[2][2];  // current A half (4 m-tiles x 2 k-steps), current B half (2 n-tiles x 2 k-steps)
     bf16x8_t bfr1[TN ? 2 : 1][2];  // TN: B half 1 in registers of its own, so that B half 0 survives phases 2 - 3 and phase 4 reads nothing (transpose reads are the
                                    // form's bottleneck: 48 instead of 56 per K tile)
     auto read_a = [&](int buf, int h) {
         const char* base = smem + buf * BUF2_BYTES + h * HALF_BYTES;
+        if constexpr (M32) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) af32[mt][ks] = *(const bf16x8_t*)(base + a_off32[ks] + mt * 4096);
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -438,6 +471,11 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     };
     auto read_b = [&](int buf, int h) {
         const char* base = smem + buf * BUF2_BYTES + (2 + h) * HALF_BYTES;
+        if constexpr (M32) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bf32[h][ks] = *(const bf16x8_t*)(base + b_off32[ks]);
+            return;
+        }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -457,6 +495,17 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                     \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                     \
             acc[(MH) * 4 + mi][(NH) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ni][kk], af[mi][kk], acc[(MH) * 4 + mi][(NH) * 2 + ni], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                       \
+    } while (0)
+    // M32: one A half against BOTH B halves = four independent 32 x 32 accumulators per phase, 16 MFMAs; the same accumulator comes round every fourth MFMA
+    // (128 cycles apart -- with two accumulators per phase, 64 apart, the dependent MFMAs stalled: 1125 instead of 1270 TF/s, profiles/EXPERIMENTS.md round 6)
+#define IADR1_HALF32(MH)                                                                                                     \
+    do {                                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                     \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                     \
+            acc32[(MH) * 2 + mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf32[nt][ks], af32[mt][ks], acc32[(MH) * 2 + mt][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                       \
     } while (0)
 #define IADR1_QUAD(MH, NH)                                                                                                   \
@@ -480,8 +529,8 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     stage_half(0, 1, 0);
     if (nk > 1) {
         stage_half(1, 0, 1);
-        stage_half(1, 3, 1);
-        stage_half(1, 1, 1);
+        stage_half(1, M32 ? 2 : 3, 1);
+        stage_half(1, M32 ? 3 : 1, 1);
         IADR1_VMCNT(6);
     } else {
         IADR1_VMCNT(0);
@@ -495,6 +544,32 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     // The region re-fill / landing rules above still hold: a reader always passes one more barrier than the wait or
     // the last read it depends on.
     if (wm == 1) __builtin_amdgcn_s_barrier();
+    if constexpr (M32) {
+        // Two phases per K tile (same role split, same rules: a region is re-filled one phase after the phase that read it, every phase retires its ds_reads before
+        // its barrier):
+        //   phase A: read A0,B0,B1(u) | DMA A1(u+1) -> other buffer            | barrier | 16 MFMA: A0 x (B0, B1) | barrier
+        //   phase B: read A1(u)       | DMA A0,B0,B1(u+2) -> this buffer, vmcnt(6): all of tile u+1 landed, three half-tiles of u+2 in flight | barrier | 16 MFMA: A1 x (B0, B1) | barrier
+        // prologue: tile 0 complete + A0,B0,B1 of tile 1 in flight.  20 ds_read_b128 per K tile (B0 is not read twice), 4 barriers instead of 8.
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1, nxt = cur ^ 1;
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+            read_a(cur, 0);
+            read_b(cur, 0);
+            read_b(cur, 1);
+            if (more1) stage_half(nxt, 1, kt + 1);
+            IADR1_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            IADR1_HALF32(0);
+            __builtin_amdgcn_s_barrier();
+
+            read_a(cur, 1);
+            if (more2) { stage_half(cur, 0, kt + 2); stage_half(cur, 2, kt + 2); stage_half(cur, 3, kt + 2); IADR1_VMCNT(6); } else if (more1) { IADR1_VMCNT(0); }
+            IADR1_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            IADR1_HALF32(1);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1, nxt = cur ^ 1;
         const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
@@ -530,9 +605,100 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt_256(GemmArgs p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();
 #undef IADR1_LGKM0
 #undef IADR1_QUAD
+#undef IADR1_HALF32
 #undef IADR1_QUAD_B
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
+    if constexpr (M32) {
+        // swapped-operand 32 x 32 accumulator: lane (lr = l & 31, lh = l >> 5) holds, of m-tile mt / n-tile nt, row mt*32 + lr and the four consecutive columns
+        // nt*32 + g*8 + lh*4 + e of accumulator elements g*4 + e (g = 0..3)
+        const int lr = l & 31, lh = l >> 5;
+        if constexpr (OUT == OUT_BF16) {
+            __syncthreads();  // every wave is done with the operand buffers
+            bf16_t* slab = (bf16_t*)smem + (size_t)w * 128 * EP_LD;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = nt * 32 + g * 8 + lh * 4;
+                    const int gn = n0 + wn * 64 + nl;
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bv[e] = (gn + e < p.N) ? bf2f(p.bias[gn + e]) : 0.f;
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc32[mt][nt][g * 4 + e] + bv[e];
+                            if (p.act == 1) v[e] = gelu_erf(v[e]);
+                        }
+                        *(u32x2_t*)(slab + (mt * 32 + lr) * EP_LD + nl) = (u32x2_t){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    }
+                }
+            bf16_t* C = (bf16_t*)p.C;
+            const bool vec_ok = ((p.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0);
+            if (vec_ok && m0 + wm * 128 + 128 <= p.M && n0 + wn * 64 + 64 <= p.N) {
+                bf16_t* dst0 = C + (long long)(m0 + wm * 128 + (l >> 3)) * p.ldc + n0 + wn * 64 + (l & 7) * 8;
+                const bf16_t* src0 = slab + (l >> 3) * EP_LD + (l & 7) * 8;
+                u32x4_t rv[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) rv[it] = *(const u32x4_t*)(src0 + it * 8 * EP_LD);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) *(u32x4_t*)(dst0 + (long long)it * 8 * p.ldc) = rv[it];
+                return;
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 8 + (l >> 3), ch = l & 7;
+                const int gm = m0 + wm * 128 + row, gn = n0 + wn * 64 + ch * 8;
+                if (gm >= p.M || gn >= p.N) continue;
+                bf16_t* dst = C + (long long)gm * p.ldc + gn;
+                if (vec_ok && gn + 8 <= p.N) {
+                    *(u32x4_t*)dst = *(const u32x4_t*)(slab + row * EP_LD + ch * 8);
+                } else {
+                    const bf16_t* sv = slab + row * EP_LD + ch * 8;
+                    for (int e = 0; e < 8 && gn + e < p.N; ++e) dst[e] = sv[e];
+                }
+            }
+        } else {
+            float* C = (float*)p.C;
+            const bool vec_ok = ((p.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int gm = m0 + wm * 128 + mt * 32 + lr;
+                if (gm >= p.M) continue;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int gn = n0 + wn * 64 + nt * 32 + g * 8 + lh * 4;
+                        if (gn >= p.N) continue;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc32[mt][nt][g * 4 + e];
+                            if (p.bias && gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
+                            if (p.act == 1) v[e] = gelu_erf(v[e]);
+                        }
+                        float* dst = C + (long long)gm * p.ldc + gn;
+                        if (vec_ok && gn + 4 <= p.N) {
+                            f32x4_t o = {v[0], v[1], v[2], v[3]};
+                            if constexpr (OUT == OUT_F32_ACC) o += *(const f32x4_t*)dst;
+                            *(f32x4_t*)dst = o;
+                        } else {
+                            for (int e = 0; e < 4 && gn + e < p.N; ++e) {
+                                if constexpr (OUT == OUT_F32_ACC) dst[e] += v[e];
+                                else dst[e] = v[e];
+                            }
+                        }
+                    }
+            }
+        }
+        return;
+    }
     const int lm = l & 15, lq = l >> 4;
     if constexpr (OUT == OUT_SWIGLU || OUT == OUT_SWIGLU_ROWS) {
         // interior tiles only (the launcher guarantees M % 256 == 0, N % 256 == 0, 16-byte aligned outputs)
@@ -826,7 +992,7 @@ struct SkinnyArgs {
     int Hq, Hkv;
     SideOut so;                // out_mode 4: p0 = roped q|k|v rows; out_mode 3 (persistent kernel): p0 = gate|up rows, p1 = SwiGLU rows (common.h)
     const float* wscale;       // non-null: W is FP8 (OCP e4m3) decode-packed (iadr1_pack_weight_fp8), wscale[n] = dequantisation scale of output row n
-    int xcd_order;             // persistent kernel with side outputs: XCD-aware order of the tile groups (IADR1_PERS_XCD_ORDER=0: plain)
+    int xcd_order;             // persistent kernel with side outputs: XCD-aware order of the tile groups
 };
 
 // FUSEV (out_mode 4, NB == 1 only): the blocks of the K heads also compute the V tile of the same head and 16-dim slice from the X fragments they have already
@@ -1237,18 +1403,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_kernel(SkinnyArgs
     // the first group's weights are requested BEFORE the X fragments: they come from HBM (the longer latency) and do not depend on anything, the
     // X fragments are 256 KB per CU out of L2 -- measured with in-kernel stamps (profiles/r02_decode_stamps.txt): 6.4 us from entry to the first
     // group's MFMAs with X first
-#ifndef IADR1_PERS_XFIRST
     if (g < ngroups) loadw(g);
-#endif
     bf16x8_t xf[KSW][4];
 #pragma unroll
     for (int j = 0; j < KSW; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             xf[j][i] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(xbase + (i < xgroups_ok ? i * xgroup : 0) + (long long)(FP8 ? 2 * (w + (j >> 1) * WAVES) + (j & 1) : w + j * WAVES) * xstep));
-#ifdef IADR1_PERS_XFIRST
-    if (g < ngroups) loadw(g);
-#endif
     float* mine = red + (size_t)w * 64 * RLD;
     for (; g < ngroups; gq += gstep, g = group_of(gq)) {
         const int g_next = group_of(gq + gstep);
@@ -1370,9 +1531,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
         }
     };
     int g = b;
-#ifdef IADR1_SPLIT_WFIRST
-    if (g < ntiles) loadw(g);
-#endif
 #pragma unroll
     for (int j = 0; j < KSW; ++j) {
         const int st = st_begin + w + j * WAVES;
@@ -1386,9 +1544,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_pers_split_kernel(Skin
                 xf[j * XS + h][i] = __builtin_bit_cast(bf16x8_t, v);
             }
     }
-#ifndef IADR1_SPLIT_WFIRST
     if (g < ntiles) loadw(g);          // after the X fragments here: measured 12.2 vs 12.8 us with the weights first (the opposite of the un-split kernel)
-#endif
     float* mine = red + (size_t)w * 64 * RLD;
     for (; g < ntiles; g += bps) {
         f32x4_t acc[4];
@@ -1562,7 +1718,7 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
     IADR1_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0, "gemm_nt: K, lda, ldb must be multiples of 8 (16-byte chunks); K=%d lda=%lld ldb=%lld", K, lda, ldb);
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, "gemm_nt: A/B must be 16-byte aligned");
     IADR1_REQUIRE(out_mode >= 0 && out_mode <= 2, "gemm_nt: bad out_mode %d", out_mode);
-    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    constexpr int band_rows = 4;      // tile rows per rasterisation band: 1 / 2 / 4 / 8 measured within 4 % on the hot shapes, 4 best (profiles/r05_gemm_band.txt)
     GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, zeros_ptr(), M, N, K, lda, ldb, ldc, act, band_rows, nullptr, 0};
     static const int force_tile = iadr1_env_int("IADR1_GEMM_TILE", 0);
     static const bool attr_done = [] {
@@ -1572,12 +1728,26 @@ extern "C" int iadr1_gemm_nt_bf16(const void* A, const void* B, void* C, const v
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32_ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+#ifdef IADR1_PROBE_MFMA32
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_BF16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32_ACC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+#endif
         return true;
     }();
     (void)attr_done;
     // 256^2 deep-pipeline kernel when the grid fills the chip with big tiles; 128^2 kernel for small / ragged problems
     const long long tiles256 = (long long)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
     const bool big = force_tile == 256 || (force_tile != 128 && M >= 512 && N >= 512 && tiles256 >= 192);
+#ifdef IADR1_PROBE_MFMA32      // probe builds only (tools/build_variant.py mfma32 -DIADR1_PROBE_MFMA32; tools/gemm_mfma32_ab.py): the 256^2 kernel on v_mfma_f32_32x32x16_bf16.
+    if (big) {                  // Measured round 6: 9 % SLOWER than the 16x16x32 form on every hot shape (profiles/r06_gemm_mfma32_ab.txt) -- not in the product build.
+        const int grid = (int)tiles256;
+        if (out_mode == 0) hipLaunchKernelGGL((gemm_nt_256<OUT_BF16, false, true>), dim3(grid), dim3(NT2), SMEM2_BYTES, stream, p);
+        else if (out_mode == 1) hipLaunchKernelGGL((gemm_nt_256<OUT_F32, false, true>), dim3(grid), dim3(NT2), SMEM2_BYTES, stream, p);
+        else hipLaunchKernelGGL((gemm_nt_256<OUT_F32_ACC, false, true>), dim3(grid), dim3(NT2), SMEM2_BYTES, stream, p);
+        return iadr1_check_launch("gemm_nt_bf16");
+    }
+#endif
     if (big) {
         const int grid = (int)tiles256;
         if (out_mode == 0) hipLaunchKernelGGL(gemm_nt_256<OUT_BF16>, dim3(grid), dim3(NT2), SMEM2_BYTES, stream, p);
@@ -1608,7 +1778,7 @@ extern "C" int iadr1_gemm_nt_splitk_acc_bf16(const void* A, const void* B, float
                   "gemm_nt_splitk: A, B, C and the workspace must be 16-byte aligned");
     const int kslice = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;      // whole 64-deep K tiles per slice
     IADR1_REQUIRE((long long)(ksplit - 1) * kslice < K, "gemm_nt_splitk: ksplit %d leaves an empty slice for K = %d", ksplit, K);
-    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    constexpr int band_rows = 4;      // tile rows per rasterisation band: 1 / 2 / 4 / 8 measured within 4 % on the hot shapes, 4 best (profiles/r05_gemm_band.txt)
     GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, workspace, nullptr, zeros_ptr(), M, N, K, lda, ldb, (long long)N, 0, band_rows, nullptr, 0};
     p.ksplit = ksplit; p.kslice = kslice; p.zstride = (long long)M * N;
     static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
@@ -1631,7 +1801,7 @@ extern "C" int iadr1_gemm_tn_acc_bf16(const void* A, const void* B, float* C, vo
     IADR1_REQUIRE(M >= 256 && N >= 256 && K > 0, "gemm_tn: needs M >= 256, N >= 256, K > 0 (M=%d N=%d K=%d)", M, N, K);
     IADR1_REQUIRE((M % 8) == 0 && (N % 8) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (N % 4) == 0 && (ldc % 4) == 0, "gemm_tn: M, N, lda, ldb multiples of 8, ldc a multiple of 4");
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 && (((uintptr_t)C) & 15) == 0, "gemm_tn: A, B, C must be 16-byte aligned");
-    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    constexpr int band_rows = 4;      // tile rows per rasterisation band: 1 / 2 / 4 / 8 measured within 4 % on the hot shapes, 4 best (profiles/r05_gemm_band.txt)
     static const bool attr_done = [] {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_F32_ACC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
@@ -1676,7 +1846,7 @@ extern "C" int iadr1_linear_logprob_fwd(const void* H, const void* W, const long
                                         long long ldh, long long ldw, hipStream_t stream) {
     if (int rc = linear_logprob_args("linear_logprob_fwd", H, W, M, V, K, ldh, ldw)) return rc;
     IADR1_REQUIRE(targets && logp && workspace && (((uintptr_t)workspace) & 7) == 0, "linear_logprob_fwd: targets, logp and an 8-byte aligned workspace are required");
-    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    constexpr int band_rows = 4;      // tile rows per rasterisation band: 1 / 2 / 4 / 8 measured within 4 % on the hot shapes, 4 best (profiles/r05_gemm_band.txt)
     const int tiles_n = (V + T2 - 1) / T2, nparts = tiles_n * 4;
     float* part = (float*)workspace;
     float* tgt_logit = part + (long long)M * nparts * 2;
@@ -1693,7 +1863,7 @@ extern "C" int iadr1_linear_logprob_dlogits(const void* H, const void* W, const 
                                             int K, long long ldh, long long ldw, hipStream_t stream) {
     if (int rc = linear_logprob_args("linear_logprob_dlogits", H, W, M, V, K, ldh, ldw)) return rc;
     IADR1_REQUIRE(targets && lse && g && dl, "linear_logprob_dlogits: targets, lse, g and dl are required");
-    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    constexpr int band_rows = 4;      // tile rows per rasterisation band: 1 / 2 / 4 / 8 measured within 4 % on the hot shapes, 4 best (profiles/r05_gemm_band.txt)
     GemmArgs p{(const bf16_t*)H, (const bf16_t*)W, dl, nullptr, zeros_ptr(), M, V, K, ldh, ldw, ldd, 0, band_rows, nullptr, 0, targets, nullptr, nullptr, lse, g, 0};
     static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_DLOGITS>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
     (void)attr_done;
@@ -1709,7 +1879,7 @@ extern "C" int iadr1_gemm_swiglu_bf16(const void* A, const void* W, void* GU, vo
     IADR1_REQUIRE((M % 256) == 0 && (I % 128) == 0 && (K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (ldaout % 8) == 0 && (GU == nullptr || (ldgu % 8) == 0),
                   "gemm_swiglu: needs M %% 256 == 0, I %% 128 == 0 and 16-byte row strides (M=%d I=%d K=%d); use gemm_nt + swiglu_fwd otherwise", M, I, K);
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)GU) & 15) == 0 && (((uintptr_t)Aout) & 15) == 0, "gemm_swiglu: operands must be 16-byte aligned");
-    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    constexpr int band_rows = 4;      // tile rows per rasterisation band: 1 / 2 / 4 / 8 measured within 4 % on the hot shapes, 4 best (profiles/r05_gemm_band.txt)
     GemmArgs p{(const bf16_t*)A, (const bf16_t*)W, GU, nullptr, zeros_ptr(), M, 2 * I, K, lda, ldw, ldgu, 0, band_rows, (bf16_t*)Aout, ldaout};
     static const bool attr_done = [] { (void)hipFuncSetAttribute((const void*)gemm_nt_256<OUT_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES); return true; }();
     (void)attr_done;
@@ -1726,7 +1896,7 @@ extern "C" int iadr1_gemm_swiglu_rows_bf16(const void* A, const void* W, void* G
                   "gemm_swiglu_rows: needs M %% 256 == 0, I %% 128 == 0 and 16-byte row strides (M=%d I=%d K=%d)", M, I, K);
     IADR1_REQUIRE(block >= 16 && (block & (block - 1)) == 0 && (M % block) == 0 && block_stride >= block, "gemm_swiglu_rows: block must be a power of two >= 16 dividing M, block_stride >= block (block=%d)", block);
     IADR1_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (((uintptr_t)GU) & 15) == 0 && (((uintptr_t)Aout) & 15) == 0, "gemm_swiglu_rows: operands must be 16-byte aligned");
-    static const int band_rows = iadr1_env_int("IADR1_GEMM_BAND", 4) >= 1 ? iadr1_env_int("IADR1_GEMM_BAND", 4) : 4;
+    constexpr int band_rows = 4;      // tile rows per rasterisation band: 1 / 2 / 4 / 8 measured within 4 % on the hot shapes, 4 best (profiles/r05_gemm_band.txt)
     GemmArgs p{(const bf16_t*)A, (const bf16_t*)W, GU, nullptr, zeros_ptr(), M, 2 * I, K, lda, ldw, ldgu, 0, band_rows, (bf16_t*)Aout, ldaout};
     p.rb_shift = __builtin_ctz((unsigned)block);
     p.rb_stride = block_stride;
@@ -1748,13 +1918,11 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     SkinnyArgs p{};
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)W; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
     p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.out_mode = out_mode;
-    static const int xcd_order = iadr1_env_int("IADR1_PERS_XCD_ORDER", 1);
-    p.xcd_order = xcd_order;
+    p.xcd_order = 1;      // (decode step with side outputs 2.886 -> 2.834 ms: profiles/EXPERIMENTS.md round 2)
     const int mz = (M + 63) / 64;
     // dynamic LDS: the cross-wave reduction buffer [WAVES][64][RLD]
     constexpr int SM1 = 16 * 64 * 17 * 4, SM2 = 8 * 64 * 33 * 4, SMW = 8 * 64 * 33 * 4, SMP = SMW, SMS = 8 * 64 * 17 * 4;
     // launcher configuration, fixed at first use: A/B switches, the CU count, LDS opt-ins of every kernel this entry point can launch
-    static const int wide_nb = iadr1_env_int("IADR1_SKINNY_WIDE_NB", -1);  // -1: 4 with packed X, 8 with row-major X
     static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1);
     static const int dev_cus_ = [] {
         int dev = 0;
@@ -1782,8 +1950,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     {
         {   // split-K slabs (down projection): <= 6 k-steps per wave in a slice, >= 4 tiles per block
             const int kst = K >> 5, per_z = (kst + ksplit - 1) / ksplit, bps = ksplit > 0 ? ncu / ksplit : 0;
-            static const int ksw10 = iadr1_env_int("IADR1_SPLIT_KSW10", 1);
-            if (pers && ksplit > 1 && out_mode == 2 && per_z <= (ksw10 ? 80 : 48) && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
+            if (pers && ksplit > 1 && out_mode == 2 && per_z <= 80 && bps >= 1 && (N >> 4) >= 4 * bps && (kst % ksplit == 0 || (ksplit - 1) * per_z < kst)) {
                 IADR1_REQUIRE(side == nullptr, "gemm_skinny: no side outputs in the split-K slab form");
                 // <= 48 k-steps per slice: 6 resident X steps per wave (3B widths: 344 / 8 = 43); <= 80: 10 (7B widths: 592 / 8 = 74; 160 VGPRs of X fragments)
                 if (per_z <= 48) hipLaunchKernelGGL((gemm_skinny_pers_split_kernel<8, 6>), dim3(bps * ksplit, mz, 1), dim3(512), SMS, stream, p, ksplit, bps);
@@ -1807,7 +1974,7 @@ extern "C" int iadr1_gemm_skinny_bf16(const void* X, const void* W, void* Y, con
     // with decode-packed X the X fragments are cheap coalesced L2 reads, and 64-column blocks (two co-resident per CU, 344
     // blocks on the 3B gate|up) beat 128-column ones: 24.6 vs 33.7 us on the 90 MB gate|up stream (tools/decode_stream.py)
     const bool big = (N >= 8192 && ksplit == 1) || out_mode == 3;
-    const int nb = (ldx == 0 && wide_nb != 8) || wide_nb == 4 ? 4 : 8;
+    const int nb = ldx == 0 ? 4 : 8;      // 64-column blocks with packed X, 128-column ones with row-major X
     if (big && nb == 4 && (N % 64) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3(N / 64, mz, 1), dim3(512), SMW, stream, p);
     else if (big && (N % 128) == 0) hipLaunchKernelGGL((gemm_skinny_wide_kernel<8, 8>), dim3((N + 127) / 128, mz, 1), dim3(512), SMW, stream, p);
     else if (ksplit > 1 && (N % 64) == 0 && (N / 64) * ksplit >= 192) hipLaunchKernelGGL((gemm_skinny_wide_kernel<4, 8>), dim3((N + 63) / 64, mz, ksplit), dim3(512), SMW, stream, p);
@@ -1850,10 +2017,9 @@ extern "C" int iadr1_gemm_qkv_rope_kv_bf16(const void* X, const void* Wp, const 
     }();
     (void)dev_cus_;
     const int ncu = iadr1_decode_cus();      // the CUs the decode stream owns (runtime.hip): persistent grids are one block per such CU
-    static const int fuse_v = iadr1_env_int("IADR1_QKV_FUSE_V", 1);
     // more tiles than CUs, but the q and k tiles alone fit: the K-head blocks take their V tile along (one round of blocks instead of two)
     const int tiles = p.N / 16, rope_tiles = (Hq + Hkv) * (D / 16);
-    if (fuse_v && tiles > ncu && rope_tiles <= ncu && (K % 64) == 0) {
+    if (tiles > ncu && rope_tiles <= ncu && (K % 64) == 0) {
         hipLaunchKernelGGL((gemm_skinny_kernel<1, 16, true>), dim3(rope_tiles, (M + 63) / 64, 1), dim3(1024), 2 * SM1, stream, p);
         return iadr1_check_launch("gemm_qkv_rope_kv_bf16");
     }
@@ -1901,7 +2067,7 @@ extern "C" int iadr1_gemm_skinny_fp8w(const void* X, const void* Wp8, const floa
     p.X = (const bf16_t*)X; p.W = (const bf16_t*)Wp8; p.wscale = wscale; p.Y = Y; p.bias = (const bf16_t*)bias; p.M = M; p.N = N; p.K = K;
     p.ldx = ldx; p.ldw = K; p.ldy = ldy; p.out_mode = out_mode;
     constexpr int SMW = 8 * 64 * 33 * 4, SMS = 8 * 64 * 17 * 4;
-    static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1) && iadr1_env_int("IADR1_SKINNY_PERS_FP8", 1);
+    static const int pers = iadr1_env_int("IADR1_SKINNY_PERS", 1);
     static const int dev_cus_ = [] {
         int dev = 0;
         hipDeviceProp_t prop;

@@ -24,15 +24,20 @@ struct PrefetchArgs {
     int* status;                // optional device int[4]: timed-out flag, units read (block 0), units dropped as stale (block 0), MiB read (block 0)
 };
 
+// One 16-byte read whose value is dropped: the destination register is the same for every load of a wave (the hardware orders the write-backs; nothing reads it), so a
+// trip keeps U requests per lane in flight with FOUR VGPRs -- the block must fit next to a resident 256 x 256 GEMM block of the side stream (432 of a SIMD's 512 VGPRs).
+// The sink is a READ-WRITE operand ("+v"): the compiler does not know that the write-back arrives later, so the four registers must stay live from the first load to
+// the final s_waitcnt -- as an output-only operand they were handed to address arithmetic between two loads and a late write-back turned an address into garbage
+// (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, round 6).
 template <bool NT>
-__device__ __forceinline__ u32x4_t pf_load(const u32x4_t* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    return *p;
+__device__ __forceinline__ void pf_touch(const u32x4_t* p, u32x4_t& sink) {
+    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(sink) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
 }
 
 template <bool NT>
-__global__ __launch_bounds__(512) void weight_prefetch_kernel(PrefetchArgs a) {
-    constexpr int U = 8;                      // 16-byte loads in flight per lane: 64 KiB per block and trip
+__global__ __launch_bounds__(256) void weight_prefetch_kernel(PrefetchArgs a) {
+    constexpr int U = 16;                     // 16-byte loads in flight per lane: 64 KiB per block and trip (256 threads: one wave per SIMD, a few VGPRs each)
     __shared__ unsigned s_cur;
     __shared__ int s_quit;
     const int t = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
@@ -69,30 +74,28 @@ __global__ __launch_bounds__(512) void weight_prefetch_kernel(PrefetchArgs a) {
         for (int s = 0; s < a.n_seg && !stale; ++s) {
             const u32x4_t* p = (const u32x4_t*)sg[2 * s];
             const long long n16 = sg[2 * s + 1] >> 4;
-            const long long stride = (long long)nb * 512;
-            long long i = (long long)b * 512 + t;
+            const long long stride = (long long)nb * 256;
+            long long i = (long long)b * 256 + t;
             for (; i + (U - 1) * stride < n16; i += U * stride) {
-                u32x4_t v[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) v[u] = pf_load<NT>(p + i + u * stride);
+                for (int u = 0; u < U; ++u) pf_touch<NT>(p + i + u * stride, sink);
                 // has the decode step moved past this unit's consumers?  (one more request per trip, the same word for every lane)
                 const unsigned now = __hip_atomic_load(a.mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int u = 0; u < U; ++u) sink ^= v[u];
                 read_bytes += U * 16;
                 if (now > unit_mark) { stale = true; break; }
             }
             if (!stale)
-                for (; i < n16; i += stride) sink ^= pf_load<NT>(p + i);
+                for (; i < n16; i += stride) pf_touch<NT>(p + i, sink);
         }
         done_units += stale ? 0 : 1;
         stale_units += stale ? 1 : 0;
     }
-    if ((sink[0] ^ sink[1] ^ sink[2] ^ sink[3]) == 0x9e3779b9u && a.status) a.status[0] |= 2;      // (keeps the loads alive)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((sink[0] ^ sink[1] ^ sink[2] ^ sink[3]) == 0x9e3779b9u && a.status) a.status[0] |= 2;      // (the sink is read once, after every load has returned)
     if (a.status && b == 0 && t == 0) {
         a.status[1] = done_units;
         a.status[2] = stale_units;
-        a.status[3] = (int)((read_bytes * 512 * nb) >> 20);
+        a.status[3] = (int)((read_bytes * 256 * nb) >> 20);
     }
 }
 }  // namespace
@@ -103,7 +106,7 @@ extern "C" int iadr1_weight_prefetch(const long long* segs, int n_units, int n_s
     IADR1_REQUIRE(first_mark <= last_mark && lead >= 0 && lead < n_units, "weight_prefetch: marks [%u, %u], lead %d of %d units", first_mark, last_mark, lead, n_units);
     IADR1_REQUIRE(n_blocks > 0 && n_blocks <= 256 && timeout_ms > 0 && timeout_ms <= 60000, "weight_prefetch: 1..256 blocks (one per CU of the stream's mask) and a timeout in (0, 60000] ms");
     PrefetchArgs a{segs, n_units, n_seg, mark, first_mark, last_mark, lead, nt, (unsigned long long)timeout_ms * 100000ull, status};
-    if (nt) hipLaunchKernelGGL(weight_prefetch_kernel<true>, dim3(n_blocks), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL(weight_prefetch_kernel<false>, dim3(n_blocks), dim3(512), 0, stream, a);
+    if (nt) hipLaunchKernelGGL(weight_prefetch_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(weight_prefetch_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, a);
     return iadr1_check_launch("weight_prefetch");
 }

@@ -26,9 +26,9 @@ def h2d(a, device):
     """Host array / CPU tensor -> device tensor through pinned memory, without blocking.  A pageable host-to-device copy synchronises the stream: the host
     would wait for everything it has enqueued so far, lose its run-ahead, and the GPU would idle while it catches up (index plans, targets, advantages are
     uploaded in the middle of enqueued phases).  A/B on the 3B bench step, three alternating pairs: 1272.0 / 1265.6 / 1268.4 ms against 1274.0 / 1270.4 / 1269.6
-    with IADR1_H2D_PINNED=0 (the pageable form)."""
+    with the pageable form."""
     t = torch.from_numpy(a) if not isinstance(a, torch.Tensor) else a
-    if torch.device(device).type != "cuda" or os.environ.get("IADR1_H2D_PINNED", "1") == "0":
+    if torch.device(device).type != "cuda":
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
 

@@ -163,28 +163,76 @@ def agree_across_ranks(ok_local: bool, group=None, device=None) -> bool:
 _SPLITS: dict = {}       # (device index, side-stream CUs, prefetch CUs) -> (decode stream, side stream, decode CUs, prefetch stream | None), or None when no clean stream pair was found
 
 
+def pick_prefetch_stream(decode, side, make_candidate, weight: torch.Tensor, tries: int = 6, log=None):
+    """A stream for the rollout's persistent weight prefetcher (wprefetch.py): its one resident, polling launch must disturb NEITHER the decode replays' chain of small
+    dependent launches NOR the side stream's big-grid GEMMs (its CUs are a subset of the side stream's: the block is small enough -- 256 threads, 28 VGPRs, 8 bytes of
+    LDS -- to sit next to a resident 256 x 256 GEMM block).  Timed like pick_concurrent_stream, with the real thing on the candidate: a prefetch launch whose mark never
+    arrives (it polls until its 40 ms timeout).  Returns the stream or None."""
+    dev = weight.device
+    K = weight.shape[1]
+    x = torch.zeros(64, K, dtype=BF16, device=dev)
+    g = torch.ones(K, dtype=BF16, device=dev)
+    y = torch.empty_like(x)
+    a = torch.zeros(2048, K, dtype=BF16, device=dev)
+    c = torch.empty(2048, weight.shape[0], dtype=BF16, device=dev)
+    segs = ops.h2d(np.asarray([[[weight.data_ptr(), 1 << 20]]], dtype=np.int64), dev)
+    mark = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def timed(stream, body, resident=None):
+        torch.cuda.synchronize(dev)
+        if resident is not None:
+            with torch.cuda.stream(resident):
+                ops.hip.call("weight_prefetch", segs, 1, 1, mark, 1, 1, 0, 0, 8, 40, None)
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            body()
+            e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1)
+
+    small = lambda: [ops.hip.call("rmsnorm_fwd", x, None, 0, None, None, None, g, y, None, 64, K, K, K, K, 1e-6, None) for _ in range(150)]
+    big = lambda: [ops.gemm_nt(a, weight, out=c) for _ in range(6)]
+    timed(decode, small), timed(side, big)
+    t_small, t_big = timed(decode, small), timed(side, big)
+    for i in range(tries):
+        cand = make_candidate()
+        r_small = timed(decode, small, cand) / max(t_small, 1e-3)
+        r_big = timed(side, big, cand) / max(t_big, 1e-3)
+        if log is not None:
+            log(f"[iadr1] prefetch stream: candidate {i}: decode chain {r_small:.2f}x, side-stream GEMMs {r_big:.2f}x their stand-alone time next to the resident prefetcher")
+        if r_small < 1.15 and r_big < 1.10:
+            return cand
+        destroy_stream(cand)
+    return None
+
+
 def cu_split(dev: torch.device, n: int, weight: torch.Tensor, prefetch_cus: int = 0):
     """The process's CU-masked streams for a side stream of n CUs on `dev` -- decode replays on the device's other CUs -- created and calibrated ONCE
     (pick_concurrent_stream; hardware queues are a finite resource and the calibration takes ~0.2 s).  Returns (decode stream, side stream, decode CUs, prefetch stream
     or None), or None when no candidate on another dispatch pipe was found: the caller then does not co-schedule at all.
-    prefetch_cus > 0 (IADR1_WPREFETCH_CUS): the first `prefetch_cus` of the n CUs go to a third stream for the rollout's weight prefetcher (wprefetch.py), the side
-    stream keeps the other n - prefetch_cus; no clean third queue -> no prefetcher (the split itself stands)."""
+    prefetch_cus > 0 (IADR1_WPREFETCH_CUS): a third stream on the FIRST `prefetch_cus` of the side stream's n CUs for the rollout's weight prefetcher (wprefetch.py).
+    They stay in the side stream's mask: CU masks are only balanced in steps of 32 (a 48-CU side stream runs its GEMMs 1.8x slower than a 64-CU one -- its shader
+    engines hold 2, 2, 1, 1 CUs and get equal shares of every grid; profiles/EXPERIMENTS.md round 6), and the prefetcher's block fits next to a GEMM block.  No clean
+    third queue -> no prefetcher (the split itself stands)."""
     import sys
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(n), int(prefetch_cus))
     if key not in _SPLITS:
         total = torch.cuda.get_device_properties(dev).multi_processor_count
-        if not (0 < n < total and n % 8 == 0 and 0 <= prefetch_cus < n and prefetch_cus % 8 == 0):
-            raise ValueError(f"IADR1_OVERLAP_CUS={n} / IADR1_WPREFETCH_CUS={prefetch_cus}: multiples of 8 (the same share of every XCD), prefetch < side < the device's {total} CUs")
+        if not (0 < n < total and n % 8 == 0 and 0 <= prefetch_cus <= n and prefetch_cus % 8 == 0):
+            raise ValueError(f"IADR1_OVERLAP_CUS={n} / IADR1_WPREFETCH_CUS={prefetch_cus}: multiples of 8 (the same share of every XCD), prefetch <= side < the device's {total} CUs")
         decode = hip.cu_mask_stream(n, total - n)
         log = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("IADR1_OVERLAP_LOG") == "1" else None
-        side, ratio = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(prefetch_cus, n - prefetch_cus), weight, log=log)
+        side, ratio = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(0, n), weight, log=log)
         pf = None
         if side is None:
             destroy_stream(decode)
             if os.environ.get("IADR1_QUIET") != "1":
                 print(f"[iadr1] co-scheduling off: no stream pair on separate dispatch pipes found (best: the dependent chain at {ratio:.1f}x its stand-alone time)", file=sys.stderr, flush=True)
         elif prefetch_cus > 0:
-            pf, _ = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(0, prefetch_cus), weight, log=log)
+            pf = pick_prefetch_stream(decode, side, lambda: hip.cu_mask_stream(0, prefetch_cus), weight, log=log)
+            if pf is None and os.environ.get("IADR1_QUIET") != "1":
+                print("[iadr1] weight prefetcher off: no third stream that leaves both the decode chain and the side stream's GEMMs alone was found", file=sys.stderr, flush=True)
         _SPLITS[key] = None if side is None else (decode, side, total - n, pf)
     return _SPLITS[key]
 
@@ -238,8 +286,9 @@ class ChunkedRefPass:
         self.T = self.T0 + N * C
         self.out_tokens = out_tokens
         # gate of every chunk: the rollout's device-resident step counter (it reads k + 1 once decode replay k has run) polled by iadr1_wait_counter on the side
-        # stream; None (IADR1_OVERLAP_GATE=event): HIP events recorded by the caller between the replays (0.06 ms per decode step dearer)
-        self.step_counter = step_counter if os.environ.get("IADR1_OVERLAP_GATE", "counter") == "counter" else None
+        # stream (HIP events recorded by the caller between the replays cost the decode stream 0.06 ms per step: EXPERIMENTS round 5); None: the caller orders the
+        # streams itself (finish(): the rest runs on the caller's stream)
+        self.step_counter = step_counter
         if self.__dict__.get("_timed_out_host") is not None and int(self._timed_out_host[0]):
             raise RuntimeError("overlap.ChunkedRefPass: a counter wait of the previous rollout timed out (the decode stream never reached the awaited step)")
         if self.step_counter is not None and self.__dict__.get("_timed_out") is None:
@@ -435,9 +484,6 @@ class ChunkedRefPass:
         """Decode steps after which a chunk is handed to the side stream: every `steps`, and once more one block before the end, so that what is left when the
         rollout ends (it runs on the caller's stream, on the whole device: finish) is one block of rows."""
         b = set(range(self.steps, C, self.steps))
-        until = int(os.environ.get("IADR1_OVERLAP_UNTIL", "0"))      # (probe: hand only the chunks up to this decode step to the side stream; the rest runs after the rollout)
-        if until > 0:
-            return {x for x in b if x <= until}
         tail = os.environ.get("IADR1_OVERLAP_TAIL", "auto")
         if C - BLOCK > 0 and (tail == "block" or (tail == "auto" and self.policy is None)):
             b.add(C - BLOCK)

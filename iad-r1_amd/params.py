@@ -806,7 +806,7 @@ class ParamStore:
         For a trainable store on the GPU the ~450 small launches (one per tensor) are captured into a hipGraph at the first call and replayed: every
         pointer is fixed for the life of the store, and the host time of launching them one by one (about 20 ms for the 3B model) is what kept the
         optimizer tail from overlapping with the next step (sc_grpo.optimizer_step(overlap=True))."""
-        if not (self.trainable and self.device.type == "cuda" and os.environ.get("IADR1_SHADOW_GRAPH", "1") != "0"):
+        if not (self.trainable and self.device.type == "cuda"):
             self.refresh_transposes()
             self.refresh_decode_pack()
             return

@@ -84,9 +84,8 @@ class Rollout:
             ncu = self.decode_cus
         if H * Hq * D >= 1 << 20:
             self.ks_o = max(1, min(2, ncu // max(1, H // 16)))
-            # (the persistent split kernel takes <= 80 k-steps per slice, <= 48 with IADR1_SPLIT_KSW10=0 -- the launcher's own gate, gemm.hip: ONE switch for both sides)
-            split_max = int(os.environ.get("IADR1_SPLIT_MAXSTEPS", "80" if os.environ.get("IADR1_SPLIT_KSW10", "1") != "0" else "48"))
-            self.ks_down = 8 if (I // 32 + 7) // 8 <= split_max else max(1, min(8, ncu // max(1, H // 64)))
+            # (the persistent split kernel takes <= 80 k-steps per slice -- the launcher's own gate, gemm.hip)
+            self.ks_down = 8 if (I // 32 + 7) // 8 <= 80 else max(1, min(8, ncu // max(1, H // 64)))
         else:
             self.ks_o, self.ks_down = 1, 1
         if os.environ.get("IADR1_DECODE_KS"):
@@ -105,7 +104,6 @@ class Rollout:
         self.wprefetch = None
         self._marks_in_graph = False
         self._toks_host, self._toks_event = None, None
-        self._join_timed_out = self._join_timed_out_host = None
         self.trace = None           # training arena filled by the decode steps (generate(train_trace=...)); part of the captured graph
         self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -226,8 +224,6 @@ class Rollout:
         N = Bp * G
         assert N == self.N, f"rollout was built for {self.N} sequences, got {N}"
         assert max_new <= self.max_new
-        if self._join_timed_out_host is not None and int(self._join_timed_out_host[0]):
-            raise RuntimeError("Rollout.generate: the counter join of the previous rollout timed out (the decode stream never finished its replays)")
         if dev.type == "cuda":
             ops.hip.set_decode_cus(self.decode_cus)      # this thread's launcher configuration (persistent grids) for the duration of the call: generate() resets it
         self.seed_dev.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)   # device-resident: a new seed per rollout does not invalidate the captured graph
@@ -289,7 +285,7 @@ class Rollout:
         chunks = 1
         if use:
             blocks = Bp * c.num_key_value_heads
-            chunks = int(os.environ.get("IADR1_DECODE_GROUP_CHUNKS", max(1, min(256 // max(blocks, 1), int(shared_tok.min()) // PAGE // 8, 16))))
+            chunks = max(1, min(256 // max(blocks, 1), int(shared_tok.min()) // PAGE // 8, 16))
         if use != self.group_attn or (use and (G != self.G or chunks != self.group_chunks)):
             self.group_attn, self.G, self.group_chunks, self.graph = use, G, chunks, None
             self.group_ws = ops.attn_decode_group_ws(self.N, G, c.num_attention_heads, c.num_key_value_heads, c.head_dim, chunks, dev) if (use and chunks > 1) else None
@@ -358,12 +354,10 @@ class Rollout:
                 t.copy_(s_)
             STATS["capture_seconds"] += _time.perf_counter() - _t0
         bounds = ()
-        gates = []          # every gate event stays alive until the rollout returns (a destroyed event's handle goes back to torch's pool and is re-recorded by the next gate)
         if shadow is not None:
             shadow.begin(plan, G, max_new, first_pos, self.out_tokens, step_counter=self.step, policy=(e, self.trace) if mlp_on_shadow else None)
             bounds = shadow.boundaries(max_new)
             gate = torch.cuda.Event()
-            gates.append(gate)
             gate.record()                  # behind the sampling of token 0 (and the prefill): the reference's vision tower, prompt rows and first log-prob start now
             shadow.prompt_phase(gate)
         if self.wprefetch is not None:     # one persistent launch for the whole rollout, on its own CU-masked stream; it polls the progress word the replays store
@@ -397,12 +391,7 @@ class Rollout:
                     self._decode_step()
                 nsteps += 1
                 if shadow is not None and it in bounds:      # replay `it` has produced token `it`: rows [.., it) of every sequence and their targets are final
-                    gate = None
-                    if shadow.step_counter is None:         # (event gating; the default gate is the device step counter, overlap.ChunkedRefPass.begin)
-                        gate = torch.cuda.Event()
-                        gates.append(gate)
-                        gate.record()
-                    shadow.chunk(it, gate)
+                    shadow.chunk(it, None)                   # (gated on the device step counter: overlap.ChunkedRefPass.chunk)
                 if live and it % POLL == 0:
                     k = (it // POLL) % self.done_host.numel()
                     self.done_host[k: k + 1].copy_(self.all_done, non_blocking=True)
@@ -430,22 +419,12 @@ class Rollout:
         if ds is not None:
             # Join on the HOST: anything left pending on the outer stream's hardware queue while the replays run -- the dependency packet of `_outer.wait_stream(ds)`
             # (the host is hundreds of replays ahead), or a kernel polling the step counter -- costs every decode launch ~8 us when that queue happens to share a
-            # dispatch pipe with the decode queue: 5.0 instead of 3.0 ms per step (tools/decode_mask_probe.py plain 192, profiles/r05_decode_join.txt).  Which queues
-            # share a pipe depends on the order in which the process created them, so nothing may be pending: the host waits for the last replay (it needs the
-            # tokens next anyway) and enqueues the rest behind it.  IADR1_DECODE_JOIN=event|counter are the A/B forms.
-            join = os.environ.get("IADR1_DECODE_JOIN", "host")
-            if join == "event":
-                _outer.wait_stream(ds)
-            elif join == "counter":
-                if self._join_timed_out is None:
-                    self._join_timed_out = torch.zeros(1, dtype=torch.int32, device=dev)
-                    self._join_timed_out_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-                ops.hip.call("wait_counter", self.step, nsteps + 1, 30000, self._join_timed_out)
-                self._join_timed_out_host.copy_(self._join_timed_out, non_blocking=True)      # read at the next generate()
-            else:
-                _je = torch.cuda.Event()
-                _je.record(ds)
-                _je.synchronize()
+            # dispatch pipe with the decode queue: 5.0 instead of 3.0 ms per step (tools/decode_mask_probe.py plain 192, profiles/r05_decode_join.txt: event join 1208.8,
+            # counter join the same, host join 1202.2 ms per step).  Which queues share a pipe depends on the order in which the process created them, so nothing may
+            # be pending: the host waits for the last replay (it needs the tokens next anyway) and enqueues the rest behind it.
+            _je = torch.cuda.Event()
+            _je.record(ds)
+            _je.synchronize()
         toks = self.out_tokens[:, :max_new].clone()
         # the host copy of the tokens leaves BEFORE the shadow pass's tail is enqueued: the caller (rewards, the training batch's plans) waits for the decode replays
         # only, and prepares the next phase while the tail runs (tokens_host)

@@ -4,16 +4,20 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r03}
+# DECODE_ARGS: extra arguments of tools/decode_step_time.py (round 6: "--trace 1"); the decode-step switches come from the environment (round 6: IADR1_OVERLAP_CUS=0
+# IADR1_DECODE_CUS=192 IADR1_DECODE_KS=1,8 = the launch set of the co-scheduled step -- grids sized for 192 CUs -- on an ordinary stream, rocprofv3 crashes with masked ones)
+DECODE_ARGS=${DECODE_ARGS:-}
 mkdir -p $R/gpurun_out
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_dec_$ctr
-  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_dec_$ctr -o d -- python $R/tools/decode_step_time.py --reps 0 --steps 24 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_dec_$ctr -o d -- python $R/tools/decode_step_time.py --reps 0 --steps 24 $DECODE_ARGS > /dev/null 2>&1
 done
 python3 - <<PY
 import sqlite3, glob, json
 out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/decode_step_time.py --reps 0 --steps 24: the decode step of the rollout, 64 sequences, "
                "Qwen2.5-VL-3B shapes, context 512 + t.  Per kernel and grid: average over its dispatches.  Raw unit KiB; gfx950 correction of MI355X_MICROARCH.md applied to reads "
                "(FETCH_SIZE counts half of the bytes of wide coalesced streaming reads -> x2): read_bytes = 2 * FETCH_SIZE * 1024.  Profiled passes serialise the graph's kernels.",
+       "decode_cus": int("${IADR1_DECODE_CUS:-0}") or None, "decode_args": "${DECODE_ARGS}", "env": {k: v for k, v in __import__("os").environ.items() if k.startswith("IADR1_")},
        "kernels": []}
 agg = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -30,3 +30,19 @@ for _ in range(3):
     flush.zero_()
     ops.gemm_swiglu_fused(a, w, None, act)
 torch.cuda.synchronize()
+# round 5's two new forms: the row-blocked fused gate|up of the co-scheduled pass (gemm_nt_256<6>: one chunk = 64 sequences x 32 steps, rows 256 apart in a sequence-major
+# arena, gate|up AND activation written) and the TN weight-gradient kernel straight from row-major dY / X (gemm_nt_256<2, true>: dW_gu [22016 x 2048] over 20480 token rows)
+Mr = 64 * 32
+xa = torch.randn(64 * 256, K, device=dev).to(torch.bfloat16)
+gu_r = torch.empty(64 * 256, 2 * I, dtype=torch.bfloat16, device=dev); a_r = torch.empty(64 * 256, I, dtype=torch.bfloat16, device=dev)
+for _ in range(3):
+    flush.zero_()
+    ops.gemm_swiglu_rows(xa, w, gu_r, a_r, 64, 32, 256)
+torch.cuda.synchronize()
+del xa, gu_r, a_r, act, a
+dy = torch.randn(20480, 2 * I, device=dev).to(torch.bfloat16); x = torch.randn(20480, K, device=dev).to(torch.bfloat16)
+dw = torch.zeros(2 * I, K, dtype=torch.float32, device=dev)
+for _ in range(3):
+    flush.zero_()
+    ops.hip.call("gemm_tn_acc_bf16", dy, x, dw, None, 2 * I, K, 20480, 2 * I, K, K, 1)
+torch.cuda.synchronize()

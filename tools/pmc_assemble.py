@@ -5,9 +5,17 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"          # round tag of the ou
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ld = lambda n: json.load(open(os.path.join(ROOT, "gpurun_out", n)))
 KiB = 1024
+import re
 def pick(rows, frag, grid=None):
-    r = [x for x in rows if frag in x["kernel"] and (grid is None or x["grid"] == grid)]
-    assert len(r) == 1, (frag, grid, r)
+    """frag "gemm_nt_256<0>" = template arguments (0) or (0, false, false); "gemm_nt_256<2,t>" = (2, true[, false]): the TN form"""
+    m = re.fullmatch(r"(\w+)<(\d+)(,t)?>", frag)
+    def ok(name):
+        if not m:
+            return frag in name
+        k = re.search(re.escape(m.group(1)) + r"<\(?(?:int\)?)?(\d+)(?:, \(?(?:bool\)?)?(true|false|1|0))?(?:, \(?(?:bool\)?)?(true|false|1|0))?>", name)
+        return bool(k) and k.group(1) == m.group(2) and ((k.group(2) in ("true", "1")) == bool(m.group(3))) and k.group(3) not in ("true", "1")
+    r = [x for x in rows if ok(x["kernel"]) and (grid is None or x["grid"] == grid)]
+    assert len(r) == 1, (frag, grid, [x["kernel"] for x in rows])
     return r[0]["avg_value"]
 gf, gw = ld("pmc_gemm_FETCH_SIZE.json"), ld("pmc_gemm_WRITE_SIZE.json")
 kern = []
@@ -15,7 +23,11 @@ for name, frag, (M, N, K), alg in (
         ("gemm_nt_256<bf16 out>", "gemm_nt_256<0>", (20480, 22016, 2048), None),
         ("gemm_nt_256<SwiGLU epilogue, only the activation written> (iadr1_gemm_swiglu_bf16, gate|up of the reference pass)", "gemm_nt_256<3>", (20480, 22016, 2048), (20480 * 2048 + 22016 * 2048 + 20480 * 11008) * 2),
         ("gemm_nt_256<bf16 out>", "gemm_nt_256<0>", (20480, 2048, 11008), None),
-        ("gemm_nt_256<bf16 out>", "gemm_nt_256<0>", (22016, 2048, 20480), None)):
+        ("gemm_nt_256<bf16 out>", "gemm_nt_256<0>", (22016, 2048, 20480), None),
+        ("gemm_nt_256<row-blocked SwiGLU epilogue: gate|up AND activation written> (iadr1_gemm_swiglu_rows_bf16: the policy's mlp rows of one chunk of the co-scheduled pass, 64 sequences x 32 steps)",
+         "gemm_nt_256<6>", (2048, 22016, 2048), (2048 * 2048 + 22016 * 2048 + 2048 * 22016 + 2048 * 11008) * 2),
+        ("gemm_nt_256<fp32 accumulate, TN> (iadr1_gemm_tn_acc_bf16: dW_gu += dY^T . X from row-major operands, no transposed copies)", "gemm_nt_256<2,t>", (22016, 2048, 20480),
+         (20480 * 22016 + 20480 * 2048) * 2 + 2 * 22016 * 2048 * 4)):
     grid = ((M + 255) // 256) * ((N + 255) // 256) * 512
     fr, wr = pick(gf, frag, grid), pick(gw, frag, grid)
     alg = alg if alg is not None else (M * K + N * K + M * N) * 2
