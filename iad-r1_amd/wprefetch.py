@@ -2,7 +2,9 @@
 one persistent launch per rollout on a small CU-masked stream pulls the decode step's weights into the 256 MB memory-side cache just ahead of the launches
 that stream them (csrc/prefetch.hip, include/iadr1_hip.h iadr1_weight_prefetch), paced by the progress word the first kernel of every decoder layer stores.
 
-Opt-in (IADR1_WPREFETCH_CUS > 0): what it measured is in profiles/EXPERIMENTS.md round 6.
+Opt-in (IADR1_WPREFETCH_CUS > 0, co-scheduled step only) and OFF by default: prefetching the next layer's q|k|v + o weights takes 0.06 - 0.08 ms off the decode step
+(2 - 2.6 %), prefetching the mlp streams does not pay at all, and inside the co-scheduled step the third queue costs the step more than the decode step gains
+(profiles/EXPERIMENTS.md round 6 has every number).
 """
 from __future__ import annotations
 
