@@ -915,6 +915,11 @@ def run_pa_sft(a, cfg, dev, rank, world):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        # which step structure every rank ran (the decision is collective -- overlap.agree_across_ranks -- so these must all be equal; printed so that a run shows it)
+        mine = {"rank": rank, "co_scheduled": bool(getattr(eng, "last_step_shadowed", False)), "decode_stream_cus": int(getattr(eng._rollout, "decode_cus", 0) or 0) or None,
+                "recompute_forced": bool(eng.pol.__dict__.get("_recompute_forced"))}
+        per_rank_structure = [None] * world
+        dist.all_gather_object(per_rank_structure, mine)
         dist.destroy_process_group()
     elif os.environ.get("IADR1_FORCE_REDUCE"):
         import torch.distributed as dist
@@ -1328,6 +1333,7 @@ def main():
                                      "ms_per_decode_step is higher (3B: 3.06 vs 2.80 ms alone on 256 CUs) although the step is shorter; roofline_gemm prices side-stream launches at their CU share"}
     dec_ev, eng._rollout.decode_events = eng._rollout.decode_events, None
     per_rank_ms = [dt / a.steps * 1e3]
+    per_rank_structure = None
     exposed_ms = eng.reducer.exposed_ms() if eng.reducer.active else None
     if world > 1:
         import torch.distributed as dist
@@ -1337,6 +1343,11 @@ def main():
         per_rank_ms = [float(x) / a.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        # which step structure every rank ran (the decision is collective -- overlap.agree_across_ranks -- so these must all be equal; printed so that a run shows it)
+        mine = {"rank": rank, "co_scheduled": bool(getattr(eng, "last_step_shadowed", False)), "decode_stream_cus": int(getattr(eng._rollout, "decode_cus", 0) or 0) or None,
+                "recompute_forced": bool(eng.pol.__dict__.get("_recompute_forced"))}
+        per_rank_structure = [None] * world
+        dist.all_gather_object(per_rank_structure, mine)
     # one extra step OUTSIDE the timed region in the reference's own layout (every prompt repeated in all G rows of its group,
     # IADR1_SHARE_PREFIX=0) so the line also says what the dedup of the prompt tokens is worth; N=1 only
     repeated = None
@@ -1421,6 +1432,7 @@ def main():
                                     "tests/test_hip_model.py::test_api_step_with_rollout_handover_matches_the_oracle)" if traced else ""))
                        if eng.args.share_prefix else "ViT once per image"},
             "per_rank_ms_per_step": [round(x, 2) for x in per_rank_ms],
+            "per_rank_step_structure": per_rank_structure,
             "repeated_rows_layout": repeated,
             "real_processor": real,
             "real_shapes": shapes,

@@ -509,6 +509,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(lines) == 1, r.stdout[-3000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["rccl_ranks"] == 2 and len(rec["per_rank_ms_per_step"]) == 2
+    st = rec["per_rank_step_structure"]                                  # one step structure for the whole job (overlap.agree_across_ranks, Engine.check_ddp_headroom)
+    assert len(st) == 2 and st[0]["co_scheduled"] == st[1]["co_scheduled"] and st[0]["recompute_forced"] == st[1]["recompute_forced"], st
     assert rec["config"]["gradient_checkpointing"] == "auto"            # the data-parallel default (static budget, Engine.recompute_wanted)
     ge = rec["config"]["grad_exchange"]
     assert ge["n_buckets"] >= 1 and ge["bytes_on_wire"] > 0 and ge["exposed_ms"] is not None and ge["exposed_ms"] >= 0.0
