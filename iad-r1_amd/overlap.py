@@ -30,7 +30,14 @@ so the rows of a chunk are one contiguous range for every token-wise kernel and 
 (iadr1_attn_fwd_chunk: query sub-range + blocked row map per segment).  Per-layer q|k|v rows of everything processed so far are kept
 ([L, T, qkv_width] bf16: 3.8 GB at the 3B bench shape) so that later chunks attend to earlier ones.
 
-Results are BIT-equal to the one-shot pass (Engine.text_forward + Engine.logprobs over the whole [prompts ++ completions] batch): same kernels,
+What is bit-equal and what is not.  The REFERENCE's log-probs and the policy's lm_head log-probs are BIT-equal to the sequential step's -- every forward
+quantity the loss reads is, hence KL, loss and the tokens.  The policy's gate|up / SwiGLU rows of the completion tokens are REBUILT by the training GEMM instead of stored by
+the decode kernel (IADR1_OVERLAP_GU=1, the default): the two kernels sum K in different orders, the rows differ in the last bf16 bit, and the GRADIENTS of the co-scheduled step
+differ from the sequential step's by that much (cosine 0.99983 through 36 layers; both hold the oracle's tolerances: tests/test_hip_model.py::
+test_api_step_with_rollout_handover_matches_the_oracle[0|64]).  Which structure runs is decided once per job (cu_split + agree_across_ranks) and logged; IADR1_OVERLAP_GU=0 keeps
+the decode kernel's rows (bit-equal gradients, +0.1 ms per decode step).
+
+The chunked reference pass itself is BIT-equal to the one-shot pass (Engine.text_forward + Engine.logprobs over the whole [prompts ++ completions] batch): same kernels,
 row-independent GEMMs (tools/gemm_rowdep_probe.py), the same 64-key attention tiles in the same order, RMSNorm kernel choice independent of the row count
 (tests/test_hip_model.py::test_chunked_reference_pass_is_bit_equal_to_the_one_shot_pass).
 """
