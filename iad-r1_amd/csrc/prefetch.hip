@@ -7,6 +7,11 @@
 // memory-side cache (plain reads whose values are dropped), so that the weight-streaming launches of the decode step (gate|up, down: 135 of a 3B layer's 171 MB)
 // find them there instead of in HBM.  What it is for and what it measured: profiles/EXPERIMENTS.md round 6.
 //
+// Start / stop without stream dependencies: the launch is enqueued with NO wait on any other stream (a dependency packet pending on its queue for a whole backward pass
+// costs the neighbours of its dispatch pipe, profiles/EXPERIMENTS.md round 5 #11) -- the progress word reads 0 between rollouts (the decode stream zeroes it behind its
+// last replay, and the host joins that stream before it goes on), and the launch returns when the `stop` word reaches its `epoch` (stored behind the last replay, also when
+// EOS ended the rollout early).
+//
 // Pacing rules: a block never starts unit n + 1 before mark n + 1 - lead has been published (at most lead + 1 layers ahead: nothing is evicted before use);
 // a block that finds the decode step already PAST its unit drops the rest of the unit (stale bytes only compete with the consumer); every wait is bounded
 // (timeout_ms) so a decode stream that never arrives cannot hang the queue.
@@ -18,6 +23,8 @@ struct PrefetchArgs {
     int n_units, n_seg;
     const unsigned* mark;       // the decode step's progress word
     unsigned first_mark, last_mark;
+    const unsigned* stop;       // optional: the launch returns once *stop >= epoch (the rollout stores its sequence number there behind its last replay)
+    unsigned epoch;
     int lead;
     int nt;                     // 1: non-temporal loads (streaming hint), 0: plain
     unsigned long long timeout_ticks;
@@ -52,6 +59,7 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PrefetchArgs a) {
             unsigned cur;
             while ((cur = __hip_atomic_load(a.mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < next) {
                 __builtin_amdgcn_s_sleep(16);       // ~0.5 us between polls: one lane of one wave per CU
+                if (a.stop && __hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.epoch) { s_quit = 1; break; }      // the rollout is over
                 if (wall_clock64() - t0 > a.timeout_ticks) {
                     if (a.status) a.status[0] = 1;
                     s_quit = 1;
@@ -100,12 +108,12 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PrefetchArgs a) {
 }
 }  // namespace
 
-extern "C" int iadr1_weight_prefetch(const long long* segs, int n_units, int n_seg, const unsigned* mark, unsigned first_mark, unsigned last_mark, int lead, int nt,
-                                     int n_blocks, int timeout_ms, int* status, hipStream_t stream) {
+extern "C" int iadr1_weight_prefetch(const long long* segs, int n_units, int n_seg, const unsigned* mark, unsigned first_mark, unsigned last_mark, const unsigned* stop,
+                                     unsigned epoch, int lead, int nt, int n_blocks, int timeout_ms, int* status, hipStream_t stream) {
     IADR1_REQUIRE(segs != nullptr && mark != nullptr && n_units > 0 && n_seg > 0, "weight_prefetch: a segment table and a progress word are required");
     IADR1_REQUIRE(first_mark <= last_mark && lead >= 0 && lead < n_units, "weight_prefetch: marks [%u, %u], lead %d of %d units", first_mark, last_mark, lead, n_units);
     IADR1_REQUIRE(n_blocks > 0 && n_blocks <= 256 && timeout_ms > 0 && timeout_ms <= 60000, "weight_prefetch: 1..256 blocks (one per CU of the stream's mask) and a timeout in (0, 60000] ms");
-    PrefetchArgs a{segs, n_units, n_seg, mark, first_mark, last_mark, lead, nt, (unsigned long long)timeout_ms * 100000ull, status};
+    PrefetchArgs a{segs, n_units, n_seg, mark, first_mark, last_mark, stop, epoch, lead, nt, (unsigned long long)timeout_ms * 100000ull, status};
     if (nt) hipLaunchKernelGGL(weight_prefetch_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(weight_prefetch_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, a);
     return iadr1_check_launch("weight_prefetch");

@@ -189,7 +189,7 @@ def pick_prefetch_stream(decode, side, make_candidate, weight: torch.Tensor, tri
         torch.cuda.synchronize(dev)
         if resident is not None:
             with torch.cuda.stream(resident):
-                ops.hip.call("weight_prefetch", segs, 1, 1, mark, 1, 1, 0, 0, 8, 40, None)
+                ops.hip.call("weight_prefetch", segs, 1, 1, mark, 1, 1, None, 0, 0, 0, 8, 40, None)
         with torch.cuda.stream(stream):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

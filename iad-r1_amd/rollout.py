@@ -101,8 +101,11 @@ class Rollout:
         # progress word of the decode step (step * layers + layer, stored by the first kernel of every decoder layer) and the weight prefetcher it paces
         # (wprefetch.WeightPrefetcher, set by the owner; None: no marks in the captured step)
         self.mark = torch.zeros(1, dtype=i32, device=dev)
+        self.pf_stop = torch.zeros(1, dtype=i32, device=dev)        # sequence number of the last finished rollout (the prefetcher's stop word)
+        self._pf_epoch = 0
         self.wprefetch = None
         self._marks_in_graph = False
+        self._marks_clean = True
         self._toks_host, self._toks_event = None, None
         self.trace = None           # training arena filled by the decode steps (generate(train_trace=...)); part of the captured graph
         self.decode_events = None   # bench.py sets a list: (start event, end event, decode steps, sum of prompt lengths over sequences) per call
@@ -350,6 +353,7 @@ class Rollout:
             torch.cuda.synchronize()
             _t0 = _time.perf_counter()
             self._capture()  # warm-up + capture advance the state twice: restore it (K/V written meanwhile are rewritten by the real steps)
+            self._marks_clean = False
             for t, s_ in zip(state, saved):
                 t.copy_(s_)
             STATS["capture_seconds"] += _time.perf_counter() - _t0
@@ -362,9 +366,13 @@ class Rollout:
             shadow.prompt_phase(gate)
         if self.wprefetch is not None:     # one persistent launch for the whole rollout, on its own CU-masked stream; it polls the progress word the replays store
             Lm = c.num_hidden_layers
-            self.mark.zero_()
-            self.wprefetch.stream.wait_stream(torch.cuda.current_stream())
-            self.wprefetch.start(self.mark, 1 * Lm, (max_new - 1) * Lm + Lm - 1)
+            if not self._marks_clean:      # (a capture / warm-up ran decode steps, or an exception cut a rollout short: the word must read 0 when the launch starts)
+                self.mark.zero_()
+                torch.cuda.current_stream().synchronize()
+                self._marks_clean = True
+            self._pf_epoch += 1
+            self.wprefetch.start(self.mark, 1 * Lm, (max_new - 1) * Lm + Lm - 1, self.pf_stop, self._pf_epoch)       # no stream dependency: see csrc/prefetch.hip
+            self._marks_clean = False
         # the CU-masked decode stream (and the host join that goes with it) only when something runs NEXT TO the replays: a rollout without the shadow pass
         # (SCGRPOTrainer.training_step's batched rollouts, step(completions=...), the evaluation harness) has nothing to hide behind the +0.2 ms per step
         ds = self.decode_stream if (shadow is not None or self.wprefetch is not None) else None
@@ -404,8 +412,10 @@ class Rollout:
                         STATS["eos_polls"] += 1
                         if int(self.done_host[k0]):
                             break
-            if self.wprefetch is not None:
-                self.mark.fill_(-1)            # behind the last replay: releases the prefetcher (also when EOS ended the rollout early)
+            if self.wprefetch is not None:     # behind the last replay (the host joins this stream below): releases the prefetcher, also when EOS ended the rollout early,
+                self.pf_stop.fill_(self._pf_epoch)      # and leaves the progress word at 0 for the next rollout's launch
+                self.mark.zero_()
+                self._marks_clean = ds is not None      # (only the masked decode stream is joined on the host below)
             STATS["decode_steps"] += nsteps
             STATS["rollouts"] += 1
             if ev:

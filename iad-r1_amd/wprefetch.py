@@ -44,11 +44,12 @@ class WeightPrefetcher:
         self.status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
         self.launched = 0
 
-    def start(self, mark: torch.Tensor, first_mark: int, last_mark: int, timeout_ms: int = 20000):
-        """Enqueue the rollout's prefetcher on its own stream (it starts polling at once; the decode replays that publish the marks follow on theirs)."""
+    def start(self, mark: torch.Tensor, first_mark: int, last_mark: int, stop: torch.Tensor, epoch: int, timeout_ms: int = 20000):
+        """Enqueue the rollout's prefetcher on its own stream, with NO dependency on any other stream (it starts polling at once; `mark` reads 0 until the decode replays
+        that follow on their stream publish the marks; it returns when `stop` reaches `epoch`)."""
         with torch.cuda.stream(self.stream):
-            hip.call("weight_prefetch", self.segs, self.n_units, self.n_seg, mark, int(first_mark), int(last_mark), self.lead, int(self.nt), self.n_cus, int(timeout_ms),
-                     self.status)
+            hip.call("weight_prefetch", self.segs, self.n_units, self.n_seg, mark, int(first_mark), int(last_mark), stop, int(epoch), self.lead, int(self.nt), self.n_cus,
+                     int(timeout_ms), self.status)
             self.status_host.copy_(self.status, non_blocking=True)
         self.launched += 1
 

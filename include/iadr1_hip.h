@@ -320,10 +320,11 @@ int iadr1_wait_counter(const unsigned* counter, unsigned target, int timeout_ms,
  * `n_blocks` = the CUs that stream owns.  `segs`: DEVICE table [n_units][n_seg][2] of (address, bytes; bytes %% 16 == 0) -- unit u = the weight segments of decoder
  * layer u in the order the step reads them.  `mark`: the decode step's progress word (iadr1_side_out_t.mark: step * n_units + layer, stored by the first kernel of
  * every layer).  On seeing mark m in [first_mark, last_mark] a block reads its share of unit (m + lead) %% n_units; it never runs further ahead than that, drops a
- * unit the decode step has passed, returns when the word exceeds last_mark (store ~0 behind the last replay) or after `timeout_ms` (<= 60000).  `nt`: 1 =
- * non-temporal loads.  `status` (optional DEVICE int[4]): timed-out flag, units read, units dropped as stale, MiB read (the last three from block 0). */
-int iadr1_weight_prefetch(const long long* segs, int n_units, int n_seg, const unsigned* mark, unsigned first_mark, unsigned last_mark, int lead, int nt,
-                          int n_blocks, int timeout_ms, int* status, iadr1_stream_t stream);
+ * unit the decode step has passed, returns when the word exceeds last_mark, when `*stop` (optional DEVICE word) reaches `epoch` (the rollout stores its sequence number there
+ * behind its last replay) or after `timeout_ms` (<= 60000).  Enqueue it WITHOUT a stream dependency: the word must read 0 when the launch starts (the rollout zeroes it behind
+ * its last replay).  `nt`: 1 = non-temporal loads.  `status` (optional DEVICE int[4]): timed-out flag, units read, units dropped as stale, MiB read (the last three from block 0). */
+int iadr1_weight_prefetch(const long long* segs, int n_units, int n_seg, const unsigned* mark, unsigned first_mark, unsigned last_mark, const unsigned* stop,
+                          unsigned epoch, int lead, int nt, int n_blocks, int timeout_ms, int* status, iadr1_stream_t stream);
 /* all_done (optional): 1 when every sequence has finished after this token -- the host polls it through pinned memory without draining the
  * queue (the reference's vLLM stops a request at EOS, REF:343-358).  inv_freq (optional, with cos_t / sin_t [B, half]): the rotary table
  * of the NEXT step's positions is written here, bit-identical to iadr1_rope_table on the bumped positions (one launch less per decode step). */

@@ -35,7 +35,7 @@ status = torch.zeros(4, dtype=torch.int32, device=dev)
 def reader(w, nt, blocks=256):
     """the prefetch kernel as a one-shot read of one tensor: mark == first == last, lead 0, one unit"""
     seg = ops.h2d(__import__("numpy").asarray([[[w.data_ptr(), w.numel() * w.element_size()]]], dtype="int64"), w.device)
-    return lambda: hip.call("weight_prefetch", seg, 1, 1, mark, 0, 0, 0, nt, blocks, 1000, status)
+    return lambda: hip.call("weight_prefetch", seg, 1, 1, mark, 0, 0, None, 0, 0, nt, blocks, 1000, status)
 
 
 shapes = [("gate|up (swiglu)", 22016, 2048, dict(swiglu=True)), ("down (8 K slices)", 2048, 11008, dict(ksplit=8)), ("q|k|v-like", 2560, 2048, {}), ("o (2 K slices)", 2048, 2048, dict(ksplit=2)),

@@ -22,7 +22,7 @@ def timed(body, resident=None, n_blocks=0, ms=250):
     torch.cuda.synchronize()
     if resident is not None:
         with torch.cuda.stream(resident):
-            ops.hip.call("weight_prefetch", segs, 1, 1, mark, 1, 1, 0, 0, n_blocks, ms, None)
+            ops.hip.call("weight_prefetch", segs, 1, 1, mark, 1, 1, None, 0, 0, 0, n_blocks, ms, None)
     with torch.cuda.stream(side):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); body(); e1.record()
