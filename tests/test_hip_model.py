@@ -1242,7 +1242,7 @@ def test_api_step_with_rollout_handover_matches_the_oracle(monkeypatch, overlap_
     dlr = np.abs(out["ref_logps"].cpu().numpy()[m] - want["ref_logps"].numpy()[m]).max()
     np.testing.assert_allclose(out["advantages"].numpy(), want["advantages"].numpy(), rtol=1e-5, atol=1e-6)
     mt = out["metrics"]
-    wl, wk = float(want["loss"]), float(want["metrics"]["kl"])
+    wl, wk = float(want["loss"].detach()), float(want["metrics"]["kl"])
     print(f"[parity] api step vs oracle: loss hip={mt['loss']:.6e} oracle={wl:.6e}  kl hip={mt['kl']:.6e} oracle={wk:.6e} ({100 * abs(mt['kl'] - wk) / wk:.1f}%)  "
           f"|dlogp|max pol={dlp:.4f} ref={dlr:.4f}  lens={lens.tolist()} eos={best}")
     assert dlp < 0.06 and dlr < 0.06, (dlp, dlr)
@@ -1928,6 +1928,40 @@ def test_policy_mlp_rows_rebuilt_under_the_rollout(monkeypatch, steps, cus, eos_
     rel = float((g0 - g1).norm() / g0.norm())
     print(f"[parity] policy mlp rows rebuilt on the side stream vs stored by the decode step: gradient cosine {cos:.7f}, relative difference {rel:.3e}")
     assert cos > 0.9999 and rel < 1.5e-2, (cos, rel)
+
+
+def test_weight_prefetcher_follows_the_decode_step_and_changes_no_token():
+    """The opt-in persistent weight prefetcher (iadr1_weight_prefetch, iad-r1_amd/wprefetch.py; REF:637-683 is the loop it runs under): attached to a rollout it is
+    paced by the progress marks the first kernel of every decoder layer stores -- it sees the (C - 1) x layers units and reads most of them, no timeout --,
+    it returns when the rollout stores its sequence number in the stop word (twice in a row: the second launch starts from a clean progress word), and the tokens are
+    those of the rollout without it (it only reads).  3B widths, 2 layers, 16 sequences, C = 24; the prefetcher on an ordinary second stream."""
+    import dataclasses
+    from iadr1_amd.wprefetch import WeightPrefetcher
+    cfg = dataclasses.replace(VLMConfig.qwen25vl_3b(), num_hidden_layers=2, v_depth=2, v_fullatt=(1,))
+    pol = ParamStore(cfg, DEV, trainable=True)
+    pol.init_random(seed=0)
+    ref = ParamStore(cfg, DEV, trainable=False)
+    ref.copy_from(pol)
+    G, C, Bp = 8, 24, 2
+    cd = _oracle_cfg_dict(cfg)
+    grids = [(1, 16, 16), (1, 16, 12)]
+    rows = [fx.synth_prompt(grids[0], 37, cd, 5), fx.synth_prompt(grids[1], 21, cd, 6)]
+    ids, mask = fx.left_pad(rows, cfg.pad_token_id)
+    batch = {"input_ids": ids, "attention_mask": mask, "pixel_values": fx.synth_pixel_values(grids, cd, seed=5), "image_grid_thw": grids}
+    eng = SCGRPOEngine(cfg, pol, ref, GRPOArgs(num_generations=G, max_prompt_length=4096, max_completion_length=C, micro_batch_seqs=Bp * G, seed=11, suppress_eos=True))
+    main = torch.cuda.Stream()
+    with torch.cuda.stream(main):
+        want = eng.rollout(batch)
+        pf = WeightPrefetcher(eng.pol, torch.cuda.Stream(), 8, what=(), next_what=("qkv", "o"), lead=0)
+        eng._rollout.wprefetch = pf
+        for _ in range(2):
+            got = eng.rollout(batch)
+            rep = pf.report()
+            assert np.array_equal(got, want)
+            n_units = (C - 1) * cfg.num_hidden_layers      # (a unit the decode step has passed is skipped or dropped: block 0 may see a few at this 2-layer depth)
+            assert not rep["timed_out"] and rep["units_read"] + rep["units_stale"] >= 0.8 * n_units and rep["units_read"] >= 0.5 * n_units, rep
+        assert pf.launched == 2 and int(eng._rollout.pf_stop.item()) == 2 and int(eng._rollout.mark.item()) == 0
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("full_depth", [False, True])
