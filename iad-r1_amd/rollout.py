@@ -426,6 +426,8 @@ class Rollout:
             # stream
             if ds is not None:
                 torch.cuda.set_stream(_outer)
+            if self.wprefetch is not None and not self._marks_clean:
+                self.pf_stop.fill_(self._pf_epoch)      # (an exception cut the loop short: release the resident prefetch launch; the next start() zeroes the progress word)
         if ds is not None:
             # Join on the HOST: anything left pending on the outer stream's hardware queue while the replays run -- the dependency packet of `_outer.wait_stream(ds)`
             # (the host is hundreds of replays ahead), or a kernel polling the step counter -- costs every decode launch ~8 us when that queue happens to share a
