@@ -141,7 +141,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-full-step", action="store_true", help="run the oracle's REAL B = 1 x G SC-GRPO step once at full 3B size on the host cores (about 6 minutes, "
-                    "~130 GB of host memory; no GPU work) and print its JSON record -- the committed record is profiles/r03_cpu_full_step.json; the default run's cpu_baseline "
+                    "~130 GB of host memory; no GPU work) and print its JSON record -- the committed record is the newest profiles/rNN_cpu_full_step.json (round 6: r06); the default run's cpu_baseline "
                     "stays the bounded component sample")
     ap.add_argument("--launch-check", action="store_true", help="only the N-rank launch contract, no GPU work: respawn under torch.distributed.run when needed, assert WORLD_SIZE == --gpus, "
                     "rendezvous over gloo on 127.0.0.1, max-reduce a per-rank value, ONE JSON line from rank 0 (what tests/test_ddp_gloo.py runs on CPU)")
