@@ -228,16 +228,23 @@ def cu_split(dev: torch.device, n: int, weight: torch.Tensor, prefetch_cus: int 
         total = torch.cuda.get_device_properties(dev).multi_processor_count
         if not (0 < n < total and n % 8 == 0 and 0 <= prefetch_cus <= n and prefetch_cus % 8 == 0):
             raise ValueError(f"IADR1_OVERLAP_CUS={n} / IADR1_WPREFETCH_CUS={prefetch_cus}: multiples of 8 (the same share of every XCD), prefetch <= side < the device's {total} CUs")
+        # the prefetcher's queue is created FIRST: one more hardware queue shifts the dispatch pipe of every queue created after it, and created in the middle it moved the
+        # weight-gradient / main queues against the decode pair (1198 -> 1239 ms per step with nothing launched on it, EXPERIMENTS round 6); created first, the others keep
+        # their positions relative to each other.  (Necessary, not sufficient: the step still loses with the prefetcher running -- r06_wprefetch_bench_ab8.txt.)
+        pf_first = hip.cu_mask_stream(0, prefetch_cus) if prefetch_cus > 0 else None
         decode = hip.cu_mask_stream(n, total - n)
         log = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("IADR1_OVERLAP_LOG") == "1" else None
         side, ratio = pick_concurrent_stream(decode, lambda: hip.cu_mask_stream(0, n), weight, log=log)
         pf = None
         if side is None:
             destroy_stream(decode)
+            if pf_first is not None:
+                destroy_stream(pf_first)
             if os.environ.get("IADR1_QUIET") != "1":
                 print(f"[iadr1] co-scheduling off: no stream pair on separate dispatch pipes found (best: the dependent chain at {ratio:.1f}x its stand-alone time)", file=sys.stderr, flush=True)
         elif prefetch_cus > 0:
-            pf = pick_prefetch_stream(decode, side, lambda: hip.cu_mask_stream(0, prefetch_cus), weight, log=log)
+            first = [pf_first]
+            pf = pick_prefetch_stream(decode, side, lambda: first.pop() if first else hip.cu_mask_stream(0, prefetch_cus), weight, log=log)
             if pf is None and os.environ.get("IADR1_QUIET") != "1":
                 print("[iadr1] weight prefetcher off: no third stream that leaves both the decode chain and the side stream's GEMMs alone was found", file=sys.stderr, flush=True)
         _SPLITS[key] = None if side is None else (decode, side, total - n, pf)
